@@ -1,0 +1,184 @@
+"""ctypes mirror of include/avirhip.h (the C ABI of libavirhip.so).
+
+Plumbing only: structure layouts, the library loader and prototype
+declarations. The loader fails loudly when the in-tree HIP library is missing
+-- there is no CPU fallback in the product path.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libavirhip.so")
+
+U8, U16, F32, F64 = 0, 1, 2, 3
+MEM_HOST, MEM_DEVICE = 0, 1
+
+STEP_FIR, STEP_UP_ZEROSTUFF, STEP_UP_FILTERED, STEP_RESIZE, STEP_RESIZE2 = range(5)
+STEP_NAMES = ["FIR", "UP_ZEROSTUFF", "UP_FILTERED", "RESIZE", "RESIZE2"]
+
+PATH_AUTO, PATH_GENERIC, PATH_TILED, PATH_FUSED = 0, 1, 2, 3
+
+_fp = C.POINTER(C.c_float)
+_ip = C.POINTER(C.c_int32)
+
+
+class RPos(C.Structure):
+    _fields_ = [("src_pos_int", C.c_int32), ("fti", C.c_int32),
+                ("phase", C.c_int32), ("x", C.c_float),
+                ("src_offs_px", C.c_int32), ("fl", C.c_int32),
+                ("ftp_off", C.c_int32)]
+
+
+class Step(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("resample_factor", C.c_int32),
+                ("in_len", C.c_int32), ("in_prefix", C.c_int32),
+                ("in_suffix", C.c_int32), ("out_len", C.c_int32),
+                ("out_prefix", C.c_int32), ("out_suffix", C.c_int32),
+                ("edge_pixel_count", C.c_int32),
+                ("flt_len", C.c_int32), ("flt_latency", C.c_int32),
+                ("flt", _fp),
+                ("prefix_dc_len", C.c_int32), ("prefix_dc", _fp),
+                ("suffix_dc_len", C.c_int32), ("suffix_dc", _fp),
+                ("bank_filter_len", C.c_int32), ("bank_order", C.c_int32),
+                ("bank_frac_count", C.c_int32), ("n_phases", C.c_int32),
+                ("phase_fti", _ip), ("phase_taps", _fp),
+                ("rpos", C.POINTER(RPos))]
+
+
+class Axis(C.Structure):
+    _fields_ = [("n_steps", C.c_int32), ("steps", C.POINTER(Step)),
+                ("build_mode", C.c_int32)]
+
+
+class PlanDesc(C.Structure):
+    _fields_ = [("src_w", C.c_int32), ("src_h", C.c_int32),
+                ("src_stride_elems", C.c_int32),
+                ("new_w", C.c_int32), ("new_h", C.c_int32),
+                ("channels", C.c_int32),
+                ("in_type", C.c_int32), ("out_type", C.c_int32),
+                ("h", Axis), ("v", Axis),
+                ("tr_mul", C.c_double), ("pk_out", C.c_double)]
+
+
+class LancirPos(C.Structure):
+    _fields_ = [("flt_index", C.c_int32), ("so", C.c_int32)]
+
+
+class LancirAxis(C.Structure):
+    _fields_ = [("kernel_len", C.c_int32), ("padl", C.c_int32),
+                ("padr", C.c_int32), ("src_len", C.c_int32),
+                ("dst_len", C.c_int32), ("n_filters", C.c_int32),
+                ("filter_frac", _ip), ("filters", _fp),
+                ("pos", C.POINTER(LancirPos))]
+
+
+class LancirDesc(C.Structure):
+    _fields_ = [("src_w", C.c_int32), ("src_h", C.c_int32),
+                ("src_stride_elems", C.c_int32),
+                ("new_w", C.c_int32), ("new_h", C.c_int32),
+                ("new_stride_elems", C.c_int32),
+                ("channels", C.c_int32),
+                ("in_type", C.c_int32), ("out_type", C.c_int32),
+                ("v", LancirAxis), ("h", LancirAxis),
+                ("out_mul", C.c_float), ("clamp", C.c_float),
+                ("is_unity_mul", C.c_int32)]
+
+
+class Params(C.Structure):
+    _fields_ = [(n, C.c_double) for n in (
+        "CorrFltAlpha", "CorrFltLen", "IntFltAlpha", "IntFltCutoff",
+        "IntFltLen", "LPFltAlpha", "LPFltBaseLen", "LPFltCutoffMult",
+        "HBFltAlpha", "HBFltCutoff", "HBFltLen")]
+
+
+class Vars(C.Structure):
+    _fields_ = [("ox", C.c_double), ("oy", C.c_double),
+                ("UseSRGBGamma", C.c_int32), ("AlphaIndex", C.c_int32),
+                ("BuildMode", C.c_int32), ("RndSeed", C.c_int32)]
+
+
+class LancirParams(C.Structure):
+    _fields_ = [("SrcSSize", C.c_int32), ("NewSSize", C.c_int32),
+                ("kx", C.c_double), ("ky", C.c_double),
+                ("ox", C.c_double), ("oy", C.c_double), ("la", C.c_double)]
+
+
+# Every symbol include/avirhip.h declares: name -> (restype, argtypes)
+_VP = C.c_void_p
+_I = C.c_int
+_D = C.c_double
+PROTOTYPES = {
+    "avirhip_device_count": (_I, []),
+    "avirhip_init": (_I, [_I]),
+    "avirhip_last_error": (C.c_char_p, []),
+    "avirhip_version": (C.c_char_p, []),
+    "avirhip_plan_create": (_I, [C.POINTER(PlanDesc), C.POINTER(_VP)]),
+    "avirhip_lancir_plan_create": (_I, [C.POINTER(LancirDesc), C.POINTER(_VP)]),
+    "avirhip_plan_destroy": (None, [_VP]),
+    "avirhip_plan_set_path": (_I, [_VP, _I]),
+    "avirhip_plan_get_path": (_I, [_VP]),
+    "avirhip_resize": (_I, [_VP, _VP, _I, _VP, _I, _VP]),
+    "avirhip_resize_band": (_I, [_VP, _VP, _I, _VP, _I, _I, _I, _VP]),
+    "avirhip_time_resize": (_I, [_VP, _VP, _VP, _I, _VP, C.POINTER(_D)]),
+    "avirhip_params_preset": (None, [_I, C.POINTER(Params)]),
+    "avirhip_vars_default": (None, [C.POINTER(Vars)]),
+    "avirhip_resizer_create": (_I, [_I, _I, C.POINTER(Params), C.POINTER(_VP)]),
+    "avirhip_resizer_destroy": (None, [_VP]),
+    "avirhip_resizer_build_desc": (_I, [_VP, _I, _I, _I, _I, _I, _I, _D,
+                                        C.POINTER(Vars), _I, _I,
+                                        C.POINTER(C.POINTER(PlanDesc))]),
+    "avirhip_plan_desc_free": (None, [C.POINTER(PlanDesc)]),
+    "avirhip_resizer_resize": (_I, [_VP, _VP, _I, _I, _I, _I, _VP, _I, _I, _I,
+                                    _I, _D, C.POINTER(Vars), _I, _I, _VP]),
+    "avirhip_resizer_get_plan": (_I, [_VP, _I, _I, _I, _I, _I, _I, _D,
+                                      C.POINTER(Vars), _I, _I, C.POINTER(_VP)]),
+    "avirhip_lancir_params_default": (None, [C.POINTER(LancirParams)]),
+    "avirhip_lancir_create": (_I, [C.POINTER(_VP)]),
+    "avirhip_lancir_destroy": (None, [_VP]),
+    "avirhip_lancir_build_desc": (_I, [_VP, _I, _I, _I, _I, _I,
+                                       C.POINTER(LancirParams), _I, _I,
+                                       C.POINTER(C.POINTER(LancirDesc))]),
+    "avirhip_lancir_desc_free": (None, [C.POINTER(LancirDesc)]),
+    "avirhip_lancir_resize": (_I, [_VP, _VP, _I, _I, _I, _VP, _I, _I, _I, _I,
+                                   C.POINTER(LancirParams), _I, _I, _VP]),
+    "avirhip_lancir_get_plan": (_I, [_VP, _I, _I, _I, _I, _I,
+                                     C.POINTER(LancirParams), _I, _I,
+                                     C.POINTER(_VP)]),
+}
+
+_lib = None
+
+
+def load():
+    """Loads libavirhip.so (in-tree) and declares every prototype.
+
+    Raises RuntimeError when the library is missing: the product path has no
+    CPU fallback, build it first with `python -c "import __graft_entry__ as g;
+    g.build()"` or `make -C avir_amd/csrc`.
+    """
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            "libavirhip.so not built (%s missing); run __graft_entry__.build()"
+            % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in PROTOTYPES.items():
+        fn = getattr(lib, name)  # AttributeError if a symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+class AvirHipError(RuntimeError):
+    pass
+
+
+def check(rc, what=""):
+    if rc < 0:
+        msg = load().avirhip_last_error()
+        raise AvirHipError("%s failed (%d): %s" % (
+            what, rc, msg.decode() if msg else "?"))
+    return rc

@@ -1,0 +1,317 @@
+/*
+ * avirhip.h -- C ABI of libavirhip: the MI355X (gfx950) executor for the
+ * separable-resize hot path of avaneev/avir.
+ *
+ * The reference (header-only C++, /root/reference) has no FFI of its own; its
+ * extension point for this path is the `fpclass` template parameter
+ * (avir.h:4569-4592), a per-scanline interface. This header is the boundary a
+ * drop-in replacement binds instead: the reference's front-end
+ * (avir::CImageResizer<>::resizeImage, avir.h:4680-4684; avir::CLancIR::
+ * resizeImage, lancir.h:386-390) keeps its signature, runs the planner on the
+ * host, and hands the immutable plan + the two image buffers across this ABI.
+ * See INTEGRATION.md for the reference-side stub.
+ *
+ * Conventions: plain C, plain pointers and sizes, no C++ exceptions cross the
+ * boundary. Every function returning `int` returns 0 on success and a negative
+ * AVIRHIP_E* code on error; avirhip_last_error() returns a thread-local
+ * message. The library copies every table it is given; the caller keeps
+ * ownership of its arrays.
+ */
+#ifndef AVIRHIP_H
+#define AVIRHIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define AVIRHIP_OK 0
+#define AVIRHIP_EINVAL (-1)      /* bad argument / malformed plan */
+#define AVIRHIP_ENODEV (-2)      /* no usable gfx950 device */
+#define AVIRHIP_EHIP (-3)        /* HIP runtime error (see last_error) */
+#define AVIRHIP_EUNSUPPORTED (-4)/* valid request outside the built scope */
+#define AVIRHIP_ENOMEM (-5)
+
+/* Element types of the source / destination image (Tin/Tout of
+ * resizeImage<Tin,Tout>, avir.h:4670-4677; lancir.h:373-381). */
+typedef enum avirhip_dtype {
+	AVIRHIP_U8 = 0,
+	AVIRHIP_U16 = 1,
+	AVIRHIP_F32 = 2,
+	AVIRHIP_F64 = 3
+} avirhip_dtype;
+
+/* Where a buffer passed to an execute call lives. */
+#define AVIRHIP_MEM_HOST 0
+#define AVIRHIP_MEM_DEVICE 1
+
+/* ---------------------------------------------------------------------
+ * AVIR plan description: a faithful, flattened mirror of the reference's
+ * per-axis filtering-step list (CImageResizerFilterStep, avir.h:2568-2728)
+ * after buildFilterSteps / updateFilterStepBuffers / updateBufLenAndRPosPtrs
+ * (avir.h:5616-6127) have run.
+ * ------------------------------------------------------------------- */
+
+typedef enum avirhip_step_kind {
+	AVIRHIP_STEP_FIR = 0,          /* doFilter, avir.h:3748-3866 */
+	AVIRHIP_STEP_UP_ZEROSTUFF = 1, /* doUpsample, FltOrig kept, 3260-3402 */
+	AVIRHIP_STEP_UP_FILTERED = 2,  /* doUpsample with filter + DC tails, 3404-3733 */
+	AVIRHIP_STEP_RESIZE = 3,       /* doResize, avir.h:3884-4096 */
+	AVIRHIP_STEP_RESIZE2 = 4       /* doResize2, avir.h:4114-4328 */
+} avirhip_step_kind;
+
+/* One entry of the resizing-position table (CResizePos, avir.h:2640-2648;
+ * filled by fillRPosBuf 5782-5808 and updateBufLenAndRPosPtrs 6063-6126). */
+typedef struct avirhip_rpos {
+	int32_t src_pos_int; /* floor(o + k*j) */
+	int32_t fti;         /* fractional-delay filter index */
+	int32_t phase;       /* index of `fti` in the step's compact phase list */
+	float x;             /* order-1 interpolation coefficient (float) */
+	int32_t src_offs_px; /* SrcOffs / ElCount: first source pixel read */
+	int32_t fl;          /* taps walked (RESIZE2: FilterLen - fo, step 2) */
+	int32_t ftp_off;     /* fo: offset of the first tap inside the phase */
+} avirhip_rpos;
+
+typedef struct avirhip_step {
+	int32_t kind;            /* avirhip_step_kind */
+	int32_t resample_factor; /* ResampleFactor (0 for RESIZE/RESIZE2) */
+	int32_t in_len, in_prefix, in_suffix;
+	int32_t out_len, out_prefix, out_suffix;
+	int32_t edge_pixel_count;
+
+	/* FIR / UP_FILTERED: the step's filter (Flt) and latency. Unused (len 0)
+	 * for UP_ZEROSTUFF and RESIZE*. */
+	int32_t flt_len;
+	int32_t flt_latency;
+	const float* flt;
+	/* UP_FILTERED only: PrefixDC / SuffixDC tails (avir.h:5307-5353). */
+	int32_t prefix_dc_len;
+	const float* prefix_dc;
+	int32_t suffix_dc_len;
+	const float* suffix_dc;
+
+	/* RESIZE / RESIZE2: the fractional-delay bank, compacted to the phases
+	 * the position table references. Phase p holds `bank_filter_len`
+	 * order-0 taps followed (order 1 only) by `bank_filter_len` difference
+	 * taps (avir.h:1838-1841). */
+	int32_t bank_filter_len;
+	int32_t bank_order;      /* 0 or 1 */
+	int32_t bank_frac_count; /* FracCount of the full bank */
+	int32_t n_phases;
+	const int32_t* phase_fti; /* [n_phases], ascending */
+	const float* phase_taps;  /* [n_phases][filter_len * (order + 1)] */
+	const avirhip_rpos* rpos; /* [out_len] */
+} avirhip_step;
+
+typedef struct avirhip_axis {
+	int32_t n_steps;
+	const avirhip_step* steps;
+	int32_t build_mode; /* informational: the mode the planner selected */
+} avirhip_axis;
+
+typedef struct avirhip_plan_desc {
+	int32_t src_w, src_h;
+	int32_t src_stride_elems; /* SrcScanlineSize (elements); <1 => w*ch */
+	int32_t new_w, new_h;
+	int32_t channels;         /* ElCountIO, 1..4 */
+	int32_t in_type, out_type;/* avirhip_dtype */
+	avirhip_axis h;           /* horizontal pass: src rows -> FltBuf */
+	avirhip_axis v;           /* vertical pass: FltBuf columns -> result */
+	/* Integer-output epilogue (avir.h:5029-5045, 4392-4419). Ignored for
+	 * float/double output. */
+	double tr_mul;            /* TrMul (1.0: no bit-depth truncation) */
+	double pk_out;            /* PkOut: 255 or 65535 */
+} avirhip_plan_desc;
+
+/* ---------------------------------------------------------------------
+ * LANCIR plan description (CLancIR internals, lancir.h:840-1381).
+ * ------------------------------------------------------------------- */
+
+typedef struct avirhip_lancir_pos {
+	int32_t flt_index; /* index into the axis' `filters` array */
+	int32_t so;        /* first source pixel read, relative to the padded
+	                      scanline start (CResizePos::so, lancir.h:1231) */
+} avirhip_lancir_pos;
+
+typedef struct avirhip_lancir_axis {
+	int32_t kernel_len;       /* KernelLen, even */
+	int32_t padl, padr;       /* CResizeScanline::padl/padr */
+	int32_t src_len, dst_len;
+	int32_t n_filters;
+	const int32_t* filter_frac; /* [n_filters] phase index 0..1000 */
+	const float* filters;       /* [n_filters][kernel_len], un-replicated */
+	const avirhip_lancir_pos* pos; /* [dst_len] */
+} avirhip_lancir_axis;
+
+typedef struct avirhip_lancir_desc {
+	int32_t src_w, src_h, src_stride_elems;
+	int32_t new_w, new_h, new_stride_elems;
+	int32_t channels;
+	int32_t in_type, out_type;
+	avirhip_lancir_axis v; /* vertical pass runs first (lancir.h:601-646) */
+	avirhip_lancir_axis h;
+	float out_mul;         /* OutMul, lancir.h:532-533 */
+	float clamp;           /* Clamp, lancir.h:531 */
+	int32_t is_unity_mul;  /* IsUnityMul, lancir.h:528-529 */
+} avirhip_lancir_desc;
+
+/* ---------------------------------------------------------------------
+ * Device / plan / execute.
+ * ------------------------------------------------------------------- */
+
+typedef struct avirhip_plan avirhip_plan;
+
+/* Number of usable gfx950 devices (0 when there is none). */
+int avirhip_device_count(void);
+/* Binds the calling thread to `device` (hipSetDevice). */
+int avirhip_init(int device);
+/* Thread-local message for the most recent failing call. */
+const char* avirhip_last_error(void);
+/* Library version string. */
+const char* avirhip_version(void);
+
+/* Uploads an AVIR plan to the current device. The plan is immutable and may
+ * be shared by threads; executions on one plan must use distinct streams or
+ * be serialized by the caller (scratch is per plan). */
+int avirhip_plan_create(const avirhip_plan_desc* desc, avirhip_plan** out);
+int avirhip_lancir_plan_create(const avirhip_lancir_desc* desc,
+	avirhip_plan** out);
+void avirhip_plan_destroy(avirhip_plan* plan);
+
+/* Plan tuning: force an execution path, for testing and A/B benchmarking.
+ * 0 = automatic (fastest applicable), 1 = generic per-step scanline kernels,
+ * 2 = tiled two-pass kernels, 3 = fused single-pass kernel. Returns
+ * AVIRHIP_EUNSUPPORTED if the path cannot run this plan. */
+int avirhip_plan_set_path(avirhip_plan* plan, int path);
+/* The path the next execution will take (1..3). */
+int avirhip_plan_get_path(const avirhip_plan* plan);
+
+/* Executes H pass + V pass (+ integer epilogue) of `plan`:
+ * src -> dst. `src_mem`/`dst_mem` are AVIRHIP_MEM_HOST or _DEVICE; host
+ * buffers are staged through device memory inside the call. `stream` is a
+ * hipStream_t (NULL = default stream). With device buffers the call is
+ * asynchronous with respect to the host. */
+int avirhip_resize(avirhip_plan* plan, const void* src, int src_mem,
+	void* dst, int dst_mem, void* stream);
+
+/* Row-band execution: computes only output rows [row0, row1) of the plan's
+ * destination image into `dst_band` (tightly packed band of row1-row0 rows).
+ * The source is the WHOLE source image (device or host). Used for multi-GPU
+ * sharding: bands computed on different devices are bit-identical to the
+ * corresponding rows of a full avirhip_resize(). */
+int avirhip_resize_band(avirhip_plan* plan, const void* src, int src_mem,
+	void* dst_band, int dst_mem, int row0, int row1, void* stream);
+
+/* Timing aid for bench.py: runs `iters` executions on device buffers and
+ * returns the average duration in milliseconds measured with HIP events on
+ * `stream` (the stream the kernels are launched on). */
+int avirhip_time_resize(avirhip_plan* plan, const void* src, void* dst,
+	int iters, void* stream, double* avg_ms);
+
+/* ---------------------------------------------------------------------
+ * Front-end mirror: the reference's host-side planner re-implemented inside
+ * the library (double precision, -ffp-contract=off, same libm), so that a
+ * caller gets "resizeImage" semantics in one call. Names and argument
+ * meaning follow avir::CImageResizer (avir.h:4630-4684) and avir::CLancIR
+ * (lancir.h:386-390).
+ * ------------------------------------------------------------------- */
+
+/* CImageResizerParams (avir.h:2262-2317). */
+typedef struct avirhip_params {
+	double CorrFltAlpha, CorrFltLen, IntFltAlpha, IntFltCutoff, IntFltLen;
+	double LPFltAlpha, LPFltBaseLen, LPFltCutoffMult;
+	double HBFltAlpha, HBFltCutoff, HBFltLen;
+} avirhip_params;
+
+/* Presets, avir.h:2328-2464. */
+typedef enum avirhip_preset {
+	AVIRHIP_PARAMS_DEF = 0,
+	AVIRHIP_PARAMS_ULR = 1,
+	AVIRHIP_PARAMS_LR = 2,
+	AVIRHIP_PARAMS_LOW = 3,
+	AVIRHIP_PARAMS_HIGH = 4,
+	AVIRHIP_PARAMS_ULTRA = 5
+} avirhip_preset;
+
+void avirhip_params_preset(int preset, avirhip_params* out);
+
+/* The caller-settable part of CImageResizerVars (avir.h:2516-2547). */
+typedef struct avirhip_vars {
+	double ox, oy;
+	int32_t UseSRGBGamma; /* must be 0: gamma is outside the built scope */
+	int32_t AlphaIndex;
+	int32_t BuildMode;    /* -1 = automatic */
+	int32_t RndSeed;
+} avirhip_vars;
+
+void avirhip_vars_default(avirhip_vars* out);
+
+typedef struct avirhip_resizer avirhip_resizer;
+
+/* CImageResizer(aResBitDepth, aSrcBitDepth, aParams), avir.h:4630-4639.
+ * `params` may be NULL (CImageResizerParamsDef). */
+int avirhip_resizer_create(int res_bit_depth, int src_bit_depth,
+	const avirhip_params* params, avirhip_resizer** out);
+void avirhip_resizer_destroy(avirhip_resizer* r);
+
+/* Host-only: runs the planner exactly as resizeImage() would for this call
+ * and returns the plan description (owned by the library; release with
+ * avirhip_plan_desc_free). Needs no GPU. */
+int avirhip_resizer_build_desc(avirhip_resizer* r, int src_w, int src_h,
+	int src_scanline_size, int new_w, int new_h, int el_count_io, double k,
+	const avirhip_vars* vars, int in_type, int out_type,
+	avirhip_plan_desc** out);
+void avirhip_plan_desc_free(avirhip_plan_desc* desc);
+
+/* resizeImage<Tin,Tout>(), avir.h:4680-4684. Plans are cached per geometry
+ * inside the resizer. Zero-sized source => destination zero-filled
+ * (NewWidth*NewHeight elements, avir.h:4686-4692); zero-sized destination
+ * => no-op. */
+int avirhip_resizer_resize(avirhip_resizer* r, const void* src, int src_mem,
+	int src_w, int src_h, int src_scanline_size, void* dst, int dst_mem,
+	int new_w, int new_h, int el_count_io, double k,
+	const avirhip_vars* vars, int in_type, int out_type, void* stream);
+
+/* Returns (and caches) the device plan resizeImage() would use for this
+ * geometry; owned by the resizer. */
+int avirhip_resizer_get_plan(avirhip_resizer* r, int src_w, int src_h,
+	int src_scanline_size, int new_w, int new_h, int el_count_io, double k,
+	const avirhip_vars* vars, int in_type, int out_type,
+	avirhip_plan** out);
+
+/* CLancIRParams, lancir.h:260-307. */
+typedef struct avirhip_lancir_params {
+	int32_t SrcSSize, NewSSize;
+	double kx, ky, ox, oy, la;
+} avirhip_lancir_params;
+
+void avirhip_lancir_params_default(avirhip_lancir_params* out);
+
+typedef struct avirhip_lancir avirhip_lancir;
+
+int avirhip_lancir_create(avirhip_lancir** out);
+void avirhip_lancir_destroy(avirhip_lancir* l);
+
+int avirhip_lancir_build_desc(avirhip_lancir* l, int src_w, int src_h,
+	int new_w, int new_h, int el_count, const avirhip_lancir_params* params,
+	int in_type, int out_type, avirhip_lancir_desc** out);
+void avirhip_lancir_desc_free(avirhip_lancir_desc* desc);
+
+/* CLancIR::resizeImage<Tin,Tout>(), lancir.h:386-390. Returns NewHeight on
+ * success, 0 on a parameter error (lancir.h:392-407), <0 on a device error. */
+int avirhip_lancir_resize(avirhip_lancir* l, const void* src, int src_mem,
+	int src_w, int src_h, void* dst, int dst_mem, int new_w, int new_h,
+	int el_count, const avirhip_lancir_params* params, int in_type,
+	int out_type, void* stream);
+
+int avirhip_lancir_get_plan(avirhip_lancir* l, int src_w, int src_h,
+	int new_w, int new_h, int el_count, const avirhip_lancir_params* params,
+	int in_type, int out_type, avirhip_plan** out);
+
+#ifdef __cplusplus
+}
+#endif
+
+#endif /* AVIRHIP_H */
