@@ -149,6 +149,26 @@ PROTOTYPES = {
 _lib = None
 
 
+def _preload_hip_runtime():
+    """One HIP runtime per process. PyTorch-ROCm wheels bundle their own
+    libamdhip64 (SONAME libamdhip64.so.7, the same as /opt/rocm's) but link it
+    by file name, so loading /opt/rocm's copy first and torch's second puts two
+    runtimes in the process and the second finds no GPU. When torch is
+    installed, its copy is loaded first (without importing torch); our
+    library's NEEDED libamdhip64.so.7 then binds to it."""
+    import importlib.util
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.submodule_search_locations:
+        return
+    cand = os.path.join(list(spec.submodule_search_locations)[0], "lib",
+                        "libamdhip64.so")
+    if os.path.exists(cand):
+        C.CDLL(cand, mode=C.RTLD_GLOBAL)
+
+
 def load():
     """Loads libavirhip.so (in-tree) and declares every prototype.
 
@@ -163,6 +183,7 @@ def load():
         raise RuntimeError(
             "libavirhip.so not built (%s missing); run __graft_entry__.build()"
             % LIB_PATH)
+    _preload_hip_runtime()
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in PROTOTYPES.items():
         fn = getattr(lib, name)  # AttributeError if a symbol is not exported

@@ -1,0 +1,972 @@
+// api.cpp -- the C ABI of libavirhip (include/avirhip.h): plan validation and
+// lowering, device upload, scratch management and pass orchestration. The
+// arithmetic lives in generic.hip / fused.hip; the host-side planner mirror
+// (avirhip_resizer_*, avirhip_lancir_*) lives in planner.cpp.
+
+#include "plan.h"
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+#include <algorithm>
+
+namespace avirhip {
+
+static thread_local char g_err[ 512 ] = "";
+
+void set_error( const char* fmt, ... )
+{
+	va_list ap;
+	va_start( ap, fmt );
+	vsnprintf( g_err, sizeof( g_err ), fmt, ap );
+	va_end( ap );
+}
+
+size_t dtype_size( int t )
+{
+	return( t == AVIRHIP_U8 ? 1 : t == AVIRHIP_U16 ? 2 : t == AVIRHIP_F32 ? 4 :
+		8 );
+}
+
+template< typename T >
+static int upload( avirhip_plan* p, const std::vector< T >& h, T** d )
+{
+	*d = nullptr;
+
+	if( h.empty() )
+	{
+		return( AVIRHIP_OK );
+	}
+
+	void* q = nullptr;
+	AVIRHIP_HIPCHECK( hipMalloc( &q, h.size() * sizeof( T )));
+	p -> allocs.push_back( q );
+	AVIRHIP_HIPCHECK( hipMemcpy( q, h.data(), h.size() * sizeof( T ),
+		hipMemcpyHostToDevice ));
+
+	*d = (T*) q;
+	return( AVIRHIP_OK );
+}
+
+static int dev_alloc( avirhip_plan* p, size_t bytes, void** out )
+{
+	void* q = nullptr;
+	AVIRHIP_HIPCHECK( hipMalloc( &q, bytes ));
+	p -> allocs.push_back( q );
+	*out = q;
+	return( AVIRHIP_OK );
+}
+
+// ---- lowering of one AVIR axis (see plan.h for the view semantics) ----
+
+static int lower_axis( const avirhip_axis& ax, int src_len, int dst_len,
+	LAxis& L )
+{
+	L.ops.clear();
+	L.src_len = src_len;
+	L.dst_len = dst_len;
+
+	if( ax.n_steps < 1 || ax.steps == nullptr )
+	{
+		set_error( "axis has no steps" );
+		return( AVIRHIP_EINVAL );
+	}
+
+	int cur_len = src_len;
+	bool zs = false;      // a zero-stuff view is pending for the next step
+	int zs_in_len = 0, zs_mmax = 0, zs_prefix = 0;
+	bool prev_upf = false;
+	int prev_prefix = 0, prev_total = 0;
+
+	for( int si = 0; si < ax.n_steps; si++ )
+	{
+		const avirhip_step& s = ax.steps[ si ];
+
+		if( s.in_len != cur_len )
+		{
+			set_error( "step %d: in_len %d != previous out_len %d", si,
+				s.in_len, cur_len );
+			return( AVIRHIP_EINVAL );
+		}
+
+		if( zs && s.kind != AVIRHIP_STEP_RESIZE2 )
+		{
+			set_error( "step %d: zero-stuff upsample must be followed by "
+				"RESIZE2", si );
+			return( AVIRHIP_EUNSUPPORTED );
+		}
+
+		LOp op;
+		op.type = 0; op.view = ( prev_upf ? VIEW_RAW : VIEW_CLAMP );
+		op.in_len = s.in_len; op.in_prefix = ( prev_upf ? prev_prefix : 0 );
+		op.zs_mmax = 0x7fffffff;
+		op.out_len = s.out_len; op.out_prefix = 0; op.out_total = s.out_len;
+		op.rf = 1; op.lat = 0; op.e = 0; op.d_flt = nullptr;
+		op.maxtaps = 0; op.d_start = nullptr; op.d_ntaps = nullptr;
+		op.d_coef = nullptr;
+		op.flen = 0; op.up_inprefix = 0; op.up_R = 0; op.sdc_len = 0;
+		op.pdc_len = 0; op.pdc_d0 = 0; op.d_sdc = nullptr; op.d_pdc = nullptr;
+
+		if( s.kind == AVIRHIP_STEP_FIR )
+		{
+			if( s.resample_factor < 1 || s.flt == nullptr ||
+				s.flt_latency < 0 || s.flt_len != 2 * s.flt_latency + 1 )
+			{
+				set_error( "step %d: malformed FIR (len %d, latency %d)", si,
+					s.flt_len, s.flt_latency );
+				return( AVIRHIP_EINVAL );
+			}
+
+			op.type = OP_FIR;
+			op.rf = s.resample_factor;
+			op.lat = s.flt_latency;
+			op.e = s.edge_pixel_count;
+			op.h_flt.assign( s.flt + s.flt_latency, s.flt + s.flt_len );
+
+			if( prev_upf )
+			{
+				// reads in[rf*(n-e) +- lat] of the raw upsample buffer
+				const int lo = -op.e * op.rf - op.lat + prev_prefix;
+				const int hi = op.rf * ( s.out_len - 1 - op.e ) + op.lat +
+					prev_prefix;
+
+				if( lo < 0 || hi >= prev_total )
+				{
+					set_error( "step %d: FIR reads outside upsample buffer",
+						si );
+					return( AVIRHIP_EINVAL );
+				}
+			}
+
+			L.ops.push_back( op );
+			prev_upf = false;
+		}
+		else
+		if( s.kind == AVIRHIP_STEP_UP_ZEROSTUFF )
+		{
+			if( s.resample_factor != 2 || prev_upf )
+			{
+				set_error( "step %d: zero-stuff upsample supports factor 2 "
+					"only", si );
+				return( AVIRHIP_EUNSUPPORTED );
+			}
+
+			zs = true;
+			zs_in_len = s.in_len;
+			zs_mmax = s.in_len - 1 + s.out_suffix / 2;
+			zs_prefix = s.out_prefix;
+		}
+		else
+		if( s.kind == AVIRHIP_STEP_UP_FILTERED )
+		{
+			if( s.resample_factor < 2 || s.flt == nullptr || s.flt_len < 1 ||
+				prev_upf )
+			{
+				set_error( "step %d: malformed filtered upsample", si );
+				return( AVIRHIP_EINVAL );
+			}
+
+			op.type = OP_UPF;
+			op.view = VIEW_CLAMP;
+			op.rf = s.resample_factor;
+			op.flen = s.flt_len;
+			op.h_flt.assign( s.flt, s.flt + s.flt_len );
+			op.up_inprefix = s.in_prefix;
+			op.up_R = s.in_prefix + s.in_len + s.in_suffix;
+			op.sdc_len = s.suffix_dc_len;
+			op.pdc_len = s.prefix_dc_len;
+			op.pdc_d0 = s.out_prefix - s.in_prefix * s.resample_factor;
+			op.out_prefix = s.out_prefix;
+			op.out_total = s.out_prefix + s.out_len + s.out_suffix;
+
+			if( op.pdc_d0 < 0 ||
+				op.pdc_d0 + op.pdc_len > op.out_total ||
+				op.up_R * op.rf + op.sdc_len > op.out_total ||
+				( op.up_R - 1 ) * op.rf + op.flen > op.out_total )
+			{
+				set_error( "step %d: upsample tails exceed buffer", si );
+				return( AVIRHIP_EINVAL );
+			}
+
+			// stash DC tails behind the filter taps: [flt | sdc | pdc]
+			if( s.suffix_dc_len > 0 )
+				op.h_flt.insert( op.h_flt.end(), s.suffix_dc,
+					s.suffix_dc + s.suffix_dc_len );
+			if( s.prefix_dc_len > 0 )
+				op.h_flt.insert( op.h_flt.end(), s.prefix_dc,
+					s.prefix_dc + s.prefix_dc_len );
+
+			L.ops.push_back( op );
+			prev_upf = true;
+			prev_prefix = op.out_prefix;
+			prev_total = op.out_total;
+		}
+		else
+		if( s.kind == AVIRHIP_STEP_RESIZE || s.kind == AVIRHIP_STEP_RESIZE2 )
+		{
+			const bool r2 = ( s.kind == AVIRHIP_STEP_RESIZE2 );
+
+			if( r2 != zs )
+			{
+				set_error( "step %d: RESIZE2 needs a preceding zero-stuff "
+					"upsample (and RESIZE must not have one)", si );
+				return( AVIRHIP_EUNSUPPORTED );
+			}
+
+			if( s.rpos == nullptr || s.phase_taps == nullptr ||
+				s.bank_filter_len < 2 || s.n_phases < 1 ||
+				( s.bank_order != 0 && s.bank_order != 1 ))
+			{
+				set_error( "step %d: malformed resize step", si );
+				return( AVIRHIP_EINVAL );
+			}
+
+			const int fl = s.bank_filter_len;
+			const int fsz = fl * ( s.bank_order + 1 );
+			op.type = OP_GATHER;
+			op.maxtaps = ( r2 ? ( fl + 1 ) / 2 : fl );
+			op.h_start.resize( s.out_len );
+			op.h_ntaps.resize( s.out_len );
+			op.h_coef.assign( (size_t) s.out_len * op.maxtaps, 0.0f );
+
+			if( r2 )
+			{
+				op.view = VIEW_ZS;
+				op.in_len = zs_in_len;
+				op.zs_mmax = zs_mmax;
+			}
+
+			for( int j = 0; j < s.out_len; j++ )
+			{
+				const avirhip_rpos& rp = s.rpos[ j ];
+
+				if( rp.phase < 0 || rp.phase >= s.n_phases || rp.ftp_off < 0 ||
+					rp.fl < 1 || rp.ftp_off + rp.fl > fl )
+				{
+					set_error( "step %d: bad rpos[%d]", si, j );
+					return( AVIRHIP_EINVAL );
+				}
+
+				const float* ftp = s.phase_taps + (size_t) rp.phase * fsz +
+					rp.ftp_off;
+				const float* ftp2 = ftp + fl;
+				float* cf = &op.h_coef[ (size_t) j * op.maxtaps ];
+				const int stp = ( r2 ? 2 : 1 );
+				int nt = 0;
+
+				for( int i = 0; i < rp.fl; i += stp )
+				{
+					// xx = ftp[i] + ftp2[i]*x in float (avir.h:3945, 4177);
+					// this TU is compiled -ffp-contract=off.
+					if( s.bank_order == 1 )
+					{
+						const float t = ftp2[ i ] * rp.x;
+						cf[ nt ] = ftp[ i ] + t;
+					}
+					else
+					{
+						cf[ nt ] = ftp[ i ];
+					}
+
+					nt++;
+				}
+
+				op.h_ntaps[ j ] = nt;
+				int lo, hi;
+
+				if( r2 )
+				{
+					if( rp.src_offs_px & 1 )
+					{
+						set_error( "step %d: odd RESIZE2 offset at %d", si,
+							j );
+						return( AVIRHIP_EINVAL );
+					}
+
+					op.h_start[ j ] = rp.src_offs_px / 2;
+					lo = op.h_start[ j ];
+					hi = lo + nt - 1;
+
+					if( 2 * lo < -zs_prefix )
+					{
+						set_error( "step %d: RESIZE2 reads before the "
+							"upsample buffer at %d", si, j );
+						return( AVIRHIP_EINVAL );
+					}
+				}
+				else
+				{
+					op.h_start[ j ] = rp.src_offs_px;
+					lo = rp.src_offs_px;
+					hi = lo + nt - 1;
+
+					if( prev_upf &&
+						( lo + prev_prefix < 0 || hi + prev_prefix >= prev_total ))
+					{
+						set_error( "step %d: RESIZE reads outside the "
+							"upsample buffer at %d", si, j );
+						return( AVIRHIP_EINVAL );
+					}
+				}
+			}
+
+			L.ops.push_back( op );
+			prev_upf = false;
+			zs = false;
+		}
+		else
+		{
+			set_error( "step %d: unknown kind %d", si, s.kind );
+			return( AVIRHIP_EINVAL );
+		}
+
+		cur_len = s.out_len;
+	}
+
+	if( zs || prev_upf || L.ops.empty() || cur_len != dst_len )
+	{
+		set_error( "axis does not end in a filtering/resizing step of length "
+			"%d (got %d)", dst_len, cur_len );
+		return( AVIRHIP_EINVAL );
+	}
+
+	return( AVIRHIP_OK );
+}
+
+static int upload_axis( avirhip_plan* p, LAxis& L )
+{
+	for( size_t i = 0; i < L.ops.size(); i++ )
+	{
+		LOp& op = L.ops[ i ];
+		int rc;
+
+		if(( rc = upload( p, op.h_flt, &op.d_flt )) != 0 ) return( rc );
+		if(( rc = upload( p, op.h_start, &op.d_start )) != 0 ) return( rc );
+		if(( rc = upload( p, op.h_ntaps, &op.d_ntaps )) != 0 ) return( rc );
+		if(( rc = upload( p, op.h_coef, &op.d_coef )) != 0 ) return( rc );
+
+		if( op.type == OP_UPF )
+		{
+			op.d_sdc = op.d_flt + op.flen;
+			op.d_pdc = op.d_sdc + op.sdc_len;
+		}
+	}
+
+	return( AVIRHIP_OK );
+}
+
+// Needed logical input range of `op` for logical outputs [a, b].
+static void need_range( const LOp& op, int a, int b, int& ia, int& ib )
+{
+	if( op.type == OP_FIR )
+	{
+		ia = op.rf * ( a - op.e ) - op.lat;
+		ib = op.rf * ( b - op.e ) + op.lat;
+	}
+	else
+	if( op.type == OP_GATHER )
+	{
+		ia = 0x7fffffff;
+		ib = -0x7fffffff;
+
+		for( int j = a; j <= b; j++ )
+		{
+			ia = std::min( ia, op.h_start[ j ]);
+			ib = std::max( ib, op.h_start[ j ] + op.h_ntaps[ j ] - 1 );
+		}
+	}
+	else
+	{
+		ia = 0;
+		ib = op.in_len - 1;
+		return;
+	}
+
+	if( op.view == VIEW_RAW )
+	{
+		return; // logical indices of the upsample buffer (may be negative)
+	}
+
+	ia = std::max( 0, std::min( ia, op.in_len - 1 ));
+	ib = std::max( 0, std::min( ib, op.in_len - 1 ));
+}
+
+static int ensure_scratch( avirhip_plan* p )
+{
+	if( p -> is_lancir )
+	{
+		if( p -> resbuf == nullptr )
+		{
+			void* q;
+			int rc = dev_alloc( p, (size_t) p -> new_h * p -> src_w *
+				p -> ch * sizeof( float ), &q );
+			if( rc != 0 ) return( rc );
+			p -> resbuf = (float*) q;
+		}
+
+		return( AVIRHIP_OK );
+	}
+
+	int rc;
+	void* q;
+
+	if( p -> in_type != AVIRHIP_F32 && p -> packed == nullptr )
+	{
+		if(( rc = dev_alloc( p, (size_t) p -> src_w * p -> src_h * p -> ch *
+			sizeof( float ), &q )) != 0 ) return( rc );
+		p -> packed = (float*) q;
+	}
+
+	if( p -> out_type != AVIRHIP_F32 && p -> resbuf == nullptr )
+	{
+		if(( rc = dev_alloc( p, (size_t) p -> new_w * p -> new_h * p -> ch *
+			sizeof( float ), &q )) != 0 ) return( rc );
+		p -> resbuf = (float*) q;
+	}
+
+	return( AVIRHIP_OK );
+}
+
+static int ensure_generic_scratch( avirhip_plan* p )
+{
+	int rc;
+	void* q;
+
+	if( p -> hbuf.empty() )
+	{
+		for( size_t i = 0; i < p -> h.ops.size(); i++ )
+		{
+			if(( rc = dev_alloc( p, (size_t) p -> h.ops[ i ].out_total *
+				p -> src_h * p -> ch * sizeof( float ), &q )) != 0 )
+				return( rc );
+			p -> hbuf.push_back( (float*) q );
+		}
+
+		for( size_t i = 0; i + 1 < p -> v.ops.size(); i++ )
+		{
+			if(( rc = dev_alloc( p, (size_t) p -> v.ops[ i ].out_total *
+				p -> new_w * p -> ch * sizeof( float ), &q )) != 0 )
+				return( rc );
+			p -> vbuf.push_back( (float*) q );
+		}
+	}
+
+	return( AVIRHIP_OK );
+}
+
+// Runs the generic chain for output rows [row0, row1) into `dst` (a float
+// surface whose row `row0` is at dst).
+static int run_generic( avirhip_plan* p, const float* src, long src_stride,
+	float* dst, int row0, int row1, hipStream_t st )
+{
+	int rc = ensure_generic_scratch( p );
+	if( rc != 0 ) return( rc );
+
+	const int ch = p -> ch;
+	const int nv = (int) p -> v.ops.size();
+	const int nh = (int) p -> h.ops.size();
+
+	// Backward range propagation through the vertical chain.
+	std::vector< int > va( nv ), vb( nv );
+	int a = row0, b = row1 - 1;
+
+	for( int i = nv - 1; i >= 0; i-- )
+	{
+		const LOp& op = p -> v.ops[ i ];
+		va[ i ] = a;
+		vb[ i ] = b;
+
+		if( op.type == OP_UPF )
+		{
+			va[ i ] = -op.out_prefix;
+			vb[ i ] = op.out_total - op.out_prefix - 1;
+		}
+
+		int ia, ib;
+		need_range( op, va[ i ], vb[ i ], ia, ib );
+		a = ia;
+		b = ib;
+	}
+
+	const int ya = a, yb = b; // FltBuf rows needed
+
+	// Horizontal pass over source rows [ya, yb].
+	Surf in;
+	in.base = (float*) src; in.scan_stride = src_stride; in.idx_stride = ch;
+	in.prefix = 0;
+
+	for( int i = 0; i < nh; i++ )
+	{
+		const LOp& op = p -> h.ops[ i ];
+		Surf out;
+		out.base = p -> hbuf[ i ];
+		out.scan_stride = (long) op.out_total * ch;
+		out.idx_stride = ch;
+		out.prefix = op.out_prefix;
+
+		if(( rc = launch_op( op, ch, true, in, out, ya, yb + 1, 0,
+			op.out_len, st )) != 0 ) return( rc );
+
+		in = out;
+	}
+
+	// Vertical pass: scanlines are the NewWidth columns of FltBuf.
+	in.base = p -> hbuf[ nh - 1 ];
+	in.scan_stride = ch;
+	in.idx_stride = (long) p -> new_w * ch;
+	in.prefix = 0;
+
+	for( int i = 0; i < nv; i++ )
+	{
+		const LOp& op = p -> v.ops[ i ];
+		Surf out;
+		out.scan_stride = ch;
+		out.idx_stride = (long) p -> new_w * ch;
+		out.prefix = op.out_prefix;
+
+		if( i == nv - 1 )
+		{
+			out.base = dst - (long) row0 * out.idx_stride;
+		}
+		else
+		{
+			out.base = p -> vbuf[ i ];
+		}
+
+		if(( rc = launch_op( op, ch, false, in, out, 0, p -> new_w, va[ i ],
+			vb[ i ] + 1, st )) != 0 ) return( rc );
+
+		in = out;
+	}
+
+	return( AVIRHIP_OK );
+}
+
+static int exec_device( avirhip_plan* p, const void* src, void* dst,
+	int row0, int row1, hipStream_t st )
+{
+	int rc = ensure_scratch( p );
+	if( rc != 0 ) return( rc );
+
+	if( p -> is_lancir )
+	{
+		return( launch_lancir_generic( p, src, dst, p -> resbuf, row0, row1,
+			st ));
+	}
+
+	const float* fsrc = (const float*) src;
+	long sstride = p -> src_stride;
+
+	if( p -> in_type != AVIRHIP_F32 )
+	{
+		if(( rc = launch_pack( src, p -> in_type, p -> packed, p -> src_w,
+			p -> src_h, p -> ch, p -> src_stride, st )) != 0 ) return( rc );
+
+		fsrc = p -> packed;
+		sstride = (long) p -> src_w * p -> ch;
+	}
+
+	float* fdst = ( p -> out_type == AVIRHIP_F32 ? (float*) dst :
+		p -> resbuf );
+
+	int path = p -> path;
+
+	if( path == 0 )
+	{
+		path = ( p -> fused_ok ? 3 : 1 );
+	}
+
+	if( path == 3 )
+	{
+		rc = fused_run( p, fsrc, fdst, row0, row1, st );
+	}
+	else
+	{
+		rc = run_generic( p, fsrc, sstride, fdst, row0, row1, st );
+	}
+
+	if( rc != 0 ) return( rc );
+
+	if( p -> out_type != AVIRHIP_F32 )
+	{
+		rc = launch_epilogue( fdst, dst, p -> out_type,
+			(long) ( row1 - row0 ) * p -> new_w * p -> ch, p -> tr_mul,
+			p -> pk_out, st );
+	}
+
+	return( rc );
+}
+
+static int exec_any( avirhip_plan* p, const void* src, int src_mem, void* dst,
+	int dst_mem, int row0, int row1, void* stream )
+{
+	if( p == nullptr || src == nullptr || dst == nullptr || row0 < 0 ||
+		row1 > p -> new_h || row0 > row1 )
+	{
+		set_error( "bad execute arguments" );
+		return( AVIRHIP_EINVAL );
+	}
+
+	hipStream_t st = (hipStream_t) stream;
+	const void* dsrc = src;
+	void* ddst = dst;
+	const size_t src_bytes = ( (size_t) ( p -> src_h - 1 ) * p -> src_stride +
+		(size_t) p -> src_w * p -> ch ) * dtype_size( p -> in_type );
+	const size_t row_bytes = (size_t) p -> new_stride *
+		dtype_size( p -> out_type );
+	const size_t dst_bytes = ( row1 > row0 ?
+		(size_t) ( row1 - row0 - 1 ) * row_bytes + (size_t) p -> new_w *
+		p -> ch * dtype_size( p -> out_type ) : 0 );
+
+	if( src_mem == AVIRHIP_MEM_HOST )
+	{
+		if( p -> stage_src_bytes < src_bytes )
+		{
+			void* q;
+			int rc = dev_alloc( p, src_bytes, &q );
+			if( rc != 0 ) return( rc );
+			p -> stage_src = q;
+			p -> stage_src_bytes = src_bytes;
+		}
+
+		AVIRHIP_HIPCHECK( hipMemcpyAsync( p -> stage_src, src, src_bytes,
+			hipMemcpyHostToDevice, st ));
+		dsrc = p -> stage_src;
+	}
+
+	if( dst_mem == AVIRHIP_MEM_HOST )
+	{
+		if( p -> stage_dst_bytes < dst_bytes )
+		{
+			void* q;
+			int rc = dev_alloc( p, dst_bytes, &q );
+			if( rc != 0 ) return( rc );
+			p -> stage_dst = q;
+			p -> stage_dst_bytes = dst_bytes;
+		}
+
+		ddst = p -> stage_dst;
+	}
+
+	int rc = exec_device( p, dsrc, ddst, row0, row1, st );
+	if( rc != 0 ) return( rc );
+
+	if( dst_mem == AVIRHIP_MEM_HOST )
+	{
+		AVIRHIP_HIPCHECK( hipMemcpyAsync( dst, ddst, dst_bytes,
+			hipMemcpyDeviceToHost, st ));
+		AVIRHIP_HIPCHECK( hipStreamSynchronize( st ));
+	}
+	else
+	if( src_mem == AVIRHIP_MEM_HOST )
+	{
+		AVIRHIP_HIPCHECK( hipStreamSynchronize( st ));
+	}
+
+	return( AVIRHIP_OK );
+}
+
+static avirhip_plan* new_plan()
+{
+	avirhip_plan* p = new avirhip_plan();
+	p -> is_lancir = 0; p -> device = 0;
+	p -> path = 0; p -> fused_ok = 0; p -> fused = nullptr;
+	p -> packed = nullptr; p -> resbuf = nullptr;
+	p -> stage_src = nullptr; p -> stage_dst = nullptr;
+	p -> stage_src_bytes = 0; p -> stage_dst_bytes = 0;
+	p -> tr_mul = 1.0; p -> pk_out = 0.0;
+	p -> l_out_mul = 1.0f; p -> l_clamp = 0.0f; p -> l_unity = 1;
+	(void) hipGetDevice( &p -> device );
+	return( p );
+}
+
+} // namespace avirhip
+
+using namespace avirhip;
+
+extern "C" {
+
+int avirhip_device_count( void )
+{
+	int n = 0;
+
+	if( hipGetDeviceCount( &n ) != hipSuccess )
+	{
+		return( 0 );
+	}
+
+	int good = 0;
+
+	for( int i = 0; i < n; i++ )
+	{
+		hipDeviceProp_t pr;
+
+		if( hipGetDeviceProperties( &pr, i ) == hipSuccess &&
+			strncmp( pr.gcnArchName, "gfx950", 6 ) == 0 )
+		{
+			good++;
+		}
+	}
+
+	return( good );
+}
+
+int avirhip_init( int device )
+{
+	if( avirhip_device_count() < 1 )
+	{
+		set_error( "no gfx950 device visible" );
+		return( AVIRHIP_ENODEV );
+	}
+
+	AVIRHIP_HIPCHECK( hipSetDevice( device ));
+	return( AVIRHIP_OK );
+}
+
+const char* avirhip_last_error( void )
+{
+	return( g_err );
+}
+
+const char* avirhip_version( void )
+{
+	return( "avirhip 0.1 (gfx950; avir v3.1 hot path)" );
+}
+
+int avirhip_plan_create( const avirhip_plan_desc* d, avirhip_plan** out )
+{
+	if( d == nullptr || out == nullptr )
+	{
+		set_error( "null argument" );
+		return( AVIRHIP_EINVAL );
+	}
+
+	*out = nullptr;
+
+	if( d -> src_w < 1 || d -> src_h < 1 || d -> new_w < 1 || d -> new_h < 1 ||
+		d -> channels < 1 || d -> channels > 4 || d -> in_type < 0 ||
+		d -> in_type > 3 || d -> out_type < 0 || d -> out_type > 3 )
+	{
+		set_error( "bad image geometry / types" );
+		return( AVIRHIP_EINVAL );
+	}
+
+	avirhip_plan* p = new_plan();
+	p -> src_w = d -> src_w; p -> src_h = d -> src_h;
+	p -> src_stride = ( d -> src_stride_elems < 1 ?
+		d -> src_w * d -> channels : d -> src_stride_elems );
+	p -> new_w = d -> new_w; p -> new_h = d -> new_h;
+	p -> new_stride = d -> new_w * d -> channels;
+	p -> ch = d -> channels;
+	p -> in_type = d -> in_type; p -> out_type = d -> out_type;
+	p -> tr_mul = d -> tr_mul; p -> pk_out = d -> pk_out;
+
+	int rc = lower_axis( d -> h, d -> src_w, d -> new_w, p -> h );
+
+	if( rc == 0 ) rc = lower_axis( d -> v, d -> src_h, d -> new_h, p -> v );
+	if( rc == 0 ) rc = upload_axis( p, p -> h );
+	if( rc == 0 ) rc = upload_axis( p, p -> v );
+	if( rc == 0 ) rc = fused_prepare( p );
+
+	if( rc != 0 )
+	{
+		avirhip_plan_destroy( p );
+		return( rc );
+	}
+
+	*out = p;
+	return( AVIRHIP_OK );
+}
+
+static int lower_lancir_axis( avirhip_plan* p, const avirhip_lancir_axis& a,
+	LancirAxisDev& L )
+{
+	if( a.kernel_len < 2 || ( a.kernel_len & 1 ) || a.n_filters < 1 ||
+		a.filters == nullptr || a.pos == nullptr || a.dst_len < 1 ||
+		a.src_len < 1 )
+	{
+		set_error( "malformed LANCIR axis" );
+		return( AVIRHIP_EINVAL );
+	}
+
+	L.kernel_len = a.kernel_len; L.src_len = a.src_len;
+	L.dst_len = a.dst_len; L.n_filters = a.n_filters;
+	L.h_flt.assign( a.filters, a.filters + (size_t) a.n_filters *
+		a.kernel_len );
+	L.h_start.resize( a.dst_len );
+	L.h_fidx.resize( a.dst_len );
+
+	for( int j = 0; j < a.dst_len; j++ )
+	{
+		if( a.pos[ j ].flt_index < 0 || a.pos[ j ].flt_index >= a.n_filters )
+		{
+			set_error( "bad LANCIR pos[%d]", j );
+			return( AVIRHIP_EINVAL );
+		}
+
+		// `so` is relative to the padded scanline; edge replication of the
+		// padding (lancir.h:1541-1594, 1698-1734) becomes an index clamp.
+		L.h_start[ j ] = a.pos[ j ].so - a.padl;
+		L.h_fidx[ j ] = a.pos[ j ].flt_index;
+	}
+
+	int rc;
+	if(( rc = upload( p, L.h_flt, &L.d_flt )) != 0 ) return( rc );
+	if(( rc = upload( p, L.h_start, &L.d_start )) != 0 ) return( rc );
+	if(( rc = upload( p, L.h_fidx, &L.d_fidx )) != 0 ) return( rc );
+	return( AVIRHIP_OK );
+}
+
+int avirhip_lancir_plan_create( const avirhip_lancir_desc* d,
+	avirhip_plan** out )
+{
+	if( d == nullptr || out == nullptr )
+	{
+		set_error( "null argument" );
+		return( AVIRHIP_EINVAL );
+	}
+
+	*out = nullptr;
+
+	if( d -> src_w < 1 || d -> src_h < 1 || d -> new_w < 1 || d -> new_h < 1 ||
+		d -> channels < 1 || d -> channels > 4 )
+	{
+		set_error( "bad image geometry" );
+		return( AVIRHIP_EINVAL );
+	}
+
+	if( d -> channels != 4 || d -> out_type != AVIRHIP_F32 ||
+		d -> in_type == AVIRHIP_F64 )
+	{
+		set_error( "LANCIR device path: 4-channel, float output only (1-3 "
+			"channels and integer output are not built yet)" );
+		return( AVIRHIP_EUNSUPPORTED );
+	}
+
+	avirhip_plan* p = new_plan();
+	p -> is_lancir = 1;
+	p -> src_w = d -> src_w; p -> src_h = d -> src_h;
+	p -> src_stride = ( d -> src_stride_elems < 1 ?
+		d -> src_w * d -> channels : d -> src_stride_elems );
+	p -> new_w = d -> new_w; p -> new_h = d -> new_h;
+	p -> new_stride = ( d -> new_stride_elems < 1 ?
+		d -> new_w * d -> channels : d -> new_stride_elems );
+	p -> ch = d -> channels;
+	p -> in_type = d -> in_type; p -> out_type = d -> out_type;
+	p -> l_out_mul = d -> out_mul; p -> l_clamp = d -> clamp;
+	p -> l_unity = d -> is_unity_mul;
+
+	int rc = lower_lancir_axis( p, d -> v, p -> lv );
+	if( rc == 0 ) rc = lower_lancir_axis( p, d -> h, p -> lh );
+	if( rc == 0 ) rc = fused_prepare( p );
+
+	if( rc != 0 )
+	{
+		avirhip_plan_destroy( p );
+		return( rc );
+	}
+
+	*out = p;
+	return( AVIRHIP_OK );
+}
+
+void avirhip_plan_destroy( avirhip_plan* p )
+{
+	if( p == nullptr )
+	{
+		return;
+	}
+
+	fused_release( p );
+
+	for( size_t i = 0; i < p -> allocs.size(); i++ )
+	{
+		(void) hipFree( p -> allocs[ i ]);
+	}
+
+	delete p;
+}
+
+int avirhip_plan_set_path( avirhip_plan* p, int path )
+{
+	if( p == nullptr || path < 0 || path > 3 )
+	{
+		set_error( "bad path" );
+		return( AVIRHIP_EINVAL );
+	}
+
+	if( path == 2 || ( path == 3 && !p -> fused_ok ))
+	{
+		set_error( "path %d cannot run this plan", path );
+		return( AVIRHIP_EUNSUPPORTED );
+	}
+
+	p -> path = path;
+	return( AVIRHIP_OK );
+}
+
+int avirhip_plan_get_path( const avirhip_plan* p )
+{
+	if( p == nullptr )
+	{
+		return( AVIRHIP_EINVAL );
+	}
+
+	return( p -> path != 0 ? p -> path : ( p -> fused_ok ? 3 : 1 ));
+}
+
+int avirhip_resize( avirhip_plan* p, const void* src, int src_mem, void* dst,
+	int dst_mem, void* stream )
+{
+	if( p == nullptr )
+	{
+		set_error( "null plan" );
+		return( AVIRHIP_EINVAL );
+	}
+
+	return( exec_any( p, src, src_mem, dst, dst_mem, 0, p -> new_h, stream ));
+}
+
+int avirhip_resize_band( avirhip_plan* p, const void* src, int src_mem,
+	void* dst_band, int dst_mem, int row0, int row1, void* stream )
+{
+	return( exec_any( p, src, src_mem, dst_band, dst_mem, row0, row1,
+		stream ));
+}
+
+int avirhip_time_resize( avirhip_plan* p, const void* src, void* dst,
+	int iters, void* stream, double* avg_ms )
+{
+	if( p == nullptr || iters < 1 || avg_ms == nullptr )
+	{
+		set_error( "bad arguments" );
+		return( AVIRHIP_EINVAL );
+	}
+
+	hipStream_t st = (hipStream_t) stream;
+	hipEvent_t e0, e1;
+	AVIRHIP_HIPCHECK( hipEventCreate( &e0 ));
+	AVIRHIP_HIPCHECK( hipEventCreate( &e1 ));
+	AVIRHIP_HIPCHECK( hipEventRecord( e0, st ));
+
+	for( int i = 0; i < iters; i++ )
+	{
+		int rc = exec_any( p, src, AVIRHIP_MEM_DEVICE, dst,
+			AVIRHIP_MEM_DEVICE, 0, p -> new_h, stream );
+
+		if( rc != 0 )
+		{
+			return( rc );
+		}
+	}
+
+	AVIRHIP_HIPCHECK( hipEventRecord( e1, st ));
+	AVIRHIP_HIPCHECK( hipEventSynchronize( e1 ));
+	float ms = 0.0f;
+	AVIRHIP_HIPCHECK( hipEventElapsedTime( &ms, e0, e1 ));
+	(void) hipEventDestroy( e0 );
+	(void) hipEventDestroy( e1 );
+	*avg_ms = (double) ms / iters;
+	return( AVIRHIP_OK );
+}
+
+} // extern "C"

@@ -1,0 +1,452 @@
+// frontend.cpp -- C ABI of the front-end mirror (include/avirhip.h, second
+// half): avirhip_resizer_* mirrors avir::CImageResizer<> (avir.h:4609-5092),
+// avirhip_lancir_* mirrors avir::CLancIR (lancir.h:327-755). Each call runs the
+// host planner (planner.cpp), caches the uploaded plan per geometry and
+// executes it on the device. There is no CPU execution path.
+
+#include "plan.h"
+#include "planner.h"
+#include <string.h>
+#include <map>
+#include <mutex>
+#include <tuple>
+
+using namespace avirhip;
+
+struct avirhip_resizer
+{
+	AvirPlanner* planner;
+	std::mutex mtx;
+	typedef std::tuple< int, int, int, int, int, int, double, double, double,
+		int, int, int > Key;
+	std::map< Key, avirhip_plan* > cache;
+};
+
+struct avirhip_lancir
+{
+	std::mutex mtx;
+	typedef std::tuple< int, int, int, int, int, int, int, double, double,
+		double, double, double, int, int > Key;
+	std::map< Key, avirhip_plan* > cache;
+};
+
+static const avirhip_vars g_defvars = { 0.0, 0.0, 0, -1, -1, 0 };
+
+extern "C" {
+
+void avirhip_params_preset( int preset, avirhip_params* p )
+{
+	if( p == nullptr )
+	{
+		return;
+	}
+
+	// Literals of CImageResizerParams* (avir.h:2300-2464).
+	static const double t[ 6 ][ 8 ] = {
+		{ 0.97946, 6.4262, 6.41341, 0.7372, 18, 4.76449, 7.55999999999998,
+			0.79285 },
+		{ 0.95521, 5.70774, 1.00766, 0.74202, 18, 1.6801, 6.62, 0.67821 },
+		{ 1, 5.865, 1.79529, 0.74325, 18, 1.87597, 6.89999999999999,
+			0.69326 },
+		{ 0.99739, 6.20326, 4.6836, 0.73879, 18, 7.86565, 6.91999999999999,
+			0.78379 },
+		{ 0.97433, 6.87893, 7.74731, 0.73844, 18, 4.8149, 8.07999999999996,
+			0.79335 },
+		{ 0.99705, 7.42695, 1.71985, 0.7571, 18, 6.71313, 8.27999999999996,
+			0.78413 } };
+
+	if( preset < 0 || preset > 5 )
+	{
+		preset = 0;
+	}
+
+	p -> CorrFltAlpha = t[ preset ][ 0 ];
+	p -> CorrFltLen = t[ preset ][ 1 ];
+	p -> IntFltAlpha = t[ preset ][ 2 ];
+	p -> IntFltCutoff = t[ preset ][ 3 ];
+	p -> IntFltLen = t[ preset ][ 4 ];
+	p -> LPFltAlpha = t[ preset ][ 5 ];
+	p -> LPFltBaseLen = t[ preset ][ 6 ];
+	p -> LPFltCutoffMult = t[ preset ][ 7 ];
+	p -> HBFltAlpha = 1.94609;
+	p -> HBFltCutoff = 0.46437;
+	p -> HBFltLen = 24;
+}
+
+void avirhip_vars_default( avirhip_vars* v )
+{
+	if( v != nullptr )
+	{
+		*v = g_defvars;
+	}
+}
+
+int avirhip_resizer_create( int res_bit_depth, int src_bit_depth,
+	const avirhip_params* params, avirhip_resizer** out )
+{
+	if( out == nullptr || res_bit_depth < 1 || res_bit_depth > 16 ||
+		src_bit_depth < 0 || src_bit_depth > 16 )
+	{
+		set_error( "resizer_create: bad arguments" );
+		return( AVIRHIP_EINVAL );
+	}
+
+	avirhip_params P;
+
+	if( params == nullptr )
+	{
+		avirhip_params_preset( AVIRHIP_PARAMS_DEF, &P );
+	}
+	else
+	{
+		P = *params;
+	}
+
+	avirhip_resizer* r = new avirhip_resizer();
+	r -> planner = new AvirPlanner( res_bit_depth, src_bit_depth, P );
+	*out = r;
+	return( AVIRHIP_OK );
+}
+
+void avirhip_resizer_destroy( avirhip_resizer* r )
+{
+	if( r == nullptr )
+	{
+		return;
+	}
+
+	for( auto& c : r -> cache )
+	{
+		avirhip_plan_destroy( c.second );
+	}
+
+	delete r -> planner;
+	delete r;
+}
+
+int avirhip_resizer_build_desc( avirhip_resizer* r, int src_w, int src_h,
+	int src_scanline_size, int new_w, int new_h, int el_count_io, double k,
+	const avirhip_vars* vars, int in_type, int out_type,
+	avirhip_plan_desc** out )
+{
+	if( r == nullptr || out == nullptr )
+	{
+		set_error( "build_desc: null argument" );
+		return( AVIRHIP_EINVAL );
+	}
+
+	const avirhip_vars& V = ( vars == nullptr ? g_defvars : *vars );
+	DescStore* S = r -> planner -> build( src_w, src_h, src_scanline_size,
+		new_w, new_h, el_count_io, k, V, in_type, out_type );
+
+	if( S == nullptr )
+	{
+		return( V.UseSRGBGamma ? AVIRHIP_EUNSUPPORTED : AVIRHIP_EINVAL );
+	}
+
+	*out = &S -> d;
+	return( AVIRHIP_OK );
+}
+
+void avirhip_plan_desc_free( avirhip_plan_desc* d )
+{
+	if( d != nullptr )
+	{
+		delete (DescStore*) ( (char*) d - offsetof( DescStore, d ));
+	}
+}
+
+int avirhip_resizer_get_plan( avirhip_resizer* r, int src_w, int src_h,
+	int src_scanline_size, int new_w, int new_h, int el_count_io, double k,
+	const avirhip_vars* vars, int in_type, int out_type, avirhip_plan** out )
+{
+	if( r == nullptr || out == nullptr )
+	{
+		set_error( "get_plan: null argument" );
+		return( AVIRHIP_EINVAL );
+	}
+
+	const avirhip_vars& V = ( vars == nullptr ? g_defvars : *vars );
+
+	if( src_scanline_size < 1 )
+	{
+		src_scanline_size = src_w * el_count_io;
+	}
+
+	const avirhip_resizer::Key key( src_w, src_h, src_scanline_size, new_w,
+		new_h, el_count_io, k, V.ox, V.oy, V.BuildMode, in_type, out_type );
+
+	std::lock_guard< std::mutex > lock( r -> mtx );
+	auto it = r -> cache.find( key );
+
+	if( it != r -> cache.end() )
+	{
+		*out = it -> second;
+		return( AVIRHIP_OK );
+	}
+
+	avirhip_plan_desc* d = nullptr;
+	int rc = avirhip_resizer_build_desc( r, src_w, src_h, src_scanline_size,
+		new_w, new_h, el_count_io, k, &V, in_type, out_type, &d );
+
+	if( rc != 0 )
+	{
+		return( rc );
+	}
+
+	avirhip_plan* p = nullptr;
+	rc = avirhip_plan_create( d, &p );
+	avirhip_plan_desc_free( d );
+
+	if( rc != 0 )
+	{
+		return( rc );
+	}
+
+	r -> cache[ key ] = p;
+	*out = p;
+	return( AVIRHIP_OK );
+}
+
+int avirhip_resizer_resize( avirhip_resizer* r, const void* src, int src_mem,
+	int src_w, int src_h, int src_scanline_size, void* dst, int dst_mem,
+	int new_w, int new_h, int el_count_io, double k, const avirhip_vars* vars,
+	int in_type, int out_type, void* stream )
+{
+	if( r == nullptr || out_type < 0 || out_type > 3 )
+	{
+		set_error( "resize: bad arguments" );
+		return( AVIRHIP_EINVAL );
+	}
+
+	// avir.h:4686-4697: zero-sized source zero-fills NewWidth*NewHeight
+	// ELEMENTS (sic, not x channels); zero-sized destination is a no-op.
+	if( src_w == 0 || src_h == 0 )
+	{
+		if( dst == nullptr || new_w < 0 || new_h < 0 )
+		{
+			set_error( "resize: bad destination" );
+			return( AVIRHIP_EINVAL );
+		}
+
+		const size_t n = (size_t) new_w * (size_t) new_h *
+			dtype_size( out_type );
+
+		if( dst_mem == AVIRHIP_MEM_HOST )
+		{
+			memset( dst, 0, n );
+		}
+		else
+		{
+			AVIRHIP_HIPCHECK( hipMemsetAsync( dst, 0, n,
+				(hipStream_t) stream ));
+		}
+
+		return( AVIRHIP_OK );
+	}
+	else
+	if( new_w == 0 || new_h == 0 )
+	{
+		return( AVIRHIP_OK );
+	}
+
+	avirhip_plan* p = nullptr;
+	int rc = avirhip_resizer_get_plan( r, src_w, src_h, src_scanline_size,
+		new_w, new_h, el_count_io, k, vars, in_type, out_type, &p );
+
+	if( rc != 0 )
+	{
+		return( rc );
+	}
+
+	return( avirhip_resize( p, src, src_mem, dst, dst_mem, stream ));
+}
+
+void avirhip_lancir_params_default( avirhip_lancir_params* p )
+{
+	if( p != nullptr )
+	{
+		p -> SrcSSize = 0; p -> NewSSize = 0;
+		p -> kx = 0.0; p -> ky = 0.0; p -> ox = 0.0; p -> oy = 0.0;
+		p -> la = 3.0;
+	}
+}
+
+int avirhip_lancir_create( avirhip_lancir** out )
+{
+	if( out == nullptr )
+	{
+		set_error( "lancir_create: null argument" );
+		return( AVIRHIP_EINVAL );
+	}
+
+	*out = new avirhip_lancir();
+	return( AVIRHIP_OK );
+}
+
+void avirhip_lancir_destroy( avirhip_lancir* l )
+{
+	if( l == nullptr )
+	{
+		return;
+	}
+
+	for( auto& c : l -> cache )
+	{
+		avirhip_plan_destroy( c.second );
+	}
+
+	delete l;
+}
+
+int avirhip_lancir_build_desc( avirhip_lancir* l, int src_w, int src_h,
+	int new_w, int new_h, int el_count, const avirhip_lancir_params* params,
+	int in_type, int out_type, avirhip_lancir_desc** out )
+{
+	if( out == nullptr )
+	{
+		set_error( "lancir_build_desc: null argument" );
+		return( AVIRHIP_EINVAL );
+	}
+
+	avirhip_lancir_params P;
+
+	if( params == nullptr )
+	{
+		avirhip_lancir_params_default( &P );
+	}
+	else
+	{
+		P = *params;
+	}
+
+	DescStore* S = lancir_build( src_w, src_h, new_w, new_h, el_count, P,
+		in_type, out_type );
+
+	if( S == nullptr )
+	{
+		return( AVIRHIP_EINVAL );
+	}
+
+	*out = &S -> ld;
+	return( AVIRHIP_OK );
+}
+
+void avirhip_lancir_desc_free( avirhip_lancir_desc* d )
+{
+	if( d != nullptr )
+	{
+		delete (DescStore*) ( (char*) d - offsetof( DescStore, ld ));
+	}
+}
+
+int avirhip_lancir_get_plan( avirhip_lancir* l, int src_w, int src_h,
+	int new_w, int new_h, int el_count, const avirhip_lancir_params* params,
+	int in_type, int out_type, avirhip_plan** out )
+{
+	if( l == nullptr || out == nullptr )
+	{
+		set_error( "lancir_get_plan: null argument" );
+		return( AVIRHIP_EINVAL );
+	}
+
+	avirhip_lancir_params P;
+
+	if( params == nullptr )
+	{
+		avirhip_lancir_params_default( &P );
+	}
+	else
+	{
+		P = *params;
+	}
+
+	const avirhip_lancir::Key key( src_w, src_h, new_w, new_h, el_count,
+		P.SrcSSize, P.NewSSize, P.kx, P.ky, P.ox, P.oy, P.la, in_type,
+		out_type );
+
+	std::lock_guard< std::mutex > lock( l -> mtx );
+	auto it = l -> cache.find( key );
+
+	if( it != l -> cache.end() )
+	{
+		*out = it -> second;
+		return( AVIRHIP_OK );
+	}
+
+	avirhip_lancir_desc* d = nullptr;
+	int rc = avirhip_lancir_build_desc( l, src_w, src_h, new_w, new_h,
+		el_count, &P, in_type, out_type, &d );
+
+	if( rc != 0 )
+	{
+		return( rc );
+	}
+
+	avirhip_plan* p = nullptr;
+	rc = avirhip_lancir_plan_create( d, &p );
+	avirhip_lancir_desc_free( d );
+
+	if( rc != 0 )
+	{
+		return( rc );
+	}
+
+	l -> cache[ key ] = p;
+	*out = p;
+	return( AVIRHIP_OK );
+}
+
+int avirhip_lancir_resize( avirhip_lancir* l, const void* src, int src_mem,
+	int src_w, int src_h, void* dst, int dst_mem, int new_w, int new_h,
+	int el_count, const avirhip_lancir_params* params, int in_type,
+	int out_type, void* stream )
+{
+	// Parameter errors return 0, lancir.h:392-407.
+	if( l == nullptr || src_w < 0 || src_h < 0 || new_w <= 0 || new_h <= 0 ||
+		src == nullptr || dst == nullptr || src == dst ||
+		( params != nullptr && params -> la < 2.0 ))
+	{
+		return( 0 );
+	}
+
+	if( src_w == 0 || src_h == 0 )
+	{
+		// Zero-filled rows honouring NewSSize, lancir.h:413-425.
+		const size_t osl = (size_t) new_w * el_count;
+		const size_t nss = ( params != nullptr && params -> NewSSize >= 1 ?
+			(size_t) params -> NewSSize : osl );
+		const size_t es = dtype_size( out_type );
+
+		for( int i = 0; i < new_h; i++ )
+		{
+			char* op = (char*) dst + (size_t) i * nss * es;
+
+			if( dst_mem == AVIRHIP_MEM_HOST )
+			{
+				memset( op, 0, osl * es );
+			}
+			else
+			{
+				AVIRHIP_HIPCHECK( hipMemsetAsync( op, 0, osl * es,
+					(hipStream_t) stream ));
+			}
+		}
+
+		return( new_h );
+	}
+
+	avirhip_plan* p = nullptr;
+	int rc = avirhip_lancir_get_plan( l, src_w, src_h, new_w, new_h, el_count,
+		params, in_type, out_type, &p );
+
+	if( rc != 0 )
+	{
+		return( rc );
+	}
+
+	rc = avirhip_resize( p, src, src_mem, dst, dst_mem, stream );
+	return( rc != 0 ? rc : new_h );
+}
+
+} // extern "C"

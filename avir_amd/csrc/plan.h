@@ -1,0 +1,145 @@
+// plan.h -- internal (not part of the C ABI): the lowered, device-resident form
+// of a plan and the launch entry points of the kernel families.
+//
+// Lowering turns the reference-shaped step list of include/avirhip.h into a
+// chain of "ops" per axis. Every op produces a materialised array of pixels
+// along the axis; it reads its input through a *view* that reproduces, by
+// index algebra, what the reference obtains by writing replicated/zeroed
+// prefix and suffix pixels into its flip-flop buffers:
+//
+//   VIEW_CLAMP  in[clamp(i, 0, in_len-1)]          (prepareInBuf, avir.h:3227)
+//   VIEW_ZS     zero-stuffed 2x view of a clamped input; the consumer reads
+//               only the even (non-zero) slots 2m -> in[clamp(m)], and slots
+//               past the last replicated pixel read 0 (doUpsample no-filter
+//               branch, avir.h:3260-3402)
+//   VIEW_RAW    in[i + prefix] of a materialised filtered-upsample buffer
+//
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+#include <vector>
+#include "../../include/avirhip.h"
+
+namespace avirhip {
+
+enum { OP_FIR = 0, OP_GATHER = 1, OP_UPF = 2 };
+enum { VIEW_CLAMP = 0, VIEW_ZS = 1, VIEW_RAW = 2 };
+
+// One lowered op. All pointers are device pointers owned by the plan.
+struct LOp
+{
+	int type;
+	int view;
+	int in_len;     // logical input length (clamp range)
+	int in_prefix;  // VIEW_RAW: pixels stored before logical index 0
+	int zs_mmax;    // VIEW_ZS: source index m > zs_mmax reads 0.0f
+	int out_len;    // logical output length
+	int out_prefix; // OP_UPF: OutPrefix pixels stored before index 0
+	int out_total;  // out_prefix + out_len + suffix (materialised length)
+
+	// OP_FIR: out[n] = f[0]*in[c] + sum_i f[i]*(in[c+i] + in[c-i]),
+	// c = rf*(n-e)  (doFilter, avir.h:3748-3866)
+	int rf, lat, e;
+	float* d_flt; // FIR: &Flt[FltLatency] (lat+1 taps); UPF: whole Flt
+	std::vector< float > h_flt;
+
+	// OP_GATHER: out[j] = 0 + sum_{t<ntaps[j]} coef[j][t]*in[start[j]+t]
+	// (doResize / doResize2, avir.h:3884-4328). coef is pre-expanded per
+	// output position: order-0 taps, or ftp[i] + ftp2[i]*x in float.
+	int maxtaps;
+	int* d_start;
+	int* d_ntaps;
+	float* d_coef; // [out_len][maxtaps]
+	std::vector< int > h_start, h_ntaps;
+	std::vector< float > h_coef;
+
+	// OP_UPF (filtered upsample, avir.h:3404-3733)
+	int flen, up_inprefix, up_R, sdc_len, pdc_len, pdc_d0;
+	float* d_sdc;
+	float* d_pdc;
+};
+
+struct LAxis
+{
+	std::vector< LOp > ops;
+	int src_len, dst_len;
+};
+
+// Image element access: address(scan, idx, c) =
+//   base + scan*scan_stride + (idx + prefix)*idx_stride + c
+struct Surf
+{
+	float* base;
+	long scan_stride;
+	long idx_stride;
+	int prefix;
+};
+
+struct LancirAxisDev
+{
+	int kernel_len, src_len, dst_len, n_filters;
+	int* d_start;   // [dst_len]: first source pixel, un-padded coordinates
+	int* d_fidx;    // [dst_len]
+	float* d_flt;   // [n_filters][kernel_len]
+	std::vector< int > h_start, h_fidx;
+	std::vector< float > h_flt;
+};
+
+} // namespace avirhip
+
+struct avirhip_plan
+{
+	int is_lancir;
+	int device;
+	int src_w, src_h, src_stride, new_w, new_h, new_stride, ch;
+	int in_type, out_type;
+	double tr_mul, pk_out;
+	avirhip::LAxis h, v;
+	// LANCIR
+	avirhip::LancirAxisDev lv, lh;
+	float l_out_mul, l_clamp;
+	int l_unity;
+
+	int path;       // forced path (0 = auto)
+	int fused_ok;   // fused kernel applicable
+	void* fused;    // fused-kernel private data
+
+	// scratch (device), lazily sized
+	std::vector< void* > allocs;
+	float* packed;  // source converted to float (non-f32 input)
+	float* resbuf;  // float result before the integer / f64 epilogue
+	std::vector< float* > hbuf, vbuf; // per-op outputs
+	void* stage_src; // host-pointer staging
+	void* stage_dst;
+	size_t stage_src_bytes, stage_dst_bytes;
+};
+
+namespace avirhip {
+
+void set_error( const char* fmt, ... );
+#define AVIRHIP_HIPCHECK( expr ) do { hipError_t e_ = ( expr ); \
+	if( e_ != hipSuccess ) { avirhip::set_error( "%s: %s (%s:%d)", #expr, \
+		hipGetErrorString( e_ ), __FILE__, __LINE__ ); \
+		return( AVIRHIP_EHIP ); } } while( 0 )
+
+size_t dtype_size( int t );
+
+// generic.hip
+int launch_pack( const void* src, int in_type, float* dst, int w, int h,
+	int ch, long src_stride, hipStream_t st );
+int launch_op( const LOp& op, int ch, bool x_is_idx, const Surf& in,
+	const Surf& out, int scan0, int scan1, int idx0, int idx1,
+	hipStream_t st );
+int launch_epilogue( const float* res, void* dst, int out_type, long n,
+	double tr_mul, double pk_out, hipStream_t st );
+int launch_lancir_generic( const avirhip_plan* p, const void* src, void* dst,
+	float* tmp, int row0, int row1, hipStream_t st );
+
+// fused.hip
+int fused_prepare( avirhip_plan* p );
+void fused_release( avirhip_plan* p );
+int fused_run( avirhip_plan* p, const float* src, float* dst, int row0,
+	int row1, hipStream_t st );
+
+} // namespace avirhip

@@ -1,0 +1,240 @@
+"""GPU parity tests (run on the MI355X box with -m gpu): the HIP path, called
+through the C ABI exactly as a drop-in front-end would call it, against the
+real reference compiled from /root/reference (oracle/_ref, prebuilt) and the
+plain-C restatement (oracle/liboracle.so). Bar: bit-exact (float outputs are
+compared as raw uint32 words; SURVEY.md 7 "expected result is 0 ULP")."""
+import os
+import numpy as np
+import pytest
+import avir_amd
+from avir_amd import abi
+from tests import refbind as rb
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _device():
+    lib = abi.load()
+    assert lib.avirhip_device_count() >= 1, "no gfx950 device"
+    abi.check(lib.avirhip_init(0), "init")
+
+
+def _checker_avir(src, nw, nh, **kw):
+    """Reference output: the real reference when its prebuilt .so is here,
+    else the restatement."""
+    if rb.have_ref():
+        return rb.ref_avir(src, nw, nh, **kw)
+    return rb.orc_avir(src, nw, nh, **kw)
+
+
+def _bits(a):
+    a = np.ascontiguousarray(a)
+    if a.dtype == np.float32:
+        return a.view(np.uint32)
+    if a.dtype == np.float64:
+        return a.view(np.uint64)
+    return a
+
+
+def _assert_same(got, want, what):
+    g, w = _bits(got), _bits(want)
+    if not np.array_equal(g, w):
+        bad = np.argwhere(g != w)
+        i = tuple(bad[0])
+        raise AssertionError("%s: %d of %d elements differ; first at %s: "
+                             "got %r want %r" % (what, len(bad), g.size, i,
+                                                 got[i], want[i]))
+
+
+def _run_avir(src, nw, nh, resbits=8, out_dtype=None, build_mode=-1, k=0.0,
+              path=0, **kw):
+    r = avir_amd.CImageResizer(resbits, kw.get("srcbits", 0))
+    v = avir_amd.CImageResizerVars()
+    v.BuildMode = build_mode
+    v.ox, v.oy = kw.get("ox", 0.0), kw.get("oy", 0.0)
+    h, w, ch = src.shape
+    out_dtype = np.dtype(out_dtype or src.dtype)
+    if path:
+        lib = abi.load()
+        p = r.plan(w, h, nw, nh, ch, k, v, rb._DT[src.dtype],
+                   rb._DT[out_dtype])
+        abi.check(lib.avirhip_plan_set_path(p, path), "set_path")
+    return r.resize(src, nw, nh, k=k, out_dtype=out_dtype, aVars=v)
+
+
+SMALL = [
+    # (sw, sh, nw, nh, ch) -- upsizing (k<=1), 1<k<2, k>=2, identity, tiny
+    (37, 21, 74, 42, 4), (64, 48, 100, 77, 4), (300, 200, 100, 67, 4),
+    (50, 40, 50, 40, 4), (200, 150, 130, 90, 3), (640, 480, 1024, 768, 4),
+    (7, 5, 13, 11, 4), (16, 9, 5, 7, 2), (100, 1, 37, 1, 1), (1, 50, 3, 20, 4),
+    (257, 129, 64, 300, 3),
+]
+
+
+@pytest.mark.parametrize("bits", [8, 16])
+@pytest.mark.parametrize("sw,sh,nw,nh,ch", SMALL)
+def test_avir_f32_generic_path(sw, sh, nw, nh, ch, bits):
+    src = rb.lcg_f32((sh, sw, ch), seed=12345 + sw)
+    want = _checker_avir(src, nw, nh, resbits=bits)
+    got = _run_avir(src, nw, nh, resbits=bits, path=abi.PATH_GENERIC)
+    _assert_same(got, want, "generic")
+
+
+@pytest.mark.parametrize("bits", [8, 16])
+@pytest.mark.parametrize("sw,sh,nw,nh,ch", SMALL)
+def test_avir_f32_auto_path(sw, sh, nw, nh, ch, bits):
+    src = rb.lcg_f32((sh, sw, ch), seed=999 + sh)
+    want = _checker_avir(src, nw, nh, resbits=bits)
+    got = _run_avir(src, nw, nh, resbits=bits)
+    _assert_same(got, want, "auto")
+
+
+@pytest.mark.parametrize("mode", [0, 1, 2, 3])
+@pytest.mark.parametrize("bits", [8, 16])
+def test_avir_forced_build_modes(mode, bits):
+    for (sw, sh, nw, nh, ch) in [(37, 21, 74, 42, 4), (64, 48, 100, 77, 3),
+                                 (300, 200, 100, 67, 4), (120, 90, 100, 70, 1),
+                                 (640, 480, 64, 48, 2)]:
+        src = rb.lcg_f32((sh, sw, ch), seed=7 + mode)
+        want = _checker_avir(src, nw, nh, resbits=bits, build_mode=mode)
+        got = _run_avir(src, nw, nh, resbits=bits, build_mode=mode)
+        _assert_same(got, want, "mode %d %dx%d->%dx%d" % (mode, sw, sh, nw, nh))
+
+
+@pytest.mark.parametrize("tin,tout", [
+    (np.uint8, np.uint8), (np.uint8, np.float32), (np.float32, np.uint8),
+    (np.uint16, np.uint16), (np.uint16, np.uint8), (np.uint8, np.uint16),
+    (np.float32, np.uint16), (np.float64, np.float64),
+    (np.float32, np.float64), (np.float64, np.float32)])
+def test_avir_io_types(tin, tout):
+    """Integer pack / round / clamp / truncating-cast epilogue, bit-exact
+    (avir.h:2777-2840, 4392-4419, 3155-3215)."""
+    for (sw, sh, nw, nh, ch, bits) in [(64, 48, 100, 77, 3, 8),
+                                       (100, 77, 64, 48, 4, 8),
+                                       (90, 60, 120, 100, 1, 6),
+                                       (90, 60, 45, 30, 2, 12)]:
+        if np.dtype(tin).kind == "u":
+            raw = rb.lcg_u8((sh, sw, ch, np.dtype(tin).itemsize), seed=3)
+            src = raw.view(tin).reshape(sh, sw, ch)
+        else:
+            src = rb.lcg_f32((sh, sw, ch), seed=5).astype(tin)
+        want = _checker_avir(src, nw, nh, resbits=bits, out_dtype=tout)
+        got = _run_avir(src, nw, nh, resbits=bits, out_dtype=tout)
+        _assert_same(got, want, "%s->%s" % (np.dtype(tin), np.dtype(tout)))
+
+
+def test_cfg1_golden_hash():
+    """BASELINE cfg1: 640x480 -> 1024x768 RGB u8 (SURVEY.md 8c hash)."""
+    src = rb.lcg_u8((480, 640, 3), seed=1)
+    got = _run_avir(src, 1024, 768, resbits=8)
+    assert rb.fnv(got) == "a6ed3dcbbad502b9"
+
+
+@pytest.mark.parametrize("sw,sh,nw,nh,bits,hash_", [
+    (1920, 1080, 3840, 2160, 16, "a493459fe7df54bd"),   # cfg2
+    (3840, 2160, 1280, 720, 16, "ddaf080cee37dfcc"),    # cfg4
+    (1920, 1080, 2500, 1400, 16, "c43c331a9672e9bc"),
+    (1920, 1080, 2500, 1400, 8, "245cfd62dc2e6a14"),
+    (1000, 700, 640, 480, 16, "67e4f5a0c45e0226"),
+    (1000, 700, 640, 480, 8, "f7b9bb61d7ad373f"),
+    (640, 480, 1024, 768, 16, "e912e2fbd4da24ac"),
+    (640, 480, 1024, 768, 8, "814e19ebad3be537"),
+])
+def test_avir_golden_hashes_rgba_f32(sw, sh, nw, nh, bits, hash_):
+    """Full-size configs against the golden FNV-1a hashes of the reference's
+    output recorded in SURVEY.md 8(c)."""
+    src = rb.lcg_f32((sh, sw, 4))
+    got = _run_avir(src, nw, nh, resbits=bits)
+    assert rb.fnv(got) == hash_
+
+
+def test_cfg3_golden_hash_device_resident():
+    """BASELINE cfg3 (the headline): 3840x2160 -> 7680x4320 RGBA f32 with the
+    buffers resident in HBM (torch tensors), hash from SURVEY.md 8(c)."""
+    import torch
+    src = rb.lcg_f32((2160, 3840, 4))
+    r = avir_amd.CImageResizer(16)
+    d = r.resize(torch.from_numpy(src).cuda(), 7680, 4320)
+    torch.cuda.synchronize()
+    assert rb.fnv(d.cpu().numpy()) == "38d7739587151f6e"
+    del d
+    r8 = avir_amd.CImageResizer(8)
+    d = r8.resize(torch.from_numpy(src).cuda(), 7680, 4320)
+    torch.cuda.synchronize()
+    assert rb.fnv(d.cpu().numpy()) == "38d7739587151f6e"
+
+
+def test_band_execution_matches_full():
+    """Row bands (the multi-GPU sharding unit) are bit-identical to the same
+    rows of a full resize."""
+    import ctypes as C
+    lib = abi.load()
+    for (sw, sh, nw, nh) in [(300, 200, 640, 431), (640, 431, 300, 200)]:
+        src = rb.lcg_f32((sh, sw, 4), seed=77)
+        r = avir_amd.CImageResizer(16)
+        full = r.resize(src, nw, nh)
+        p = r.plan(sw, sh, nw, nh, 4)
+        for g in (2, 3, 8):
+            cuts = [nh * i // g for i in range(g + 1)]
+            for a, b in zip(cuts[:-1], cuts[1:]):
+                band = np.empty((b - a, nw, 4), np.float32)
+                abi.check(lib.avirhip_resize_band(
+                    p, src.ctypes.data, abi.MEM_HOST, band.ctypes.data,
+                    abi.MEM_HOST, a, b, None), "band")
+                _assert_same(band, full[a:b], "band [%d,%d)" % (a, b))
+
+
+def test_zero_sized_and_errors():
+    r = avir_amd.CImageResizer(8)
+    dst = np.full((4, 5, 3), 7, np.uint8)
+    r.resizeImage(np.zeros((0,), np.uint8), 0, 0, 0, dst, 5, 4, 3, 0.0)
+    # avir.h:4686-4692 zero-fills NewWidth*NewHeight ELEMENTS only
+    assert dst.reshape(-1)[:20].sum() == 0 and dst.reshape(-1)[20:].min() == 7
+    v = avir_amd.CImageResizerVars()
+    v.UseSRGBGamma = 1
+    with pytest.raises(avir_amd.AvirHipError):
+        r.resize(np.zeros((8, 8, 3), np.uint8), 4, 4, aVars=v)
+
+
+# ---- LANCIR ----
+
+LANCIR_CASES = [(37, 21, 74, 42), (64, 48, 100, 77), (300, 200, 100, 67),
+                (50, 40, 50, 40), (640, 480, 1024, 768), (8, 8, 3, 3),
+                (5, 300, 60, 20)]
+
+
+@pytest.mark.parametrize("sw,sh,nw,nh", LANCIR_CASES)
+def test_lancir_rgba_f32(sw, sh, nw, nh):
+    src = rb.lcg_f32((sh, sw, 4), seed=4242)
+    want = rb.ref_lancir(src, nw, nh) if rb.have_ref() else \
+        rb.orc_lancir(src, nw, nh)
+    got = avir_amd.CLancIR().resize(src, nw, nh)
+    _assert_same(got, want, "lancir")
+
+
+@pytest.mark.parametrize("sw,sh,nw,nh,hash_", [
+    (3840, 2160, 7680, 4320, "a966d7a452c1b91d"),  # cfg5
+    (1920, 1080, 3840, 2160, "7b1a482ddd30e75b"),
+    (3840, 2160, 1280, 720, "aea7806e77c5710d"),
+    (640, 480, 1024, 768, "5581cf15fdf7556a"),
+])
+def test_lancir_golden_hashes(sw, sh, nw, nh, hash_):
+    src = rb.lcg_f32((sh, sw, 4))
+    got = avir_amd.CLancIR().resize(src, nw, nh)
+    assert rb.fnv(got) == hash_
+
+
+def test_lancir_parameter_errors():
+    l = avir_amd.CLancIR()
+    a = np.zeros((4, 4, 4), np.float32)
+    b = np.zeros((8, 8, 4), np.float32)
+    assert l.resizeImage(a, 4, 4, b, 0, 8, 4) == 0      # NewWidth <= 0
+    assert l.resizeImage(a, -1, 4, b, 8, 8, 4) == 0     # negative source
+    assert l.resizeImage(a, 4, 4, a, 8, 8, 4) == 0      # SrcBuf == NewBuf
+    p = avir_amd.CLancIRParams()
+    p.la = 1.5
+    assert l.resizeImage(a, 4, 4, b, 8, 8, 4, p) == 0   # la < 2
+    b[:] = 1
+    assert l.resizeImage(a, 0, 4, b, 8, 8, 4) == 8      # empty source
+    assert not b.any()

@@ -1,0 +1,95 @@
+"""Host-side planner parity (no GPU): the product planner's plan description
+must equal, bit for bit, the dump of the reference's own planner
+(oracle/_ref, SURVEY.md 8a rows a2/a3 + the 3.3 step shapes): step kinds and
+bookkeeping, every float table, the per-output position table and the chosen
+build mode."""
+import itertools
+import pytest
+from avir_amd import abi
+from tests import refbind as rb, plancmp as pc
+from tests.helpers import product_desc, free_product_desc, PRESETS
+
+pytestmark = pytest.mark.skipif(not rb.have_ref(),
+                                reason="oracle/_ref not built")
+
+
+def _check(sw, sh, nw, nh, ch, **kw):
+    refkw = dict(kw)
+    rd = rb.ref_avir_plan(sw, sh, nw, nh, ch, **refkw)
+    r, pd = product_desc(sw, sh, nw, nh, ch, **kw)
+    try:
+        bad = pc.compare_desc(rd.contents, pd.contents)
+        assert not bad, "%s\nref H %s\nref V %s\nprd H %s\nprd V %s" % (
+            bad[:8], pc.axis_summary(rd.contents.h),
+            pc.axis_summary(rd.contents.v), pc.axis_summary(pd.contents.h),
+            pc.axis_summary(pd.contents.v))
+        return rd.contents.h.build_mode, rd.contents.v.build_mode
+    finally:
+        free_product_desc(r, pd)
+        rb.ref().ref_avir_plan_free(rd)
+
+
+BASELINE = [
+    (640, 480, 1024, 768, 3, abi.U8, 8),      # cfg1
+    (1920, 1080, 3840, 2160, 4, abi.F32, 16),  # cfg2
+    (3840, 2160, 7680, 4320, 4, abi.F32, 16),  # cfg3
+    (3840, 2160, 1280, 720, 4, abi.F32, 16),   # cfg4
+    (5184, 3456, 1920, 1280, 3, abi.U8, 8),    # README case
+]
+
+
+@pytest.mark.parametrize("sw,sh,nw,nh,ch,t,bits", BASELINE)
+def test_baseline_configs(sw, sh, nw, nh, ch, t, bits):
+    modes = _check(sw, sh, nw, nh, ch, in_type=t, out_type=t, resbits=bits)
+    assert modes == (1, 1)  # all BASELINE configs pick mode 1
+
+
+SIZES_SRC = [(7, 5), (16, 9), (37, 21), (64, 48), (300, 200), (640, 480),
+             (1000, 700)]
+SIZES_DST = [(5, 7), (13, 11), (50, 40), (100, 77), (640, 480), (1024, 768),
+             (2500, 1400)]
+
+
+@pytest.mark.parametrize("bits", [8, 16])
+def test_size_sweep_auto_mode(bits):
+    seen = set()
+    for (sw, sh), (nw, nh) in itertools.product(SIZES_SRC, SIZES_DST):
+        seen.add(_check(sw, sh, nw, nh, 4, resbits=bits))
+    # the sweep must exercise more than one build mode
+    assert len(seen) > 1
+
+
+@pytest.mark.parametrize("mode", [0, 1, 2, 3])
+@pytest.mark.parametrize("bits", [8, 16])
+def test_forced_build_modes(mode, bits):
+    for (sw, sh, nw, nh) in [(37, 21, 74, 42), (64, 48, 100, 77),
+                             (300, 200, 100, 67), (1000, 700, 640, 480),
+                             (640, 480, 64, 48), (50, 40, 50, 40)]:
+        _check(sw, sh, nw, nh, 4, resbits=bits, build_mode=mode)
+
+
+@pytest.mark.parametrize("preset", sorted(PRESETS))
+def test_parameter_presets(preset):
+    for (sw, sh, nw, nh) in [(64, 48, 100, 77), (300, 200, 100, 67),
+                             (200, 150, 130, 90)]:
+        _check(sw, sh, nw, nh, 3, params=PRESETS[preset], resbits=8)
+        _check(sw, sh, nw, nh, 3, params=PRESETS[preset], resbits=16)
+
+
+@pytest.mark.parametrize("k", [0.37, 0.5, 1.0, 1.3, 2.0, 3.7, -0.8, -2.5])
+def test_explicit_step_and_offsets(k):
+    _check(200, 120, 150, 90, 4, k=k, resbits=8)
+    _check(200, 120, 150, 90, 1, k=k, resbits=16, ox=0.35, oy=-1.25)
+
+
+@pytest.mark.parametrize("it,ot", [(abi.U8, abi.U8), (abi.U8, abi.F32),
+                                   (abi.F32, abi.U8), (abi.U16, abi.U8),
+                                   (abi.U8, abi.U16), (abi.F32, abi.U16),
+                                   (abi.F64, abi.F64), (abi.F32, abi.F64)])
+def test_io_types_and_bit_depths(it, ot):
+    # OutMul folds into the first filter of the H axis and is undone on the V
+    # axis in float (modifyCorrFilterDCGain, avir.h:6137-6157).
+    for bits in (6, 8, 12, 16):
+        _check(120, 90, 200, 160, 3, in_type=it, out_type=ot, resbits=bits)
+        _check(200, 160, 120, 90, 2, in_type=it, out_type=ot, resbits=bits,
+               srcbits=8)
