@@ -1,0 +1,262 @@
+#!/usr/bin/env python
+"""bench.py -- headline benchmark of the separable-resize hot path on MI355X.
+
+Metric (BASELINE.json): output Mpixels/s for 3840x2160 -> 7680x4320 RGBA
+float32 (cfg3) through avir::CImageResizer<>(16), plus the fraction of the HBM
+roofline achieved by the dominant kernel.
+
+  python bench.py --gpus N --steps K --warmup W
+
+A "step" is one full resize of one synthetic 4K frame already resident in HBM
+(H pass + V pass). N > 1 (launched by torch.distributed.run, one rank per GPU)
+shards independent frames across ranks -- no data-path collective, weak
+scaling; value = frames * Mpix over the max-over-ranks wall time. After the
+timed region (never inside it) rank 0 also reports, in the same JSON line:
+  roofline      dominant-kernel launch duration from HIP events on the launch
+                stream -> algorithmic bytes / s against the 8 TB/s HBM peak
+  cpu_baseline  the reference's own CPU path (oracle/_ref) timed on the host
+                cores, N == 1 only, bounded sample
+  band_gather   (N > 1) one frame split into N row bands, one band per GPU,
+                stitched on rank 0 with an RCCL gather over xGMI; compute and
+                gather timed separately
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+SRC_W, SRC_H, NEW_W, NEW_H, CH = 3840, 2160, 7680, 4320, 4
+ALGO_BYTES = (SRC_W * SRC_H + NEW_W * NEW_H) * CH * 4
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s
+
+
+def cpu_baseline(src_np, threads):
+    """Reference CPU path on the host cores (bounded: a few frames)."""
+    from tests import refbind as rb
+    out = {}
+    if rb.have_ref():
+        kind, fn = "reference", lambda t: rb.ref_avir(
+            src_np, NEW_W, NEW_H, resbits=16, threads=t)
+    else:
+        kind, fn = "port", lambda t: rb.orc_avir(
+            src_np, NEW_W, NEW_H, resbits=16)
+        threads = 1
+    best = {}
+    for t in sorted(set([1, threads])):
+        ts = []
+        budget = time.perf_counter() + 12.0
+        while len(ts) < 3 and (not ts or time.perf_counter() < budget):
+            t0 = time.perf_counter()
+            fn(t)
+            ts.append(time.perf_counter() - t0)
+        best[t] = min(ts)
+    out = {"value": round(NEW_W * NEW_H / best[threads] / 1e6, 2),
+           "unit": "Mpixels/s", "cores": threads, "kind": kind,
+           "sample": "%s frames of cfg3 (3840x2160->7680x4320 RGBA f32), "
+                     "avir::CImageResizer<fpclass_def<float>>(16) built "
+                     "-O2 -ffp-contract=off, best of runs; std::thread pool"
+                     % ("1-3"),
+           "ms_per_frame": round(best[threads] * 1e3, 1),
+           "single_thread_value": round(NEW_W * NEW_H / best[1] / 1e6, 2),
+           "single_thread_ms": round(best[1] * 1e3, 1)}
+    return out
+
+
+def read_traffic():
+    """HBM bytes per launch from the committed PMC pass (profiles/), or None.
+    Collected separately with rocprofv3 --pmc as MI355X_MICROARCH.md
+    prescribes; see profiles/README.md."""
+    p = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    try:
+        with open(p) as f:
+            return json.load(f).get("traffic_bytes_per_launch")
+    except (OSError, ValueError):
+        return None
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--path", type=int, default=0,
+                    help="0 auto, 1 generic, 3 fused (A/B testing)")
+    ap.add_argument("--no-cpu", action="store_true",
+                    help="skip the CPU baseline leg")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    import avir_amd
+    from avir_amd import abi
+    from tests import refbind as rb
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    lib = abi.load()
+    assert lib.avirhip_device_count() >= 1, "no gfx950 device"
+    abi.check(lib.avirhip_init(local), "avirhip_init")
+
+    src_np = rb.lcg_f32((SRC_H, SRC_W, CH))  # SURVEY.md 8(c) generator
+    src = torch.from_numpy(src_np).to(dev)
+    dst = torch.empty((NEW_H, NEW_W, CH), dtype=torch.float32, device=dev)
+
+    rz = avir_amd.CImageResizer(16)
+    plan = rz.plan(SRC_W, SRC_H, NEW_W, NEW_H, CH)
+    if args.path:
+        abi.check(lib.avirhip_plan_set_path(plan, args.path), "set_path")
+    path = lib.avirhip_plan_get_path(plan)
+    stream = torch.cuda.current_stream(dev).cuda_stream
+
+    def step():
+        abi.check(lib.avirhip_resize(plan, src.data_ptr(), abi.MEM_DEVICE,
+                                     dst.data_ptr(), abi.MEM_DEVICE, stream),
+                  "avirhip_resize")
+
+    def barrier():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    e0 = torch.cuda.Event(enable_timing=True)
+    e1 = torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    e0.record()
+    for _ in range(args.steps):
+        step()
+    e1.record()
+    barrier()
+    t = time.perf_counter() - t0
+
+    if world > 1:
+        tt = torch.tensor([t], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        t = float(tt.item())
+
+    ev_ms = e0.elapsed_time(e1) / args.steps  # kernel time on the launch stream
+    mpix = NEW_W * NEW_H / 1e6
+    value = world * args.steps * mpix / t
+
+    out = {
+        "metric": "Mpixels/sec (output) for 4K->8K RGBA resize",
+        "value": round(value, 1), "unit": "Mpixels/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(t / args.steps * 1e3, 4),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "cfg3: 3840x2160->7680x4320 RGBA float32, "
+                               "avir::CImageResizer<>(16), k=0, default params, "
+                               "frame resident in HBM",
+                   "sharding": "independent frames per GPU (no data-path "
+                               "collective)",
+                   "exec_path": {1: "generic per-step kernels",
+                                 3: "fused single kernel"}.get(path, str(path))},
+    }
+
+    # parity spot check on the very buffer that was timed
+    if rank == 0:
+        h = rb.fnv(dst.cpu().numpy())
+        out["parity"] = {"fnv1a64": h, "golden": "38d7739587151f6e",
+                         "ok": h == "38d7739587151f6e"}
+
+    if rank == 0:
+        achieved = ALGO_BYTES / (ev_ms * 1e-3) / 1e9
+        out["roofline"] = {
+            "bound": "hbm", "achieved": round(achieved, 1),
+            "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(achieved / HBM_PEAK_GBS, 4),
+            "traffic": read_traffic(),
+            "algorithmic_bytes": ALGO_BYTES,
+            "kernel_ms": round(ev_ms, 4),
+            "kernels_per_step": {1: "5 (per-step generic chain)",
+                                 3: "1"}.get(path, "?")}
+
+    if world > 1:
+        out["band_gather"] = band_gather(lib, plan, src, dev, world, rank, dist,
+                                         torch)
+
+    if rank == 0 and world == 1 and not args.no_cpu:
+        out["cpu_baseline"] = cpu_baseline(src_np, os.cpu_count() or 1)
+
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def band_gather(lib, plan, src, dev, world, rank, dist, torch, iters=20):
+    """One frame, N row bands, one band per GPU, gather on rank 0 (RCCL over
+    xGMI). Bands are bit-identical to the rows of a full-frame resize
+    (tests/test_gpu_parity.py::test_band_execution_matches_full)."""
+    from avir_amd import abi
+    r0, r1 = NEW_H * rank // world, NEW_H * (rank + 1) // world
+    band = torch.empty((r1 - r0, NEW_W, CH), dtype=torch.float32, device=dev)
+    rows = [NEW_H * (i + 1) // world - NEW_H * i // world for i in range(world)]
+    parts = None
+    if rank == 0:
+        full = torch.empty((NEW_H, NEW_W, CH), dtype=torch.float32, device=dev)
+        parts, o = [], 0
+        for n in rows:
+            parts.append(full[o:o + n])
+            o += n
+    stream = torch.cuda.current_stream(dev).cuda_stream
+
+    def compute():
+        abi.check(lib.avirhip_resize_band(
+            plan, src.data_ptr(), abi.MEM_DEVICE, band.data_ptr(),
+            abi.MEM_DEVICE, r0, r1, stream), "band")
+
+    def gather():
+        # uneven bands -> grouped send/recv (ncclGather needs equal counts)
+        if rank == 0:
+            parts[0].copy_(band)
+            reqs = [dist.P2POp(dist.irecv, parts[i], i) for i in range(1, world)]
+        else:
+            reqs = [dist.P2POp(dist.isend, band, 0)]
+        for w in dist.batch_isend_irecv(reqs):
+            w.wait()
+
+    compute(); gather()
+    torch.cuda.synchronize(dev); dist.barrier()
+    tc = tg = 0.0
+    for _ in range(iters):
+        t0 = time.perf_counter()
+        compute(); torch.cuda.synchronize(dev); dist.barrier()
+        t1 = time.perf_counter()
+        gather(); torch.cuda.synchronize(dev); dist.barrier()
+        t2 = time.perf_counter()
+        tc += t1 - t0
+        tg += t2 - t1
+    res = {"compute_ms": round(tc / iters * 1e3, 4),
+           "gather_ms": round(tg / iters * 1e3, 4),
+           "stitched_mpix_s": round(NEW_W * NEW_H / 1e6 / ((tc + tg) / iters), 1),
+           "compute_only_mpix_s": round(NEW_W * NEW_H / 1e6 / (tc / iters), 1),
+           "bytes_per_rank": int(band.numel() * 4)}
+    if rank == 0:
+        from tests import refbind as rb
+        res["stitched_fnv1a64_ok"] = rb.fnv(full.cpu().numpy()) == "38d7739587151f6e"
+    return res
+
+
+if __name__ == "__main__":
+    main()
