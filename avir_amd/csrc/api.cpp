@@ -568,18 +568,22 @@ static int exec_device( avirhip_plan* p, const void* src, void* dst,
 	float* fdst = ( p -> out_type == AVIRHIP_F32 ? (float*) dst :
 		p -> resbuf );
 
-	int path = p -> path;
+	const int path = ( p -> path != 0 ? p -> path : p -> auto_path );
+	rc = 1;
 
-	if( path == 0 )
+	if( path == 2 || path == 3 )
 	{
-		path = ( p -> fused_ok ? 3 : 1 );
+		rc = fused_run( p, path, fsrc, sstride, fdst, row0, row1, st );
+
+		if( rc == 1 && p -> path != 0 )
+		{
+			set_error( "path %d cannot run this call (unaligned buffers?)",
+				path );
+			return( AVIRHIP_EUNSUPPORTED );
+		}
 	}
 
-	if( path == 3 )
-	{
-		rc = fused_run( p, fsrc, fdst, row0, row1, st );
-	}
-	else
+	if( rc == 1 )
 	{
 		rc = run_generic( p, fsrc, sstride, fdst, row0, row1, st );
 	}
@@ -669,7 +673,7 @@ static avirhip_plan* new_plan()
 {
 	avirhip_plan* p = new avirhip_plan();
 	p -> is_lancir = 0; p -> device = 0;
-	p -> path = 0; p -> fused_ok = 0; p -> fused = nullptr;
+	p -> path = 0; p -> fused_ok = 0; p -> auto_path = 1; p -> fused = nullptr;
 	p -> packed = nullptr; p -> resbuf = nullptr;
 	p -> stage_src = nullptr; p -> stage_dst = nullptr;
 	p -> stage_src_bytes = 0; p -> stage_dst_bytes = 0;
@@ -894,7 +898,9 @@ int avirhip_plan_set_path( avirhip_plan* p, int path )
 		return( AVIRHIP_EINVAL );
 	}
 
-	if( path == 2 || ( path == 3 && !p -> fused_ok ))
+	if(( path == 2 && !( p -> fused_ok & 1 )) ||
+		( path == 3 && !( p -> fused_ok & 2 )) ||
+		( p -> is_lancir && path > 1 ))
 	{
 		set_error( "path %d cannot run this plan", path );
 		return( AVIRHIP_EUNSUPPORTED );
@@ -911,7 +917,7 @@ int avirhip_plan_get_path( const avirhip_plan* p )
 		return( AVIRHIP_EINVAL );
 	}
 
-	return( p -> path != 0 ? p -> path : ( p -> fused_ok ? 3 : 1 ));
+	return( p -> path != 0 ? p -> path : p -> auto_path );
 }
 
 int avirhip_resize( avirhip_plan* p, const void* src, int src_mem, void* dst,

@@ -1,8 +1,684 @@
-// fused.hip -- fused single-pass kernels (placeholder until the generic path is parity-green).
+// fused.hip -- LDS-tiled executor for RGBA (4-channel) float plans.
+//
+// One kernel, k_tile, runs a chain of lowered ops over a 2-D output tile with
+// every intermediate kept in LDS:
+//
+//   path 3 "fused"    H chain + V chain in one launch: source tile (with its
+//                     halo) -> LDS -> ... -> destination tile. The horizontally
+//                     resized intermediate image (the reference's FltBuf,
+//                     avir.h:4881) never exists in HBM; traffic ~= the
+//                     algorithmic bytes. Chosen for upsizing, where FltBuf is
+//                     large and the vertical support is short.
+//   path 2 "two-pass" the same kernel launched twice (H chain only into
+//                     FltBuf, then V chain only). Chosen for downsizing, where
+//                     FltBuf is small and a fused tile's halo would be huge.
+//
+// gfx950 mapping: a workgroup is 256 threads = 4 wave64; lanes run along the
+// image x axis in every stage, so global loads/stores of a wave are contiguous
+// 16-byte-per-lane segments and LDS accesses of a lane group are consecutive
+// 16-byte slots (conflict-free ds_read_b128 / ds_write_b128). Per-tile filter
+// coefficient rows are staged into LDS once per stage (coalesced) and then
+// read as broadcast / 48-byte-stride b128 words. Tiles are dealt to workgroups
+// so that consecutive tiles (which share halo rows/columns) land on the same
+// XCD and hit in its private L2.
+//
+// Arithmetic contract: -ffp-contract=off, separate mul/add in the reference's
+// tap order, sums started from +0.0f (see generic.hip) => bit-identical.
+
 #include "plan.h"
+#include <algorithm>
+
 namespace avirhip {
-int fused_prepare( avirhip_plan* p ) { p -> fused_ok = 0; return( AVIRHIP_OK ); }
-void fused_release( avirhip_plan* p ) { }
-int fused_run( avirhip_plan* p, const float* src, float* dst, int row0, int row1, hipStream_t st )
-{ set_error( "fused path not available" ); return( AVIRHIP_EUNSUPPORTED ); }
+
+typedef float f4 __attribute__(( ext_vector_type( 4 )));
+
+#define MAXCHAIN 3
+
+struct TOp
+{
+	int type, view, in_len, zs_mmax;
+	int rf, lat, e;
+	const float* flt;
+	const int* start;
+	const int* ntaps;
+	const float* coef;
+	int maxtaps;
+};
+
+struct TileParams
+{
+	int nh, nv;
+	TOp hop[ MAXCHAIN ];
+	TOp vop[ MAXCHAIN ];
+	const int* hrng; // [ntx][nh+1][2] (lo, count); [.][nh] = tile columns
+	const int* vrng; // [nty][nv+1][2]
+	int ntx, nty, ty0; // ty0: first tile row launched (bands)
+	const float* src; long src_ss; // floats per source row
+	float* dst; long dst_ss;       // floats per destination row
+	int dst_row0;                  // row index stored at dst
+	int srow_lo, srow_hi;          // store mask on the final-axis index
+	int maxA, maxB, maxC;          // LDS carve (pixels, pixels, floats)
+};
+
+__device__ __forceinline__ int view_index( const TOp& op, int i, bool& zero )
+{
+	zero = ( op.view == VIEW_ZS && i > op.zs_mmax );
+	return( i < 0 ? 0 : ( i >= op.in_len ? op.in_len - 1 : i ));
 }
+
+// One op over a tile held in LDS. `in` is [irows][icols] pixels; the op runs
+// along x (ALONG_X) or along y. Logical input indices [ilo, ilo+in_n) are
+// present along the op's axis. Output logical indices [olo, olo+on).
+template< bool ALONG_X, bool TO_GLOBAL >
+__device__ __forceinline__ void run_op( const TOp& op, const f4* in,
+	const int ipitch, const int ilo, f4* out, const int opitch,
+	const int olo, const int on, const int other_n, float* cfl, int* sti,
+	const TileParams& P, const int g_other_lo )
+{
+	const int tx = threadIdx.x; // 0..31
+	const int ty = threadIdx.y; // 0..7
+	const int mt = ( op.maxtaps + 3 ) & ~3;
+
+	if( op.type == OP_GATHER )
+	{
+		// stage start/ntaps/coefficients of this tile's outputs
+		const int tid = ty * 32 + tx;
+
+		for( int i = tid; i < on; i += 256 )
+		{
+			sti[ i * 2 ] = op.start[ olo + i ];
+			sti[ i * 2 + 1 ] = op.ntaps[ olo + i ];
+		}
+
+		const int tot = on * op.maxtaps;
+
+		for( int i = tid; i < tot; i += 256 )
+		{
+			const int j = i / op.maxtaps;
+			const int t = i - j * op.maxtaps;
+			cfl[ j * mt + t ] = op.coef[ (long) olo * op.maxtaps + i ];
+		}
+
+		__syncthreads();
+	}
+
+	// loops: x over lanes, y over thread rows
+	const int nx = ( ALONG_X ? on : other_n );
+	const int ny = ( ALONG_X ? other_n : on );
+
+	for( int y = ty; y < ny; y += 8 )
+	{
+		for( int x = tx; x < nx; x += 32 )
+		{
+			const int n = ( ALONG_X ? x : y );     // output index in tile
+			const int o = ( ALONG_X ? y : x );     // position on other axis
+			const int g = olo + n;                 // logical output index
+			const f4* base = ( ALONG_X ? in + o * ipitch : in + o );
+			const int istep = ( ALONG_X ? 1 : ipitch );
+			f4 acc;
+
+			if( op.type == OP_FIR )
+			{
+				const int cp = op.rf * ( g - op.e );
+				bool z;
+				int q = view_index( op, cp, z );
+				acc = op.flt[ 0 ] * base[ ( q - ilo ) * istep ];
+
+				for( int i = 1; i <= op.lat; i++ )
+				{
+					const int q1 = view_index( op, cp + i, z );
+					const int q2 = view_index( op, cp - i, z );
+					const f4 s = base[ ( q1 - ilo ) * istep ] +
+						base[ ( q2 - ilo ) * istep ];
+
+					acc = acc + op.flt[ i ] * s;
+				}
+			}
+			else
+			{
+				const int st = sti[ n * 2 ];
+				const int nt = sti[ n * 2 + 1 ];
+				const float* cf = cfl + n * mt;
+				acc = (f4) 0.0f;
+				int t = 0;
+
+				for( ; t + 4 <= nt; t += 4 )
+				{
+					const f4 c4 = *(const f4*) ( cf + t );
+#pragma unroll
+					for( int u = 0; u < 4; u++ )
+					{
+						bool z;
+						const int q = view_index( op, st + t + u, z );
+						f4 v = base[ ( q - ilo ) * istep ];
+
+						if( z )
+						{
+							v = (f4) 0.0f;
+						}
+
+						acc = acc + c4[ u ] * v;
+					}
+				}
+
+				for( ; t < nt; t++ )
+				{
+					bool z;
+					const int q = view_index( op, st + t, z );
+					f4 v = base[ ( q - ilo ) * istep ];
+
+					if( z )
+					{
+						v = (f4) 0.0f;
+					}
+
+					acc = acc + cf[ t ] * v;
+				}
+			}
+
+			if( TO_GLOBAL )
+			{
+				// final op of the launch: x is always image x
+				const int gx = ( ALONG_X ? g : g_other_lo + o );
+				const int gy = ( ALONG_X ? g_other_lo + o : g );
+				const int gm = ( ALONG_X ? gy : g ); // masked (row) index
+
+				if( P.nv == 0 || ( gm >= P.srow_lo && gm < P.srow_hi ))
+				{
+					*(f4*) ( P.dst + (long) ( gy - P.dst_row0 ) * P.dst_ss +
+						(long) gx * 4 ) = acc;
+				}
+			}
+			else
+			{
+				out[ ( ALONG_X ? o * opitch + n : n * opitch + o ) ] = acc;
+			}
+		}
+	}
+}
+
+__global__ void __launch_bounds__( 256 ) k_tile( const TileParams P )
+{
+	extern __shared__ __attribute__(( aligned( 16 ))) char smem[];
+	f4* bufA = (f4*) smem;
+	f4* bufB = bufA + P.maxA;
+	float* cfl = (float*) ( bufB + P.maxB );
+	int* sti = (int*) ( cfl + P.maxC );
+
+	// XCD-aware tile dealing: workgroup b runs on XCD b % 8 (observed);
+	// give each XCD a contiguous run of tiles so halo re-reads hit its L2.
+	const int nwg = gridDim.x;
+	const int b = blockIdx.x;
+	const int xcd = b & 7;
+	const int qd = nwg >> 3;
+	const int rm = nwg & 7;
+	const int tile = ( xcd < rm ? xcd * ( qd + 1 ) :
+		rm * ( qd + 1 ) + ( xcd - rm ) * qd ) + ( b >> 3 );
+
+	const int txi = tile % P.ntx;
+	const int tyi = P.ty0 + tile / P.ntx;
+	const int* hr = P.hrng + txi * ( P.nh + 1 ) * 2;
+	const int* vr = P.vrng + tyi * ( P.nv + 1 ) * 2;
+
+	const int col_lo = hr[ 0 ], cols = hr[ 1 ];
+	const int row_lo = vr[ 0 ], rows = vr[ 1 ];
+	const int tx = threadIdx.x;
+	const int ty = threadIdx.y;
+
+	// source tile -> LDS (16 B per lane, contiguous along x)
+	for( int y = ty; y < rows; y += 8 )
+	{
+		const float* sp = P.src + (long) ( row_lo + y ) * P.src_ss +
+			(long) col_lo * 4;
+
+		for( int x = tx; x < cols; x += 32 )
+		{
+			bufA[ y * cols + x ] = *(const f4*) ( sp + x * 4 );
+		}
+	}
+
+	__syncthreads();
+
+	f4* cur = bufA;
+	f4* oth = bufB;
+	int ilo = col_lo;
+	int ipitch = cols;
+
+	for( int s = 0; s < P.nh; s++ )
+	{
+		const int olo = hr[ ( s + 1 ) * 2 ];
+		const int on = hr[ ( s + 1 ) * 2 + 1 ];
+
+		if( s == P.nh - 1 && P.nv == 0 )
+		{
+			run_op< true, true >( P.hop[ s ], cur, ipitch, ilo, oth, on, olo,
+				on, rows, cfl, sti, P, row_lo );
+		}
+		else
+		{
+			run_op< true, false >( P.hop[ s ], cur, ipitch, ilo, oth, on, olo,
+				on, rows, cfl, sti, P, row_lo );
+		}
+
+		__syncthreads();
+		f4* t = cur; cur = oth; oth = t;
+		ilo = olo;
+		ipitch = on;
+	}
+
+	// after the H chain the tile is [rows][tcols]
+	const int tcol_lo = ( P.nh > 0 ? hr[ P.nh * 2 ] : col_lo );
+	const int tcols = ( P.nh > 0 ? hr[ P.nh * 2 + 1 ] : cols );
+	ilo = row_lo;
+
+	for( int s = 0; s < P.nv; s++ )
+	{
+		const int olo = vr[ ( s + 1 ) * 2 ];
+		const int on = vr[ ( s + 1 ) * 2 + 1 ];
+
+		if( s == P.nv - 1 )
+		{
+			run_op< false, true >( P.vop[ s ], cur, tcols, ilo, oth, tcols,
+				olo, on, tcols, cfl, sti, P, tcol_lo );
+		}
+		else
+		{
+			run_op< false, false >( P.vop[ s ], cur, tcols, ilo, oth, tcols,
+				olo, on, tcols, cfl, sti, P, tcol_lo );
+		}
+
+		__syncthreads();
+		f4* t = cur; cur = oth; oth = t;
+		ilo = olo;
+	}
+}
+
+// ---------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------
+
+struct TileGeom
+{
+	int tw, th, ntx, nty;
+	int* d_hrng;
+	int* d_vrng;
+	int maxA, maxB, maxC;
+	size_t lds;
+	bool ok;
+};
+
+struct FusedData
+{
+	TileGeom fused; // path 3
+	TileGeom hpass; // path 2, pass 1 (H chain only)
+	TileGeom vpass; // path 2, pass 2 (V chain only)
+	float* fltbuf;  // path 2 intermediate [src_h][new_w] pixels
+	std::vector< void* > allocs;
+};
+
+static void op_need( const LOp& op, int a, int b, int& ia, int& ib )
+{
+	if( op.type == OP_FIR )
+	{
+		ia = op.rf * ( a - op.e ) - op.lat;
+		ib = op.rf * ( b - op.e ) + op.lat;
+	}
+	else
+	{
+		ia = 0x7fffffff;
+		ib = -0x7fffffff;
+
+		for( int j = a; j <= b; j++ )
+		{
+			ia = std::min( ia, op.h_start[ j ]);
+			ib = std::max( ib, op.h_start[ j ] + op.h_ntaps[ j ] - 1 );
+		}
+	}
+
+	ia = std::max( 0, std::min( ia, op.in_len - 1 ));
+	ib = std::max( 0, std::min( ib, op.in_len - 1 ));
+}
+
+// Range table of one axis for tiles of `tsz` outputs: rng[t][s] = (lo, count)
+// of the input of op s; rng[t][n] = the tile's outputs.
+static void build_ranges( const LAxis& ax, int nops, int out_len, int tsz,
+	std::vector< int >& rng, int& ntiles, std::vector< int >& maxn )
+{
+	ntiles = ( out_len + tsz - 1 ) / tsz;
+	rng.assign( (size_t) ntiles * ( nops + 1 ) * 2, 0 );
+	maxn.assign( nops + 1, 0 );
+
+	for( int t = 0; t < ntiles; t++ )
+	{
+		int a = t * tsz;
+		int b = std::min( out_len, a + tsz ) - 1;
+		int* r = &rng[ (size_t) t * ( nops + 1 ) * 2 ];
+		r[ nops * 2 ] = a;
+		r[ nops * 2 + 1 ] = b - a + 1;
+
+		for( int s = nops - 1; s >= 0; s-- )
+		{
+			int ia, ib;
+			op_need( ax.ops[ s ], a, b, ia, ib );
+			r[ s * 2 ] = ia;
+			r[ s * 2 + 1 ] = ib - ia + 1;
+			a = ia;
+			b = ib;
+		}
+
+		for( int s = 0; s <= nops; s++ )
+		{
+			maxn[ s ] = std::max( maxn[ s ], r[ s * 2 + 1 ]);
+		}
+	}
+}
+
+static bool chain_ok( const LAxis& ax )
+{
+	if( ax.ops.empty() || ax.ops.size() > MAXCHAIN )
+	{
+		return( false );
+	}
+
+	for( size_t i = 0; i < ax.ops.size(); i++ )
+	{
+		if( ax.ops[ i ].type == OP_UPF || ax.ops[ i ].view == VIEW_RAW )
+		{
+			return( false );
+		}
+	}
+
+	return( true );
+}
+
+// Builds geometry for running `useh` / `usev` chains with tile (tw, th).
+static int make_geom( avirhip_plan* p, FusedData* F, bool useh, bool usev,
+	int tw, int th, size_t lds_cap, TileGeom& G )
+{
+	G.ok = false;
+	G.tw = tw;
+	G.th = th;
+	const int nh = ( useh ? (int) p -> h.ops.size() : 0 );
+	const int nv = ( usev ? (int) p -> v.ops.size() : 0 );
+	std::vector< int > hr, vr, hm, vm;
+
+	// x extent: outputs of the H chain (new_w) when it runs, or when only the
+	// V chain runs (its columns are FltBuf columns = new_w as well)
+	build_ranges( p -> h, nh, p -> new_w, tw, hr, G.ntx, hm );
+	// y extent: V chain outputs (new_h), or source rows for an H-only pass
+	build_ranges( p -> v, nv, ( usev ? p -> new_h : p -> src_h ), th, vr,
+		G.nty, vm );
+
+	// stage regions alternate A, B, A, ...: S | H ops | V ops (last -> global)
+	std::vector< long > reg;
+	reg.push_back( (long) hm[ 0 ] * vm[ 0 ]);
+
+	for( int s = 1; s <= nh; s++ )
+	{
+		reg.push_back( (long) hm[ s ] * vm[ 0 ]);
+	}
+
+	for( int s = 1; s <= nv; s++ )
+	{
+		reg.push_back( (long) hm[ nh ] * vm[ s ]);
+	}
+
+	reg.pop_back(); // the last stage writes to global memory
+	long mA = 0, mB = 0;
+
+	for( size_t i = 0; i < reg.size(); i++ )
+	{
+		if( i & 1 ) mB = std::max( mB, reg[ i ]);
+		else mA = std::max( mA, reg[ i ]);
+	}
+
+	long mC = 4, mS = 2;
+
+	for( int s = 0; s < nh; s++ )
+	{
+		const LOp& op = p -> h.ops[ s ];
+
+		if( op.type == OP_GATHER )
+		{
+			mC = std::max( mC, (long) hm[ s + 1 ] * (( op.maxtaps + 3 ) & ~3 ));
+			mS = std::max( mS, (long) hm[ s + 1 ] * 2 );
+		}
+	}
+
+	for( int s = 0; s < nv; s++ )
+	{
+		const LOp& op = p -> v.ops[ s ];
+
+		if( op.type == OP_GATHER )
+		{
+			mC = std::max( mC, (long) vm[ s + 1 ] * (( op.maxtaps + 3 ) & ~3 ));
+			mS = std::max( mS, (long) vm[ s + 1 ] * 2 );
+		}
+	}
+
+	if( mB < 1 ) mB = 1;
+	G.maxA = (int) mA;
+	G.maxB = (int) mB;
+	G.maxC = (int) mC;
+	G.lds = (size_t) ( mA + mB ) * 16 + (size_t) mC * 4 + (size_t) mS * 4;
+
+	if( G.lds > lds_cap )
+	{
+		return( AVIRHIP_OK ); // not usable with this tile; caller tries next
+	}
+
+	void* q;
+	AVIRHIP_HIPCHECK( hipMalloc( &q, hr.size() * sizeof( int )));
+	F -> allocs.push_back( q );
+	AVIRHIP_HIPCHECK( hipMemcpy( q, hr.data(), hr.size() * sizeof( int ),
+		hipMemcpyHostToDevice ));
+	G.d_hrng = (int*) q;
+	AVIRHIP_HIPCHECK( hipMalloc( &q, vr.size() * sizeof( int )));
+	F -> allocs.push_back( q );
+	AVIRHIP_HIPCHECK( hipMemcpy( q, vr.data(), vr.size() * sizeof( int ),
+		hipMemcpyHostToDevice ));
+	G.d_vrng = (int*) q;
+	G.ok = true;
+	return( AVIRHIP_OK );
+}
+
+static int pick_geom( avirhip_plan* p, FusedData* F, bool useh, bool usev,
+	const int ( *cand )[ 2 ], int ncand, TileGeom& G )
+{
+	// first try to fit >= 2 workgroups per CU (64 KiB), then anything <= 150 KiB
+	const size_t caps[ 2 ] = { 64 * 1024, 150 * 1024 };
+
+	for( int c = 0; c < 2; c++ )
+	{
+		for( int i = 0; i < ncand; i++ )
+		{
+			int rc = make_geom( p, F, useh, usev, cand[ i ][ 0 ],
+				cand[ i ][ 1 ], caps[ c ], G );
+
+			if( rc != 0 ) return( rc );
+			if( G.ok ) return( AVIRHIP_OK );
+		}
+	}
+
+	return( AVIRHIP_OK );
+}
+
+int fused_prepare( avirhip_plan* p )
+{
+	p -> fused_ok = 0;
+	p -> auto_path = 1;
+	p -> fused = nullptr;
+
+	if( p -> is_lancir || p -> ch != 4 || !chain_ok( p -> h ) ||
+		!chain_ok( p -> v ))
+	{
+		return( AVIRHIP_OK );
+	}
+
+	FusedData* F = new FusedData();
+	F -> fltbuf = nullptr;
+	F -> fused.ok = F -> hpass.ok = F -> vpass.ok = false;
+	p -> fused = F;
+
+	static const int cf[][ 2 ] = { { 32, 64 }, { 32, 32 }, { 64, 32 },
+		{ 32, 16 }, { 64, 16 }, { 16, 16 }, { 16, 8 }, { 8, 8 } };
+	static const int ch[][ 2 ] = { { 64, 8 }, { 128, 4 }, { 64, 4 }, { 32, 4 },
+		{ 32, 2 }, { 16, 2 }, { 8, 1 } };
+	static const int cv[][ 2 ] = { { 32, 32 }, { 64, 16 }, { 32, 16 },
+		{ 32, 8 }, { 16, 8 }, { 16, 4 }, { 8, 4 } };
+
+	int rc = pick_geom( p, F, true, true, cf, 8, F -> fused );
+	if( rc == 0 ) rc = pick_geom( p, F, true, false, ch, 7, F -> hpass );
+	if( rc == 0 ) rc = pick_geom( p, F, false, true, cv, 7, F -> vpass );
+
+	if( rc != 0 )
+	{
+		fused_release( p );
+		return( rc );
+	}
+
+	const bool two = ( F -> hpass.ok && F -> vpass.ok );
+	p -> fused_ok = ( F -> fused.ok ? 2 : 0 ) | ( two ? 1 : 0 );
+
+	// Upsizing (both axes): the intermediate is the big image -> keep it in
+	// LDS (fused). Downsizing: the intermediate is small and a fused tile's
+	// vertical halo is k times taller -> two passes.
+	const bool up = ( p -> new_w >= p -> src_w && p -> new_h >= p -> src_h );
+
+	if( up )
+	{
+		p -> auto_path = ( F -> fused.ok ? 3 : ( two ? 2 : 1 ));
+	}
+	else
+	{
+		p -> auto_path = ( two ? 2 : ( F -> fused.ok ? 3 : 1 ));
+	}
+
+	return( AVIRHIP_OK );
+}
+
+void fused_release( avirhip_plan* p )
+{
+	FusedData* F = (FusedData*) p -> fused;
+
+	if( F == nullptr )
+	{
+		return;
+	}
+
+	for( size_t i = 0; i < F -> allocs.size(); i++ )
+	{
+		(void) hipFree( F -> allocs[ i ]);
+	}
+
+	delete F;
+	p -> fused = nullptr;
+}
+
+static void fill_ops( const LAxis& ax, int n, TOp* out )
+{
+	for( int i = 0; i < n; i++ )
+	{
+		const LOp& o = ax.ops[ i ];
+		out[ i ].type = o.type; out[ i ].view = o.view;
+		out[ i ].in_len = o.in_len; out[ i ].zs_mmax = o.zs_mmax;
+		out[ i ].rf = o.rf; out[ i ].lat = o.lat; out[ i ].e = o.e;
+		out[ i ].flt = o.d_flt; out[ i ].start = o.d_start;
+		out[ i ].ntaps = o.d_ntaps; out[ i ].coef = o.d_coef;
+		out[ i ].maxtaps = o.maxtaps;
+	}
+}
+
+static int launch_tiles( avirhip_plan* p, const TileGeom& G, bool useh,
+	bool usev, const float* src, long src_ss, float* dst, long dst_ss,
+	int dst_row0, int a, int b, hipStream_t st )
+{
+	// [a, b) = range on the y extent (output rows, or source rows for an
+	// H-only pass)
+	if( b <= a )
+	{
+		return( AVIRHIP_OK );
+	}
+
+	TileParams P;
+	P.nh = ( useh ? (int) p -> h.ops.size() : 0 );
+	P.nv = ( usev ? (int) p -> v.ops.size() : 0 );
+	fill_ops( p -> h, P.nh, P.hop );
+	fill_ops( p -> v, P.nv, P.vop );
+	P.hrng = G.d_hrng; P.vrng = G.d_vrng;
+	P.ntx = G.ntx; P.nty = G.nty;
+	P.ty0 = a / G.th;
+	const int ty1 = ( b - 1 ) / G.th;
+	P.src = src; P.src_ss = src_ss;
+	P.dst = dst; P.dst_ss = dst_ss; P.dst_row0 = dst_row0;
+	P.srow_lo = a; P.srow_hi = b;
+	P.maxA = G.maxA; P.maxB = G.maxB; P.maxC = G.maxC;
+
+	const int ntiles = G.ntx * ( ty1 - P.ty0 + 1 );
+	AVIRHIP_HIPCHECK( hipFuncSetAttribute( (const void*) k_tile,
+		hipFuncAttributeMaxDynamicSharedMemorySize, (int) G.lds ));
+
+	hipLaunchKernelGGL( k_tile, dim3( ntiles ), dim3( 32, 8 ), G.lds, st, P );
+	AVIRHIP_HIPCHECK( hipGetLastError() );
+	return( AVIRHIP_OK );
+}
+
+// mode 3: fused; mode 2: two-pass.
+int fused_run( avirhip_plan* p, int mode, const float* src, long src_stride,
+	float* dst, int row0, int row1, hipStream_t st )
+{
+	FusedData* F = (FusedData*) p -> fused;
+
+	if( F == nullptr || ( mode == 3 && !( p -> fused_ok & 2 )) ||
+		( mode == 2 && !( p -> fused_ok & 1 )) || ( mode != 2 && mode != 3 ))
+	{
+		return( 1 );
+	}
+
+	if(( (uintptr_t) src & 15 ) || ( (uintptr_t) dst & 15 ) ||
+		( src_stride & 3 ))
+	{
+		return( 1 ); // tiled paths need 16-byte aligned rows
+	}
+
+	const long dss = (long) p -> new_w * 4;
+
+	if( mode == 3 )
+	{
+		return( launch_tiles( p, F -> fused, true, true, src, src_stride,
+			dst, dss, row0, row0, row1, st ));
+	}
+
+	// two-pass: which FltBuf rows does the band need?
+	int a = row0, b = row1 - 1;
+
+	for( int i = (int) p -> v.ops.size() - 1; i >= 0; i-- )
+	{
+		int ia, ib;
+		op_need( p -> v.ops[ i ], a, b, ia, ib );
+		a = ia;
+		b = ib;
+	}
+
+	if( F -> fltbuf == nullptr )
+	{
+		void* q;
+		AVIRHIP_HIPCHECK( hipMalloc( &q, (size_t) p -> src_h * p -> new_w *
+			4 * sizeof( float )));
+		F -> allocs.push_back( q );
+		F -> fltbuf = (float*) q;
+	}
+
+	int rc = launch_tiles( p, F -> hpass, true, false, src, src_stride,
+		F -> fltbuf, dss, 0, a, b + 1, st );
+
+	if( rc != 0 )
+	{
+		return( rc );
+	}
+
+	return( launch_tiles( p, F -> vpass, false, true, F -> fltbuf, dss, dst,
+		dss, row0, row0, row1, st ));
+}
+
+} // namespace avirhip

@@ -102,8 +102,9 @@ struct avirhip_plan
 	int l_unity;
 
 	int path;       // forced path (0 = auto)
-	int fused_ok;   // fused kernel applicable
-	void* fused;    // fused-kernel private data
+	int fused_ok;   // tiled kernels: bit 0 = two-pass (path 2), bit 1 = fused (3)
+	int auto_path;  // path taken when `path` == 0
+	void* fused;    // tiled-kernel private data
 
 	// scratch (device), lazily sized
 	std::vector< void* > allocs;
@@ -139,7 +140,9 @@ int launch_lancir_generic( const avirhip_plan* p, const void* src, void* dst,
 // fused.hip
 int fused_prepare( avirhip_plan* p );
 void fused_release( avirhip_plan* p );
-int fused_run( avirhip_plan* p, const float* src, float* dst, int row0,
-	int row1, hipStream_t st );
+// Runs path `mode` (2 = two-pass tiled, 3 = fused). Returns 1 when the call
+// cannot take a tiled path (e.g. unaligned rows) and the generic path should.
+int fused_run( avirhip_plan* p, int mode, const float* src, long src_stride,
+	float* dst, int row0, int row1, hipStream_t st );
 
 } // namespace avirhip

@@ -81,6 +81,33 @@ def test_avir_f32_generic_path(sw, sh, nw, nh, ch, bits):
     _assert_same(got, want, "generic")
 
 
+TILED = [c for c in SMALL if c[4] == 4] + [
+    (1000, 700, 640, 480, 4), (333, 222, 700, 500, 4), (700, 500, 333, 222, 4),
+    (640, 480, 161, 97, 4), (129, 65, 1290, 650, 4), (64, 3000, 130, 1500, 4),
+    (3000, 64, 1500, 130, 4)]
+
+
+@pytest.mark.parametrize("path", [abi.PATH_TILED, abi.PATH_FUSED])
+@pytest.mark.parametrize("bits", [8, 16])
+@pytest.mark.parametrize("sw,sh,nw,nh,ch", TILED)
+def test_avir_f32_tiled_paths(sw, sh, nw, nh, ch, bits, path):
+    """LDS-tiled kernels (two-pass and fused) on RGBA plans, every ratio
+    class; build modes whose plans contain a filtered upsample are refused by
+    set_path and run on the generic path instead."""
+    src = rb.lcg_f32((sh, sw, ch), seed=4321 + nw)
+    for mode in (-1, 1, 3):
+        if mode == 3 and bits == 16:
+            continue
+        want = _checker_avir(src, nw, nh, resbits=bits, build_mode=mode)
+        try:
+            got = _run_avir(src, nw, nh, resbits=bits, build_mode=mode,
+                            path=path)
+        except avir_amd.AvirHipError as e:
+            assert "cannot run this plan" in str(e)
+            continue
+        _assert_same(got, want, "path %d mode %d" % (path, mode))
+
+
 @pytest.mark.parametrize("bits", [8, 16])
 @pytest.mark.parametrize("sw,sh,nw,nh,ch", SMALL)
 def test_avir_f32_auto_path(sw, sh, nw, nh, ch, bits):
@@ -175,14 +202,17 @@ def test_band_execution_matches_full():
         r = avir_amd.CImageResizer(16)
         full = r.resize(src, nw, nh)
         p = r.plan(sw, sh, nw, nh, 4)
-        for g in (2, 3, 8):
-            cuts = [nh * i // g for i in range(g + 1)]
-            for a, b in zip(cuts[:-1], cuts[1:]):
-                band = np.empty((b - a, nw, 4), np.float32)
-                abi.check(lib.avirhip_resize_band(
-                    p, src.ctypes.data, abi.MEM_HOST, band.ctypes.data,
-                    abi.MEM_HOST, a, b, None), "band")
-                _assert_same(band, full[a:b], "band [%d,%d)" % (a, b))
+        for path in (abi.PATH_GENERIC, abi.PATH_TILED, abi.PATH_FUSED):
+            abi.check(lib.avirhip_plan_set_path(p, path), "set_path")
+            for g in (2, 3, 8):
+                cuts = [nh * i // g for i in range(g + 1)]
+                for a, b in zip(cuts[:-1], cuts[1:]):
+                    band = np.empty((b - a, nw, 4), np.float32)
+                    abi.check(lib.avirhip_resize_band(
+                        p, src.ctypes.data, abi.MEM_HOST, band.ctypes.data,
+                        abi.MEM_HOST, a, b, None), "band")
+                    _assert_same(band, full[a:b],
+                                 "path %d band [%d,%d)" % (path, a, b))
 
 
 def test_zero_sized_and_errors():
