@@ -16,7 +16,7 @@ MEM_HOST, MEM_DEVICE = 0, 1
 STEP_FIR, STEP_UP_ZEROSTUFF, STEP_UP_FILTERED, STEP_RESIZE, STEP_RESIZE2 = range(5)
 STEP_NAMES = ["FIR", "UP_ZEROSTUFF", "UP_FILTERED", "RESIZE", "RESIZE2"]
 
-PATH_AUTO, PATH_GENERIC, PATH_TILED, PATH_FUSED = 0, 1, 2, 3
+PATH_AUTO, PATH_GENERIC, PATH_TILED, PATH_FUSED, PATH_UP2 = 0, 1, 2, 3, 4
 
 _fp = C.POINTER(C.c_float)
 _ip = C.POINTER(C.c_int32)

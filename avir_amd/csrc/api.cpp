@@ -571,9 +571,16 @@ static int exec_device( avirhip_plan* p, const void* src, void* dst,
 	const int path = ( p -> path != 0 ? p -> path : p -> auto_path );
 	rc = 1;
 
-	if( path == 2 || path == 3 )
+	if( path >= 2 && path <= 4 )
 	{
-		rc = fused_run( p, path, fsrc, sstride, fdst, row0, row1, st );
+		if( path == 4 )
+		{
+			rc = up2_run( p, fsrc, sstride, fdst, row0, row1, st );
+		}
+		else
+		{
+			rc = fused_run( p, path, fsrc, sstride, fdst, row0, row1, st );
+		}
 
 		if( rc == 1 && p -> path != 0 )
 		{
@@ -673,7 +680,7 @@ static avirhip_plan* new_plan()
 {
 	avirhip_plan* p = new avirhip_plan();
 	p -> is_lancir = 0; p -> device = 0;
-	p -> path = 0; p -> fused_ok = 0; p -> auto_path = 1; p -> fused = nullptr;
+	p -> path = 0; p -> fused_ok = 0; p -> auto_path = 1; p -> fused = nullptr; p -> up2 = nullptr;
 	p -> packed = nullptr; p -> resbuf = nullptr;
 	p -> stage_src = nullptr; p -> stage_dst = nullptr;
 	p -> stage_src_bytes = 0; p -> stage_dst_bytes = 0;
@@ -770,6 +777,7 @@ int avirhip_plan_create( const avirhip_plan_desc* d, avirhip_plan** out )
 	if( rc == 0 ) rc = upload_axis( p, p -> h );
 	if( rc == 0 ) rc = upload_axis( p, p -> v );
 	if( rc == 0 ) rc = fused_prepare( p );
+	if( rc == 0 ) rc = up2_prepare( p );
 
 	if( rc != 0 )
 	{
@@ -881,6 +889,7 @@ void avirhip_plan_destroy( avirhip_plan* p )
 	}
 
 	fused_release( p );
+	up2_release( p );
 
 	for( size_t i = 0; i < p -> allocs.size(); i++ )
 	{
@@ -892,7 +901,7 @@ void avirhip_plan_destroy( avirhip_plan* p )
 
 int avirhip_plan_set_path( avirhip_plan* p, int path )
 {
-	if( p == nullptr || path < 0 || path > 3 )
+	if( p == nullptr || path < 0 || path > 4 )
 	{
 		set_error( "bad path" );
 		return( AVIRHIP_EINVAL );
@@ -900,6 +909,7 @@ int avirhip_plan_set_path( avirhip_plan* p, int path )
 
 	if(( path == 2 && !( p -> fused_ok & 1 )) ||
 		( path == 3 && !( p -> fused_ok & 2 )) ||
+		( path == 4 && !( p -> fused_ok & 4 )) ||
 		( p -> is_lancir && path > 1 ))
 	{
 		set_error( "path %d cannot run this plan", path );

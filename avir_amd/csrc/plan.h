@@ -105,6 +105,7 @@ struct avirhip_plan
 	int fused_ok;   // tiled kernels: bit 0 = two-pass (path 2), bit 1 = fused (3)
 	int auto_path;  // path taken when `path` == 0
 	void* fused;    // tiled-kernel private data
+	void* up2;      // exact-2x marching kernel private data (fused_ok bit 2)
 
 	// scratch (device), lazily sized
 	std::vector< void* > allocs;
@@ -144,5 +145,11 @@ void fused_release( avirhip_plan* p );
 // cannot take a tiled path (e.g. unaligned rows) and the generic path should.
 int fused_run( avirhip_plan* p, int mode, const float* src, long src_stride,
 	float* dst, int row0, int row1, hipStream_t st );
+
+// up2.hip: specialised exact-2x RGBA kernel (path 4)
+int up2_prepare( avirhip_plan* p );
+void up2_release( avirhip_plan* p );
+int up2_run( avirhip_plan* p, const float* src, long src_stride, float* dst,
+	int row0, int row1, hipStream_t st );
 
 } // namespace avirhip

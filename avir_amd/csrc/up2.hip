@@ -1,0 +1,384 @@
+// up2.hip -- the headline kernel: exact 2x RGBA upsizing (cfg2/cfg3 of
+// BASELINE.json), H pass + V pass fused in ONE launch.
+//
+// What the plan looks like (default parameters, mode 1 or 3), per
+// axis with source length W:
+//   C[m]  = f0*S[m-3] + sum_{i=1..3} f_i*(S[m-3+i] + S[m-3-i])     (7-tap FIR,
+//           EdgePixelCount 3; doFilter avir.h:3748)
+//   up    = zero-stuffed 2x view of C                   (doUpsample, 3260-3402)
+//   o[2q]   = 0 + sum_{t<12} Fe[t]*C[q-3+t]             (doResize2, 4114-4328:
+//   o[2q+1] = 0 + sum_{t<12} Fo[t]*C[q-2+t]              one bank phase, x = 0)
+// with every index clamped to the producing array's range. Because edge
+// replication makes Sext[u] = S[clamp(u)] constant outside the image, the
+// clamped C equals FIR(Sext[m-6..m]) for EVERY m -- so no border special
+// cases exist anywhere below, only clamped source loads.
+//
+// Structure ("marching strip"): a workgroup of 128 threads owns a strip of 128
+// output columns and a chunk of output rows, and marches down the source 16
+// rows at a time:
+//   S   16 source rows x 82 px (halo 9+9), coalesced 16 B/lane   HBM -> LDS
+//   H1  C rows  = FIR7 along x                                   LDS -> LDS
+//   H2  T rows  = 12-tap even/odd interpolation along x (2 outputs per
+//       thread share one 13-pixel window)                        LDS -> LDS
+//   V   each thread owns ONE output column and keeps the vertical FIR window
+//       (7 px) and the vertical interpolation window (13 px) in REGISTERS,
+//       rotating through statically-indexed ring slots (the 16-row step is
+//       fully unrolled), consuming one T row per step from LDS and emitting
+//       two output rows per step straight to HBM (coalesced 2 KiB per row).
+// The horizontally resized intermediate (the reference's FltBuf) never exists
+// in memory, vertical work is never recomputed inside a chunk, and all 56
+// filter coefficients live in SGPRs (wave-uniform kernel arguments).
+//
+// Arithmetic contract: -ffp-contract=off, mul then add in the reference's tap
+// order, interpolation sums started from +0.0f => bit-identical output.
+
+#include "plan.h"
+#include <algorithm>
+#include <string.h>
+
+namespace avirhip {
+
+typedef float f4 __attribute__(( ext_vector_type( 4 )));
+
+#define U2_TW 128 // output columns per strip == threads per workgroup
+#define U2_RB 16  // source rows per marching step
+#define U2_SW ( U2_TW / 2 + 18 ) // S tile width (px)
+#define U2_CW ( U2_TW / 2 + 12 ) // C tile width (px)
+
+struct Up2Params
+{
+	const float* src; long src_ss; int sw, sh;
+	float* dst; long dst_ss; int dst_row0; int nw, nh;
+	int srow_lo, srow_hi;
+	int nstrips, chunk0, cr; // cr: output rows per chunk (even)
+	const float* coef; // device: [fh 4 | feh 12 | foh 12 | pad 4 | fv 4 | fev 12 | fov 12 | pad 4]
+};
+
+// 28 wave-uniform filter taps of one axis, held in SGPRs for the duration of
+// one phase only. A volatile scalar load keeps the compiler from hoisting all
+// 56 taps of both axes out of the marching loop (which overflowed the SGPR file
+// and spilled ~270 values into VGPR lanes).
+typedef float f8 __attribute__(( ext_vector_type( 8 )));
+
+struct Taps
+{
+	f8 a, b, c; // f[0..3] fe[0..3] | fe[4..11] | fo[0..7]
+	f4 d;       // fo[8..11]
+	__device__ __forceinline__ float f( int i ) const { return( a[ i ]); }
+	__device__ __forceinline__ float fe( int i ) const
+		{ return( i < 4 ? a[ 4 + i ] : b[ i - 4 ]); }
+	__device__ __forceinline__ float fo( int i ) const
+		{ return( i < 8 ? c[ i ] : d[ i - 8 ]); }
+};
+
+__device__ __forceinline__ Taps load_taps( const float* p )
+{
+	Taps t;
+	asm volatile( "s_load_dwordx8 %0, %4, 0x0\n\t"
+		"s_load_dwordx8 %1, %4, 0x20\n\t"
+		"s_load_dwordx8 %2, %4, 0x40\n\t"
+		"s_load_dwordx4 %3, %4, 0x60\n\t"
+		"s_waitcnt lgkmcnt(0)"
+		: "=s"( t.a ), "=s"( t.b ), "=s"( t.c ), "=s"( t.d )
+		: "s"( p ) : "memory" );
+	return( t );
+}
+
+__device__ __forceinline__ int clampi( int i, int hi )
+{
+	return( i < 0 ? 0 : ( i > hi ? hi : i ));
+}
+
+__global__ void __launch_bounds__( U2_TW ) k_up2( const Up2Params P )
+{
+	// S and T share storage: S is dead once H1 has run
+	__shared__ __attribute__(( aligned( 16 ))) f4 sST[ U2_RB * U2_TW ];
+	__shared__ __attribute__(( aligned( 16 ))) f4 sC[ U2_RB * U2_CW ];
+
+	// XCD-aware dealing of (strip, chunk) work items (see fused.hip)
+	const int nwg = gridDim.x;
+	const int b = blockIdx.x;
+	const int xcd = b & 7;
+	const int qd = nwg >> 3;
+	const int rm = nwg & 7;
+	const int item = ( xcd < rm ? xcd * ( qd + 1 ) :
+		rm * ( qd + 1 ) + ( xcd - rm ) * qd ) + ( b >> 3 );
+
+	const int strip = item % P.nstrips;
+	const int chunk = P.chunk0 + item / P.nstrips;
+	const int tid = threadIdx.x;
+
+	const int qx0 = strip * ( U2_TW / 2 );
+	const int qy0 = chunk * ( P.cr >> 1 );
+	const int qy1 = min( qy0 + ( P.cr >> 1 ), P.nh >> 1 );
+	const int u0 = qy0 - 9;               // first Text row index consumed
+	const int nsteps = qy1 - qy0 + 18;    // 6 preload + 12 warm-up + rows
+	const int xo = qx0 * 2 + tid;         // this thread's output column
+	const bool xok = ( xo < P.nw );
+
+	f4 tw[ 8 ];  // ring of the last T values of this column   (slot u & 7)
+	f4 cw[ 16 ]; // ring of the last C2 values of this column  (slot u & 15)
+
+#pragma unroll
+	for( int i = 0; i < 8; i++ ) tw[ i ] = (f4) 0.0f;
+#pragma unroll
+	for( int i = 0; i < 16; i++ ) cw[ i ] = (f4) 0.0f;
+
+	for( int sb = 0; sb < nsteps; sb += U2_RB )
+	{
+		const int ub = u0 + sb;
+
+		// ---- S: 16 rows x 82 px, clamped coordinates, coalesced along x
+		for( int i = tid; i < U2_RB * U2_SW; i += U2_TW )
+		{
+			const int r = i / U2_SW;
+			const int c = i - r * U2_SW;
+			const int sy = clampi( ub + r, P.sh - 1 );
+			const int sx = clampi( qx0 - 9 + c, P.sw - 1 );
+			sST[ r * U2_SW + c ] = *(const f4*) ( P.src + (long) sy *
+				P.src_ss + (long) sx * 4 );
+		}
+
+		__syncthreads();
+
+		// ---- H1: C[m] for m = qx0-3 .. qx0+72: window S[c .. c+6]
+		const Taps H = load_taps( P.coef );
+
+		for( int i = tid; i < U2_RB * U2_CW; i += U2_TW )
+		{
+			const int r = i / U2_CW;
+			const int c = i - r * U2_CW;
+			const f4* s = &sST[ r * U2_SW + c ];
+			f4 a = H.f( 0 ) * s[ 3 ];
+			a = a + H.f( 1 ) * ( s[ 4 ] + s[ 2 ]);
+			a = a + H.f( 2 ) * ( s[ 5 ] + s[ 1 ]);
+			a = a + H.f( 3 ) * ( s[ 6 ] + s[ 0 ]);
+			sC[ r * U2_CW + c ] = a;
+		}
+
+		__syncthreads();
+
+		// ---- H2: T[2q], T[2q+1] from the 13-px window C[qq .. qq+12]
+		{
+			const int qq = tid & 63;
+
+			for( int r = ( tid >> 6 ); r < U2_RB; r += 2 )
+			{
+				const f4* c = &sC[ r * U2_CW + qq ];
+				f4 w[ 13 ];
+#pragma unroll
+				for( int t = 0; t < 13; t++ ) w[ t ] = c[ t ];
+
+				f4 e = (f4) 0.0f;
+				f4 o = (f4) 0.0f;
+#pragma unroll
+				for( int t = 0; t < 12; t++ )
+				{
+					e = e + H.fe( t ) * w[ t ];
+					o = o + H.fo( t ) * w[ t + 1 ];
+				}
+
+				sST[ r * U2_TW + qq * 2 ] = e;
+				sST[ r * U2_TW + qq * 2 + 1 ] = o;
+			}
+		}
+
+		__syncthreads();
+
+		// ---- V: one column per thread, 16 statically unrolled marching steps
+		const Taps V = load_taps( P.coef + 32 );
+#pragma unroll
+		for( int rr = 0; rr < U2_RB; rr++ )
+		{
+			const int u = ub + rr;
+			tw[ rr & 7 ] = sST[ rr * U2_TW + tid ];
+
+			f4 c2 = V.f( 0 ) * tw[ ( rr - 3 ) & 7 ];
+			c2 = c2 + V.f( 1 ) * ( tw[ ( rr - 2 ) & 7 ] + tw[ ( rr - 4 ) & 7 ]);
+			c2 = c2 + V.f( 2 ) * ( tw[ ( rr - 1 ) & 7 ] + tw[ ( rr - 5 ) & 7 ]);
+			c2 = c2 + V.f( 3 ) * ( tw[ rr & 7 ] + tw[ ( rr - 6 ) & 7 ]);
+			cw[ rr & 15 ] = c2;
+
+			const int qy = u - 9;
+
+			if( qy >= qy0 && qy < qy1 )
+			{
+				f4 e = (f4) 0.0f;
+				f4 o = (f4) 0.0f;
+#pragma unroll
+				for( int t = 0; t < 12; t++ )
+				{
+					e = e + V.fe( t ) * cw[ ( rr - 12 + t ) & 15 ];
+					o = o + V.fo( t ) * cw[ ( rr - 11 + t ) & 15 ];
+				}
+
+				const int y0 = qy * 2;
+
+				if( xok )
+				{
+					if( y0 >= P.srow_lo && y0 < P.srow_hi )
+					{
+						*(f4*) ( P.dst + (long) ( y0 - P.dst_row0 ) *
+							P.dst_ss + (long) xo * 4 ) = e;
+					}
+
+					if( y0 + 1 >= P.srow_lo && y0 + 1 < P.srow_hi )
+					{
+						*(f4*) ( P.dst + (long) ( y0 + 1 - P.dst_row0 ) *
+							P.dst_ss + (long) xo * 4 ) = o;
+					}
+				}
+			}
+		}
+
+		__syncthreads();
+	}
+}
+
+// ---------------------------------------------------------------------
+// host side: recognise the plan shape and extract the 28 taps per axis
+// ---------------------------------------------------------------------
+
+struct Up2Axis
+{
+	float f[ 4 ], fe[ 12 ], fo[ 12 ];
+};
+
+static bool match_axis( const LAxis& ax, Up2Axis& A )
+{
+	if( ax.ops.size() != 2 || ax.dst_len != ax.src_len * 2 )
+	{
+		return( false );
+	}
+
+	const LOp& a = ax.ops[ 0 ];
+	const LOp& g = ax.ops[ 1 ];
+
+	if( a.type != OP_FIR || a.view != VIEW_CLAMP || a.rf != 1 || a.lat != 3 ||
+		a.e != 3 || a.in_len != ax.src_len || a.out_len != ax.src_len + 6 ||
+		g.type != OP_GATHER || g.view != VIEW_ZS || g.maxtaps != 12 ||
+		g.in_len != a.out_len || g.out_len != ax.dst_len )
+	{
+		return( false );
+	}
+
+	for( int i = 0; i < 4; i++ )
+	{
+		A.f[ i ] = a.h_flt[ i ];
+	}
+
+	for( int t = 0; t < 12; t++ )
+	{
+		A.fe[ t ] = g.h_coef[ t ];
+		A.fo[ t ] = g.h_coef[ 12 + t ];
+	}
+
+	for( int j = 0; j < g.out_len; j++ )
+	{
+		const int q = j >> 1;
+		const int st = ( j & 1 ? q - 2 : q - 3 );
+		const float* cf = &g.h_coef[ (size_t) j * 12 ];
+		const float* rf = ( j & 1 ? A.fo : A.fe );
+
+		if( g.h_start[ j ] != st || g.h_ntaps[ j ] != 12 ||
+			st + 11 > g.zs_mmax || memcmp( cf, rf, 12 * sizeof( float )) != 0 )
+		{
+			return( false );
+		}
+	}
+
+	return( true );
+}
+
+struct Up2Data
+{
+	Up2Axis h, v;
+	float* d_coef;
+};
+
+int up2_prepare( avirhip_plan* p )
+{
+	p -> up2 = nullptr;
+
+	if( p -> is_lancir || p -> ch != 4 )
+	{
+		return( AVIRHIP_OK );
+	}
+
+	Up2Data* D = new Up2Data();
+
+	if( match_axis( p -> h, D -> h ) && match_axis( p -> v, D -> v ))
+	{
+		float hc[ 64 ] = { 0 };
+		memcpy( hc, D -> h.f, 4 * sizeof( float ));
+		memcpy( hc + 4, D -> h.fe, 12 * sizeof( float ));
+		memcpy( hc + 16, D -> h.fo, 12 * sizeof( float ));
+		memcpy( hc + 32, D -> v.f, 4 * sizeof( float ));
+		memcpy( hc + 36, D -> v.fe, 12 * sizeof( float ));
+		memcpy( hc + 48, D -> v.fo, 12 * sizeof( float ));
+		void* q = nullptr;
+		AVIRHIP_HIPCHECK( hipMalloc( &q, sizeof( hc )));
+		p -> allocs.push_back( q );
+		AVIRHIP_HIPCHECK( hipMemcpy( q, hc, sizeof( hc ),
+			hipMemcpyHostToDevice ));
+		D -> d_coef = (float*) q;
+		p -> up2 = D;
+		p -> fused_ok |= 4;
+		p -> auto_path = 4;
+	}
+	else
+	{
+		delete D;
+	}
+
+	return( AVIRHIP_OK );
+}
+
+void up2_release( avirhip_plan* p )
+{
+	delete (Up2Data*) p -> up2;
+	p -> up2 = nullptr;
+}
+
+int up2_run( avirhip_plan* p, const float* src, long src_stride, float* dst,
+	int row0, int row1, hipStream_t st )
+{
+	const Up2Data* D = (const Up2Data*) p -> up2;
+
+	if( D == nullptr || ( (uintptr_t) src & 15 ) || ( (uintptr_t) dst & 15 ) ||
+		( src_stride & 3 ))
+	{
+		return( 1 );
+	}
+
+	if( row1 <= row0 )
+	{
+		return( AVIRHIP_OK );
+	}
+
+	Up2Params P;
+	P.src = src; P.src_ss = src_stride; P.sw = p -> src_w; P.sh = p -> src_h;
+	P.dst = dst; P.dst_ss = (long) p -> new_w * 4; P.dst_row0 = row0;
+	P.nw = p -> new_w; P.nh = p -> new_h;
+	P.srow_lo = row0; P.srow_hi = row1;
+	P.nstrips = ( p -> new_w + U2_TW - 1 ) / U2_TW;
+
+	// chunk height: enough work items to fill 256 CUs x 3 workgroups about
+	// twice over, but at least 4 marching steps (128 output rows) per chunk so
+	// the 18-row warm-up stays a small fraction
+	int want = ( 2 * 768 + P.nstrips - 1 ) / P.nstrips;
+	int cr = ( p -> new_h + want - 1 ) / want;
+	cr = std::max( 128, ( cr + 31 ) & ~31 );
+	P.cr = cr;
+	P.chunk0 = row0 / cr;
+	const int chunk1 = ( row1 - 1 ) / cr;
+
+	P.coef = D -> d_coef;
+
+	const int items = P.nstrips * ( chunk1 - P.chunk0 + 1 );
+	hipLaunchKernelGGL( k_up2, dim3( items ), dim3( U2_TW ), 0, st, P );
+	AVIRHIP_HIPCHECK( hipGetLastError() );
+	return( AVIRHIP_OK );
+}
+
+} // namespace avirhip

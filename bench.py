@@ -85,7 +85,7 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--path", type=int, default=0,
-                    help="0 auto, 1 generic, 3 fused (A/B testing)")
+                    help="0 auto, 1 generic, 2 two-pass, 3 fused tile, 4 up2 (A/B)")
     ap.add_argument("--no-cpu", action="store_true",
                     help="skip the CPU baseline leg")
     args = ap.parse_args()
@@ -168,7 +168,10 @@ def main():
                    "sharding": "independent frames per GPU (no data-path "
                                "collective)",
                    "exec_path": {1: "generic per-step kernels",
-                                 3: "fused single kernel"}.get(path, str(path))},
+                                 2: "LDS-tiled two-pass kernels",
+                                 3: "LDS-tiled fused kernel",
+                                 4: "exact-2x marching kernel (single launch)"
+                                 }.get(path, str(path))},
     }
 
     # parity spot check on the very buffer that was timed
@@ -186,8 +189,7 @@ def main():
             "traffic": read_traffic(),
             "algorithmic_bytes": ALGO_BYTES,
             "kernel_ms": round(ev_ms, 4),
-            "kernels_per_step": {1: "5 (per-step generic chain)",
-                                 3: "1"}.get(path, "?")}
+            "kernels_per_step": {1: 5, 2: 2, 3: 1, 4: 1}.get(path)}
 
     if world > 1:
         out["band_gather"] = band_gather(lib, plan, src, dev, world, rank, dist,

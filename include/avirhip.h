@@ -181,11 +181,12 @@ int avirhip_lancir_plan_create(const avirhip_lancir_desc* desc,
 void avirhip_plan_destroy(avirhip_plan* plan);
 
 /* Plan tuning: force an execution path, for testing and A/B benchmarking.
- * 0 = automatic (fastest applicable), 1 = generic per-step scanline kernels,
- * 2 = tiled two-pass kernels, 3 = fused single-pass kernel. Returns
+ * 0 = automatic (fastest applicable), 1 = generic per-step kernels (every
+ * plan), 2 = LDS-tiled two-pass kernels, 3 = LDS-tiled fused single launch,
+ * 4 = specialised exact-2x RGBA marching kernel (single launch). Returns
  * AVIRHIP_EUNSUPPORTED if the path cannot run this plan. */
 int avirhip_plan_set_path(avirhip_plan* plan, int path);
-/* The path the next execution will take (1..3). */
+/* The path the next execution will take (1..4). */
 int avirhip_plan_get_path(const avirhip_plan* plan);
 
 /* Executes H pass + V pass (+ integer epilogue) of `plan`:

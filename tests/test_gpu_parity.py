@@ -108,6 +108,45 @@ def test_avir_f32_tiled_paths(sw, sh, nw, nh, ch, bits, path):
         _assert_same(got, want, "path %d mode %d" % (path, mode))
 
 
+UP2 = [(37, 21), (64, 48), (300, 200), (129, 65), (1, 1), (5, 300),
+       (300, 5), (257, 255), (640, 480)]
+
+
+@pytest.mark.parametrize("bits", [8, 16])
+@pytest.mark.parametrize("sw,sh", UP2)
+def test_avir_exact_2x_marching_kernel(sw, sh, bits):
+    """The headline kernel (path 4, up2.hip): exact 2x RGBA upsizing, H+V
+    fused in one launch, against the reference bit for bit -- including
+    images smaller than one strip / one marching step and forced mode 3."""
+    src = rb.lcg_f32((sh, sw, 4), seed=2024 + sw)
+    for mode in ((-1, 1, 3) if bits == 8 else (-1, 1)):
+        want = _checker_avir(src, 2 * sw, 2 * sh, resbits=bits,
+                             build_mode=mode)
+        try:
+            got = _run_avir(src, 2 * sw, 2 * sh, resbits=bits,
+                            build_mode=mode, path=abi.PATH_UP2)
+        except avir_amd.AvirHipError as e:
+            # tiny images make the planner pick build modes with a filtered
+            # upsample; those plans are not this kernel's shape
+            assert "cannot run this plan" in str(e) and mode == -1
+            continue
+        _assert_same(got, want, "up2 %dx%d mode %d" % (sw, sh, mode))
+
+
+def test_avir_exact_2x_other_io_types():
+    """u8 / u16 / f64 I/O around the 2x kernel (pack + epilogue kernels)."""
+    for tin, tout in [(np.uint8, np.uint8), (np.uint8, np.float32),
+                      (np.float32, np.uint16), (np.float64, np.float64)]:
+        raw = rb.lcg_u8((100, 150, 4, np.dtype(tin).itemsize), seed=3)
+        src = (raw.view(tin).reshape(100, 150, 4) if np.dtype(tin).kind == "u"
+               else rb.lcg_f32((100, 150, 4), seed=5).astype(tin))
+        want = _checker_avir(src, 300, 200, resbits=8, out_dtype=tout,
+                             build_mode=1)
+        got = _run_avir(src, 300, 200, resbits=8, out_dtype=tout,
+                        build_mode=1, path=abi.PATH_UP2)
+        _assert_same(got, want, "up2 %s->%s" % (np.dtype(tin), np.dtype(tout)))
+
+
 @pytest.mark.parametrize("bits", [8, 16])
 @pytest.mark.parametrize("sw,sh,nw,nh,ch", SMALL)
 def test_avir_f32_auto_path(sw, sh, nw, nh, ch, bits):
@@ -197,12 +236,16 @@ def test_band_execution_matches_full():
     rows of a full resize."""
     import ctypes as C
     lib = abi.load()
-    for (sw, sh, nw, nh) in [(300, 200, 640, 431), (640, 431, 300, 200)]:
+    for (sw, sh, nw, nh) in [(300, 200, 640, 431), (640, 431, 300, 200),
+                             (320, 431, 640, 862)]:
         src = rb.lcg_f32((sh, sw, 4), seed=77)
         r = avir_amd.CImageResizer(16)
         full = r.resize(src, nw, nh)
         p = r.plan(sw, sh, nw, nh, 4)
-        for path in (abi.PATH_GENERIC, abi.PATH_TILED, abi.PATH_FUSED):
+        paths = [abi.PATH_GENERIC, abi.PATH_TILED, abi.PATH_FUSED]
+        if nw == 2 * sw and nh == 2 * sh:
+            paths.append(abi.PATH_UP2)
+        for path in paths:
             abi.check(lib.avirhip_plan_set_path(p, path), "set_path")
             for g in (2, 3, 8):
                 cuts = [nh * i // g for i in range(g + 1)]
