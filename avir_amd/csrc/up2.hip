@@ -50,7 +50,7 @@ struct Up2Params
 	const float* src; long src_ss; int sw, sh;
 	float* dst; long dst_ss; int dst_row0; int nw, nh;
 	int srow_lo, srow_hi;
-	int nstrips, chunk0, cr; // cr: output rows per chunk (even)
+	int nstrips, chunk0, cq; // cq: source rows (output row pairs) per chunk
 	const float* coef; // device: [fh 4 | feh 12 | foh 12 | pad 4 | fv 4 | fev 12 | fov 12 | pad 4]
 };
 
@@ -109,12 +109,15 @@ __global__ void __launch_bounds__( U2_TW ) k_up2( const Up2Params P )
 	const int tid = threadIdx.x;
 
 	const int qx0 = strip * ( U2_TW / 2 );
-	const int qy0 = chunk * ( P.cr >> 1 );
-	const int qy1 = min( qy0 + ( P.cr >> 1 ), P.nh >> 1 );
+	const int qy0 = chunk * P.cq;
+	const int qy1 = min( qy0 + P.cq, P.nh >> 1 );
 	const int u0 = qy0 - 9;               // first Text row index consumed
 	const int nsteps = qy1 - qy0 + 18;    // 6 preload + 12 warm-up + rows
 	const int xo = qx0 * 2 + tid;         // this thread's output column
-	const bool xok = ( xo < P.nw );
+	// rows this work item may store: its chunk, clipped to the band
+	const int ylo = max( qy0 * 2, P.srow_lo );
+	const int yhi = ( xo < P.nw ? min( qy1 * 2, P.srow_hi ) : ylo );
+	float* const dcol = P.dst + (long) xo * 4 - (long) P.dst_row0 * P.dst_ss;
 
 	f4 tw[ 8 ];  // ring of the last T values of this column   (slot u & 7)
 	f4 cw[ 16 ]; // ring of the last C2 values of this column  (slot u & 15)
@@ -124,19 +127,47 @@ __global__ void __launch_bounds__( U2_TW ) k_up2( const Up2Params P )
 #pragma unroll
 	for( int i = 0; i < 16; i++ ) cw[ i ] = (f4) 0.0f;
 
-	for( int sb = 0; sb < nsteps; sb += U2_RB )
-	{
-		const int ub = u0 + sb;
+	// Source pixels of the NEXT marching step are fetched into registers while
+	// the current step's vertical phase computes (HBM latency hidden behind
+	// ~7k cycles of VALU work); they are written to LDS at the top of the loop.
+	constexpr int NPRE = ( U2_RB * U2_SW + U2_TW - 1 ) / U2_TW; // 11
+	f4 pre[ NPRE ];
 
-		// ---- S: 16 rows x 82 px, clamped coordinates, coalesced along x
-		for( int i = tid; i < U2_RB * U2_SW; i += U2_TW )
+	auto prefetch = [&]( const int ub )
+	{
+#pragma unroll
+		for( int k = 0; k < NPRE; k++ )
 		{
+			const int i = tid + k * U2_TW;
 			const int r = i / U2_SW;
 			const int c = i - r * U2_SW;
 			const int sy = clampi( ub + r, P.sh - 1 );
 			const int sx = clampi( qx0 - 9 + c, P.sw - 1 );
-			sST[ r * U2_SW + c ] = *(const f4*) ( P.src + (long) sy *
-				P.src_ss + (long) sx * 4 );
+
+			if( i < U2_RB * U2_SW )
+			{
+				pre[ k ] = *(const f4*) ( P.src + (long) sy * P.src_ss +
+					(long) sx * 4 );
+			}
+		}
+	};
+
+	prefetch( u0 );
+
+	for( int sb = 0; sb < nsteps; sb += U2_RB )
+	{
+		const int ub = u0 + sb;
+
+		// ---- S: 16 rows x 82 px (clamped coordinates) registers -> LDS
+#pragma unroll
+		for( int k = 0; k < NPRE; k++ )
+		{
+			const int i = tid + k * U2_TW;
+
+			if( i < U2_RB * U2_SW )
+			{
+				sST[ i ] = pre[ k ];
+			}
 		}
 
 		__syncthreads();
@@ -186,12 +217,23 @@ __global__ void __launch_bounds__( U2_TW ) k_up2( const Up2Params P )
 		__syncthreads();
 
 		// ---- V: one column per thread, 16 statically unrolled marching steps
+		if( sb + U2_RB < nsteps )
+		{
+			prefetch( ub + U2_RB );
+		}
+
 		const Taps V = load_taps( P.coef + 32 );
+		tw[ 0 ] = sST[ tid ];
 #pragma unroll
 		for( int rr = 0; rr < U2_RB; rr++ )
 		{
 			const int u = ub + rr;
-			tw[ rr & 7 ] = sST[ rr * U2_TW + tid ];
+
+			if( rr + 1 < U2_RB )
+			{
+				// ring slot (rr+1)&7 holds T[u-7], already outside the window
+				tw[ ( rr + 1 ) & 7 ] = sST[ ( rr + 1 ) * U2_TW + tid ];
+			}
 
 			f4 c2 = V.f( 0 ) * tw[ ( rr - 3 ) & 7 ];
 			c2 = c2 + V.f( 1 ) * ( tw[ ( rr - 2 ) & 7 ] + tw[ ( rr - 4 ) & 7 ]);
@@ -199,9 +241,9 @@ __global__ void __launch_bounds__( U2_TW ) k_up2( const Up2Params P )
 			c2 = c2 + V.f( 3 ) * ( tw[ rr & 7 ] + tw[ ( rr - 6 ) & 7 ]);
 			cw[ rr & 15 ] = c2;
 
-			const int qy = u - 9;
+			const int y0 = ( u - 9 ) * 2;
 
-			if( qy >= qy0 && qy < qy1 )
+			if( y0 + 1 >= ylo && y0 < yhi )
 			{
 				f4 e = (f4) 0.0f;
 				f4 o = (f4) 0.0f;
@@ -212,21 +254,16 @@ __global__ void __launch_bounds__( U2_TW ) k_up2( const Up2Params P )
 					o = o + V.fo( t ) * cw[ ( rr - 11 + t ) & 15 ];
 				}
 
-				const int y0 = qy * 2;
+				float* const dp = dcol + (long) y0 * P.dst_ss;
 
-				if( xok )
+				if( y0 >= ylo )
 				{
-					if( y0 >= P.srow_lo && y0 < P.srow_hi )
-					{
-						*(f4*) ( P.dst + (long) ( y0 - P.dst_row0 ) *
-							P.dst_ss + (long) xo * 4 ) = e;
-					}
+					*(f4*) dp = e;
+				}
 
-					if( y0 + 1 >= P.srow_lo && y0 + 1 < P.srow_hi )
-					{
-						*(f4*) ( P.dst + (long) ( y0 + 1 - P.dst_row0 ) *
-							P.dst_ss + (long) xo * 4 ) = o;
-					}
+				if( y0 + 1 < yhi )
+				{
+					*(f4*) ( dp + P.dst_ss ) = o;
 				}
 			}
 		}
@@ -363,13 +400,15 @@ int up2_run( avirhip_plan* p, const float* src, long src_stride, float* dst,
 	P.srow_lo = row0; P.srow_hi = row1;
 	P.nstrips = ( p -> new_w + U2_TW - 1 ) / U2_TW;
 
-	// chunk height: enough work items to fill 256 CUs x 3 workgroups about
-	// twice over, but at least 4 marching steps (128 output rows) per chunk so
-	// the 18-row warm-up stays a small fraction
-	int want = ( 2 * 768 + P.nstrips - 1 ) / P.nstrips;
-	int cr = ( p -> new_h + want - 1 ) / want;
-	cr = std::max( 128, ( cr + 31 ) & ~31 );
-	P.cr = cr;
+	// Chunk height. A chunk of cq source rows costs cq + 18 marching steps (6
+	// preload + 12 warm-up) in units of 16, so cq = 16k - 18 wastes nothing.
+	// Aim for about two rounds of 256 CUs x 3 resident workgroups, but keep
+	// k >= 5 so the warm-up stays below a quarter of the horizontal work.
+	const int want = ( 2 * 768 + P.nstrips - 1 ) / P.nstrips;
+	int k16 = (( p -> src_h + want - 1 ) / want + 18 + 15 ) / 16;
+	k16 = std::max( 5, k16 );
+	P.cq = k16 * 16 - 18;
+	const int cr = P.cq * 2;
 	P.chunk0 = row0 / cr;
 	const int chunk1 = ( row1 - 1 ) / cr;
 
