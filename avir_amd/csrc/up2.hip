@@ -35,13 +35,17 @@
 #include "plan.h"
 #include <algorithm>
 #include <string.h>
+#include <stdlib.h>
+#include <type_traits>
 
 namespace avirhip {
 
 typedef float f4 __attribute__(( ext_vector_type( 4 )));
 
 #define U2_TW 128 // output columns per strip == threads per workgroup
-#define U2_RB 16  // source rows per marching step
+#ifndef U2_RB
+#define U2_RB 8   // source rows per marching step (8 or 16)
+#endif
 #define U2_SW ( U2_TW / 2 + 18 ) // S tile width (px)
 #define U2_CW ( U2_TW / 2 + 12 ) // C tile width (px)
 
@@ -51,6 +55,7 @@ struct Up2Params
 	float* dst; long dst_ss; int dst_row0; int nw, nh;
 	int srow_lo, srow_hi;
 	int nstrips, chunk0, cq; // cq: source rows (output row pairs) per chunk
+	int dbg; // timing ablations (AVIRHIP_UP2_DBG): 1 no stores, 2 no H, 4 no V emit
 	const float* coef; // device: [fh 4 | feh 12 | foh 12 | pad 4 | fv 4 | fev 12 | fov 12 | pad 4]
 };
 
@@ -129,8 +134,8 @@ __global__ void __launch_bounds__( U2_TW ) k_up2( const Up2Params P )
 
 	// Source pixels of the NEXT marching step are fetched into registers while
 	// the current step's vertical phase computes (HBM latency hidden behind
-	// ~7k cycles of VALU work); they are written to LDS at the top of the loop.
-	constexpr int NPRE = ( U2_RB * U2_SW + U2_TW - 1 ) / U2_TW; // 11
+	// thousands of cycles of VALU work); they go to LDS at the top of a step.
+	constexpr int NPRE = ( U2_RB * U2_SW + U2_TW - 1 ) / U2_TW;
 	f4 pre[ NPRE ];
 
 	auto prefetch = [&]( const int ub )
@@ -152,13 +157,13 @@ __global__ void __launch_bounds__( U2_TW ) k_up2( const Up2Params P )
 		}
 	};
 
-	prefetch( u0 );
-
-	for( int sb = 0; sb < nsteps; sb += U2_RB )
+	// One marching step of U2_RB source rows. R0 = ring phase of its first
+	// row (compile-time), so every ring access below is a fixed register.
+	auto march = [&]( auto R0C, const int ub, const bool more )
 	{
-		const int ub = u0 + sb;
+		constexpr int R0 = decltype( R0C )::value;
 
-		// ---- S: 16 rows x 82 px (clamped coordinates) registers -> LDS
+		// ---- S: U2_RB rows x 82 px (clamped coordinates) registers -> LDS
 #pragma unroll
 		for( int k = 0; k < NPRE; k++ )
 		{
@@ -172,6 +177,8 @@ __global__ void __launch_bounds__( U2_TW ) k_up2( const Up2Params P )
 
 		__syncthreads();
 
+		if( !( P.dbg & 2 ))
+		{
 		// ---- H1: C[m] for m = qx0-3 .. qx0+72: window S[c .. c+6]
 		const Taps H = load_taps( P.coef );
 
@@ -215,60 +222,93 @@ __global__ void __launch_bounds__( U2_TW ) k_up2( const Up2Params P )
 		}
 
 		__syncthreads();
+		}
 
-		// ---- V: one column per thread, 16 statically unrolled marching steps
-		if( sb + U2_RB < nsteps )
+		// ---- V: one column per thread, statically unrolled marching steps
+		if( more )
 		{
 			prefetch( ub + U2_RB );
 		}
 
 		const Taps V = load_taps( P.coef + 32 );
-		tw[ 0 ] = sST[ tid ];
+		tw[ R0 & 7 ] = sST[ tid ];
 #pragma unroll
 		for( int rr = 0; rr < U2_RB; rr++ )
 		{
+			constexpr int dummy = 0; (void) dummy;
 			const int u = ub + rr;
+			const int g = R0 + rr; // ring phase of this row
 
 			if( rr + 1 < U2_RB )
 			{
-				// ring slot (rr+1)&7 holds T[u-7], already outside the window
-				tw[ ( rr + 1 ) & 7 ] = sST[ ( rr + 1 ) * U2_TW + tid ];
+				// ring slot (g+1)&7 holds T[u-7], already outside the window
+				tw[ ( g + 1 ) & 7 ] = sST[ ( rr + 1 ) * U2_TW + tid ];
 			}
 
-			f4 c2 = V.f( 0 ) * tw[ ( rr - 3 ) & 7 ];
-			c2 = c2 + V.f( 1 ) * ( tw[ ( rr - 2 ) & 7 ] + tw[ ( rr - 4 ) & 7 ]);
-			c2 = c2 + V.f( 2 ) * ( tw[ ( rr - 1 ) & 7 ] + tw[ ( rr - 5 ) & 7 ]);
-			c2 = c2 + V.f( 3 ) * ( tw[ rr & 7 ] + tw[ ( rr - 6 ) & 7 ]);
-			cw[ rr & 15 ] = c2;
+			f4 c2 = V.f( 0 ) * tw[ ( g - 3 ) & 7 ];
+			c2 = c2 + V.f( 1 ) * ( tw[ ( g - 2 ) & 7 ] + tw[ ( g - 4 ) & 7 ]);
+			c2 = c2 + V.f( 2 ) * ( tw[ ( g - 1 ) & 7 ] + tw[ ( g - 5 ) & 7 ]);
+			c2 = c2 + V.f( 3 ) * ( tw[ g & 7 ] + tw[ ( g - 6 ) & 7 ]);
+			cw[ g & 15 ] = c2;
 
 			const int y0 = ( u - 9 ) * 2;
 
-			if( y0 + 1 >= ylo && y0 < yhi )
+			if( y0 + 1 >= ylo && y0 < yhi && !( P.dbg & 4 ))
 			{
 				f4 e = (f4) 0.0f;
 				f4 o = (f4) 0.0f;
 #pragma unroll
 				for( int t = 0; t < 12; t++ )
 				{
-					e = e + V.fe( t ) * cw[ ( rr - 12 + t ) & 15 ];
-					o = o + V.fo( t ) * cw[ ( rr - 11 + t ) & 15 ];
+					e = e + V.fe( t ) * cw[ ( g - 12 + t ) & 15 ];
+					o = o + V.fo( t ) * cw[ ( g - 11 + t ) & 15 ];
 				}
 
 				float* const dp = dcol + (long) y0 * P.dst_ss;
 
-				if( y0 >= ylo )
+				if( P.dbg & 1 )
 				{
-					*(f4*) dp = e;
+					if( e.x == 1234.5f && o.y == 0.1234f )
+					{
+						*(f4*) dp = e + o;
+					}
 				}
-
-				if( y0 + 1 < yhi )
+				else
 				{
-					*(f4*) ( dp + P.dst_ss ) = o;
+					if( y0 >= ylo )
+					{
+						*(f4*) dp = e;
+					}
+
+					if( y0 + 1 < yhi )
+					{
+						*(f4*) ( dp + P.dst_ss ) = o;
+					}
 				}
 			}
 		}
 
 		__syncthreads();
+	};
+
+	prefetch( u0 );
+
+	// the ring period is 16 rows: 16 / U2_RB marching steps per trip
+	for( int sb = 0; sb < nsteps; sb += 16 )
+	{
+#if U2_RB == 16
+		march( std::integral_constant< int, 0 >(), u0 + sb, sb + 16 < nsteps );
+#else
+		march( std::integral_constant< int, 0 >(), u0 + sb, sb + 8 < nsteps );
+
+		if( sb + 8 >= nsteps )
+		{
+			break;
+		}
+
+		march( std::integral_constant< int, 8 >(), u0 + sb + 8,
+			sb + 16 < nsteps );
+#endif
 	}
 }
 
@@ -401,18 +441,20 @@ int up2_run( avirhip_plan* p, const float* src, long src_stride, float* dst,
 	P.nstrips = ( p -> new_w + U2_TW - 1 ) / U2_TW;
 
 	// Chunk height. A chunk of cq source rows costs cq + 18 marching steps (6
-	// preload + 12 warm-up) in units of 16, so cq = 16k - 18 wastes nothing.
+	// preload + 12 warm-up) in units of 16, so cq = U2_RB*k - 18 wastes nothing.
 	// Aim for about two rounds of 256 CUs x 3 resident workgroups, but keep
 	// k >= 5 so the warm-up stays below a quarter of the horizontal work.
 	const int want = ( 2 * 768 + P.nstrips - 1 ) / P.nstrips;
-	int k16 = (( p -> src_h + want - 1 ) / want + 18 + 15 ) / 16;
-	k16 = std::max( 5, k16 );
-	P.cq = k16 * 16 - 18;
+	int k16 = (( p -> src_h + want - 1 ) / want + 18 + U2_RB - 1 ) / U2_RB;
+	k16 = std::max( 80 / U2_RB, k16 );
+	P.cq = k16 * U2_RB - 18;
 	const int cr = P.cq * 2;
 	P.chunk0 = row0 / cr;
 	const int chunk1 = ( row1 - 1 ) / cr;
 
 	P.coef = D -> d_coef;
+	const char* dbg = getenv( "AVIRHIP_UP2_DBG" );
+	P.dbg = ( dbg != nullptr ? atoi( dbg ) : 0 );
 
 	const int items = P.nstrips * ( chunk1 - P.chunk0 + 1 );
 	hipLaunchKernelGGL( k_up2, dim3( items ), dim3( U2_TW ), 0, st, P );
