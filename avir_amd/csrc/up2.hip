@@ -13,10 +13,13 @@
 // clamped C equals FIR(Sext[m-6..m]) for EVERY m -- so no border special
 // cases exist anywhere below, only clamped source loads.
 //
-// Structure ("marching strip"): a workgroup of 128 threads owns a strip of 128
-// output columns and a chunk of output rows, and marches down the source 16
-// rows at a time:
-//   S   16 source rows x 82 px (halo 9+9), coalesced 16 B/lane   HBM -> LDS
+// Structure ("marching strip"): a workgroup owns a strip of 128 output columns
+// and a chunk of output rows, and marches down the source U2_RB rows at a time.
+// The unit of work is a HALF pixel (2 of the 4 channels, one 8-byte f2): 256
+// threads = 128 columns x 2 halves. Halving the per-thread state (the register
+// windows below) doubles the resident waves per SIMD, which is what hides the
+// LDS latency of the horizontal phases behind the VALU-bound vertical phase.
+//   S   U2_RB source rows x 82 px (halo 9+9), coalesced 8 B/lane  HBM -> LDS
 //   H1  C rows  = FIR7 along x                                   LDS -> LDS
 //   H2  T rows  = 12-tap even/odd interpolation along x (2 outputs per
 //       thread share one 13-pixel window)                        LDS -> LDS
@@ -41,8 +44,10 @@
 namespace avirhip {
 
 typedef float f4 __attribute__(( ext_vector_type( 4 )));
+typedef float f2 __attribute__(( ext_vector_type( 2 )));
 
-#define U2_TW 128 // output columns per strip == threads per workgroup
+#define U2_TW 128 // output columns per strip
+#define U2_NT ( U2_TW * 2 ) // threads per workgroup: one per half pixel
 #ifndef U2_RB
 #define U2_RB 8   // source rows per marching step (8 or 16)
 #endif
@@ -94,11 +99,12 @@ __device__ __forceinline__ int clampi( int i, int hi )
 	return( i < 0 ? 0 : ( i > hi ? hi : i ));
 }
 
-__global__ void __launch_bounds__( U2_TW ) k_up2( const Up2Params P )
+__global__ void __launch_bounds__( U2_NT ) k_up2( const Up2Params P )
 {
-	// S and T share storage: S is dead once H1 has run
-	__shared__ __attribute__(( aligned( 16 ))) f4 sST[ U2_RB * U2_TW ];
-	__shared__ __attribute__(( aligned( 16 ))) f4 sC[ U2_RB * U2_CW ];
+	// all LDS arrays are indexed in half-pixel (f2) units: px * 2 + half
+	__shared__ __attribute__(( aligned( 16 ))) f2 sS[ U2_RB * U2_SW * 2 ];
+	__shared__ __attribute__(( aligned( 16 ))) f2 sC[ U2_RB * U2_CW * 2 ];
+	__shared__ __attribute__(( aligned( 16 ))) f2 sT[ U2_RB * U2_TW * 2 ];
 
 	// XCD-aware dealing of (strip, chunk) work items (see fused.hip)
 	const int nwg = gridDim.x;
@@ -112,47 +118,67 @@ __global__ void __launch_bounds__( U2_TW ) k_up2( const Up2Params P )
 	const int strip = item % P.nstrips;
 	const int chunk = P.chunk0 + item / P.nstrips;
 	const int tid = threadIdx.x;
+	const int hf = tid & 1;   // which half of the pixel (channels 0-1 / 2-3)
+	const int col = tid >> 1; // column within the strip (vertical phase)
 
 	const int qx0 = strip * ( U2_TW / 2 );
 	const int qy0 = chunk * P.cq;
 	const int qy1 = min( qy0 + P.cq, P.nh >> 1 );
 	const int u0 = qy0 - 9;               // first Text row index consumed
 	const int nsteps = qy1 - qy0 + 18;    // 6 preload + 12 warm-up + rows
-	const int xo = qx0 * 2 + tid;         // this thread's output column
-	// rows this work item may store: its chunk, clipped to the band
+	const int xo = qx0 * 2 + col;         // this thread's output column
+	// rows this work item may store: its chunk, clipped to the band (uniform)
 	const int ylo = max( qy0 * 2, P.srow_lo );
-	const int yhi = ( xo < P.nw ? min( qy1 * 2, P.srow_hi ) : ylo );
-	float* const dcol = P.dst + (long) xo * 4 - (long) P.dst_row0 * P.dst_ss;
+	const int yhi = min( qy1 * 2, P.srow_hi );
+	const bool xok = ( xo < P.nw );
+	const unsigned dlane = (unsigned) ( xo * 4 + hf * 2 ); // float offset in row
 
-	f4 tw[ 8 ];  // ring of the last T values of this column   (slot u & 7)
-	f4 cw[ 16 ]; // ring of the last C2 values of this column  (slot u & 15)
+	f2 tw[ 8 ];  // ring of the last T values of this column   (slot u & 7)
+	f2 cw[ 16 ]; // ring of the last C2 values of this column  (slot u & 15)
 
 #pragma unroll
-	for( int i = 0; i < 8; i++ ) tw[ i ] = (f4) 0.0f;
+	for( int i = 0; i < 8; i++ ) tw[ i ] = (f2) 0.0f;
 #pragma unroll
-	for( int i = 0; i < 16; i++ ) cw[ i ] = (f4) 0.0f;
+	for( int i = 0; i < 16; i++ ) cw[ i ] = (f2) 0.0f;
 
-	// Source pixels of the NEXT marching step are fetched into registers while
-	// the current step's vertical phase computes (HBM latency hidden behind
-	// thousands of cycles of VALU work); they go to LDS at the top of a step.
-	constexpr int NPRE = ( U2_RB * U2_SW + U2_TW - 1 ) / U2_TW;
-	f4 pre[ NPRE ];
+	// Source half-pixels of the NEXT marching step are fetched into registers
+	// while the current step's vertical phase computes (HBM latency hidden
+	// behind the VALU work); they go to LDS at the top of a step.
+	constexpr int SN = U2_RB * U2_SW * 2; // half-pixels in the S tile
+	constexpr int NPRE = ( SN + U2_NT - 1 ) / U2_NT;
+	f2 pre[ NPRE ];
 
 	auto prefetch = [&]( const int ub )
 	{
 #pragma unroll
 		for( int k = 0; k < NPRE; k++ )
 		{
-			const int i = tid + k * U2_TW;
-			const int r = i / U2_SW;
-			const int c = i - r * U2_SW;
+			const int i = tid + k * U2_NT;
+			const int r = i / ( U2_SW * 2 );
+			const int c2 = i - r * ( U2_SW * 2 );
 			const int sy = clampi( ub + r, P.sh - 1 );
-			const int sx = clampi( qx0 - 9 + c, P.sw - 1 );
+			const int sx = clampi( qx0 - 9 + ( c2 >> 1 ), P.sw - 1 );
 
-			if( i < U2_RB * U2_SW )
+			if( i < SN )
 			{
-				pre[ k ] = *(const f4*) ( P.src + (long) sy * P.src_ss +
-					(long) sx * 4 );
+				const unsigned off = (unsigned) sy * (unsigned) P.src_ss +
+					(unsigned) ( sx * 4 + ( c2 & 1 ) * 2 );
+
+				pre[ k ] = *(const f2*) ( P.src + off );
+			}
+		}
+	};
+
+	auto store_pre = [&]()
+	{
+#pragma unroll
+		for( int k = 0; k < NPRE; k++ )
+		{
+			const int i = tid + k * U2_NT;
+
+			if( i < SN )
+			{
+				sS[ i ] = pre[ k ];
 			}
 		}
 	};
@@ -163,52 +189,46 @@ __global__ void __launch_bounds__( U2_TW ) k_up2( const Up2Params P )
 	{
 		constexpr int R0 = decltype( R0C )::value;
 
-		// ---- S: U2_RB rows x 82 px (clamped coordinates) registers -> LDS
-#pragma unroll
-		for( int k = 0; k < NPRE; k++ )
+		// the NEXT step's source tile starts its trip from HBM now and is
+		// parked in LDS just before this step's vertical phase, so the only
+		// vmcnt(0) wait of the loop never waits for this step's own stores
+		if( more )
 		{
-			const int i = tid + k * U2_TW;
-
-			if( i < U2_RB * U2_SW )
-			{
-				sST[ i ] = pre[ k ];
-			}
+			prefetch( ub + U2_RB );
 		}
-
-		__syncthreads();
 
 		if( !( P.dbg & 2 ))
 		{
 		// ---- H1: C[m] for m = qx0-3 .. qx0+72: window S[c .. c+6]
 		const Taps H = load_taps( P.coef );
 
-		for( int i = tid; i < U2_RB * U2_CW; i += U2_TW )
+		for( int i = tid; i < U2_RB * U2_CW * 2; i += U2_NT )
 		{
-			const int r = i / U2_CW;
-			const int c = i - r * U2_CW;
-			const f4* s = &sST[ r * U2_SW + c ];
-			f4 a = H.f( 0 ) * s[ 3 ];
-			a = a + H.f( 1 ) * ( s[ 4 ] + s[ 2 ]);
-			a = a + H.f( 2 ) * ( s[ 5 ] + s[ 1 ]);
-			a = a + H.f( 3 ) * ( s[ 6 ] + s[ 0 ]);
-			sC[ r * U2_CW + c ] = a;
+			const int r = i / ( U2_CW * 2 );
+			const int c2 = i - r * ( U2_CW * 2 ); // C half-pixel index in row
+			const f2* s = &sS[ r * ( U2_SW * 2 ) + c2 ];
+			f2 a = H.f( 0 ) * s[ 6 ];
+			a = a + H.f( 1 ) * ( s[ 8 ] + s[ 4 ]);
+			a = a + H.f( 2 ) * ( s[ 10 ] + s[ 2 ]);
+			a = a + H.f( 3 ) * ( s[ 12 ] + s[ 0 ]);
+			sC[ r * ( U2_CW * 2 ) + c2 ] = a;
 		}
 
 		__syncthreads();
 
 		// ---- H2: T[2q], T[2q+1] from the 13-px window C[qq .. qq+12]
 		{
-			const int qq = tid & 63;
+			const int qh = tid & 127; // (pair index qq) * 2 + half
 
-			for( int r = ( tid >> 6 ); r < U2_RB; r += 2 )
+			for( int r = ( tid >> 7 ); r < U2_RB; r += 2 )
 			{
-				const f4* c = &sC[ r * U2_CW + qq ];
-				f4 w[ 13 ];
+				const f2* c = &sC[ r * ( U2_CW * 2 ) + qh ];
+				f2 w[ 13 ];
 #pragma unroll
-				for( int t = 0; t < 13; t++ ) w[ t ] = c[ t ];
+				for( int t = 0; t < 13; t++ ) w[ t ] = c[ t * 2 ];
 
-				f4 e = (f4) 0.0f;
-				f4 o = (f4) 0.0f;
+				f2 e = (f2) 0.0f;
+				f2 o = (f2) 0.0f;
 #pragma unroll
 				for( int t = 0; t < 12; t++ )
 				{
@@ -216,36 +236,38 @@ __global__ void __launch_bounds__( U2_TW ) k_up2( const Up2Params P )
 					o = o + H.fo( t ) * w[ t + 1 ];
 				}
 
-				sST[ r * U2_TW + qq * 2 ] = e;
-				sST[ r * U2_TW + qq * 2 + 1 ] = o;
+				const int qq = qh >> 1;
+				f2* tp = &sT[ r * ( U2_TW * 2 ) + qq * 4 + ( qh & 1 )];
+				tp[ 0 ] = e;
+				tp[ 2 ] = o;
 			}
 		}
 
 		__syncthreads();
 		}
 
-		// ---- V: one column per thread, statically unrolled marching steps
+		// ---- S of the next step: registers -> LDS (H1 above is done with sS)
 		if( more )
 		{
-			prefetch( ub + U2_RB );
+			store_pre();
 		}
 
+		// ---- V: one half-column per thread, statically unrolled marching
 		const Taps V = load_taps( P.coef + 32 );
-		tw[ R0 & 7 ] = sST[ tid ];
+		tw[ R0 & 7 ] = sT[ tid ];
 #pragma unroll
 		for( int rr = 0; rr < U2_RB; rr++ )
 		{
-			constexpr int dummy = 0; (void) dummy;
 			const int u = ub + rr;
 			const int g = R0 + rr; // ring phase of this row
 
 			if( rr + 1 < U2_RB )
 			{
 				// ring slot (g+1)&7 holds T[u-7], already outside the window
-				tw[ ( g + 1 ) & 7 ] = sST[ ( rr + 1 ) * U2_TW + tid ];
+				tw[ ( g + 1 ) & 7 ] = sT[ ( rr + 1 ) * ( U2_TW * 2 ) + tid ];
 			}
 
-			f4 c2 = V.f( 0 ) * tw[ ( g - 3 ) & 7 ];
+			f2 c2 = V.f( 0 ) * tw[ ( g - 3 ) & 7 ];
 			c2 = c2 + V.f( 1 ) * ( tw[ ( g - 2 ) & 7 ] + tw[ ( g - 4 ) & 7 ]);
 			c2 = c2 + V.f( 2 ) * ( tw[ ( g - 1 ) & 7 ] + tw[ ( g - 5 ) & 7 ]);
 			c2 = c2 + V.f( 3 ) * ( tw[ g & 7 ] + tw[ ( g - 6 ) & 7 ]);
@@ -255,8 +277,8 @@ __global__ void __launch_bounds__( U2_TW ) k_up2( const Up2Params P )
 
 			if( y0 + 1 >= ylo && y0 < yhi && !( P.dbg & 4 ))
 			{
-				f4 e = (f4) 0.0f;
-				f4 o = (f4) 0.0f;
+				f2 e = (f2) 0.0f;
+				f2 o = (f2) 0.0f;
 #pragma unroll
 				for( int t = 0; t < 12; t++ )
 				{
@@ -264,25 +286,27 @@ __global__ void __launch_bounds__( U2_TW ) k_up2( const Up2Params P )
 					o = o + V.fo( t ) * cw[ ( g - 11 + t ) & 15 ];
 				}
 
-				float* const dp = dcol + (long) y0 * P.dst_ss;
+				// uniform row pointer + 32-bit lane offset
+				float* const dp = P.dst + (long) ( y0 - P.dst_row0 ) * P.dst_ss;
 
 				if( P.dbg & 1 )
 				{
 					if( e.x == 1234.5f && o.y == 0.1234f )
 					{
-						*(f4*) dp = e + o;
+						*(f2*) ( dp + dlane ) = e + o;
 					}
 				}
 				else
+				if( xok )
 				{
 					if( y0 >= ylo )
 					{
-						*(f4*) dp = e;
+						*(f2*) ( dp + dlane ) = e;
 					}
 
 					if( y0 + 1 < yhi )
 					{
-						*(f4*) ( dp + P.dst_ss ) = o;
+						*(f2*) ( dp + P.dst_ss + dlane ) = o;
 					}
 				}
 			}
@@ -292,6 +316,8 @@ __global__ void __launch_bounds__( U2_TW ) k_up2( const Up2Params P )
 	};
 
 	prefetch( u0 );
+	store_pre();
+	__syncthreads();
 
 	// the ring period is 16 rows: 16 / U2_RB marching steps per trip
 	for( int sb = 0; sb < nsteps; sb += 16 )
@@ -422,8 +448,8 @@ int up2_run( avirhip_plan* p, const float* src, long src_stride, float* dst,
 {
 	const Up2Data* D = (const Up2Data*) p -> up2;
 
-	if( D == nullptr || ( (uintptr_t) src & 15 ) || ( (uintptr_t) dst & 15 ) ||
-		( src_stride & 3 ))
+	if( D == nullptr || ( (uintptr_t) src & 7 ) || ( (uintptr_t) dst & 7 ) ||
+		( src_stride & 1 ))
 	{
 		return( 1 );
 	}
@@ -431,6 +457,13 @@ int up2_run( avirhip_plan* p, const float* src, long src_stride, float* dst,
 	if( row1 <= row0 )
 	{
 		return( AVIRHIP_OK );
+	}
+
+	// the kernel addresses rows with 32-bit float offsets
+	if( (long) p -> src_h * src_stride >= ( 1L << 31 ) ||
+		(long) p -> new_w * 4 >= ( 1L << 30 ))
+	{
+		return( 1 );
 	}
 
 	Up2Params P;
@@ -457,7 +490,7 @@ int up2_run( avirhip_plan* p, const float* src, long src_stride, float* dst,
 	P.dbg = ( dbg != nullptr ? atoi( dbg ) : 0 );
 
 	const int items = P.nstrips * ( chunk1 - P.chunk0 + 1 );
-	hipLaunchKernelGGL( k_up2, dim3( items ), dim3( U2_TW ), 0, st, P );
+	hipLaunchKernelGGL( k_up2, dim3( items ), dim3( U2_NT ), 0, st, P );
 	AVIRHIP_HIPCHECK( hipGetLastError() );
 	return( AVIRHIP_OK );
 }
