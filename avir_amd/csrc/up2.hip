@@ -185,17 +185,10 @@ __global__ void __launch_bounds__( U2_NT ) k_up2( const Up2Params P )
 
 	// One marching step of U2_RB source rows. R0 = ring phase of its first
 	// row (compile-time), so every ring access below is a fixed register.
-	auto march = [&]( auto R0C, const int ub, const bool more )
+	auto march = [&]( auto R0C, const int ub, const bool more,
+		const bool more2 )
 	{
 		constexpr int R0 = decltype( R0C )::value;
-
-		// the NEXT step's source tile starts its trip from HBM now and is
-		// parked in LDS just before this step's vertical phase, so the only
-		// vmcnt(0) wait of the loop never waits for this step's own stores
-		if( more )
-		{
-			prefetch( ub + U2_RB );
-		}
 
 		if( !( P.dbg & 2 ))
 		{
@@ -246,10 +239,19 @@ __global__ void __launch_bounds__( U2_NT ) k_up2( const Up2Params P )
 		__syncthreads();
 		}
 
-		// ---- S of the next step: registers -> LDS (H1 above is done with sS)
+		// ---- S of the next step: registers -> LDS (H1 above is done with sS).
+		// Those loads were issued at this point of the PREVIOUS step, a whole
+		// vertical phase ago, and the only younger memory operations are that
+		// phase's stores, by now long retired: the vmcnt(0) here is free.
 		if( more )
 		{
 			store_pre();
+		}
+
+		// the tile two steps ahead starts its trip from HBM now
+		if( more2 )
+		{
+			prefetch( ub + 2 * U2_RB );
 		}
 
 		// ---- V: one half-column per thread, statically unrolled marching
@@ -317,15 +319,18 @@ __global__ void __launch_bounds__( U2_NT ) k_up2( const Up2Params P )
 
 	prefetch( u0 );
 	store_pre();
+	prefetch( u0 + U2_RB );
 	__syncthreads();
 
 	// the ring period is 16 rows: 16 / U2_RB marching steps per trip
 	for( int sb = 0; sb < nsteps; sb += 16 )
 	{
 #if U2_RB == 16
-		march( std::integral_constant< int, 0 >(), u0 + sb, sb + 16 < nsteps );
+		march( std::integral_constant< int, 0 >(), u0 + sb, sb + 16 < nsteps,
+			sb + 32 < nsteps );
 #else
-		march( std::integral_constant< int, 0 >(), u0 + sb, sb + 8 < nsteps );
+		march( std::integral_constant< int, 0 >(), u0 + sb, sb + 8 < nsteps,
+			sb + 16 < nsteps );
 
 		if( sb + 8 >= nsteps )
 		{
@@ -333,7 +338,7 @@ __global__ void __launch_bounds__( U2_NT ) k_up2( const Up2Params P )
 		}
 
 		march( std::integral_constant< int, 8 >(), u0 + sb + 8,
-			sb + 16 < nsteps );
+			sb + 16 < nsteps, sb + 24 < nsteps );
 #endif
 	}
 }
@@ -474,13 +479,34 @@ int up2_run( avirhip_plan* p, const float* src, long src_stride, float* dst,
 	P.nstrips = ( p -> new_w + U2_TW - 1 ) / U2_TW;
 
 	// Chunk height. A chunk of cq source rows costs cq + 18 marching steps (6
-	// preload + 12 warm-up) in units of 16, so cq = U2_RB*k - 18 wastes nothing.
-	// Aim for about two rounds of 256 CUs x 3 resident workgroups, but keep
-	// k >= 5 so the warm-up stays below a quarter of the horizontal work.
-	const int want = ( 2 * 768 + P.nstrips - 1 ) / P.nstrips;
-	int k16 = (( p -> src_h + want - 1 ) / want + 18 + U2_RB - 1 ) / U2_RB;
-	k16 = std::max( 80 / U2_RB, k16 );
-	P.cq = k16 * U2_RB - 18;
+	// preload + 12 warm-up) in units of U2_RB, so cq = U2_RB*k - 18 wastes
+	// nothing. The chip holds 256 CUs x 4 resident workgroups; size the chunks
+	// so that all work items fit in a whole number of such rounds (a partly
+	// filled last round leaves CUs idle), preferring the fewest rounds whose
+	// chunks are still >= 62 rows (warm-up <= ~1/4 of the horizontal work).
+	const int slots = 256 * 4;
+	int cq = 0;
+
+	for( int rounds = 1; rounds <= 8 && cq == 0; rounds++ )
+	{
+		const int nch = std::max( 1, rounds * slots / P.nstrips );
+		int c = ( p -> src_h + nch - 1 ) / nch;
+		c = (( c + 18 + U2_RB - 1 ) / U2_RB ) * U2_RB - 18;
+
+		if( c >= 62 || rounds == 8 )
+		{
+			cq = std::max( c, 62 );
+		}
+	}
+
+	const char* ecq = getenv( "AVIRHIP_UP2_CQ" );
+
+	if( ecq != nullptr && atoi( ecq ) >= 6 )
+	{
+		cq = (( atoi( ecq ) + 18 + U2_RB - 1 ) / U2_RB ) * U2_RB - 18;
+	}
+
+	P.cq = cq;
 	const int cr = P.cq * 2;
 	P.chunk0 = row0 / cr;
 	const int chunk1 = ( row1 - 1 ) / cr;
