@@ -607,9 +607,36 @@ static int exec_device( avirhip_plan* p, const void* src, void* dst,
 	return( rc );
 }
 
+} // namespace avirhip
+
+// AVIRHIP_MEM_AUTO: device memory if the HIP runtime knows the pointer as such.
+extern "C" int avirhip_resolve_mem( const void* ptr, int mem )
+{
+	if( mem != AVIRHIP_MEM_AUTO )
+	{
+		return( mem );
+	}
+
+	hipPointerAttribute_t at;
+
+	if( ptr != nullptr && hipPointerGetAttributes( &at, ptr ) == hipSuccess &&
+		( at.type == hipMemoryTypeDevice || at.type == hipMemoryTypeManaged ))
+	{
+		return( AVIRHIP_MEM_DEVICE );
+	}
+
+	(void) hipGetLastError(); // unregistered host memory reports an error
+	return( AVIRHIP_MEM_HOST );
+}
+
+namespace avirhip {
+
 static int exec_any( avirhip_plan* p, const void* src, int src_mem, void* dst,
 	int dst_mem, int row0, int row1, void* stream )
 {
+	src_mem = avirhip_resolve_mem( src, src_mem );
+	dst_mem = avirhip_resolve_mem( dst, dst_mem );
+
 	if( p == nullptr || src == nullptr || dst == nullptr || row0 < 0 ||
 		row1 > p -> new_h || row0 > row1 )
 	{

@@ -13,6 +13,8 @@
 
 using namespace avirhip;
 
+extern "C" int avirhip_resolve_mem( const void* ptr, int mem );
+
 struct avirhip_resizer
 {
 	AvirPlanner* planner;
@@ -232,6 +234,8 @@ int avirhip_resizer_resize( avirhip_resizer* r, const void* src, int src_mem,
 		const size_t n = (size_t) new_w * (size_t) new_h *
 			dtype_size( out_type );
 
+		dst_mem = avirhip_resolve_mem( dst, dst_mem );
+
 		if( dst_mem == AVIRHIP_MEM_HOST )
 		{
 			memset( dst, 0, n );
@@ -417,6 +421,7 @@ int avirhip_lancir_resize( avirhip_lancir* l, const void* src, int src_mem,
 		const size_t nss = ( params != nullptr && params -> NewSSize >= 1 ?
 			(size_t) params -> NewSSize : osl );
 		const size_t es = dtype_size( out_type );
+		dst_mem = avirhip_resolve_mem( dst, dst_mem );
 
 		for( int i = 0; i < new_h; i++ )
 		{

@@ -147,9 +147,8 @@ def main():
     t = time.perf_counter() - t0
 
     if world > 1:
-        tt = torch.tensor([t], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        t = float(tt.item())
+        from avir_amd import sharding
+        t = sharding.max_over_ranks(t, dist, dev)
 
     ev_ms = e0.elapsed_time(e1) / args.steps  # kernel time on the launch stream
     mpix = NEW_W * NEW_H / 1e6
@@ -207,20 +206,15 @@ def main():
 
 
 def band_gather(lib, plan, src, dev, world, rank, dist, torch, iters=20):
-    """One frame, N row bands, one band per GPU, gather on rank 0 (RCCL over
-    xGMI). Bands are bit-identical to the rows of a full-frame resize
-    (tests/test_gpu_parity.py::test_band_execution_matches_full)."""
-    from avir_amd import abi
-    r0, r1 = NEW_H * rank // world, NEW_H * (rank + 1) // world
+    """One frame, N row bands, one band per GPU, stitched on rank 0 (RCCL over
+    xGMI; avir_amd/sharding.py). Bands are bit-identical to the rows of a
+    full-frame resize (tests/test_gpu_parity.py::
+    test_band_execution_matches_full)."""
+    from avir_amd import abi, sharding
+    r0, r1 = sharding.band_rows(NEW_H, world, rank)
     band = torch.empty((r1 - r0, NEW_W, CH), dtype=torch.float32, device=dev)
-    rows = [NEW_H * (i + 1) // world - NEW_H * i // world for i in range(world)]
-    parts = None
-    if rank == 0:
-        full = torch.empty((NEW_H, NEW_W, CH), dtype=torch.float32, device=dev)
-        parts, o = [], 0
-        for n in rows:
-            parts.append(full[o:o + n])
-            o += n
+    full = (torch.empty((NEW_H, NEW_W, CH), dtype=torch.float32, device=dev)
+            if rank == 0 else None)
     stream = torch.cuda.current_stream(dev).cuda_stream
 
     def compute():
@@ -229,14 +223,7 @@ def band_gather(lib, plan, src, dev, world, rank, dist, torch, iters=20):
             abi.MEM_DEVICE, r0, r1, stream), "band")
 
     def gather():
-        # uneven bands -> grouped send/recv (ncclGather needs equal counts)
-        if rank == 0:
-            parts[0].copy_(band)
-            reqs = [dist.P2POp(dist.irecv, parts[i], i) for i in range(1, world)]
-        else:
-            reqs = [dist.P2POp(dist.isend, band, 0)]
-        for w in dist.batch_isend_irecv(reqs):
-            w.wait()
+        sharding.gather_bands(band, full, rank, world, dist)
 
     compute(); gather()
     torch.cuda.synchronize(dev); dist.barrier()

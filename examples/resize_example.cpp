@@ -1,0 +1,102 @@
+// examples/resize_example.cpp -- a program written against the REFERENCE's API
+// (avir::CImageResizer<>, avir::CLancIR; reference README.md:83-150), compiled
+// against the drop-in headers of this repository instead:
+//
+//   g++ -O2 -Iinclude/avir_hip examples/resize_example.cpp \
+//       -Lavir_amd/lib -lavirhip -Wl,-rpath,$PWD/avir_amd/lib \
+//       -Wl,-rpath-link,/opt/rocm/lib -o resize_example
+//
+// It resizes synthetic images (the LCG generators of SURVEY.md 8c) and prints
+// the FNV-1a-64 hash of each result, which tests/test_cpp_frontend.py compares
+// with the golden hashes of the reference's own output.
+#include <cstdio>
+#include <cstdint>
+#include <vector>
+#include "avir.h"
+#include "lancir.h"
+
+static uint64_t fnv1a64( const void* p, size_t n )
+{
+	const uint8_t* b = (const uint8_t*) p;
+	uint64_t h = 1469598103934665603ULL;
+
+	for( size_t i = 0; i < n; i++ )
+	{
+		h ^= b[ i ];
+		h *= 1099511628211ULL;
+	}
+
+	return( h );
+}
+
+int main()
+{
+	try
+	{
+		// cfg1 of BASELINE.json: 640x480 -> 1024x768 RGB uint8
+		std :: vector< uint8_t > In8( 640 * 480 * 3 );
+		uint32_t s = 1;
+
+		for( size_t i = 0; i < In8.size(); i++ )
+		{
+			s = s * 1664525u + 1013904223u;
+			In8[ i ] = (uint8_t) ( s >> 24 );
+		}
+
+		std :: vector< uint8_t > Out8( 1024 * 768 * 3 );
+		avir :: CImageResizer<> ImageResizer( 8 );
+		ImageResizer.resizeImage( In8.data(), 640, 480, 0, Out8.data(), 1024,
+			768, 3, 0 );
+
+		printf( "cfg1 %016llx\n", (unsigned long long) fnv1a64( Out8.data(),
+			Out8.size() ));
+
+		// RGBA float, non-default parameters and variables
+		std :: vector< float > InF( 640 * 480 * 4 );
+		s = 12345;
+
+		for( size_t i = 0; i < InF.size(); i++ )
+		{
+			s = s * 1664525u + 1013904223u;
+			InF[ i ] = (float) ( s >> 8 ) * ( 1.0f / 16777216.0f );
+		}
+
+		std :: vector< float > OutF( 1024 * 768 * 4 );
+		avir :: CImageResizer< avir :: fpclass_def< float > > Resizer16( 16 );
+		avir :: CImageResizerVars Vars;
+		Resizer16.resizeImage( InF.data(), 640, 480, 0, OutF.data(), 1024, 768,
+			4, 0.0, &Vars );
+
+		printf( "f32x4_16 %016llx\n", (unsigned long long) fnv1a64(
+			OutF.data(), OutF.size() * sizeof( float )));
+
+		avir :: CImageResizer<> ResizerUltra( 8, 0,
+			avir :: CImageResizerParamsUltra() );
+
+		std :: vector< float > OutU( 400 * 300 * 4 );
+		ResizerUltra.resizeImage( InF.data(), 640, 480, 0, OutU.data(), 400,
+			300, 4, 0.0 );
+
+		printf( "ultra %016llx\n", (unsigned long long) fnv1a64( OutU.data(),
+			OutU.size() * sizeof( float )));
+
+		// LANCIR, 4-channel float
+		avir :: CLancIR LancIR;
+		const int rc = LancIR.resizeImage( InF.data(), 640, 480, OutF.data(),
+			1024, 768, 4 );
+
+		printf( "lancir rc=%d %016llx\n", rc, (unsigned long long) fnv1a64(
+			OutF.data(), OutF.size() * sizeof( float )));
+
+		// parameter error -> 0, like the reference
+		printf( "lancir_err rc=%d\n", LancIR.resizeImage( InF.data(), 640, 480,
+			OutF.data(), 0, 768, 4 ));
+	}
+	catch( const std :: exception& e )
+	{
+		fprintf( stderr, "error: %s\n", e.what() );
+		return( 1 );
+	}
+
+	return( 0 );
+}

@@ -1,0 +1,262 @@
+/*
+ * avir_hip/avir.h -- drop-in front end: the public API of the reference's
+ * avir.h (avaneev/avir v3.1) re-implemented as a thin shell over the C ABI of
+ * libavirhip (include/avirhip.h). A program written against the reference
+ * compiles against this header unchanged:
+ *
+ *     #include "avir.h"          // -I<repo>/include/avir_hip, link -lavirhip
+ *     avir :: CImageResizer<> ImageResizer( 8 );
+ *     ImageResizer.resizeImage( InBuf, 640, 480, 0, OutBuf, 1024, 768, 3, 0 );
+ *
+ * Same names, argument order and meaning as the reference (file:line cited at
+ * each declaration): avir::CImageResizer<fpclass>(aResBitDepth, aSrcBitDepth,
+ * aParams) and resizeImage<Tin,Tout>(SrcBuf, SrcWidth, SrcHeight,
+ * SrcScanlineSize, NewBuf, NewWidth, NewHeight, ElCountIO, k, aVars), the
+ * CImageResizerParams* presets, CImageResizerVars and the (unused on a GPU)
+ * CImageResizerThreadPool hook. The planner runs on the host inside the
+ * library; H pass, V pass and the integer epilogue run as HIP kernels on
+ * gfx950. SrcBuf/NewBuf may be host pointers (staged) or device pointers
+ * (detected; zero-copy).
+ *
+ * Differences by design: there is NO CPU execution path -- if the library
+ * cannot run the call (no gfx950 device, or a feature outside the built scope
+ * such as UseSRGBGamma) resizeImage() throws std::runtime_error instead of
+ * silently computing elsewhere. Only the float pipeline is provided
+ * (fpclass_def<float>, the reference's default).
+ */
+#ifndef AVIR_HIP_AVIR_H
+#define AVIR_HIP_AVIR_H
+
+#include <stdint.h>
+#include <stdexcept>
+#include <string>
+#include "../avirhip.h"
+
+#define AVIR_VERSION "3.1" /* API level mirrored (reference avir.h:99) */
+
+namespace avir {
+
+/* avir.h:2119-2225. Kept so that callers which install a pool still compile;
+ * the GPU executor parallelises across workgroups instead. */
+class CImageResizerThreadPool
+{
+public:
+	CImageResizerThreadPool() { }
+	virtual ~CImageResizerThreadPool() { }
+
+	class CWorkload
+	{
+	public:
+		virtual ~CWorkload() { }
+		virtual void process() = 0;
+	};
+
+	virtual int getSuggestedWorkloadCount() const { return( 1 ); }
+	virtual void addWorkload( CWorkload* const ) { }
+	virtual void startAllWorkloads() { }
+	virtual void waitAllWorkloadsToFinish() { }
+	virtual void removeAllWorkloads() { }
+};
+
+/* avir.h:2262-2317. */
+struct CImageResizerParams
+{
+	double CorrFltAlpha;
+	double CorrFltLen;
+	double IntFltAlpha;
+	double IntFltCutoff;
+	double IntFltLen;
+	double LPFltAlpha;
+	double LPFltBaseLen;
+	double LPFltCutoffMult;
+
+	CImageResizerParams()
+		: HBFltAlpha( 1.94609 )
+		, HBFltCutoff( 0.46437 )
+		, HBFltLen( 24 )
+	{
+	}
+
+	double HBFltAlpha;
+	double HBFltCutoff;
+	double HBFltLen;
+
+protected:
+	void preset( const int i )
+	{
+		avirhip_params p;
+		avirhip_params_preset( i, &p );
+		CorrFltAlpha = p.CorrFltAlpha; CorrFltLen = p.CorrFltLen;
+		IntFltAlpha = p.IntFltAlpha; IntFltCutoff = p.IntFltCutoff;
+		IntFltLen = p.IntFltLen; LPFltAlpha = p.LPFltAlpha;
+		LPFltBaseLen = p.LPFltBaseLen; LPFltCutoffMult = p.LPFltCutoffMult;
+	}
+};
+
+/* Presets, avir.h:2328-2464. */
+struct CImageResizerParamsDef : public CImageResizerParams
+	{ CImageResizerParamsDef() { preset( AVIRHIP_PARAMS_DEF ); } };
+struct CImageResizerParamsULR : public CImageResizerParams
+	{ CImageResizerParamsULR() { preset( AVIRHIP_PARAMS_ULR ); } };
+struct CImageResizerParamsLR : public CImageResizerParams
+	{ CImageResizerParamsLR() { preset( AVIRHIP_PARAMS_LR ); } };
+struct CImageResizerParamsLow : public CImageResizerParams
+	{ CImageResizerParamsLow() { preset( AVIRHIP_PARAMS_LOW ); } };
+struct CImageResizerParamsHigh : public CImageResizerParams
+	{ CImageResizerParamsHigh() { preset( AVIRHIP_PARAMS_HIGH ); } };
+struct CImageResizerParamsUltra : public CImageResizerParams
+	{ CImageResizerParamsUltra() { preset( AVIRHIP_PARAMS_ULTRA ); } };
+
+/* avir.h:2473-2506: overwritten by resizeImage(), as in the reference. */
+class CImageResizerVarsBase
+{
+public:
+	int ElCount;
+	int ElCountIO;
+	int fppack;
+	int fpalign;
+	int elalign;
+	int packmode;
+	int BufLen[ 2 ];
+	int BufOffs[ 2 ];
+	double k;
+	double o;
+	int ResizeStep;
+	bool IsResize2;
+	double InGammaMult;
+	double OutGammaMult;
+};
+
+/* avir.h:2516-2547. */
+class CImageResizerVars : public CImageResizerVarsBase
+{
+public:
+	double ox;
+	double oy;
+	CImageResizerThreadPool* ThreadPool;
+	bool UseSRGBGamma;
+	int AlphaIndex;
+	int BuildMode;
+	int RndSeed;
+
+	CImageResizerVars()
+		: ox( 0.0 )
+		, oy( 0.0 )
+		, ThreadPool( nullptr )
+		, UseSRGBGamma( false )
+		, AlphaIndex( -1 )
+		, BuildMode( -1 )
+		, RndSeed( 0 )
+	{
+	}
+};
+
+/* avir.h:4569-4592 -- accepted for source compatibility. The device pipeline
+ * is the interleaved float one, i.e. fpclass_def< float >. */
+template< typename afptype, typename afptypeatom = afptype >
+class fpclass_def
+{
+public:
+	typedef afptype fptype;
+	typedef afptypeatom fptypeatom;
+	static const int fppack = sizeof( fptype ) / sizeof( fptypeatom );
+	static const int fpalign = sizeof( fptype );
+	static const int elalign = 1;
+	static const int packmode = 0;
+};
+
+namespace hipdetail {
+
+template< typename T > struct dtype_of;
+template<> struct dtype_of< uint8_t > { static const int v = AVIRHIP_U8; };
+template<> struct dtype_of< uint16_t > { static const int v = AVIRHIP_U16; };
+template<> struct dtype_of< float > { static const int v = AVIRHIP_F32; };
+template<> struct dtype_of< double > { static const int v = AVIRHIP_F64; };
+
+inline void check( const int rc, const char* const what )
+{
+	if( rc < 0 )
+	{
+		throw std::runtime_error( std::string( what ) + ": " +
+			avirhip_last_error() );
+	}
+}
+
+} // namespace hipdetail
+
+/* avir.h:4609-5092. */
+template< class fpclass = fpclass_def< float > >
+class CImageResizer
+{
+	CImageResizer( const CImageResizer& );
+	CImageResizer& operator = ( const CImageResizer& );
+
+public:
+	/* avir.h:4630-4639. */
+	CImageResizer( const int aResBitDepth = 8, const int aSrcBitDepth = 0,
+		const CImageResizerParams& aParams = CImageResizerParamsDef() )
+		: h( nullptr )
+	{
+		static_assert( sizeof( typename fpclass :: fptype ) == sizeof( float ),
+			"avir_hip: only the float pipeline (fpclass_def<float>) exists" );
+
+		avirhip_params p;
+		p.CorrFltAlpha = aParams.CorrFltAlpha; p.CorrFltLen = aParams.CorrFltLen;
+		p.IntFltAlpha = aParams.IntFltAlpha;
+		p.IntFltCutoff = aParams.IntFltCutoff;
+		p.IntFltLen = aParams.IntFltLen; p.LPFltAlpha = aParams.LPFltAlpha;
+		p.LPFltBaseLen = aParams.LPFltBaseLen;
+		p.LPFltCutoffMult = aParams.LPFltCutoffMult;
+		p.HBFltAlpha = aParams.HBFltAlpha; p.HBFltCutoff = aParams.HBFltCutoff;
+		p.HBFltLen = aParams.HBFltLen;
+
+		hipdetail :: check( avirhip_resizer_create( aResBitDepth,
+			aSrcBitDepth, &p, &h ), "avirhip_resizer_create" );
+	}
+
+	~CImageResizer()
+	{
+		avirhip_resizer_destroy( h );
+	}
+
+	/* avir.h:4680-4684. Thread-safe for concurrent calls with distinct
+	 * aVars, like the reference (plans are cached under a mutex). */
+	template< typename Tin, typename Tout >
+	void resizeImage( const Tin* const SrcBuf, const int SrcWidth,
+		const int SrcHeight, int SrcScanlineSize, Tout* const NewBuf,
+		const int NewWidth, const int NewHeight, const int ElCountIO,
+		const double k, CImageResizerVars* const aVars = nullptr ) const
+	{
+		avirhip_vars v;
+		avirhip_vars_default( &v );
+
+		if( aVars != nullptr )
+		{
+			v.ox = aVars -> ox; v.oy = aVars -> oy;
+			v.UseSRGBGamma = ( aVars -> UseSRGBGamma ? 1 : 0 );
+			v.AlphaIndex = aVars -> AlphaIndex;
+			v.BuildMode = aVars -> BuildMode;
+			v.RndSeed = aVars -> RndSeed;
+			aVars -> ElCount = ElCountIO;
+			aVars -> ElCountIO = ElCountIO;
+			aVars -> fppack = 1;
+			aVars -> fpalign = 4;
+			aVars -> elalign = 1;
+			aVars -> packmode = 0;
+		}
+
+		hipdetail :: check( avirhip_resizer_resize( h, SrcBuf,
+			AVIRHIP_MEM_AUTO, SrcWidth, SrcHeight, SrcScanlineSize, NewBuf,
+			AVIRHIP_MEM_AUTO, NewWidth, NewHeight, ElCountIO, k, &v,
+			hipdetail :: dtype_of< Tin > :: v,
+			hipdetail :: dtype_of< Tout > :: v, nullptr ),
+			"avir::CImageResizer::resizeImage" );
+	}
+
+private:
+	avirhip_resizer* h;
+};
+
+} // namespace avir
+
+#endif // AVIR_HIP_AVIR_H

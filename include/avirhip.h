@@ -46,6 +46,7 @@ typedef enum avirhip_dtype {
 /* Where a buffer passed to an execute call lives. */
 #define AVIRHIP_MEM_HOST 0
 #define AVIRHIP_MEM_DEVICE 1
+#define AVIRHIP_MEM_AUTO 2 /* ask the HIP runtime (hipPointerGetAttributes) */
 
 /* ---------------------------------------------------------------------
  * AVIR plan description: a faithful, flattened mirror of the reference's
