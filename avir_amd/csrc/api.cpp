@@ -403,6 +403,16 @@ static int ensure_scratch( avirhip_plan* p )
 			p -> resbuf = (float*) q;
 		}
 
+		if( p -> lres == nullptr &&
+			!( p -> out_type == AVIRHIP_F32 && p -> l_unity ))
+		{
+			void* q;
+			int rc = dev_alloc( p, (size_t) p -> new_h * p -> new_w *
+				p -> ch * sizeof( float ), &q );
+			if( rc != 0 ) return( rc );
+			p -> lres = (float*) q;
+		}
+
 		return( AVIRHIP_OK );
 	}
 
@@ -708,7 +718,7 @@ static avirhip_plan* new_plan()
 	avirhip_plan* p = new avirhip_plan();
 	p -> is_lancir = 0; p -> device = 0;
 	p -> path = 0; p -> fused_ok = 0; p -> auto_path = 1; p -> fused = nullptr; p -> up2 = nullptr;
-	p -> packed = nullptr; p -> resbuf = nullptr;
+	p -> packed = nullptr; p -> resbuf = nullptr; p -> lres = nullptr;
 	p -> stage_src = nullptr; p -> stage_dst = nullptr;
 	p -> stage_src_bytes = 0; p -> stage_dst_bytes = 0;
 	p -> tr_mul = 1.0; p -> pk_out = 0.0;
@@ -873,11 +883,10 @@ int avirhip_lancir_plan_create( const avirhip_lancir_desc* d,
 		return( AVIRHIP_EINVAL );
 	}
 
-	if( d -> channels != 4 || d -> out_type != AVIRHIP_F32 ||
-		d -> in_type == AVIRHIP_F64 )
+	if( d -> in_type < 0 || d -> in_type > AVIRHIP_F32 || d -> out_type < 0 ||
+		d -> out_type > AVIRHIP_F32 )
 	{
-		set_error( "LANCIR device path: 4-channel, float output only (1-3 "
-			"channels and integer output are not built yet)" );
+		set_error( "LANCIR: element types are uint8, uint16 or float" );
 		return( AVIRHIP_EUNSUPPORTED );
 	}
 

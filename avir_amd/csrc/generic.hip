@@ -333,13 +333,157 @@ int launch_epilogue( const float* res, void* dst, int out_type, long n,
 
 // ---------------------------------------------------------------------
 // LANCIR generic kernels (lancir.h:541-710): vertical pass first into a float
-// intermediate [rows][SrcWidth], then the horizontal pass. 4-channel x86
-// summation order (resize4, lancir.h:2466-2544): even taps and odd taps are
-// accumulated separately (first term is the bare product) and added last.
+// intermediate [rows][SrcWidth], then the horizontal pass, then the output
+// stage. The dot product of one output pixel reproduces the lane structure of
+// the reference's x86 SSE2 code (resize1..4, lancir.h:2102-2544), written out
+// as scalar expressions -- the summation ORDER is the parity contract:
+//   4 ch: even taps and odd taps accumulate separately, added at the end
+//   1 ch: four lane sums over taps 4g+L, then (s0+s2)+(s1+s3); a kernel length
+//         with kl%4 == 2 adds its last two taps to the two partial sums first
+//   2 ch: lanes {4g, 4g+1} and {4g+2, 4g+3} per channel, folded A+B, optional
+//         tail taps, then lane0 + lane2
+//   3 ch: the 12 products of 4 taps x 3 channels fill three 4-lane vectors
+// In every lane the first term is the bare product (no +0).
 // ---------------------------------------------------------------------
 
-template< typename Tin >
-__global__ void __launch_bounds__( 256 ) k_lancir_v4( const Tin* src,
+// P( t, c ): input sample of tap t, channel c (edge-clamped by the caller).
+template< int CH, typename PX >
+__device__ __forceinline__ void lancir_dot( const float* __restrict__ f,
+	const int kl, PX P, float* out )
+{
+	if( CH == 4 )
+	{
+		float ea[ 4 ], oa[ 4 ];
+
+		for( int c = 0; c < 4; c++ )
+		{
+			ea[ c ] = f[ 0 ] * P( 0, c );
+			oa[ c ] = f[ 1 ] * P( 1, c );
+		}
+
+		for( int t = 2; t < kl; t += 2 )
+		{
+			for( int c = 0; c < 4; c++ )
+			{
+				ea[ c ] += f[ t ] * P( t, c );
+				oa[ c ] += f[ t + 1 ] * P( t + 1, c );
+			}
+		}
+
+		for( int c = 0; c < 4; c++ )
+		{
+			out[ c ] = ea[ c ] + oa[ c ];
+		}
+	}
+	else
+	if( CH == 1 )
+	{
+		const int ci = kl >> 2;
+		float s0 = f[ 0 ] * P( 0, 0 ), s1 = f[ 1 ] * P( 1, 0 );
+		float s2 = f[ 2 ] * P( 2, 0 ), s3 = f[ 3 ] * P( 3, 0 );
+
+		for( int g = 1; g < ci; g++ )
+		{
+			const int q = g * 4;
+			s0 += f[ q ] * P( q, 0 );
+			s1 += f[ q + 1 ] * P( q + 1, 0 );
+			s2 += f[ q + 2 ] * P( q + 2, 0 );
+			s3 += f[ q + 3 ] * P( q + 3, 0 );
+		}
+
+		if(( kl & 3 ) == 0 )
+		{
+			out[ 0 ] = ( s0 + s2 ) + ( s1 + s3 );
+		}
+		else
+		{
+			const float e0 = f[ kl - 2 ] * P( kl - 2, 0 );
+			const float e1 = f[ kl - 1 ] * P( kl - 1, 0 );
+			out[ 0 ] = (( s0 + s2 ) + e0 ) + (( s1 + s3 ) + e1 );
+		}
+	}
+	else
+	if( CH == 2 )
+	{
+		const int ci = kl >> 2;
+
+		for( int c = 0; c < 2; c++ )
+		{
+			float a0 = f[ 0 ] * P( 0, c ), a2 = f[ 1 ] * P( 1, c );
+			float b0 = f[ 2 ] * P( 2, c ), b2 = f[ 3 ] * P( 3, c );
+
+			for( int g = 1; g < ci; g++ )
+			{
+				const int q = g * 4;
+				a0 += f[ q ] * P( q, c );
+				a2 += f[ q + 1 ] * P( q + 1, c );
+				b0 += f[ q + 2 ] * P( q + 2, c );
+				b2 += f[ q + 3 ] * P( q + 3, c );
+			}
+
+			a0 = a0 + b0;
+			a2 = a2 + b2;
+
+			if(( kl & 3 ) == 2 )
+			{
+				a0 += f[ kl - 2 ] * P( kl - 2, c );
+				a2 += f[ kl - 1 ] * P( kl - 1, c );
+			}
+
+			out[ c ] = a0 + a2;
+		}
+	}
+	else
+	{
+		// products e[i], i = 3*tap + channel; vector lanes hold i mod 12
+		const int ci = kl >> 2;
+		float r[ 12 ];
+
+		for( int i = 0; i < 12; i++ )
+		{
+			r[ i ] = f[ i / 3 ] * P( i / 3, i % 3 );
+		}
+
+		for( int g = 1; g < ci; g++ )
+		{
+			for( int i = 0; i < 12; i++ )
+			{
+				const int t = g * 4 + i / 3;
+				r[ i ] += f[ t ] * P( t, i % 3 );
+			}
+		}
+
+		if(( kl & 3 ) == 2 )
+		{
+			const int t = ci * 4;
+			r[ 0 ] += f[ t ] * P( t, 0 );
+			r[ 1 ] += f[ t ] * P( t, 1 );
+			r[ 2 ] += f[ t ] * P( t, 2 );
+			r[ 3 ] += f[ t + 1 ] * P( t + 1, 0 );
+		}
+
+		float o0 = r[ 0 ] + r[ 3 ];
+		float o1 = r[ 1 ] + r[ 4 ];
+		float o2 = r[ 2 ] + r[ 5 ];
+		o0 += r[ 6 ] + r[ 9 ];
+		o1 += r[ 7 ] + r[ 10 ];
+		o2 += r[ 8 ] + r[ 11 ];
+
+		if(( kl & 3 ) == 2 )
+		{
+			const int t = ci * 4 + 1;
+			o1 += f[ t ] * P( t, 1 );
+			o2 += f[ t ] * P( t, 2 );
+		}
+
+		out[ 0 ] = o0;
+		out[ 1 ] = o1;
+		out[ 2 ] = o2;
+	}
+}
+
+template< typename Tin, int CH >
+__global__ void __launch_bounds__( 256 ) k_lancir_v( const Tin* src,
 	float* tmp, int sw, int sh, long src_stride, int row0, int nrows,
 	const int* start, const int* fidx, const float* flt, int kl )
 {
@@ -354,44 +498,26 @@ __global__ void __launch_bounds__( 256 ) k_lancir_v4( const Tin* src,
 	const int r = row0 + ry;
 	const int st = start[ r ];
 	const float* f = flt + (long) fidx[ r ] * kl;
-	float ea[ 4 ], oa[ 4 ];
+	const Tin* col = src + (long) x * CH;
+	float o[ CH ];
 
-	for( int t = 0; t < kl; t += 2 )
-	{
-		int y0 = st + t;
-		int y1 = st + t + 1;
-		y0 = ( y0 < 0 ? 0 : ( y0 >= sh ? sh - 1 : y0 ));
-		y1 = ( y1 < 0 ? 0 : ( y1 >= sh ? sh - 1 : y1 ));
-		const Tin* p0 = src + (long) y0 * src_stride + (long) x * 4;
-		const Tin* p1 = src + (long) y1 * src_stride + (long) x * 4;
-
-		for( int c = 0; c < 4; c++ )
+	lancir_dot< CH >( f, kl, [&]( const int t, const int c ) -> float
 		{
-			const float e = f[ t ] * (float) p0[ c ];
-			const float o = f[ t + 1 ] * (float) p1[ c ];
+			int y = st + t;
+			y = ( y < 0 ? 0 : ( y >= sh ? sh - 1 : y ));
+			return( (float) col[ (long) y * src_stride + c ]);
+		}, o );
 
-			if( t == 0 )
-			{
-				ea[ c ] = e;
-				oa[ c ] = o;
-			}
-			else
-			{
-				ea[ c ] += e;
-				oa[ c ] += o;
-			}
-		}
-	}
+	float* op = tmp + ( (long) ry * sw + x ) * CH;
 
-	float* op = tmp + ( (long) ry * sw + x ) * 4;
-
-	for( int c = 0; c < 4; c++ )
+	for( int c = 0; c < CH; c++ )
 	{
-		op[ c ] = ea[ c ] + oa[ c ];
+		op[ c ] = o[ c ];
 	}
 }
 
-__global__ void __launch_bounds__( 256 ) k_lancir_h4( const float* tmp,
+template< int CH >
+__global__ void __launch_bounds__( 256 ) k_lancir_h( const float* tmp,
 	float* res, int sw, int nw, long res_stride, int nrows, const int* start,
 	const int* fidx, const float* flt, int kl )
 {
@@ -405,40 +531,90 @@ __global__ void __launch_bounds__( 256 ) k_lancir_h4( const float* tmp,
 
 	const int st = start[ j ];
 	const float* f = flt + (long) fidx[ j ] * kl;
-	const float* row = tmp + (long) ry * sw * 4;
-	float ea[ 4 ], oa[ 4 ];
+	const float* row = tmp + (long) ry * sw * CH;
+	float o[ CH ];
 
-	for( int t = 0; t < kl; t += 2 )
-	{
-		int x0 = st + t;
-		int x1 = st + t + 1;
-		x0 = ( x0 < 0 ? 0 : ( x0 >= sw ? sw - 1 : x0 ));
-		x1 = ( x1 < 0 ? 0 : ( x1 >= sw ? sw - 1 : x1 ));
-
-		for( int c = 0; c < 4; c++ )
+	lancir_dot< CH >( f, kl, [&]( const int t, const int c ) -> float
 		{
-			const float e = f[ t ] * row[ x0 * 4 + c ];
-			const float o = f[ t + 1 ] * row[ x1 * 4 + c ];
+			int x = st + t;
+			x = ( x < 0 ? 0 : ( x >= sw ? sw - 1 : x ));
+			return( row[ x * CH + c ]);
+		}, o );
 
-			if( t == 0 )
-			{
-				ea[ c ] = e;
-				oa[ c ] = o;
-			}
-			else
-			{
-				ea[ c ] += e;
-				oa[ c ] += o;
-			}
-		}
-	}
+	float* op = res + (long) ry * res_stride + (long) j * CH;
 
-	float* op = res + (long) ry * res_stride + (long) j * 4;
-
-	for( int c = 0; c < 4; c++ )
+	for( int c = 0; c < CH; c++ )
 	{
-		op[ c ] = ea[ c ] + oa[ c ];
+		op[ c ] = o[ c ];
 	}
+}
+
+// outputScanline, lancir.h:1772-2056 (x86 SSE2 build): float output is a
+// copy or a multiply; integer output clamps, then the elements of each full
+// group of four round to nearest-even (cvtps) while the 1-3 element tail of
+// the scanline uses roundclamp's +0.5 truncation (lancir.h:1746-1750).
+template< typename Tout >
+__global__ void __launch_bounds__( 256 ) k_lancir_out( const float* res,
+	Tout* dst, int l, long res_stride, long dst_stride, int nrows, int unity,
+	float out_mul, float clampv, int is_float )
+{
+	const int i = blockIdx.x * blockDim.x + threadIdx.x;
+	const int ry = blockIdx.y;
+
+	if( i >= l || ry >= nrows )
+	{
+		return;
+	}
+
+	float v = res[ (long) ry * res_stride + i ];
+
+	if( !unity )
+	{
+		v = v * out_mul;
+	}
+
+	Tout* op = dst + (long) ry * dst_stride + i;
+
+	if( is_float )
+	{
+		*op = (Tout) v;
+		return;
+	}
+
+	if( i < ( l & ~3 ))
+	{
+		v = ( v < clampv ? v : clampv );
+		v = ( v > 0.0f ? v : 0.0f );
+		*op = (Tout) (int) rintf( v );
+	}
+	else
+	{
+		*op = (Tout) (int) (( v > clampv ? clampv :
+			( v < 0.0f ? 0.0f : v )) + 0.5f );
+	}
+}
+
+template< typename Tin >
+static void launch_lancir_v( const avirhip_plan* p, const void* src,
+	float* tmp, int row0, int nrows, hipStream_t st )
+{
+	const LancirAxisDev& V = p -> lv;
+	const dim3 gv(( p -> src_w + 255 ) / 256, nrows );
+
+#define LV( CH ) hipLaunchKernelGGL(( k_lancir_v< Tin, CH > ), gv, dim3( 256 ), \
+		0, st, (const Tin*) src, tmp, p -> src_w, p -> src_h, \
+		(long) p -> src_stride, row0, nrows, V.d_start, V.d_fidx, V.d_flt, \
+		V.kernel_len )
+
+	switch( p -> ch )
+	{
+		case 1: LV( 1 ); break;
+		case 2: LV( 2 ); break;
+		case 3: LV( 3 ); break;
+		default: LV( 4 ); break;
+	}
+
+#undef LV
 }
 
 int launch_lancir_generic( const avirhip_plan* p, const void* src, void* dst,
@@ -451,34 +627,59 @@ int launch_lancir_generic( const avirhip_plan* p, const void* src, void* dst,
 		return( AVIRHIP_OK );
 	}
 
-	const LancirAxisDev& V = p -> lv;
 	const LancirAxisDev& H = p -> lh;
-	const dim3 gv(( p -> src_w + 255 ) / 256, nrows );
 
 	if( p -> in_type == AVIRHIP_U8 )
-		hipLaunchKernelGGL( k_lancir_v4< uint8_t >, gv, dim3( 256 ), 0, st,
-			(const uint8_t*) src, tmp, p -> src_w, p -> src_h,
-			(long) p -> src_stride, row0, nrows, V.d_start, V.d_fidx, V.d_flt,
-			V.kernel_len );
+		launch_lancir_v< uint8_t >( p, src, tmp, row0, nrows, st );
 	else if( p -> in_type == AVIRHIP_U16 )
-		hipLaunchKernelGGL( k_lancir_v4< uint16_t >, gv, dim3( 256 ), 0, st,
-			(const uint16_t*) src, tmp, p -> src_w, p -> src_h,
-			(long) p -> src_stride, row0, nrows, V.d_start, V.d_fidx, V.d_flt,
-			V.kernel_len );
+		launch_lancir_v< uint16_t >( p, src, tmp, row0, nrows, st );
 	else
-		hipLaunchKernelGGL( k_lancir_v4< float >, gv, dim3( 256 ), 0, st,
-			(const float*) src, tmp, p -> src_w, p -> src_h,
-			(long) p -> src_stride, row0, nrows, V.d_start, V.d_fidx, V.d_flt,
-			V.kernel_len );
+		launch_lancir_v< float >( p, src, tmp, row0, nrows, st );
 
 	AVIRHIP_HIPCHECK( hipGetLastError() );
+
+	// float -> float with unity gain writes straight into the destination
+	const bool direct = ( p -> out_type == AVIRHIP_F32 && p -> l_unity );
+	float* res = ( direct ? (float*) dst : p -> lres );
+	const long rstride = ( direct ? (long) p -> new_stride :
+		(long) p -> new_w * p -> ch );
 
 	const dim3 gh(( p -> new_w + 255 ) / 256, nrows );
-	hipLaunchKernelGGL( k_lancir_h4, gh, dim3( 256 ), 0, st, tmp,
-		(float*) dst, p -> src_w, p -> new_w, (long) p -> new_stride, nrows,
-		H.d_start, H.d_fidx, H.d_flt, H.kernel_len );
+
+#define LH( CH ) hipLaunchKernelGGL( k_lancir_h< CH >, gh, dim3( 256 ), 0, st, \
+		tmp, res, p -> src_w, p -> new_w, rstride, nrows, H.d_start, H.d_fidx, \
+		H.d_flt, H.kernel_len )
+
+	switch( p -> ch )
+	{
+		case 1: LH( 1 ); break;
+		case 2: LH( 2 ); break;
+		case 3: LH( 3 ); break;
+		default: LH( 4 ); break;
+	}
+
+#undef LH
 
 	AVIRHIP_HIPCHECK( hipGetLastError() );
+
+	if( !direct )
+	{
+		const int l = p -> new_w * p -> ch;
+		const dim3 go(( l + 255 ) / 256, nrows );
+
+#define LO( T, isf ) hipLaunchKernelGGL( k_lancir_out< T >, go, dim3( 256 ), 0, \
+			st, res, (T*) dst, l, rstride, (long) p -> new_stride, nrows, \
+			p -> l_unity, p -> l_out_mul, p -> l_clamp, isf )
+
+		if( p -> out_type == AVIRHIP_U8 ) { LO( uint8_t, 0 ); }
+		else if( p -> out_type == AVIRHIP_U16 ) { LO( uint16_t, 0 ); }
+		else { LO( float, 1 ); }
+
+#undef LO
+
+		AVIRHIP_HIPCHECK( hipGetLastError() );
+	}
+
 	return( AVIRHIP_OK );
 }
 

@@ -111,6 +111,7 @@ struct avirhip_plan
 	std::vector< void* > allocs;
 	float* packed;  // source converted to float (non-f32 input)
 	float* resbuf;  // float result before the integer / f64 epilogue
+	float* lres;    // LANCIR: float result rows before the output stage
 	std::vector< float* > hbuf, vbuf; // per-op outputs
 	void* stage_src; // host-pointer staging
 	void* stage_dst;
