@@ -559,6 +559,25 @@ static int exec_device( avirhip_plan* p, const void* src, void* dst,
 
 	if( p -> is_lancir )
 	{
+		const int lpath = ( p -> path != 0 ? p -> path : p -> auto_path );
+
+		if( lpath == 4 )
+		{
+			rc = lanc2_run( p, (const float*) src, (float*) dst, row0, row1,
+				st );
+
+			if( rc != 1 )
+			{
+				return( rc );
+			}
+
+			if( p -> path != 0 )
+			{
+				set_error( "path 4 cannot run this call (unaligned buffers?)" );
+				return( AVIRHIP_EUNSUPPORTED );
+			}
+		}
+
 		return( launch_lancir_generic( p, src, dst, p -> resbuf, row0, row1,
 			st ));
 	}
@@ -717,7 +736,7 @@ static avirhip_plan* new_plan()
 {
 	avirhip_plan* p = new avirhip_plan();
 	p -> is_lancir = 0; p -> device = 0;
-	p -> path = 0; p -> fused_ok = 0; p -> auto_path = 1; p -> fused = nullptr; p -> up2 = nullptr;
+	p -> path = 0; p -> fused_ok = 0; p -> auto_path = 1; p -> fused = nullptr; p -> up2 = nullptr; p -> lanc2 = nullptr;
 	p -> packed = nullptr; p -> resbuf = nullptr; p -> lres = nullptr;
 	p -> stage_src = nullptr; p -> stage_dst = nullptr;
 	p -> stage_src_bytes = 0; p -> stage_dst_bytes = 0;
@@ -906,6 +925,7 @@ int avirhip_lancir_plan_create( const avirhip_lancir_desc* d,
 	int rc = lower_lancir_axis( p, d -> v, p -> lv );
 	if( rc == 0 ) rc = lower_lancir_axis( p, d -> h, p -> lh );
 	if( rc == 0 ) rc = fused_prepare( p );
+	if( rc == 0 ) rc = lanc2_prepare( p );
 
 	if( rc != 0 )
 	{
@@ -926,6 +946,7 @@ void avirhip_plan_destroy( avirhip_plan* p )
 
 	fused_release( p );
 	up2_release( p );
+	lanc2_release( p );
 
 	for( size_t i = 0; i < p -> allocs.size(); i++ )
 	{
@@ -946,7 +967,7 @@ int avirhip_plan_set_path( avirhip_plan* p, int path )
 	if(( path == 2 && !( p -> fused_ok & 1 )) ||
 		( path == 3 && !( p -> fused_ok & 2 )) ||
 		( path == 4 && !( p -> fused_ok & 4 )) ||
-		( p -> is_lancir && path > 1 ))
+		( p -> is_lancir && ( path == 2 || path == 3 )))
 	{
 		set_error( "path %d cannot run this plan", path );
 		return( AVIRHIP_EUNSUPPORTED );

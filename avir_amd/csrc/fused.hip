@@ -545,14 +545,13 @@ int fused_prepare( avirhip_plan* p )
 	// vertical halo is k times taller -> two passes.
 	const bool up = ( p -> new_w >= p -> src_w && p -> new_h >= p -> src_h );
 
-	if( up )
-	{
-		p -> auto_path = ( F -> fused.ok ? 3 : ( two ? 2 : 1 ));
-	}
-	else
-	{
-		p -> auto_path = ( two ? 2 : ( F -> fused.ok ? 3 : 1 ));
-	}
+	// Measured on MI355X (bench.py --workload): the two-pass launch beats the
+	// fused tile for every ratio class (cfg3 0.71 vs 0.75 ms, 1.3x non-integer
+	// upsizing 0.10 vs 0.17 ms, 3x downsizing 0.18 vs 2.3 ms) -- the fused
+	// tile's halo recomputation costs more than FltBuf's round trip. Path 3
+	// stays selectable; exact-2x plans take the marching kernel (path 4).
+	(void) up;
+	p -> auto_path = ( two ? 2 : ( F -> fused.ok ? 3 : 1 ));
 
 	return( AVIRHIP_OK );
 }

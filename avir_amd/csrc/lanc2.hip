@@ -1,0 +1,349 @@
+// lanc2.hip -- LANCIR exact 2x RGBA float (cfg5 of BASELINE.json), vertical +
+// horizontal Lanczos passes fused in ONE launch.
+//
+// CLancIR at k = 0.5, la = 3 (lancir.h:430-483, 882-1351): KernelLen 6, two
+// filter phases (frac 0.75 for even outputs, 0.25 for odd ones); per axis
+//   o[2q]   = dot6( fa, in[q-3 .. q+2] ),   o[2q+1] = dot6( fb, in[q-2 .. q+3] )
+// with indices clamped to the image (copyScanline*v / padScanline*h edge
+// replication), and the x86 summation order of resize4 (lancir.h:2466-2544):
+//   dot6 = ((f0*p0 + f2*p2) + f4*p4) + ((f1*p1 + f3*p3) + f5*p5).
+// LANCIR is vertical-first: the vertical pass produces a float intermediate of
+// SrcWidth x NewHeight which the horizontal pass then resizes.
+//
+// Structure: like up2.hip, a workgroup (256 threads, half-pixel = 8-byte units)
+// owns a strip of 128 output columns and a chunk of source rows and marches
+// down 8 source rows per step:
+//   V  one thread per source half-column (70 px incl. halo): the 7-row window
+//      lives in registers (ring of 8, statically unrolled); source rows are
+//      read straight from HBM, coalesced, prefetched one step ahead; each row
+//      yields two intermediate rows -> LDS (16 rows x 70 px = 17.9 KB)
+//   H  one thread per output half-column: 6 LDS reads + dot6 per output row,
+//      16 rows per step, written to HBM coalesced (2 KiB per row)
+// The SrcWidth x NewHeight intermediate never exists in HBM. Compute is light
+// (~72 flop per output pixel): the kernel is HBM-bound.
+
+#include "plan.h"
+#include <algorithm>
+#include <string.h>
+#include <stdlib.h>
+#include <type_traits>
+
+namespace avirhip {
+
+typedef float f2 __attribute__(( ext_vector_type( 2 )));
+typedef float f4 __attribute__(( ext_vector_type( 4 )));
+typedef float f8 __attribute__(( ext_vector_type( 8 )));
+
+#define L2_TW 128                 // output columns per strip
+#define L2_NT ( L2_TW * 2 )       // threads: one per output half pixel
+#define L2_RB 8                   // source rows per marching step
+#define L2_SW ( L2_TW / 2 + 6 )   // source / intermediate columns incl. halo
+
+struct Lanc2Params
+{
+	const float* src; long src_ss; int sw, sh;
+	float* dst; long dst_ss; int dst_row0; int nw, nh;
+	int srow_lo, srow_hi;
+	int nstrips, chunk0, cq;
+	const float* coef; // device: [va 6 | vb 6 | pad 4 | ha 6 | hb 6 | pad 4]
+};
+
+struct Taps12
+{
+	f8 a; f4 b; // fa[0..5] fb[0..1] | fb[2..5]
+	__device__ __forceinline__ float fa( int i ) const { return( a[ i ]); }
+	__device__ __forceinline__ float fb( int i ) const
+		{ return( i < 2 ? a[ 6 + i ] : b[ i - 2 ]); }
+};
+
+__device__ __forceinline__ Taps12 load_taps12( const float* p )
+{
+	Taps12 t;
+	asm volatile( "s_load_dwordx8 %0, %2, 0x0\n\t"
+		"s_load_dwordx4 %1, %2, 0x20\n\t"
+		"s_waitcnt lgkmcnt(0)"
+		: "=s"( t.a ), "=s"( t.b ) : "s"( p ) : "memory" );
+	return( t );
+}
+
+// resize4's x86 order: even and odd taps accumulate separately.
+#define L2_DOT6( F, p0, p1, p2, p3, p4, p5 ) \
+	((( F( 0 ) * ( p0 ) + F( 2 ) * ( p2 )) + F( 4 ) * ( p4 )) + \
+	(( F( 1 ) * ( p1 ) + F( 3 ) * ( p3 )) + F( 5 ) * ( p5 )))
+
+__global__ void __launch_bounds__( L2_NT ) k_lanc2( const Lanc2Params P )
+{
+	// intermediate rows of this step, half-pixel units: [16][L2_SW * 2]
+	__shared__ __attribute__(( aligned( 16 ))) f2 sT[ 2 * L2_RB * L2_SW * 2 ];
+
+	const int nwg = gridDim.x;
+	const int b = blockIdx.x;
+	const int xcd = b & 7;
+	const int qd = nwg >> 3;
+	const int rm = nwg & 7;
+	const int item = ( xcd < rm ? xcd * ( qd + 1 ) :
+		rm * ( qd + 1 ) + ( xcd - rm ) * qd ) + ( b >> 3 );
+
+	const int strip = item % P.nstrips;
+	const int chunk = P.chunk0 + item / P.nstrips;
+	const int tid = threadIdx.x;
+	const int hf = tid & 1;
+
+	const int qx0 = strip * ( L2_TW / 2 );
+	const int qy0 = chunk * P.cq;
+	const int qy1 = min( qy0 + P.cq, P.nh >> 1 );
+	const int u0 = qy0 - 3;            // first source row index consumed
+	const int nsteps = qy1 - qy0 + 6;  // 6 warm-up rows + chunk rows
+
+	// vertical phase: this thread's source half-column (threads >= 2*L2_SW idle)
+	const bool vact = ( tid < L2_SW * 2 );
+	const int sx = min( max( qx0 - 3 + ( tid >> 1 ), 0 ), P.sw - 1 );
+	const unsigned scol = (unsigned) ( sx * 4 + hf * 2 );
+
+	// horizontal phase: this thread's output half-column
+	const int xo = qx0 * 2 + ( tid >> 1 );
+	const bool xok = ( xo < P.nw );
+	const unsigned dlane = (unsigned) ( xo * 4 + hf * 2 );
+	const int hq = ( tid >> 2 );       // pair index within the strip
+	const int hodd = ( tid >> 1 ) & 1; // odd output column?
+	const int ylo = max( qy0 * 2, P.srow_lo );
+	const int yhi = min( qy1 * 2, P.srow_hi );
+
+	f2 ring[ 8 ];
+#pragma unroll
+	for( int i = 0; i < 8; i++ ) ring[ i ] = (f2) 0.0f;
+
+	f2 pre[ L2_RB ];
+
+	auto prefetch = [&]( const int ub )
+	{
+		if( vact )
+		{
+#pragma unroll
+			for( int r = 0; r < L2_RB; r++ )
+			{
+				const int sy = min( max( ub + r, 0 ), P.sh - 1 );
+				pre[ r ] = *(const f2*) ( P.src + ( (unsigned) sy *
+					(unsigned) P.src_ss + scol ));
+			}
+		}
+	};
+
+	prefetch( u0 );
+
+	for( int sb = 0; sb < nsteps; sb += L2_RB )
+	{
+		const int ub = u0 + sb;
+
+		// ---- V: 8 source rows -> 16 intermediate rows (ring phase == row & 7)
+		if( vact )
+		{
+			const Taps12 V = load_taps12( P.coef );
+#define VA( i ) V.fa( i )
+#define VB( i ) V.fb( i )
+#pragma unroll
+			for( int rr = 0; rr < L2_RB; rr++ )
+			{
+				ring[ rr ] = pre[ rr ];
+				// rows u-6 .. u of the ring, u = ub + rr
+				const f2 m6 = ring[ ( rr - 6 ) & 7 ], m5 = ring[ ( rr - 5 ) & 7 ];
+				const f2 m4 = ring[ ( rr - 4 ) & 7 ], m3 = ring[ ( rr - 3 ) & 7 ];
+				const f2 m2 = ring[ ( rr - 2 ) & 7 ], m1 = ring[ ( rr - 1 ) & 7 ];
+				const f2 m0 = ring[ rr ];
+				sT[ ( 2 * rr ) * ( L2_SW * 2 ) + tid ] =
+					L2_DOT6( VA, m6, m5, m4, m3, m2, m1 );
+				sT[ ( 2 * rr + 1 ) * ( L2_SW * 2 ) + tid ] =
+					L2_DOT6( VB, m5, m4, m3, m2, m1, m0 );
+			}
+#undef VA
+#undef VB
+		}
+
+		__syncthreads();
+
+		// next step's source rows start their trip from HBM now
+		if( sb + L2_RB < nsteps )
+		{
+			prefetch( ub + L2_RB );
+		}
+
+		// ---- H: 16 intermediate rows -> 16 output rows of this strip
+		{
+			const Taps12 H = load_taps12( P.coef + 16 );
+#define HA( i ) H.fa( i )
+#define HB( i ) H.fb( i )
+			// even output 2q reads columns q-3..q+2 -> local q..q+5;
+			// odd output 2q+1 reads q-2..q+3 -> local q+1..q+6
+			const f2* base = &sT[ ( hq + hodd ) * 2 + hf ];
+#pragma unroll 4
+			for( int r = 0; r < 2 * L2_RB; r++ )
+			{
+				const int y = ( ub + ( r >> 1 ) - 3 ) * 2 + ( r & 1 );
+				const f2* t = base + r * ( L2_SW * 2 );
+				const f2 p0 = t[ 0 ], p1 = t[ 2 ], p2 = t[ 4 ];
+				const f2 p3 = t[ 6 ], p4 = t[ 8 ], p5 = t[ 10 ];
+				f2 o;
+
+				if( hodd )
+				{
+					o = L2_DOT6( HB, p0, p1, p2, p3, p4, p5 );
+				}
+				else
+				{
+					o = L2_DOT6( HA, p0, p1, p2, p3, p4, p5 );
+				}
+
+				if( xok && y >= ylo && y < yhi )
+				{
+					*(f2*) ( P.dst + (long) ( y - P.dst_row0 ) * P.dst_ss +
+						dlane ) = o;
+				}
+			}
+#undef HA
+#undef HB
+		}
+
+		__syncthreads();
+	}
+}
+
+// ---------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------
+
+struct Lanc2Data
+{
+	float* d_coef;
+};
+
+static bool match_lanc_axis( const LancirAxisDev& A, float* fa, float* fb )
+{
+	if( A.kernel_len != 6 || A.dst_len != A.src_len * 2 || A.n_filters != 2 )
+	{
+		return( false );
+	}
+
+	const int ia = A.h_fidx[ 0 ];
+	const int ib = ( A.dst_len > 1 ? A.h_fidx[ 1 ] : 1 - ia );
+
+	if( ia == ib )
+	{
+		return( false );
+	}
+
+	for( int j = 0; j < A.dst_len; j++ )
+	{
+		const int q = j >> 1;
+
+		if( A.h_start[ j ] != ( j & 1 ? q - 2 : q - 3 ) ||
+			A.h_fidx[ j ] != ( j & 1 ? ib : ia ))
+		{
+			return( false );
+		}
+	}
+
+	memcpy( fa, &A.h_flt[ (size_t) ia * 6 ], 6 * sizeof( float ));
+	memcpy( fb, &A.h_flt[ (size_t) ib * 6 ], 6 * sizeof( float ));
+	return( true );
+}
+
+int lanc2_prepare( avirhip_plan* p )
+{
+	p -> lanc2 = nullptr;
+
+	if( !p -> is_lancir || p -> ch != 4 || p -> in_type != AVIRHIP_F32 ||
+		p -> out_type != AVIRHIP_F32 || !p -> l_unity ||
+		p -> new_stride != p -> new_w * 4 )
+	{
+		return( AVIRHIP_OK );
+	}
+
+	float hc[ 32 ] = { 0 };
+
+	if( !match_lanc_axis( p -> lv, hc, hc + 6 ) ||
+		!match_lanc_axis( p -> lh, hc + 16, hc + 22 ))
+	{
+		return( AVIRHIP_OK );
+	}
+
+	void* q = nullptr;
+	AVIRHIP_HIPCHECK( hipMalloc( &q, sizeof( hc )));
+	p -> allocs.push_back( q );
+	AVIRHIP_HIPCHECK( hipMemcpy( q, hc, sizeof( hc ), hipMemcpyHostToDevice ));
+	Lanc2Data* D = new Lanc2Data();
+	D -> d_coef = (float*) q;
+	p -> lanc2 = D;
+	p -> fused_ok |= 4;
+	p -> auto_path = 4;
+	return( AVIRHIP_OK );
+}
+
+void lanc2_release( avirhip_plan* p )
+{
+	delete (Lanc2Data*) p -> lanc2;
+	p -> lanc2 = nullptr;
+}
+
+int lanc2_run( avirhip_plan* p, const float* src, float* dst, int row0,
+	int row1, hipStream_t st )
+{
+	const Lanc2Data* D = (const Lanc2Data*) p -> lanc2;
+
+	if( D == nullptr || ( (uintptr_t) src & 7 ) || ( (uintptr_t) dst & 7 ) ||
+		( p -> src_stride & 1 ) ||
+		(long) p -> src_h * p -> src_stride >= ( 1L << 31 ) ||
+		(long) p -> new_w * 4 >= ( 1L << 30 ))
+	{
+		return( 1 );
+	}
+
+	if( row1 <= row0 )
+	{
+		return( AVIRHIP_OK );
+	}
+
+	Lanc2Params P;
+	P.src = src; P.src_ss = p -> src_stride; P.sw = p -> src_w;
+	P.sh = p -> src_h;
+	P.dst = dst; P.dst_ss = (long) p -> new_w * 4; P.dst_row0 = row0;
+	P.nw = p -> new_w; P.nh = p -> new_h;
+	P.srow_lo = row0; P.srow_hi = row1;
+	P.nstrips = ( p -> new_w + L2_TW - 1 ) / L2_TW;
+	P.coef = D -> d_coef;
+
+	// chunk = 8k - 6 source rows (6 warm-up rows per chunk); fill whole rounds
+	// of 256 CUs x 8 resident workgroups with chunks of >= 58 rows
+	const int slots = 256 * 8;
+	int cq = 0;
+
+	for( int rounds = 1; rounds <= 8 && cq == 0; rounds++ )
+	{
+		const int nch = std::max( 1, rounds * slots / P.nstrips );
+		int c = ( p -> src_h + nch - 1 ) / nch;
+		c = (( c + 6 + L2_RB - 1 ) / L2_RB ) * L2_RB - 6;
+
+		if( c >= 58 || rounds == 8 )
+		{
+			cq = std::max( c, 58 );
+		}
+	}
+
+	const char* ecq = getenv( "AVIRHIP_LANC2_CQ" );
+
+	if( ecq != nullptr && atoi( ecq ) >= 2 )
+	{
+		cq = (( atoi( ecq ) + 6 + L2_RB - 1 ) / L2_RB ) * L2_RB - 6;
+	}
+
+	P.cq = cq;
+	const int cr = cq * 2;
+	P.chunk0 = row0 / cr;
+	const int chunk1 = ( row1 - 1 ) / cr;
+	const int items = P.nstrips * ( chunk1 - P.chunk0 + 1 );
+
+	hipLaunchKernelGGL( k_lanc2, dim3( items ), dim3( L2_NT ), 0, st, P );
+	AVIRHIP_HIPCHECK( hipGetLastError() );
+	return( AVIRHIP_OK );
+}
+
+} // namespace avirhip

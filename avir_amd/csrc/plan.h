@@ -106,6 +106,7 @@ struct avirhip_plan
 	int auto_path;  // path taken when `path` == 0
 	void* fused;    // tiled-kernel private data
 	void* up2;      // exact-2x marching kernel private data (fused_ok bit 2)
+	void* lanc2;    // LANCIR exact-2x kernel private data (fused_ok bit 2)
 
 	// scratch (device), lazily sized
 	std::vector< void* > allocs;
@@ -152,5 +153,11 @@ int up2_prepare( avirhip_plan* p );
 void up2_release( avirhip_plan* p );
 int up2_run( avirhip_plan* p, const float* src, long src_stride, float* dst,
 	int row0, int row1, hipStream_t st );
+
+// lanc2.hip: LANCIR exact-2x RGBA float kernel (path 4 of LANCIR plans)
+int lanc2_prepare( avirhip_plan* p );
+void lanc2_release( avirhip_plan* p );
+int lanc2_run( avirhip_plan* p, const float* src, float* dst, int row0,
+	int row1, hipStream_t st );
 
 } // namespace avirhip

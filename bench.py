@@ -34,6 +34,55 @@ SRC_W, SRC_H, NEW_W, NEW_H, CH = 3840, 2160, 7680, 4320, 4
 ALGO_BYTES = (SRC_W * SRC_H + NEW_W * NEW_H) * CH * 4
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s
 
+# The other BASELINE.json configs (parity-test cases; `--workload` times them
+# for DESIGN.md, the driver's line is always cfg3): name -> (api, sw, sh, nw, nh)
+OTHER = {"cfg2": ("avir", 1920, 1080, 3840, 2160),
+         "cfg4": ("avir", 3840, 2160, 1280, 720),
+         "cfg5": ("lancir", 3840, 2160, 7680, 4320),
+         "nonint": ("avir", 1920, 1080, 2500, 1400)}
+
+
+def time_other(name, steps, warmup, path):
+    """Times one of the non-headline configs (device-resident RGBA f32)."""
+    import torch
+    import avir_amd
+    from avir_amd import abi
+    from tests import refbind as rb
+    api, sw, sh, nw, nh = OTHER[name]
+    lib = abi.load()
+    dev = torch.device("cuda", 0)
+    src = torch.from_numpy(rb.lcg_f32((sh, sw, 4))).to(dev)
+    dst = torch.empty((nh, nw, 4), dtype=torch.float32, device=dev)
+    if api == "avir":
+        obj = avir_amd.CImageResizer(16)
+        plan = obj.plan(sw, sh, nw, nh, 4)
+    else:
+        obj = avir_amd.CLancIR()
+        plan = obj.plan(sw, sh, nw, nh, 4)
+    if path:
+        abi.check(lib.avirhip_plan_set_path(plan, path), "set_path")
+    st = torch.cuda.current_stream(dev).cuda_stream
+
+    def step():
+        abi.check(lib.avirhip_resize(plan, src.data_ptr(), abi.MEM_DEVICE,
+                                     dst.data_ptr(), abi.MEM_DEVICE, st), "resize")
+    for _ in range(warmup):
+        step()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(steps):
+        step()
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / steps
+    algo = (sw * sh + nw * nh) * 16
+    print(json.dumps({"workload": name, "api": api, "ms_per_step": round(ms, 4),
+                      "value": round(nw * nh / 1e6 / (ms * 1e-3), 1),
+                      "unit": "Mpixels/s", "path": lib.avirhip_plan_get_path(plan),
+                      "roofline_frac": round(algo / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                      "fnv1a64": rb.fnv(dst.cpu().numpy())}), flush=True)
+
 
 def cpu_baseline(src_np, threads):
     """Reference CPU path on the host cores (bounded: a few frames)."""
@@ -88,7 +137,14 @@ def main():
                     help="0 auto, 1 generic, 2 two-pass, 3 fused tile, 4 up2 (A/B)")
     ap.add_argument("--no-cpu", action="store_true",
                     help="skip the CPU baseline leg")
+    ap.add_argument("--workload", default="cfg3",
+                    help="cfg3 (the headline, default) or one of: "
+                         + ", ".join(sorted(OTHER)))
     args = ap.parse_args()
+
+    if args.workload != "cfg3":
+        time_other(args.workload, args.steps, args.warmup, args.path)
+        return
 
     import numpy as np
     import torch

@@ -324,6 +324,32 @@ def test_lancir_channels_and_io_types(ch, tin, tout):
             ch, np.dtype(tin), np.dtype(tout), sw, sh))
 
 
+@pytest.mark.parametrize("sw,sh", [(37, 21), (64, 48), (300, 200), (129, 65),
+                                   (1, 1), (5, 300), (300, 5), (640, 480)])
+def test_lancir_exact_2x_kernel(sw, sh):
+    """lanc2.hip (path 4 of LANCIR plans): 2x RGBA float, both passes fused."""
+    lib = abi.load()
+    checker = rb.ref_lancir if rb.have_ref() else rb.orc_lancir
+    src = rb.lcg_f32((sh, sw, 4), seed=77 + sw)
+    want = checker(src, 2 * sw, 2 * sh)
+    l = avir_amd.CLancIR()
+    p = l.plan(sw, sh, 2 * sw, 2 * sh, 4)
+    abi.check(lib.avirhip_plan_set_path(p, abi.PATH_UP2), "set_path")
+    got = l.resize(src, 2 * sw, 2 * sh)
+    _assert_same(got, want, "lanc2 %dx%d" % (sw, sh))
+    # row bands through the same kernel
+    nh = 2 * sh
+    for a, b in [(0, nh // 3), (nh // 3, nh // 3 + 1), (nh // 3 + 1, nh)]:
+        if b > a:
+            band = np.empty((b - a, 2 * sw, 4), np.float32)
+            abi.check(lib.avirhip_resize_band(
+                p, src.ctypes.data, abi.MEM_HOST, band.ctypes.data,
+                abi.MEM_HOST, a, b, None), "band")
+            _assert_same(band, want[a:b], "lanc2 band [%d,%d)" % (a, b))
+    abi.check(lib.avirhip_plan_set_path(p, abi.PATH_GENERIC), "set_path")
+    _assert_same(l.resize(src, 2 * sw, 2 * sh), want, "lancir generic")
+
+
 def test_lancir_params_steps_offsets_la():
     checker = rb.ref_lancir if rb.have_ref() else rb.orc_lancir
     s = rb.lcg_f32((60, 80, 4), seed=9)
