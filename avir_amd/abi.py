@@ -8,7 +8,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libavirhip.so")
+LIB_PATH = os.environ.get("AVIRHIP_LIB") or os.path.join(
+    _HERE, "lib", "libavirhip.so")  # AVIRHIP_LIB: alternate build (experiments)
 
 U8, U16, F32, F64 = 0, 1, 2, 3
 MEM_HOST, MEM_DEVICE = 0, 1

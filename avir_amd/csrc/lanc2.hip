@@ -62,7 +62,7 @@ __device__ __forceinline__ Taps12 load_taps12( const float* p )
 	asm volatile( "s_load_dwordx8 %0, %2, 0x0\n\t"
 		"s_load_dwordx4 %1, %2, 0x20\n\t"
 		"s_waitcnt lgkmcnt(0)"
-		: "=s"( t.a ), "=s"( t.b ) : "s"( p ) : "memory" );
+		: "=&s"( t.a ), "=&s"( t.b ) : "s"( p ) : "memory" );
 	return( t );
 }
 

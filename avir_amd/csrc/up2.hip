@@ -39,14 +39,18 @@
 #include <algorithm>
 #include <string.h>
 #include <stdlib.h>
+#include <stdio.h>
 #include <type_traits>
 
 namespace avirhip {
 
 typedef float f4 __attribute__(( ext_vector_type( 4 )));
 typedef float f2 __attribute__(( ext_vector_type( 2 )));
+typedef unsigned u2 __attribute__(( ext_vector_type( 2 )));
 
-#define U2_TW 128 // output columns per strip
+#ifndef U2_TW
+#define U2_TW 64 // output columns per strip (32: one autonomous wave per strip)
+#endif
 #define U2_NT ( U2_TW * 2 ) // threads per workgroup: one per half pixel
 #ifndef U2_RB
 #define U2_RB 8   // source rows per marching step (8 or 16)
@@ -60,36 +64,47 @@ struct Up2Params
 	float* dst; long dst_ss; int dst_row0; int nw, nh;
 	int srow_lo, srow_hi;
 	int nstrips, chunk0, cq; // cq: source rows (output row pairs) per chunk
-	int dbg; // timing ablations (AVIRHIP_UP2_DBG): 1 no stores, 2 no H, 4 no V emit
-	const float* coef; // device: [fh 4 | feh 12 | foh 12 | pad 4 | fv 4 | fev 12 | fov 12 | pad 4]
+#ifdef U2_DBG
+	int dbg; // timing ablations (debug build only)
+#endif
+	const float* coef; // device: 2 axes x 64 floats, every tap stored twice:
+		// [f 4x2 | fe 12x2 | fo 12x2 | pad 8]; horizontal axis first
 };
 
-// 28 wave-uniform filter taps of one axis, held in SGPRs for the duration of
-// one phase only. A volatile scalar load keeps the compiler from hoisting all
-// 56 taps of both axes out of the marching loop (which overflowed the SGPR file
-// and spilled ~270 values into VGPR lanes).
+// The 28 wave-uniform filter taps of one axis, each held as an aligned SGPR
+// PAIR {c, c} so that v_pk_mul_f32 takes it directly as its 64-bit scalar
+// operand (no s_mov to build pairs, no op_sel games). They are loaded per phase
+// with a volatile scalar load: letting the compiler hoist both axes' taps out
+// of the marching loop overflowed the SGPR file and spilled into VGPR lanes.
 typedef float f8 __attribute__(( ext_vector_type( 8 )));
+typedef float f16 __attribute__(( ext_vector_type( 16 )));
 
 struct Taps
 {
-	f8 a, b, c; // f[0..3] fe[0..3] | fe[4..11] | fo[0..7]
-	f4 d;       // fo[8..11]
-	__device__ __forceinline__ float f( int i ) const { return( a[ i ]); }
-	__device__ __forceinline__ float fe( int i ) const
-		{ return( i < 4 ? a[ 4 + i ] : b[ i - 4 ]); }
-	__device__ __forceinline__ float fo( int i ) const
-		{ return( i < 8 ? c[ i ] : d[ i - 8 ]); }
+	f16 a, b, c; // f0..3 fe0..3 | fe4..11 | fo0..7   (as pairs)
+	f8 d;        // fo8..11
+	__device__ __forceinline__ f2 pr( const f16& v, int i ) const
+		{ f2 r; r.x = v[ 2 * i ]; r.y = v[ 2 * i + 1 ]; return( r ); }
+	__device__ __forceinline__ f2 f( int i ) const { return( pr( a, i )); }
+	__device__ __forceinline__ f2 fe( int i ) const
+		{ return( i < 4 ? pr( a, 4 + i ) : pr( b, i - 4 )); }
+	__device__ __forceinline__ f2 fo( int i ) const
+	{
+		if( i < 8 ) return( pr( c, i ));
+		f2 r; r.x = d[ 2 * ( i - 8 )]; r.y = d[ 2 * ( i - 8 ) + 1 ];
+		return( r );
+	}
 };
 
 __device__ __forceinline__ Taps load_taps( const float* p )
 {
 	Taps t;
-	asm volatile( "s_load_dwordx8 %0, %4, 0x0\n\t"
-		"s_load_dwordx8 %1, %4, 0x20\n\t"
-		"s_load_dwordx8 %2, %4, 0x40\n\t"
-		"s_load_dwordx4 %3, %4, 0x60\n\t"
+	asm volatile( "s_load_dwordx16 %0, %4, 0x0\n\t"
+		"s_load_dwordx16 %1, %4, 0x40\n\t"
+		"s_load_dwordx16 %2, %4, 0x80\n\t"
+		"s_load_dwordx8 %3, %4, 0xc0\n\t"
 		"s_waitcnt lgkmcnt(0)"
-		: "=s"( t.a ), "=s"( t.b ), "=s"( t.c ), "=s"( t.d )
+		: "=&s"( t.a ), "=&s"( t.b ), "=&s"( t.c ), "=&s"( t.d )
 		: "s"( p ) : "memory" );
 	return( t );
 }
@@ -99,11 +114,32 @@ __device__ __forceinline__ int clampi( int i, int hi )
 	return( i < 0 ? 0 : ( i > hi ? hi : i ));
 }
 
+// With one wave per workgroup no s_barrier is needed: LDS operations of a wave
+// execute in program order, only the compiler must not reorder them.
+#if U2_TW == 32
+#define U2_SYNC() __builtin_amdgcn_fence( __ATOMIC_RELEASE, "wavefront" ); \
+	__builtin_amdgcn_wave_barrier(); \
+	__builtin_amdgcn_fence( __ATOMIC_ACQUIRE, "wavefront" )
+#else
+#define U2_SYNC() __syncthreads()
+#endif
+
+#ifdef U2_DBG
+#define U2_ON( bit ) ( !( P.dbg & ( bit )))
+#else
+#define U2_ON( bit ) true
+#endif
+
+#define U2_PITCH ( U2_SW * 2 ) // half-pixels per S row; C rows use the same pitch
+
 __global__ void __launch_bounds__( U2_NT ) k_up2( const Up2Params P )
 {
-	// all LDS arrays are indexed in half-pixel (f2) units: px * 2 + half
-	__shared__ __attribute__(( aligned( 16 ))) f2 sS[ U2_RB * U2_SW * 2 ];
-	__shared__ __attribute__(( aligned( 16 ))) f2 sC[ U2_RB * U2_CW * 2 ];
+	// all LDS arrays are indexed in half-pixel (f2) units: px * 2 + half.
+	// C is computed for every S position (flat index, no row/column split);
+	// only its first U2_CW px per row are meaningful. sS is padded so the
+	// windows of the last (unused) positions stay inside the array.
+	__shared__ __attribute__(( aligned( 16 ))) f2 sS[ U2_RB * U2_PITCH + 16 ];
+	__shared__ __attribute__(( aligned( 16 ))) f2 sC[ U2_RB * U2_PITCH ];
 	__shared__ __attribute__(( aligned( 16 ))) f2 sT[ U2_RB * U2_TW * 2 ];
 
 	// XCD-aware dealing of (strip, chunk) work items (see fused.hip)
@@ -131,7 +167,22 @@ __global__ void __launch_bounds__( U2_NT ) k_up2( const Up2Params P )
 	const int ylo = max( qy0 * 2, P.srow_lo );
 	const int yhi = min( qy1 * 2, P.srow_hi );
 	const bool xok = ( xo < P.nw );
-	const unsigned dlane = (unsigned) ( xo * 4 + hf * 2 ); // float offset in row
+	const bool strip_full = ( qx0 * 2 + U2_TW <= P.nw );
+	const int dlane_b = ( xo * 4 + hf * 2 ) * 4; // byte offset within a row
+	const int drow_b = (int) P.dst_ss * 4;   // bytes per destination row
+	const int srow_b = (int) P.src_ss * 4;   // bytes per source row
+
+	// Buffer addressing (uniform 128-bit resource + 32-bit lane offset + scalar
+	// row offset): a load/store moves ONE address dword per lane instead of a
+	// 64-bit flat address -- store issue cost is proportional to the dwords a
+	// wave sends to the memory pipeline. Both resources are based at this work
+	// item's first row so every offset fits 31 bits for any image size.
+	const int ubase = max( u0, 0 );
+	const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+		(void*) ( P.src + (long) ubase * P.src_ss ), 0, 0x7fffffff, 0x00020000 );
+	const __amdgpu_buffer_rsrc_t rdst = __builtin_amdgcn_make_buffer_rsrc(
+		(void*) ( P.dst + (long) ( qy0 * 2 - P.dst_row0 ) * P.dst_ss ), 0,
+		0x7fffffff, 0x00020000 );
 
 	f2 tw[ 8 ];  // ring of the last T values of this column   (slot u & 7)
 	f2 cw[ 16 ]; // ring of the last C2 values of this column  (slot u & 15)
@@ -141,30 +192,61 @@ __global__ void __launch_bounds__( U2_NT ) k_up2( const Up2Params P )
 #pragma unroll
 	for( int i = 0; i < 16; i++ ) cw[ i ] = (f2) 0.0f;
 
-	// Source half-pixels of the NEXT marching step are fetched into registers
-	// while the current step's vertical phase computes (HBM latency hidden
-	// behind the VALU work); they go to LDS at the top of a step.
-	constexpr int SN = U2_RB * U2_SW * 2; // half-pixels in the S tile
+	// ---- source prefetch: the S tile of a later marching step travels from
+	// HBM into registers while the current step computes. The per-thread
+	// addressing is loop-invariant and precomputed: in the interior of the
+	// image a load is "uniform row base + constant lane offset".
+	constexpr int SN = U2_RB * U2_PITCH; // half-pixels in the S tile
 	constexpr int NPRE = ( SN + U2_NT - 1 ) / U2_NT;
 	f2 pre[ NPRE ];
+	int poff_b[ NPRE ]; // row-in-tile * row pitch + column, bytes
+
+#pragma unroll
+	for( int k = 0; k < NPRE; k++ )
+	{
+		const int i = tid + k * U2_NT;
+		const int r = i / U2_PITCH;
+		const int c2 = i - r * U2_PITCH;
+		const int sx = clampi( qx0 - 9 + ( c2 >> 1 ), P.sw - 1 );
+		poff_b[ k ] = r * srow_b + ( sx * 4 + ( c2 & 1 ) * 2 ) * 4;
+	}
 
 	auto prefetch = [&]( const int ub )
 	{
-#pragma unroll
-		for( int k = 0; k < NPRE; k++ )
+		if( ub >= 0 && ub + U2_RB <= P.sh )
 		{
-			const int i = tid + k * U2_NT;
-			const int r = i / ( U2_SW * 2 );
-			const int c2 = i - r * ( U2_SW * 2 );
-			const int sy = clampi( ub + r, P.sh - 1 );
-			const int sx = clampi( qx0 - 9 + ( c2 >> 1 ), P.sw - 1 );
-
-			if( i < SN )
+			const int so = ( ub - ubase ) * srow_b;
+#pragma unroll
+			for( int k = 0; k < NPRE; k++ )
 			{
-				const unsigned off = (unsigned) sy * (unsigned) P.src_ss +
-					(unsigned) ( sx * 4 + ( c2 & 1 ) * 2 );
+				if(( k + 1 ) * U2_NT <= SN || tid + k * U2_NT < SN )
+				{
+					pre[ k ] = __builtin_bit_cast( f2,
+						__builtin_amdgcn_raw_buffer_load_b64( rsrc,
+						poff_b[ k ], so, 0 ));
+				}
+			}
+		}
+		else
+		{
+#pragma unroll
+			for( int k = 0; k < NPRE; k++ )
+			{
+				// image top / bottom: rows clamp individually (rare path,
+				// addressing recomputed from scratch)
+				const int i = tid + k * U2_NT;
+				const int r = i / U2_PITCH;
+				const int c2 = i - r * U2_PITCH;
+				const int sx = clampi( qx0 - 9 + ( c2 >> 1 ), P.sw - 1 );
+				const int sy = clampi( ub + r, P.sh - 1 );
 
-				pre[ k ] = *(const f2*) ( P.src + off );
+				if( i < SN )
+				{
+					pre[ k ] = __builtin_bit_cast( f2,
+						__builtin_amdgcn_raw_buffer_load_b64( rsrc,
+						( sy - ubase ) * srow_b +
+						( sx * 4 + ( c2 & 1 ) * 2 ) * 4, 0, 0 ));
+				}
 			}
 		}
 	};
@@ -174,11 +256,9 @@ __global__ void __launch_bounds__( U2_NT ) k_up2( const Up2Params P )
 #pragma unroll
 		for( int k = 0; k < NPRE; k++ )
 		{
-			const int i = tid + k * U2_NT;
-
-			if( i < SN )
+			if(( k + 1 ) * U2_NT <= SN || tid + k * U2_NT < SN )
 			{
-				sS[ i ] = pre[ k ];
+				sS[ tid + k * U2_NT ] = pre[ k ];
 			}
 		}
 	};
@@ -190,32 +270,29 @@ __global__ void __launch_bounds__( U2_NT ) k_up2( const Up2Params P )
 	{
 		constexpr int R0 = decltype( R0C )::value;
 
-		if( !( P.dbg & 2 ))
+		if( U2_ON( 2 ))
 		{
-		// ---- H1: C[m] for m = qx0-3 .. qx0+72: window S[c .. c+6]
-		const Taps H = load_taps( P.coef );
+			// ---- H1: C = FIR7 along x, flat over the whole S tile
+			const Taps H = load_taps( P.coef );
 
-		for( int i = tid; i < U2_RB * U2_CW * 2; i += U2_NT )
-		{
-			const int r = i / ( U2_CW * 2 );
-			const int c2 = i - r * ( U2_CW * 2 ); // C half-pixel index in row
-			const f2* s = &sS[ r * ( U2_SW * 2 ) + c2 ];
-			f2 a = H.f( 0 ) * s[ 6 ];
-			a = a + H.f( 1 ) * ( s[ 8 ] + s[ 4 ]);
-			a = a + H.f( 2 ) * ( s[ 10 ] + s[ 2 ]);
-			a = a + H.f( 3 ) * ( s[ 12 ] + s[ 0 ]);
-			sC[ r * ( U2_CW * 2 ) + c2 ] = a;
-		}
-
-		__syncthreads();
-
-		// ---- H2: T[2q], T[2q+1] from the 13-px window C[qq .. qq+12]
-		{
-			const int qh = tid & 127; // (pair index qq) * 2 + half
-
-			for( int r = ( tid >> 7 ); r < U2_RB; r += 2 )
+			for( int i = tid; i < SN; i += U2_NT )
 			{
-				const f2* c = &sC[ r * ( U2_CW * 2 ) + qh ];
+				const f2* s = &sS[ i ];
+				f2 a = H.f( 0 ) * s[ 6 ];
+				a = a + H.f( 1 ) * ( s[ 8 ] + s[ 4 ]);
+				a = a + H.f( 2 ) * ( s[ 10 ] + s[ 2 ]);
+				a = a + H.f( 3 ) * ( s[ 12 ] + s[ 0 ]);
+				sC[ i ] = a;
+			}
+
+			U2_SYNC();
+
+			// ---- H2: T[2q], T[2q+1] from the 13-px window C[qq .. qq+12]
+			const int qh = tid & ( U2_TW - 1 ); // (pair index qq) * 2 + half
+
+			for( int r = tid / U2_TW; r < U2_RB; r += 2 )
+			{
+				const f2* c = &sC[ r * U2_PITCH + qh ];
 				f2 w[ 13 ];
 #pragma unroll
 				for( int t = 0; t < 13; t++ ) w[ t ] = c[ t * 2 ];
@@ -234,93 +311,113 @@ __global__ void __launch_bounds__( U2_NT ) k_up2( const Up2Params P )
 				tp[ 0 ] = e;
 				tp[ 2 ] = o;
 			}
-		}
 
-		__syncthreads();
+			U2_SYNC();
 		}
 
 		// ---- S of the next step: registers -> LDS (H1 above is done with sS).
 		// Those loads were issued at this point of the PREVIOUS step, a whole
 		// vertical phase ago, and the only younger memory operations are that
 		// phase's stores, by now long retired: the vmcnt(0) here is free.
-		if( more )
+		if( more && U2_ON( 8 ))
 		{
 			store_pre();
 		}
 
 		// the tile two steps ahead starts its trip from HBM now
-		if( more2 )
+		if( more2 && U2_ON( 8 ))
 		{
 			prefetch( ub + 2 * U2_RB );
 		}
 
-		// ---- V: one half-column per thread, statically unrolled marching
-		const Taps V = load_taps( P.coef + 32 );
-		tw[ R0 & 7 ] = sT[ tid ];
-#pragma unroll
-		for( int rr = 0; rr < U2_RB; rr++ )
+		// ---- V: one half-column per thread, statically unrolled marching.
+		// FAST: every row of this step is stored by every lane (interior of
+		// the chunk, full strip): no per-row conditions at all.
+		const Taps V = load_taps( P.coef + 64 );
+		const int yb = ( ub - 9 ) * 2; // output row pair of the step's first row
+		int so = ( yb - qy0 * 2 ) * drow_b; // scalar byte offset of row yb
+
+		auto vsteps = [&]( auto FASTC )
 		{
-			const int u = ub + rr;
-			const int g = R0 + rr; // ring phase of this row
-
-			if( rr + 1 < U2_RB )
-			{
-				// ring slot (g+1)&7 holds T[u-7], already outside the window
-				tw[ ( g + 1 ) & 7 ] = sT[ ( rr + 1 ) * ( U2_TW * 2 ) + tid ];
-			}
-
-			f2 c2 = V.f( 0 ) * tw[ ( g - 3 ) & 7 ];
-			c2 = c2 + V.f( 1 ) * ( tw[ ( g - 2 ) & 7 ] + tw[ ( g - 4 ) & 7 ]);
-			c2 = c2 + V.f( 2 ) * ( tw[ ( g - 1 ) & 7 ] + tw[ ( g - 5 ) & 7 ]);
-			c2 = c2 + V.f( 3 ) * ( tw[ g & 7 ] + tw[ ( g - 6 ) & 7 ]);
-			cw[ g & 15 ] = c2;
-
-			const int y0 = ( u - 9 ) * 2;
-
-			if( y0 + 1 >= ylo && y0 < yhi && !( P.dbg & 4 ))
-			{
-				f2 e = (f2) 0.0f;
-				f2 o = (f2) 0.0f;
+			constexpr bool FAST = decltype( FASTC )::value;
+			tw[ R0 & 7 ] = sT[ tid ];
 #pragma unroll
-				for( int t = 0; t < 12; t++ )
+			for( int rr = 0; rr < U2_RB; rr++ )
+			{
+				const int g = R0 + rr; // ring phase of this row
+
+				if( rr + 1 < U2_RB )
 				{
-					e = e + V.fe( t ) * cw[ ( g - 12 + t ) & 15 ];
-					o = o + V.fo( t ) * cw[ ( g - 11 + t ) & 15 ];
+					// ring slot (g+1)&7 holds T[u-7], outside the window
+					tw[ ( g + 1 ) & 7 ] =
+						sT[ ( rr + 1 ) * ( U2_TW * 2 ) + tid ];
 				}
 
-				// uniform row pointer + 32-bit lane offset
-				float* const dp = P.dst + (long) ( y0 - P.dst_row0 ) * P.dst_ss;
+				f2 c2 = V.f( 0 ) * tw[ ( g - 3 ) & 7 ];
+				c2 = c2 + V.f( 1 ) * ( tw[ ( g - 2 ) & 7 ] +
+					tw[ ( g - 4 ) & 7 ]);
+				c2 = c2 + V.f( 2 ) * ( tw[ ( g - 1 ) & 7 ] +
+					tw[ ( g - 5 ) & 7 ]);
+				c2 = c2 + V.f( 3 ) * ( tw[ g & 7 ] + tw[ ( g - 6 ) & 7 ]);
+				cw[ g & 15 ] = c2;
 
-				if( P.dbg & 1 )
+				const int y0 = yb + rr * 2;
+
+				if(( FAST || ( y0 + 1 >= ylo && y0 < yhi )) && U2_ON( 4 ))
 				{
-					if( e.x == 1234.5f && o.y == 0.1234f )
+					f2 e = (f2) 0.0f;
+					f2 o = (f2) 0.0f;
+#pragma unroll
+					for( int t = 0; t < 12; t++ )
 					{
-						*(f2*) ( dp + dlane ) = e + o;
+						// mul, mul, add, add: a dependent v_pk op needs one
+						// issue slot of distance; pin the order so that slot
+						// is the other accumulator's op and not an s_nop
+						const f2 pe = V.fe( t ) * cw[ ( g - 12 + t ) & 15 ];
+						const f2 po = V.fo( t ) * cw[ ( g - 11 + t ) & 15 ];
+						__builtin_amdgcn_sched_barrier( 0 );
+						e = e + pe;
+						o = o + po;
+						__builtin_amdgcn_sched_barrier( 0 );
+					}
+
+					// uniform row pointer + 32-bit lane byte offset
+					if(( FAST || ( xok && y0 >= ylo )) &&
+						( U2_ON( 1 ) || e.x == 1234.5f ))
+					{
+						__builtin_amdgcn_raw_buffer_store_b64(
+							__builtin_bit_cast( u2, e ), rdst, dlane_b, so, 0 );
+					}
+
+					if(( FAST || ( xok && y0 + 1 < yhi )) &&
+						( U2_ON( 1 ) || o.y == 1234.5f ))
+					{
+						__builtin_amdgcn_raw_buffer_store_b64(
+							__builtin_bit_cast( u2, o ), rdst, dlane_b,
+							so + drow_b, 0 );
 					}
 				}
-				else
-				if( xok )
-				{
-					if( y0 >= ylo )
-					{
-						*(f2*) ( dp + dlane ) = e;
-					}
 
-					if( y0 + 1 < yhi )
-					{
-						*(f2*) ( dp + P.dst_ss + dlane ) = o;
-					}
-				}
+				so += 2 * drow_b;
 			}
+		};
+
+		if( strip_full && yb >= ylo && yb + 2 * U2_RB <= yhi )
+		{
+			vsteps( std::true_type() );
+		}
+		else
+		{
+			vsteps( std::false_type() );
 		}
 
-		__syncthreads();
+		U2_SYNC();
 	};
 
 	prefetch( u0 );
 	store_pre();
 	prefetch( u0 + U2_RB );
-	__syncthreads();
+	U2_SYNC();
 
 	// the ring period is 16 rows: 16 / U2_RB marching steps per trip
 	for( int sb = 0; sb < nsteps; sb += 16 )
@@ -417,13 +514,25 @@ int up2_prepare( avirhip_plan* p )
 
 	if( match_axis( p -> h, D -> h ) && match_axis( p -> v, D -> v ))
 	{
-		float hc[ 64 ] = { 0 };
-		memcpy( hc, D -> h.f, 4 * sizeof( float ));
-		memcpy( hc + 4, D -> h.fe, 12 * sizeof( float ));
-		memcpy( hc + 16, D -> h.fo, 12 * sizeof( float ));
-		memcpy( hc + 32, D -> v.f, 4 * sizeof( float ));
-		memcpy( hc + 36, D -> v.fe, 12 * sizeof( float ));
-		memcpy( hc + 48, D -> v.fo, 12 * sizeof( float ));
+		float hc[ 128 ] = { 0 };
+		const Up2Axis* ax[ 2 ] = { &D -> h, &D -> v };
+
+		for( int a = 0; a < 2; a++ )
+		{
+			float* o = hc + a * 64;
+
+			for( int i = 0; i < 4; i++ )
+			{
+				o[ 2 * i ] = o[ 2 * i + 1 ] = ax[ a ] -> f[ i ];
+			}
+
+			for( int t = 0; t < 12; t++ )
+			{
+				o[ 8 + 2 * t ] = o[ 9 + 2 * t ] = ax[ a ] -> fe[ t ];
+				o[ 32 + 2 * t ] = o[ 33 + 2 * t ] = ax[ a ] -> fo[ t ];
+			}
+		}
+
 		void* q = nullptr;
 		AVIRHIP_HIPCHECK( hipMalloc( &q, sizeof( hc )));
 		p -> allocs.push_back( q );
@@ -465,8 +574,8 @@ int up2_run( avirhip_plan* p, const float* src, long src_stride, float* dst,
 	}
 
 	// the kernel addresses rows with 32-bit float offsets
-	if( (long) p -> src_h * src_stride >= ( 1L << 31 ) ||
-		(long) p -> new_w * 4 >= ( 1L << 30 ))
+	if( (long) src_stride * 4 >= ( 1L << 22 ) ||
+		(long) p -> new_w * 16 >= ( 1L << 22 ))
 	{
 		return( 1 );
 	}
@@ -484,7 +593,7 @@ int up2_run( avirhip_plan* p, const float* src, long src_stride, float* dst,
 	// so that all work items fit in a whole number of such rounds (a partly
 	// filled last round leaves CUs idle), preferring the fewest rounds whose
 	// chunks are still >= 62 rows (warm-up <= ~1/4 of the horizontal work).
-	const int slots = 256 * 4;
+	const int slots = 256 * ( U2_TW == 32 ? 12 : ( U2_TW == 64 ? 6 : 4 ));
 	int cq = 0;
 
 	for( int rounds = 1; rounds <= 8 && cq == 0; rounds++ )
@@ -512,11 +621,25 @@ int up2_run( avirhip_plan* p, const float* src, long src_stride, float* dst,
 	const int chunk1 = ( row1 - 1 ) / cr;
 
 	P.coef = D -> d_coef;
-	const char* dbg = getenv( "AVIRHIP_UP2_DBG" );
-	P.dbg = ( dbg != nullptr ? atoi( dbg ) : 0 );
+#ifdef U2_DBG
+	P.dbg = ( getenv( "AVIRHIP_UP2_DBG" ) != nullptr ?
+		atoi( getenv( "AVIRHIP_UP2_DBG" )) : 0 );
+#endif
 
 	const int items = P.nstrips * ( chunk1 - P.chunk0 + 1 );
-	hipLaunchKernelGGL( k_up2, dim3( items ), dim3( U2_NT ), 0, st, P );
+
+	if( getenv( "AVIRHIP_VERBOSE" ) != nullptr )
+	{
+		int nb = -1;
+		(void) hipOccupancyMaxActiveBlocksPerMultiprocessor( &nb,
+			(const void*) k_up2, U2_NT, 0 );
+		fprintf( stderr, "k_up2: %d items (strips %d, cq %d), occupancy API "
+			"%d workgroups/CU\n", items, P.nstrips, P.cq, nb );
+	}
+
+	const char* pad = getenv( "AVIRHIP_UP2_LDSPAD" ); // residency experiments
+	hipLaunchKernelGGL( k_up2, dim3( items ), dim3( U2_NT ),
+		( pad != nullptr ? atoi( pad ) : 0 ), st, P );
 	AVIRHIP_HIPCHECK( hipGetLastError() );
 	return( AVIRHIP_OK );
 }
