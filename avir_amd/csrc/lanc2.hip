@@ -195,8 +195,9 @@ __global__ void __launch_bounds__( L2_NT ) k_lanc2( const Lanc2Params P )
 
 				if( xok && y >= ylo && y < yhi )
 				{
-					*(f2*) ( P.dst + (long) ( y - P.dst_row0 ) * P.dst_ss +
-						dlane ) = o;
+					// streaming store (never re-read): nt, measured -10 %
+					__builtin_nontemporal_store( o, (f2*) ( P.dst +
+						(long) ( y - P.dst_row0 ) * P.dst_ss + dlane ));
 				}
 			}
 #undef HA

@@ -130,6 +130,14 @@ __device__ __forceinline__ int clampi( int i, int hi )
 #define U2_ON( bit ) true
 #endif
 
+#ifndef U2_STAUX
+#define U2_STAUX 2 // destination stores are streaming: nt (measured -10 %)
+#endif
+
+#ifndef U2_LDAUX
+#define U2_LDAUX 0 // cache policy of the source loads
+#endif
+
 #define U2_PITCH ( U2_SW * 2 ) // half-pixels per S row; C rows use the same pitch
 
 __global__ void __launch_bounds__( U2_NT ) k_up2( const Up2Params P )
@@ -223,7 +231,7 @@ __global__ void __launch_bounds__( U2_NT ) k_up2( const Up2Params P )
 				{
 					pre[ k ] = __builtin_bit_cast( f2,
 						__builtin_amdgcn_raw_buffer_load_b64( rsrc,
-						poff_b[ k ], so, 0 ));
+						poff_b[ k ], so, U2_LDAUX ));
 				}
 			}
 		}
@@ -386,7 +394,7 @@ __global__ void __launch_bounds__( U2_NT ) k_up2( const Up2Params P )
 						( U2_ON( 1 ) || e.x == 1234.5f ))
 					{
 						__builtin_amdgcn_raw_buffer_store_b64(
-							__builtin_bit_cast( u2, e ), rdst, dlane_b, so, 0 );
+							__builtin_bit_cast( u2, e ), rdst, dlane_b, so, U2_STAUX );
 					}
 
 					if(( FAST || ( xok && y0 + 1 < yhi )) &&
@@ -394,7 +402,7 @@ __global__ void __launch_bounds__( U2_NT ) k_up2( const Up2Params P )
 					{
 						__builtin_amdgcn_raw_buffer_store_b64(
 							__builtin_bit_cast( u2, o ), rdst, dlane_b,
-							so + drow_b, 0 );
+							so + drow_b, U2_STAUX );
 					}
 				}
 
