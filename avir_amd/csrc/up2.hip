@@ -54,6 +54,9 @@ typedef unsigned u2 __attribute__(( ext_vector_type( 2 )));
 #define U2_NT ( U2_TW * 2 ) // threads per workgroup: one per half pixel
 #ifndef U2_RB
 #define U2_RB 8   // source rows per marching step (8 or 16)
+#ifndef U2_BPC
+#define U2_BPC 8 // resident workgroups per CU the launch is sized for (TW 64)
+#endif
 #endif
 #define U2_SW ( U2_TW / 2 + 18 ) // S tile width (px)
 #define U2_CW ( U2_TW / 2 + 12 ) // C tile width (px)
@@ -109,6 +112,14 @@ __device__ __forceinline__ Taps load_taps( const float* p )
 	return( t );
 }
 
+__device__ __forceinline__ f8 load_f8( const float* p )
+{
+	f8 t;
+	asm volatile( "s_load_dwordx8 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)"
+		: "=&s"( t ) : "s"( p ) : "memory" );
+	return( t );
+}
+
 __device__ __forceinline__ int clampi( int i, int hi )
 {
 	return( i < 0 ? 0 : ( i > hi ? hi : i ));
@@ -138,16 +149,18 @@ __device__ __forceinline__ int clampi( int i, int hi )
 #define U2_LDAUX 0 // cache policy of the source loads
 #endif
 
-#define U2_PITCH ( U2_SW * 2 ) // half-pixels per S row; C rows use the same pitch
+#define U2_PITCH ( U2_SW * 2 ) // half-pixels per S row
+#define U2_CPITCH ( U2_CW * 2 ) // half-pixels per C row
 
-__global__ void __launch_bounds__( U2_NT ) k_up2( const Up2Params P )
+__global__ void __launch_bounds__( U2_NT )
+__attribute__(( amdgpu_waves_per_eu( 4, 4 ))) k_up2( const Up2Params P )
 {
 	// all LDS arrays are indexed in half-pixel (f2) units: px * 2 + half.
 	// C is computed for every S position (flat index, no row/column split);
 	// only its first U2_CW px per row are meaningful. sS is padded so the
 	// windows of the last (unused) positions stay inside the array.
 	__shared__ __attribute__(( aligned( 16 ))) f2 sS[ U2_RB * U2_PITCH + 16 ];
-	__shared__ __attribute__(( aligned( 16 ))) f2 sC[ U2_RB * U2_PITCH ];
+	__shared__ __attribute__(( aligned( 16 ))) f2 sC[ U2_RB * U2_CPITCH ];
 	__shared__ __attribute__(( aligned( 16 ))) f2 sT[ U2_RB * U2_TW * 2 ];
 
 	// XCD-aware dealing of (strip, chunk) work items (see fused.hip)
@@ -200,73 +213,51 @@ __global__ void __launch_bounds__( U2_NT ) k_up2( const Up2Params P )
 #pragma unroll
 	for( int i = 0; i < 16; i++ ) cw[ i ] = (f2) 0.0f;
 
-	// ---- source prefetch: the S tile of a later marching step travels from
-	// HBM into registers while the current step computes. The per-thread
-	// addressing is loop-invariant and precomputed: in the interior of the
-	// image a load is "uniform row base + constant lane offset".
+	// ---- source tiles: LDS-DMA (buffer_load_dwordx4 ... lds), HBM -> LDS
+	// without passing through registers. One instruction moves whole pixels
+	// of U2_RPI consecutive tile rows: lane f takes pixel f % U2_SW of row
+	// f / U2_SW, and the hardware writes lane l of a wave to M0 + l * 16, i.e.
+	// exactly the flat (row, px) order of sS. The per-lane source offset is
+	// loop-invariant; the row group is selected by the scalar offset.
 	constexpr int SN = U2_RB * U2_PITCH; // half-pixels in the S tile
-	constexpr int NPRE = ( SN + U2_NT - 1 ) / U2_NT;
-	f2 pre[ NPRE ];
-	int poff_b[ NPRE ]; // row-in-tile * row pitch + column, bytes
+	constexpr int RPI = U2_NT / U2_SW;   // tile rows per DMA instruction
+	constexpr int NDMA = U2_RB / RPI;
+	static_assert( RPI >= 1 && U2_RB % RPI == 0, "S tile / DMA geometry" );
 
-#pragma unroll
-	for( int k = 0; k < NPRE; k++ )
-	{
-		const int i = tid + k * U2_NT;
-		const int r = i / U2_PITCH;
-		const int c2 = i - r * U2_PITCH;
-		const int sx = clampi( qx0 - 9 + ( c2 >> 1 ), P.sw - 1 );
-		poff_b[ k ] = r * srow_b + ( sx * 4 + ( c2 & 1 ) * 2 ) * 4;
-	}
+	const int pr_r = tid / U2_SW;
+	const int pr_sx = clampi( qx0 - 9 + ( tid - pr_r * U2_SW ), P.sw - 1 );
+	const bool pr_on = ( tid < RPI * U2_SW );
+	const int pr_voff = pr_r * srow_b + pr_sx * 16;
+	typedef __attribute__(( address_space( 3 ))) void* ldsptr;
+	const int wave_b = __builtin_amdgcn_readfirstlane( tid >> 6 ) * 1024;
 
 	auto prefetch = [&]( const int ub )
 	{
+		if( !pr_on )
+		{
+			return;
+		}
+
 		if( ub >= 0 && ub + U2_RB <= P.sh )
 		{
-			const int so = ( ub - ubase ) * srow_b;
 #pragma unroll
-			for( int k = 0; k < NPRE; k++ )
+			for( int k = 0; k < NDMA; k++ )
 			{
-				if(( k + 1 ) * U2_NT <= SN || tid + k * U2_NT < SN )
-				{
-					pre[ k ] = __builtin_bit_cast( f2,
-						__builtin_amdgcn_raw_buffer_load_b64( rsrc,
-						poff_b[ k ], so, U2_LDAUX ));
-				}
+				__builtin_amdgcn_raw_ptr_buffer_load_lds( rsrc,
+					(ldsptr) ((char*) sS + k * RPI * U2_SW * 16 + wave_b ), 16,
+					pr_voff, ( ub - ubase + k * RPI ) * srow_b, 0, U2_LDAUX );
 			}
 		}
 		else
 		{
 #pragma unroll
-			for( int k = 0; k < NPRE; k++ )
+			for( int k = 0; k < NDMA; k++ )
 			{
-				// image top / bottom: rows clamp individually (rare path,
-				// addressing recomputed from scratch)
-				const int i = tid + k * U2_NT;
-				const int r = i / U2_PITCH;
-				const int c2 = i - r * U2_PITCH;
-				const int sx = clampi( qx0 - 9 + ( c2 >> 1 ), P.sw - 1 );
-				const int sy = clampi( ub + r, P.sh - 1 );
-
-				if( i < SN )
-				{
-					pre[ k ] = __builtin_bit_cast( f2,
-						__builtin_amdgcn_raw_buffer_load_b64( rsrc,
-						( sy - ubase ) * srow_b +
-						( sx * 4 + ( c2 & 1 ) * 2 ) * 4, 0, 0 ));
-				}
-			}
-		}
-	};
-
-	auto store_pre = [&]()
-	{
-#pragma unroll
-		for( int k = 0; k < NPRE; k++ )
-		{
-			if(( k + 1 ) * U2_NT <= SN || tid + k * U2_NT < SN )
-			{
-				sS[ tid + k * U2_NT ] = pre[ k ];
+				// image top / bottom: rows clamp individually (rare path)
+				const int sy = clampi( ub + k * RPI + pr_r, P.sh - 1 );
+				__builtin_amdgcn_raw_ptr_buffer_load_lds( rsrc,
+					(ldsptr) ((char*) sS + k * RPI * U2_SW * 16 + wave_b ), 16,
+					( sy - ubase ) * srow_b + pr_sx * 16, 0, 0, U2_LDAUX );
 			}
 		}
 	};
@@ -278,29 +269,24 @@ __global__ void __launch_bounds__( U2_NT ) k_up2( const Up2Params P )
 	{
 		constexpr int R0 = decltype( R0C )::value;
 
+		// ======== interval B: H2 of this step, while the S tile of the next
+		// step lands in sS (nobody reads sS in this interval: H1 of this step
+		// ran inside the previous vertical phase). The DMA is complete
+		// (vmcnt) before the closing barrier.
+		if( more && U2_ON( 8 ))
+		{
+			prefetch( ub + U2_RB );
+		}
+
 		if( U2_ON( 2 ))
 		{
-			// ---- H1: C = FIR7 along x, flat over the whole S tile
-			const Taps H = load_taps( P.coef );
-
-			for( int i = tid; i < SN; i += U2_NT )
-			{
-				const f2* s = &sS[ i ];
-				f2 a = H.f( 0 ) * s[ 6 ];
-				a = a + H.f( 1 ) * ( s[ 8 ] + s[ 4 ]);
-				a = a + H.f( 2 ) * ( s[ 10 ] + s[ 2 ]);
-				a = a + H.f( 3 ) * ( s[ 12 ] + s[ 0 ]);
-				sC[ i ] = a;
-			}
-
-			U2_SYNC();
-
 			// ---- H2: T[2q], T[2q+1] from the 13-px window C[qq .. qq+12]
+			const Taps H = load_taps( P.coef );
 			const int qh = tid & ( U2_TW - 1 ); // (pair index qq) * 2 + half
 
 			for( int r = tid / U2_TW; r < U2_RB; r += 2 )
 			{
-				const f2* c = &sC[ r * U2_PITCH + qh ];
+				const f2* c = &sC[ r * U2_CPITCH + qh ];
 				f2 w[ 13 ];
 #pragma unroll
 				for( int t = 0; t < 13; t++ ) w[ t ] = c[ t * 2 ];
@@ -319,29 +305,29 @@ __global__ void __launch_bounds__( U2_NT ) k_up2( const Up2Params P )
 				tp[ 0 ] = e;
 				tp[ 2 ] = o;
 			}
-
-			U2_SYNC();
 		}
 
-		// ---- S of the next step: registers -> LDS (H1 above is done with sS).
-		// Those loads were issued at this point of the PREVIOUS step, a whole
-		// vertical phase ago, and the only younger memory operations are that
-		// phase's stores, by now long retired: the vmcnt(0) here is free.
-		if( more && U2_ON( 8 ))
-		{
-			store_pre();
-		}
+		U2_SYNC();
 
-		// the tile two steps ahead starts its trip from HBM now
-		if( more2 && U2_ON( 8 ))
-		{
-			prefetch( ub + 2 * U2_RB );
-		}
-
+		// ======== interval A: V of this step, with H1 of the NEXT step woven
+		// into it (its LDS latency hides behind the vertical VALU work)
 		// ---- V: one half-column per thread, statically unrolled marching.
 		// FAST: every row of this step is stored by every lane (interior of
 		// the chunk, full strip): no per-row conditions at all.
 		const Taps V = load_taps( P.coef + 64 );
+		// horizontal FIR taps (4 pairs), parked in VGPRs: the vertical taps
+		// already fill the SGPR file
+		f2 hv[ 4 ];
+		{
+			const f8 HF = load_f8( P.coef );
+#pragma unroll
+			for( int t = 0; t < 4; t++ )
+			{
+				asm volatile( "v_mov_b32 %0, %2\n\tv_mov_b32 %1, %3"
+					: "=&v"( hv[ t ].x ), "=&v"( hv[ t ].y )
+					: "s"( HF[ t * 2 ]), "s"( HF[ t * 2 + 1 ]));
+			}
+		}
 		const int yb = ( ub - 9 ) * 2; // output row pair of the step's first row
 		int so = ( yb - qy0 * 2 ) * drow_b; // scalar byte offset of row yb
 
@@ -407,6 +393,29 @@ __global__ void __launch_bounds__( U2_NT ) k_up2( const Up2Params P )
 				}
 
 				so += 2 * drow_b;
+
+				// ---- H1 of the next step, iteration rr: C = FIR7 along x,
+				// flat over the whole S tile
+				if( rr * U2_NT < SN && more && U2_ON( 2 ))
+				{
+					const int i = tid + rr * U2_NT;
+
+					if(( rr + 1 ) * U2_NT <= SN || i < SN )
+					{
+						const f2* s = &sS[ i ];
+						f2 a = hv[ 0 ] * s[ 6 ];
+						a = a + hv[ 1 ] * ( s[ 8 ] + s[ 4 ]);
+						a = a + hv[ 2 ] * ( s[ 10 ] + s[ 2 ]);
+						a = a + hv[ 3 ] * ( s[ 12 ] + s[ 0 ]);
+						const int r = (int) ((unsigned) i / U2_PITCH );
+						const int c = i - r * U2_PITCH;
+
+						if( c < U2_CPITCH )
+						{
+							sC[ r * U2_CPITCH + c ] = a;
+						}
+					}
+				}
 			}
 		};
 
@@ -422,9 +431,35 @@ __global__ void __launch_bounds__( U2_NT ) k_up2( const Up2Params P )
 		U2_SYNC();
 	};
 
+	static_assert(( SN + U2_NT - 1 ) / U2_NT <= U2_RB,
+		"H1 iterations must fit into the marching steps" );
+
 	prefetch( u0 );
-	store_pre();
-	prefetch( u0 + U2_RB );
+	U2_SYNC();
+
+	{
+		// H1 of the first tile (later tiles: woven into the vertical phase)
+		const f8 HF = load_f8( P.coef );
+		const f2 h0 = { HF[ 0 ], HF[ 1 ]}, h1 = { HF[ 2 ], HF[ 3 ]};
+		const f2 h2 = { HF[ 4 ], HF[ 5 ]}, h3 = { HF[ 6 ], HF[ 7 ]};
+
+		for( int i = tid; i < SN; i += U2_NT )
+		{
+			const f2* s = &sS[ i ];
+			f2 a = h0 * s[ 6 ];
+			a = a + h1 * ( s[ 8 ] + s[ 4 ]);
+			a = a + h2 * ( s[ 10 ] + s[ 2 ]);
+			a = a + h3 * ( s[ 12 ] + s[ 0 ]);
+			const int r = (int) ((unsigned) i / U2_PITCH );
+			const int c = i - r * U2_PITCH;
+
+			if( c < U2_CPITCH )
+			{
+				sC[ r * U2_CPITCH + c ] = a;
+			}
+		}
+	}
+
 	U2_SYNC();
 
 	// the ring period is 16 rows: 16 / U2_RB marching steps per trip
@@ -570,8 +605,10 @@ int up2_run( avirhip_plan* p, const float* src, long src_stride, float* dst,
 {
 	const Up2Data* D = (const Up2Data*) p -> up2;
 
-	if( D == nullptr || ( (uintptr_t) src & 7 ) || ( (uintptr_t) dst & 7 ) ||
-		( src_stride & 1 ))
+	// source pixels travel as 16-byte LDS-DMA pieces, destination half-pixels
+	// as 8-byte stores
+	if( D == nullptr || ( (uintptr_t) src & 15 ) || ( (uintptr_t) dst & 7 ) ||
+		( src_stride & 3 ))
 	{
 		return( 1 );
 	}
@@ -601,7 +638,7 @@ int up2_run( avirhip_plan* p, const float* src, long src_stride, float* dst,
 	// so that all work items fit in a whole number of such rounds (a partly
 	// filled last round leaves CUs idle), preferring the fewest rounds whose
 	// chunks are still >= 62 rows (warm-up <= ~1/4 of the horizontal work).
-	const int slots = 256 * ( U2_TW == 32 ? 12 : ( U2_TW == 64 ? 6 : 4 ));
+	const int slots = 256 * ( U2_TW == 32 ? 12 : ( U2_TW == 64 ? U2_BPC : 4 ));
 	int cq = 0;
 
 	for( int rounds = 1; rounds <= 8 && cq == 0; rounds++ )
