@@ -66,9 +66,10 @@ struct Up2Params
 	const float* src; long src_ss; int sw, sh;
 	float* dst; long dst_ss; int dst_row0; int nw, nh;
 	int srow_lo, srow_hi;
-	int nstrips, chunk0, cq; // cq: source rows (output row pairs) per chunk
+	int nstrips, chunk0, nchunks, cq; // cq: source rows (output row pairs) per chunk
 #ifdef U2_DBG
 	int dbg; // timing ablations (debug build only)
+	unsigned long long* clk; // [items][4]: shader cycles, start, end (100 MHz ticks), hw id
 #endif
 	const float* coef; // device: 2 axes x 64 floats, every tap stored twice:
 		// [f 4x2 | fe 12x2 | fo 12x2 | pad 8]; horizontal axis first
@@ -120,6 +121,14 @@ __device__ __forceinline__ f8 load_f8( const float* p )
 	return( t );
 }
 
+// (wave-uniform tap pair) * (whole pixel) = two v_pk_mul_f32
+__device__ __forceinline__ f4 tmul( const f2 t, const f4 v )
+{
+	const f2 lo = t * v.lo;
+	const f2 hi = t * v.hi;
+	return( __builtin_shufflevector( lo, hi, 0, 1, 2, 3 ));
+}
+
 __device__ __forceinline__ int clampi( int i, int hi )
 {
 	return( i < 0 ? 0 : ( i > hi ? hi : i ));
@@ -149,20 +158,27 @@ __device__ __forceinline__ int clampi( int i, int hi )
 #define U2_LDAUX 0 // cache policy of the source loads
 #endif
 
-#define U2_PITCH ( U2_SW * 2 ) // half-pixels per S row
-#define U2_CPITCH ( U2_CW * 2 ) // half-pixels per C row
+#define U2_TPL ( U2_RB * ( U2_TW / 2 ) + 8 ) // px per T plane, incl. the 128-B skew
 
 __global__ void __launch_bounds__( U2_NT )
 __attribute__(( amdgpu_waves_per_eu( 4, 4 ))) k_up2( const Up2Params P )
 {
-	// all LDS arrays are indexed in half-pixel (f2) units: px * 2 + half.
-	// C is computed for every S position (flat index, no row/column split);
-	// only its first U2_CW px per row are meaningful. sS is padded so the
-	// windows of the last (unused) positions stay inside the array.
-	__shared__ __attribute__(( aligned( 16 ))) f2 sS[ U2_RB * U2_PITCH + 16 ];
-	__shared__ __attribute__(( aligned( 16 ))) f2 sC[ U2_RB * U2_CPITCH ];
-	__shared__ __attribute__(( aligned( 16 ))) f2 sT[ U2_RB * U2_TW * 2 ];
+	// LDS tiles, whole pixels (16 B). The horizontal phases work on whole
+	// pixels so that every LDS access is a conflict-free 128-bit one; the
+	// vertical phase reads half pixels (8 B) of T.
+	//   sS  U2_RB rows x U2_SW px, flat: exactly the lane order of the DMA
+	//   sC  U2_RB rows x U2_CW px, flat
+	//   sT  two planes (even / odd output column), U2_RB rows x U2_TW/2 px
+	//       each; the planes sit 128 B (mod 256 B) apart so that the vertical
+	//       phase's alternating-plane reads fall into disjoint banks
+	__shared__ __attribute__(( aligned( 16 ))) f4 sS[ U2_RB * U2_SW ];
+	__shared__ __attribute__(( aligned( 16 ))) f4 sC[ U2_RB * U2_CW ];
+	__shared__ __attribute__(( aligned( 16 ))) f4 sT[ U2_TPL * 2 - 8 ];
 
+#ifdef U2_DBG
+	const unsigned long long dbg_c0 = clock64();
+	const unsigned long long dbg_w0 = wall_clock64();
+#endif
 	// XCD-aware dealing of (strip, chunk) work items (see fused.hip)
 	const int nwg = gridDim.x;
 	const int b = blockIdx.x;
@@ -172,8 +188,10 @@ __attribute__(( amdgpu_waves_per_eu( 4, 4 ))) k_up2( const Up2Params P )
 	const int item = ( xcd < rm ? xcd * ( qd + 1 ) :
 		rm * ( qd + 1 ) + ( xcd - rm ) * qd ) + ( b >> 3 );
 
-	const int strip = item % P.nstrips;
-	const int chunk = P.chunk0 + item / P.nstrips;
+	// strip-major: an XCD's contiguous item range holds whole strips, i.e.
+	// the same mix of full and short (last) chunks as every other XCD
+	const int strip = item / P.nchunks;
+	const int chunk = P.chunk0 + item - strip * P.nchunks;
 	const int tid = threadIdx.x;
 	const int hf = tid & 1;   // which half of the pixel (channels 0-1 / 2-3)
 	const int col = tid >> 1; // column within the strip (vertical phase)
@@ -219,7 +237,6 @@ __attribute__(( amdgpu_waves_per_eu( 4, 4 ))) k_up2( const Up2Params P )
 	// f / U2_SW, and the hardware writes lane l of a wave to M0 + l * 16, i.e.
 	// exactly the flat (row, px) order of sS. The per-lane source offset is
 	// loop-invariant; the row group is selected by the scalar offset.
-	constexpr int SN = U2_RB * U2_PITCH; // half-pixels in the S tile
 	constexpr int RPI = U2_NT / U2_SW;   // tile rows per DMA instruction
 	constexpr int NDMA = U2_RB / RPI;
 	static_assert( RPI >= 1 && U2_RB % RPI == 0, "S tile / DMA geometry" );
@@ -262,6 +279,31 @@ __attribute__(( amdgpu_waves_per_eu( 4, 4 ))) k_up2( const Up2Params P )
 		}
 	};
 
+	// ---- H1: C = FIR7 along x, one whole pixel per thread and iteration,
+	// flat over the C tile (7 ds_read_b128 + 1 ds_write_b128 per pixel)
+	constexpr int CN = U2_RB * U2_CW;
+	constexpr int NH1 = ( CN + U2_NT - 1 ) / U2_NT;
+	constexpr int H1EVERY = U2_RB / NH1; // woven into every H1EVERY-th V step
+	static_assert( NH1 <= U2_RB, "H1 iterations must fit into the marching steps" );
+
+	auto h1_iter = [&]( const int k, const f2 ( &h )[ 4 ])
+	{
+		const int i = tid + k * U2_NT;
+
+		if(( k + 1 ) * U2_NT <= CN || i < CN )
+		{
+			const int r = (int) ((unsigned) i / U2_CW );
+			const f4* s = &sS[ i + r * ( U2_SW - U2_CW )];
+			const f4 s0 = s[ 0 ], s1 = s[ 1 ], s2 = s[ 2 ], s3 = s[ 3 ];
+			const f4 s4 = s[ 4 ], s5 = s[ 5 ], s6 = s[ 6 ];
+			f4 a = tmul( h[ 0 ], s3 );
+			a = a + tmul( h[ 1 ], s4 + s2 );
+			a = a + tmul( h[ 2 ], s5 + s1 );
+			a = a + tmul( h[ 3 ], s6 + s0 );
+			sC[ i ] = a;
+		}
+	};
+
 	// One marching step of U2_RB source rows. R0 = ring phase of its first
 	// row (compile-time), so every ring access below is a fixed register.
 	auto march = [&]( auto R0C, const int ub, const bool more,
@@ -280,30 +322,41 @@ __attribute__(( amdgpu_waves_per_eu( 4, 4 ))) k_up2( const Up2Params P )
 
 		if( U2_ON( 2 ))
 		{
-			// ---- H2: T[2q], T[2q+1] from the 13-px window C[qq .. qq+12]
+			// ---- H2: T[2q], T[2q+1] from the 13-px window C[qq .. qq+12], one
+			// source pixel (two whole output pixels) per thread and iteration
 			const Taps H = load_taps( P.coef );
-			const int qh = tid & ( U2_TW - 1 ); // (pair index qq) * 2 + half
+			const int qq = tid & ( U2_TW / 2 - 1 );
 
-			for( int r = tid / U2_TW; r < U2_RB; r += 2 )
+			for( int r = tid / ( U2_TW / 2 ); r < U2_RB;
+				r += U2_NT / ( U2_TW / 2 ))
 			{
-				const f2* c = &sC[ r * U2_CPITCH + qh ];
-				f2 w[ 13 ];
+				const f4* c = &sC[ r * U2_CW + qq ];
+				f4 e = (f4) 0.0f;
+				f4 o = (f4) 0.0f;
+				f4 w[ 13 ];
 #pragma unroll
-				for( int t = 0; t < 13; t++ ) w[ t ] = c[ t * 2 ];
-
-				f2 e = (f2) 0.0f;
-				f2 o = (f2) 0.0f;
+				for( int t = 0; t < 7; t++ ) w[ t ] = c[ t ];
 #pragma unroll
-				for( int t = 0; t < 12; t++ )
+				for( int t = 0; t < 6; t++ )
 				{
-					e = e + H.fe( t ) * w[ t ];
-					o = o + H.fo( t ) * w[ t + 1 ];
+					e = e + tmul( H.fe( t ), w[ t ]);
+					o = o + tmul( H.fo( t ), w[ t + 1 ]);
 				}
 
-				const int qq = qh >> 1;
-				f2* tp = &sT[ r * ( U2_TW * 2 ) + qq * 4 + ( qh & 1 )];
-				tp[ 0 ] = e;
-				tp[ 2 ] = o;
+				// second half of the window only now: 13 pixels at once
+				// would cost 52 VGPRs
+				__builtin_amdgcn_sched_barrier( 0 );
+#pragma unroll
+				for( int t = 7; t < 13; t++ ) w[ t ] = c[ t ];
+#pragma unroll
+				for( int t = 6; t < 12; t++ )
+				{
+					e = e + tmul( H.fe( t ), w[ t ]);
+					o = o + tmul( H.fo( t ), w[ t + 1 ]);
+				}
+
+				sT[ r * ( U2_TW / 2 ) + qq ] = e;
+				sT[ U2_TPL + r * ( U2_TW / 2 ) + qq ] = o;
 			}
 		}
 
@@ -331,10 +384,14 @@ __attribute__(( amdgpu_waves_per_eu( 4, 4 ))) k_up2( const Up2Params P )
 		const int yb = ( ub - 9 ) * 2; // output row pair of the step's first row
 		int so = ( yb - qy0 * 2 ) * drow_b; // scalar byte offset of row yb
 
+		// this thread's half pixel of T: plane = column parity
+		const f2* sT2 = (const f2*) sT +
+			((( col & 1 ) * U2_TPL + ( col >> 1 )) * 2 + hf );
+
 		auto vsteps = [&]( auto FASTC )
 		{
 			constexpr bool FAST = decltype( FASTC )::value;
-			tw[ R0 & 7 ] = sT[ tid ];
+			tw[ R0 & 7 ] = sT2[ 0 ];
 #pragma unroll
 			for( int rr = 0; rr < U2_RB; rr++ )
 			{
@@ -343,8 +400,7 @@ __attribute__(( amdgpu_waves_per_eu( 4, 4 ))) k_up2( const Up2Params P )
 				if( rr + 1 < U2_RB )
 				{
 					// ring slot (g+1)&7 holds T[u-7], outside the window
-					tw[ ( g + 1 ) & 7 ] =
-						sT[ ( rr + 1 ) * ( U2_TW * 2 ) + tid ];
+					tw[ ( g + 1 ) & 7 ] = sT2[ ( rr + 1 ) * U2_TW ];
 				}
 
 				f2 c2 = V.f( 0 ) * tw[ ( g - 3 ) & 7 ];
@@ -394,27 +450,11 @@ __attribute__(( amdgpu_waves_per_eu( 4, 4 ))) k_up2( const Up2Params P )
 
 				so += 2 * drow_b;
 
-				// ---- H1 of the next step, iteration rr: C = FIR7 along x,
-				// flat over the whole S tile
-				if( rr * U2_NT < SN && more && U2_ON( 2 ))
+				// ---- H1 of the next step, one iteration
+				if( rr % H1EVERY == 0 && rr / H1EVERY < NH1 && more &&
+					U2_ON( 2 ))
 				{
-					const int i = tid + rr * U2_NT;
-
-					if(( rr + 1 ) * U2_NT <= SN || i < SN )
-					{
-						const f2* s = &sS[ i ];
-						f2 a = hv[ 0 ] * s[ 6 ];
-						a = a + hv[ 1 ] * ( s[ 8 ] + s[ 4 ]);
-						a = a + hv[ 2 ] * ( s[ 10 ] + s[ 2 ]);
-						a = a + hv[ 3 ] * ( s[ 12 ] + s[ 0 ]);
-						const int r = (int) ((unsigned) i / U2_PITCH );
-						const int c = i - r * U2_PITCH;
-
-						if( c < U2_CPITCH )
-						{
-							sC[ r * U2_CPITCH + c ] = a;
-						}
-					}
+					h1_iter( rr / H1EVERY, hv );
 				}
 			}
 		};
@@ -431,32 +471,24 @@ __attribute__(( amdgpu_waves_per_eu( 4, 4 ))) k_up2( const Up2Params P )
 		U2_SYNC();
 	};
 
-	static_assert(( SN + U2_NT - 1 ) / U2_NT <= U2_RB,
-		"H1 iterations must fit into the marching steps" );
-
 	prefetch( u0 );
 	U2_SYNC();
 
 	{
 		// H1 of the first tile (later tiles: woven into the vertical phase)
 		const f8 HF = load_f8( P.coef );
-		const f2 h0 = { HF[ 0 ], HF[ 1 ]}, h1 = { HF[ 2 ], HF[ 3 ]};
-		const f2 h2 = { HF[ 4 ], HF[ 5 ]}, h3 = { HF[ 6 ], HF[ 7 ]};
-
-		for( int i = tid; i < SN; i += U2_NT )
+		f2 hp[ 4 ];
+#pragma unroll
+		for( int t = 0; t < 4; t++ )
 		{
-			const f2* s = &sS[ i ];
-			f2 a = h0 * s[ 6 ];
-			a = a + h1 * ( s[ 8 ] + s[ 4 ]);
-			a = a + h2 * ( s[ 10 ] + s[ 2 ]);
-			a = a + h3 * ( s[ 12 ] + s[ 0 ]);
-			const int r = (int) ((unsigned) i / U2_PITCH );
-			const int c = i - r * U2_PITCH;
+			hp[ t ].x = HF[ t * 2 ];
+			hp[ t ].y = HF[ t * 2 + 1 ];
+		}
 
-			if( c < U2_CPITCH )
-			{
-				sC[ r * U2_CPITCH + c ] = a;
-			}
+#pragma unroll
+		for( int k = 0; k < NH1; k++ )
+		{
+			h1_iter( k, hp );
 		}
 	}
 
@@ -481,6 +513,18 @@ __attribute__(( amdgpu_waves_per_eu( 4, 4 ))) k_up2( const Up2Params P )
 			sb + 16 < nsteps, sb + 24 < nsteps );
 #endif
 	}
+
+#ifdef U2_DBG
+	if( tid == 0 && P.clk != nullptr )
+	{
+		P.clk[ blockIdx.x * 4 ] = clock64() - dbg_c0;
+		P.clk[ blockIdx.x * 4 + 1 ] = dbg_w0;
+		P.clk[ blockIdx.x * 4 + 2 ] = wall_clock64();
+		P.clk[ blockIdx.x * 4 + 3 ] =
+			(unsigned) __builtin_amdgcn_s_getreg(( 31 << 11 ) | 4 ) |
+			((unsigned long long) __builtin_amdgcn_s_getreg(( 31 << 11 ) | 20 ) << 32 );
+	}
+#endif
 }
 
 // ---------------------------------------------------------------------
@@ -669,9 +713,19 @@ int up2_run( avirhip_plan* p, const float* src, long src_stride, float* dst,
 #ifdef U2_DBG
 	P.dbg = ( getenv( "AVIRHIP_UP2_DBG" ) != nullptr ?
 		atoi( getenv( "AVIRHIP_UP2_DBG" )) : 0 );
+	static unsigned long long* dclk = nullptr;
+	static int dclk_calls = 0;
+
+	if( dclk == nullptr )
+	{
+		(void) hipMalloc( &dclk, 8192 * 32 );
+	}
+
+	P.clk = dclk;
 #endif
 
-	const int items = P.nstrips * ( chunk1 - P.chunk0 + 1 );
+	P.nchunks = chunk1 - P.chunk0 + 1;
+	const int items = P.nstrips * P.nchunks;
 
 	if( getenv( "AVIRHIP_VERBOSE" ) != nullptr )
 	{
@@ -686,6 +740,47 @@ int up2_run( avirhip_plan* p, const float* src, long src_stride, float* dst,
 	hipLaunchKernelGGL( k_up2, dim3( items ), dim3( U2_NT ),
 		( pad != nullptr ? atoi( pad ) : 0 ), st, P );
 	AVIRHIP_HIPCHECK( hipGetLastError() );
+#ifdef U2_DBG
+	if( ++dclk_calls == 60 && items <= 8192 )
+	{
+		// in-kernel clocks of a launch in the middle of a timing loop
+		std::vector< unsigned long long > h( items * 4 );
+		(void) hipStreamSynchronize( st );
+		(void) hipMemcpy( h.data(), dclk, items * 32, hipMemcpyDeviceToHost );
+		double sc = 0.0, sw = 0.0, mx = 0.0;
+		unsigned long long t0 = ~0ULL, t1 = 0;
+
+		for( int i = 0; i < items; i++ )
+		{
+			const double w = (double) ( h[ i * 4 + 2 ] - h[ i * 4 + 1 ]);
+			sc += (double) h[ i * 4 ];
+			sw += w;
+			mx = std::max( mx, w );
+			t0 = std::min( t0, h[ i * 4 + 1 ]);
+			t1 = std::max( t1, h[ i * 4 + 2 ]);
+		}
+
+		fprintf( stderr, "k_up2 clocks: mean item %.0f shader cycles, %.2f us "
+			"(max %.2f us, first start to last end %.2f us) => %.3f GHz\n",
+			sc / items, sw / items / 100.0, mx / 100.0,
+			(double) ( t1 - t0 ) / 100.0, sc / sw * 0.1 );
+
+		const char* dump = getenv( "AVIRHIP_UP2_CLKDUMP" );
+
+		if( dump != nullptr )
+		{
+			FILE* f = fopen( dump, "w" );
+
+			for( int i = 0; f != nullptr && i < items; i++ )
+			{
+				fprintf( f, "%d %llu %llu %llu %llx\n", i, h[ i * 4 ],
+					h[ i * 4 + 1 ] - t0, h[ i * 4 + 2 ] - t0, h[ i * 4 + 3 ]);
+			}
+
+			if( f != nullptr ) fclose( f );
+		}
+	}
+#endif
 	return( AVIRHIP_OK );
 }
 
