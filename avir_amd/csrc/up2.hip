@@ -13,24 +13,26 @@
 // clamped C equals FIR(Sext[m-6..m]) for EVERY m -- so no border special
 // cases exist anywhere below, only clamped source loads.
 //
-// Structure ("marching strip"): a workgroup owns a strip of 128 output columns
-// and a chunk of output rows, and marches down the source U2_RB rows at a time.
-// The unit of work is a HALF pixel (2 of the 4 channels, one 8-byte f2): 256
-// threads = 128 columns x 2 halves. Halving the per-thread state (the register
-// windows below) doubles the resident waves per SIMD, which is what hides the
-// LDS latency of the horizontal phases behind the VALU-bound vertical phase.
-//   S   U2_RB source rows x 82 px (halo 9+9), coalesced 8 B/lane  HBM -> LDS
-//   H1  C rows  = FIR7 along x                                   LDS -> LDS
-//   H2  T rows  = 12-tap even/odd interpolation along x (2 outputs per
-//       thread share one 13-pixel window)                        LDS -> LDS
-//   V   each thread owns ONE output column and keeps the vertical FIR window
-//       (7 px) and the vertical interpolation window (13 px) in REGISTERS,
-//       rotating through statically-indexed ring slots (the 16-row step is
-//       fully unrolled), consuming one T row per step from LDS and emitting
-//       two output rows per step straight to HBM (coalesced 2 KiB per row).
+// Structure ("marching strip"): a workgroup (2 waves) owns a strip of 64 output
+// columns and a chunk of output rows, and marches down the source U2_RB rows
+// at a time, two barriers per step:
+//   S   U2_RB source rows x 50 px (halo 9+9): HBM -> LDS by LDS-DMA
+//       (buffer_load_dwordx4 ... lds), no staging registers
+//   H1  C rows  = FIR7 along x, whole pixels                     LDS -> LDS
+//   H2  T rows  = 12-tap even/odd interpolation along x (one source pixel
+//       = two whole output pixels per thread, one 13-pixel window of 128-bit
+//       LDS reads)                                               LDS -> LDS
+//   V   each thread owns ONE HALF-PIXEL output column (8 bytes) and keeps the
+//       vertical FIR window (7) and the vertical interpolation window (13) in
+//       REGISTERS, rotating through statically-indexed ring slots (the 16-row
+//       ring period is fully unrolled), consuming one T row per step from LDS
+//       and streaming two output rows per step straight to HBM (nt stores,
+//       512 contiguous bytes per wave-instruction).
+// Pipeline: interval B = {DMA of the next S tile in flight, H2 of this step};
+// interval A = {V of this step with H1 of the NEXT step woven into it}.
 // The horizontally resized intermediate (the reference's FltBuf) never exists
 // in memory, vertical work is never recomputed inside a chunk, and all 56
-// filter coefficients live in SGPRs (wave-uniform kernel arguments).
+// filter coefficients are wave-uniform SGPR pairs.
 //
 // Arithmetic contract: -ffp-contract=off, mul then add in the reference's tap
 // order, interpolation sums started from +0.0f => bit-identical output.
