@@ -42,7 +42,7 @@ OTHER = {"cfg2": ("avir", 1920, 1080, 3840, 2160),
          "nonint": ("avir", 1920, 1080, 2500, 1400)}
 
 
-def time_other(name, steps, warmup, path):
+def time_other(name, steps, warmup, path, settle_ms=300.0):
     """Times one of the non-headline configs (device-resident RGBA f32)."""
     import torch
     import avir_amd
@@ -66,6 +66,11 @@ def time_other(name, steps, warmup, path):
     def step():
         abi.check(lib.avirhip_resize(plan, src.data_ptr(), abi.MEM_DEVICE,
                                      dst.data_ptr(), abi.MEM_DEVICE, st), "resize")
+    t_settle = time.perf_counter()
+    while (time.perf_counter() - t_settle) * 1e3 < settle_ms:
+        for _ in range(50):
+            step()
+        torch.cuda.synchronize()
     for _ in range(warmup):
         step()
     torch.cuda.synchronize()
@@ -133,6 +138,10 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--settle-ms", type=float, default=300.0,
+                    help="untimed run-in before the W warmup steps: the idle GPU "
+                         "sits at its lowest clock and DVFS needs tens of ms of "
+                         "load to settle (0 = none)")
     ap.add_argument("--path", type=int, default=0,
                     help="0 auto, 1 generic, 2 two-pass, 3 fused tile, 4 up2 (A/B)")
     ap.add_argument("--no-cpu", action="store_true",
@@ -143,7 +152,8 @@ def main():
     args = ap.parse_args()
 
     if args.workload != "cfg3":
-        time_other(args.workload, args.steps, args.warmup, args.path)
+        time_other(args.workload, args.steps, args.warmup, args.path,
+                   args.settle_ms)
         return
 
     import numpy as np
@@ -189,6 +199,13 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
+    # untimed run-in: steady-state clocks (a fresh process finds the GPU in its
+    # low-power state; the first ~100 ms of load run at ramping clocks)
+    t_settle = time.perf_counter()
+    while (time.perf_counter() - t_settle) * 1e3 < args.settle_ms:
+        for _ in range(50):
+            step()
+        torch.cuda.synchronize(dev)
     for _ in range(args.warmup):
         step()
     barrier()
@@ -214,6 +231,7 @@ def main():
         "metric": "Mpixels/sec (output) for 4K->8K RGBA resize",
         "value": round(value, 1), "unit": "Mpixels/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "settle_ms": args.settle_ms,
         "ms_per_step": round(t / args.steps * 1e3, 4),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
