@@ -36,7 +36,10 @@ typedef float f4 __attribute__(( ext_vector_type( 4 )));
 
 struct TOp
 {
-	int type, view, in_len, zs_mmax;
+	int type;
+	int out_len;    // logical output length (producer-side clamp range)
+	int zero_above; // consumer is a zero-stuffed view: outputs with a logical
+	                // index above this are stored as 0 (INT_MAX: none)
 	int rf, lat, e;
 	const float* flt;
 	const int* start;
@@ -54,20 +57,27 @@ struct TileParams
 	const int* vrng; // [nty][nv+1][2]
 	int ntx, nty, ty0; // ty0: first tile row launched (bands)
 	const float* src; long src_ss; // floats per source row
+	int src_w, src_h;              // extent of `src` (clamp range of the load)
+	int xzero_above, yzero_above;  // zero-stuffed first views (INT_MAX: none)
 	float* dst; long dst_ss;       // floats per destination row
 	int dst_row0;                  // row index stored at dst
 	int srow_lo, srow_hi;          // store mask on the final-axis index
 	int maxA, maxB, maxC;          // LDS carve (pixels, pixels, floats)
 };
 
-__device__ __forceinline__ int view_index( const TOp& op, int i, bool& zero )
+// Every buffer in LDS holds the *extended* index range its consumer touches:
+// slots whose logical index lies outside the producing array are filled by
+// the producer with the value the reference's replicated prefix / suffix (or
+// the zero tail of a zero-stuffed buffer) would hold there. The consumer's
+// tap loops therefore carry no clamps, no zero tests and no view logic at
+// all -- index = start + tap.
+__device__ __forceinline__ int clampi( int i, int hi )
 {
-	zero = ( op.view == VIEW_ZS && i > op.zs_mmax );
-	return( i < 0 ? 0 : ( i >= op.in_len ? op.in_len - 1 : i ));
+	return( i < 0 ? 0 : ( i > hi ? hi : i ));
 }
 
 // One op over a tile held in LDS. `in` is [irows][icols] pixels; the op runs
-// along x (ALONG_X) or along y. Logical input indices [ilo, ilo+in_n) are
+// along x (ALONG_X) or along y. Logical input indices from `ilo` on are
 // present along the op's axis. Output logical indices [olo, olo+on).
 template< bool ALONG_X, bool TO_GLOBAL >
 __device__ __forceinline__ void run_op( const TOp& op, const f4* in,
@@ -78,25 +88,30 @@ __device__ __forceinline__ void run_op( const TOp& op, const f4* in,
 	const int tx = threadIdx.x; // 0..31
 	const int ty = threadIdx.y; // 0..7
 	const int mt = ( op.maxtaps + 3 ) & ~3;
+	const int olast = op.out_len - 1;
 
 	if( op.type == OP_GATHER )
 	{
-		// stage start/ntaps/coefficients of this tile's outputs
+		// stage (start - ilo, ntaps) and the coefficient rows of this tile's
+		// outputs; an output outside the array is its clamped neighbour
 		const int tid = ty * 32 + tx;
 
 		for( int i = tid; i < on; i += 256 )
 		{
-			sti[ i * 2 ] = op.start[ olo + i ];
-			sti[ i * 2 + 1 ] = op.ntaps[ olo + i ];
+			const int ge = clampi( olo + i, olast );
+			sti[ i * 2 ] = op.start[ ge ] - ilo;
+			sti[ i * 2 + 1 ] = op.ntaps[ ge ];
 		}
 
-		const int tot = on * op.maxtaps;
+		const int tot = on * mt;
 
 		for( int i = tid; i < tot; i += 256 )
 		{
-			const int j = i / op.maxtaps;
-			const int t = i - j * op.maxtaps;
-			cfl[ j * mt + t ] = op.coef[ (long) olo * op.maxtaps + i ];
+			const int j = i / mt;
+			const int t = i - j * mt;
+			const int ge = clampi( olo + j, olast );
+			cfl[ i ] = ( t < op.maxtaps ?
+				op.coef[ (long) ge * op.maxtaps + t ] : 0.0f );
 		}
 
 		__syncthreads();
@@ -105,6 +120,7 @@ __device__ __forceinline__ void run_op( const TOp& op, const f4* in,
 	// loops: x over lanes, y over thread rows
 	const int nx = ( ALONG_X ? on : other_n );
 	const int ny = ( ALONG_X ? other_n : on );
+	const int istep = ( ALONG_X ? 1 : ipitch );
 
 	for( int y = ty; y < ny; y += 8 )
 	{
@@ -114,29 +130,23 @@ __device__ __forceinline__ void run_op( const TOp& op, const f4* in,
 			const int o = ( ALONG_X ? y : x );     // position on other axis
 			const int g = olo + n;                 // logical output index
 			const f4* base = ( ALONG_X ? in + o * ipitch : in + o );
-			const int istep = ( ALONG_X ? 1 : ipitch );
 			f4 acc;
 
 			if( op.type == OP_FIR )
 			{
-				const int cp = op.rf * ( g - op.e );
-				bool z;
-				int q = view_index( op, cp, z );
-				acc = op.flt[ 0 ] * base[ ( q - ilo ) * istep ];
+				const int cp = op.rf * ( clampi( g, olast ) - op.e ) - ilo;
+				const f4* c = base + cp * istep;
+				acc = op.flt[ 0 ] * c[ 0 ];
 
 				for( int i = 1; i <= op.lat; i++ )
 				{
-					const int q1 = view_index( op, cp + i, z );
-					const int q2 = view_index( op, cp - i, z );
-					const f4 s = base[ ( q1 - ilo ) * istep ] +
-						base[ ( q2 - ilo ) * istep ];
-
+					const f4 s = c[ i * istep ] + c[ -i * istep ];
 					acc = acc + op.flt[ i ] * s;
 				}
 			}
 			else
 			{
-				const int st = sti[ n * 2 ];
+				const f4* c = base + sti[ n * 2 ] * istep;
 				const int nt = sti[ n * 2 + 1 ];
 				const float* cf = cfl + n * mt;
 				acc = (f4) 0.0f;
@@ -145,34 +155,33 @@ __device__ __forceinline__ void run_op( const TOp& op, const f4* in,
 				for( ; t + 4 <= nt; t += 4 )
 				{
 					const f4 c4 = *(const f4*) ( cf + t );
-#pragma unroll
-					for( int u = 0; u < 4; u++ )
-					{
-						bool z;
-						const int q = view_index( op, st + t + u, z );
-						f4 v = base[ ( q - ilo ) * istep ];
-
-						if( z )
-						{
-							v = (f4) 0.0f;
-						}
-
-						acc = acc + c4[ u ] * v;
-					}
+					const f4 v0 = c[ 0 ];
+					const f4 v1 = c[ istep ];
+					const f4 v2 = c[ 2 * istep ];
+					const f4 v3 = c[ 3 * istep ];
+					acc = acc + c4.x * v0;
+					acc = acc + c4.y * v1;
+					acc = acc + c4.z * v2;
+					acc = acc + c4.w * v3;
+					c += 4 * istep;
 				}
 
-				for( ; t < nt; t++ )
+				if( t < nt )
 				{
-					bool z;
-					const int q = view_index( op, st + t, z );
-					f4 v = base[ ( q - ilo ) * istep ];
+					// 1..3 remaining taps (the padded coefficients are never
+					// multiplied: x * 0 is not a no-op for non-finite x)
+					const f4 c4 = *(const f4*) ( cf + t );
+					acc = acc + c4.x * c[ 0 ];
 
-					if( z )
+					if( t + 1 < nt )
 					{
-						v = (f4) 0.0f;
-					}
+						acc = acc + c4.y * c[ istep ];
 
-					acc = acc + cf[ t ] * v;
+						if( t + 2 < nt )
+						{
+							acc = acc + c4.z * c[ 2 * istep ];
+						}
+					}
 				}
 			}
 
@@ -191,6 +200,11 @@ __device__ __forceinline__ void run_op( const TOp& op, const f4* in,
 			}
 			else
 			{
+				if( g > op.zero_above )
+				{
+					acc = (f4) 0.0f;
+				}
+
 				out[ ( ALONG_X ? o * opitch + n : n * opitch + o ) ] = acc;
 			}
 		}
@@ -225,15 +239,24 @@ __global__ void __launch_bounds__( 256 ) k_tile( const TileParams P )
 	const int tx = threadIdx.x;
 	const int ty = threadIdx.y;
 
-	// source tile -> LDS (16 B per lane, contiguous along x)
+	// source tile -> LDS (16 B per lane, contiguous along x), extended range:
+	// coordinates clamp to the image, zero-stuffed tails read 0
 	for( int y = ty; y < rows; y += 8 )
 	{
-		const float* sp = P.src + (long) ( row_lo + y ) * P.src_ss +
-			(long) col_lo * 4;
+		const int gy = row_lo + y;
+		const float* sp = P.src + (long) clampi( gy, P.src_h - 1 ) * P.src_ss;
 
 		for( int x = tx; x < cols; x += 32 )
 		{
-			bufA[ y * cols + x ] = *(const f4*) ( sp + x * 4 );
+			const int gx = col_lo + x;
+			f4 v = *(const f4*) ( sp + (long) clampi( gx, P.src_w - 1 ) * 4 );
+
+			if( gx > P.xzero_above || gy > P.yzero_above )
+			{
+				v = (f4) 0.0f;
+			}
+
+			bufA[ y * cols + x ] = v;
 		}
 	}
 
@@ -316,8 +339,15 @@ struct FusedData
 	std::vector< void* > allocs;
 };
 
+// Input index range touched by outputs [a, b] of `op` (a, b may lie outside
+// the array: such outputs are copies of the clamped edge output). The result
+// is NOT clamped to the input array: the producer of that buffer fills the
+// out-of-array slots (see run_op).
 static void op_need( const LOp& op, int a, int b, int& ia, int& ib )
 {
+	a = std::max( 0, std::min( a, op.out_len - 1 ));
+	b = std::max( 0, std::min( b, op.out_len - 1 ));
+
 	if( op.type == OP_FIR )
 	{
 		ia = op.rf * ( a - op.e ) - op.lat;
@@ -334,9 +364,6 @@ static void op_need( const LOp& op, int a, int b, int& ia, int& ib )
 			ib = std::max( ib, op.h_start[ j ] + op.h_ntaps[ j ] - 1 );
 		}
 	}
-
-	ia = std::max( 0, std::min( ia, op.in_len - 1 ));
-	ib = std::max( 0, std::min( ib, op.in_len - 1 ));
 }
 
 // Range table of one axis for tiles of `tsz` outputs: rng[t][s] = (lo, count)
@@ -574,13 +601,20 @@ void fused_release( avirhip_plan* p )
 	p -> fused = nullptr;
 }
 
+static int zero_above_of( const LOp& consumer )
+{
+	return( consumer.view == VIEW_ZS ? consumer.zs_mmax : 0x7fffffff );
+}
+
 static void fill_ops( const LAxis& ax, int n, TOp* out )
 {
 	for( int i = 0; i < n; i++ )
 	{
 		const LOp& o = ax.ops[ i ];
-		out[ i ].type = o.type; out[ i ].view = o.view;
-		out[ i ].in_len = o.in_len; out[ i ].zs_mmax = o.zs_mmax;
+		out[ i ].type = o.type;
+		out[ i ].out_len = o.out_len;
+		out[ i ].zero_above = ( i + 1 < n ? zero_above_of( ax.ops[ i + 1 ]) :
+			0x7fffffff );
 		out[ i ].rf = o.rf; out[ i ].lat = o.lat; out[ i ].e = o.e;
 		out[ i ].flt = o.d_flt; out[ i ].start = o.d_start;
 		out[ i ].ntaps = o.d_ntaps; out[ i ].coef = o.d_coef;
@@ -609,6 +643,11 @@ static int launch_tiles( avirhip_plan* p, const TileGeom& G, bool useh,
 	P.ty0 = a / G.th;
 	const int ty1 = ( b - 1 ) / G.th;
 	P.src = src; P.src_ss = src_ss;
+	// extent of the array at `src`: the source image, or FltBuf [src_h][new_w]
+	P.src_w = ( useh ? p -> src_w : p -> new_w );
+	P.src_h = p -> src_h;
+	P.xzero_above = ( useh ? zero_above_of( p -> h.ops[ 0 ]) : 0x7fffffff );
+	P.yzero_above = ( usev ? zero_above_of( p -> v.ops[ 0 ]) : 0x7fffffff );
 	P.dst = dst; P.dst_ss = dst_ss; P.dst_row0 = dst_row0;
 	P.srow_lo = a; P.srow_hi = b;
 	P.maxA = G.maxA; P.maxB = G.maxB; P.maxC = G.maxC;
@@ -658,6 +697,9 @@ int fused_run( avirhip_plan* p, int mode, const float* src, long src_stride,
 		a = ia;
 		b = ib;
 	}
+
+	a = std::max( a, 0 );
+	b = std::min( b, p -> src_h - 1 );
 
 	if( F -> fltbuf == nullptr )
 	{
