@@ -1,0 +1,612 @@
+// dn.hip -- integer-ratio downsizing passes (cfg4 of BASELINE.json: 3x; also 2x)
+// for the two-pass tiled path (path 2), RGBA float.
+//
+// What the plan looks like (build mode 1, k = 2 or 3), per axis:
+//   T[j]  = 0 + sum_{t<NT} c[t] * S[clamp(K*j + c0 + t)]    (doResize,
+//           avir.h:3884-4096: ONE bank phase, so every output has the same NT
+//           coefficients, and the source offset advances by exactly K)
+//   O[j]  = f0*T[j] + sum_{i=1..3} f_i*(T[clamp(j+i)] + T[clamp(j-i)])
+//           (correction filter, doFilter avir.h:3748-3866)
+// with (K, NT) = (2, 24) or (3, 38) for the default parameters.
+//
+// Because the coefficients are uniform and the offsets regular, a thread can
+// produce R consecutive outputs from ONE pass over NT + (R-1)*K inputs with
+// every index known at compile time: each input value is read once (from LDS
+// in the H pass, from L2 in the V pass) and feeds up to ceil(NT/K) multiply-
+// adds in registers, instead of one LDS read per multiply-add as in k_tile.
+// Each accumulator still receives its taps in ascending order starting from
+// +0.0f, mul then add, so the result is bit-identical to the reference.
+//
+//   k_dnh   one wave per source row segment: row -> LDS by LDS-DMA (clamped
+//           columns), R = 3 resize outputs per lane (lane stride R*K pixels is
+//           bank-conflict free for K = 3), T -> LDS, FIR7 along x, coalesced
+//           store into FltBuf. Waves are autonomous: no barrier in the loop.
+//   k_dnv   one lane per pixel column, R = 4 resize outputs per lane, rows
+//           streamed from FltBuf (L2/MALL resident: it is the small image) as
+//           coalesced 1-KiB wave loads; no LDS at all.
+//   k_dnvf  FIR7 along y over the (small) resized image.
+
+#include "plan.h"
+#include <algorithm>
+#include <string.h>
+#include <type_traits>
+#include <utility>
+
+namespace avirhip {
+
+typedef float f4 __attribute__(( ext_vector_type( 4 )));
+typedef unsigned u4 __attribute__(( ext_vector_type( 4 )));
+typedef __attribute__(( address_space( 3 ))) void* ldsptr;
+
+#define DN_MAXNT 40
+
+struct DnAxisP
+{
+	int K, NT, c0;       // offset of output j: K*j + c0
+	int in_len, out_len;
+	const float* coef;   // device: NT resize coefficients, then 4 FIR taps
+};
+
+struct DnHParams
+{
+	DnAxisP A;
+	const float* src; long src_ss; // floats per source row
+	float* dst; long dst_ss;       // FltBuf, floats per row
+	int row_lo, row_hi;            // source rows to process
+};
+
+struct DnVParams
+{
+	DnAxisP A;
+	const float* src; long src_ss; // FltBuf
+	float* dst; long dst_ss;       // T1 [out_len][width]
+	int width;                     // pixels per row
+	int g_lo, g_hi;                // output groups (of R rows) to process
+};
+
+struct DnFParams
+{
+	const float* src; float* dst; long ss; // both [rows][width] pixels
+	int width, rows;
+	int row_lo, row_hi, dst_row0;  // rows to store; row stored at dst
+	const float* fir;              // 4 taps
+};
+
+__device__ __forceinline__ int dn_clampi( int i, int hi )
+{
+	return( i < 0 ? 0 : ( i > hi ? hi : i ));
+}
+
+// compile-time loop: every index below must be a constant so that the arrays
+// stay in registers (a rolled loop would index them dynamically -> scratch)
+template< int... I, class F >
+__device__ __forceinline__ void dn_static_for_impl(
+	std::integer_sequence< int, I... >, F&& f )
+{
+	( f( std::integral_constant< int, I >()), ... );
+}
+
+template< int N, class F >
+__device__ __forceinline__ void dn_static_for( F&& f )
+{
+	dn_static_for_impl( std::make_integer_sequence< int, N >(), f );
+}
+
+// input i feeds tap i - K*r of output r
+template< int K, int NT, int R, int I >
+__device__ __forceinline__ void dn_feed( const float ( &c )[ NT ],
+	f4 ( &acc )[ R ], const f4 v )
+{
+	dn_static_for< R >( [&]( auto rc )
+	{
+		constexpr int r = decltype( rc )::value;
+		constexpr int t = I - K * r;
+
+		if constexpr( t >= 0 && t < NT )
+		{
+			// coefficient from an SGPR, plain v_mul_f32 / v_add_f32 (the packed
+			// form would need {c, c} register pairs: hipcc builds them with
+			// v_mov and runs out of VGPRs; the scalar form has the same flop
+			// rate and full hardware interlocks)
+			// (the adds are in the statement too: left to hipcc they sink to the
+			// end of the kernel and every product is spilled meanwhile)
+			float p0, p1, p2, p3;
+			float a0 = acc[ r ].x, a1 = acc[ r ].y, a2 = acc[ r ].z,
+				a3 = acc[ r ].w;
+			asm volatile( "v_mul_f32 %4, %8, %9\n\t"
+				"v_mul_f32 %5, %8, %10\n\t"
+				"v_mul_f32 %6, %8, %11\n\t"
+				"v_mul_f32 %7, %8, %12\n\t"
+				"v_add_f32 %0, %0, %4\n\t"
+				"v_add_f32 %1, %1, %5\n\t"
+				"v_add_f32 %2, %2, %6\n\t"
+				"v_add_f32 %3, %3, %7"
+				: "+v"( a0 ), "+v"( a1 ), "+v"( a2 ), "+v"( a3 ),
+				"=&v"( p0 ), "=&v"( p1 ), "=&v"( p2 ), "=&v"( p3 )
+				: "s"( c[ t ]), "v"( v.x ), "v"( v.y ), "v"( v.z ), "v"( v.w ));
+			acc[ r ].x = a0; acc[ r ].y = a1; acc[ r ].z = a2; acc[ r ].w = a3;
+		}
+	} );
+}
+
+// R outputs from one pass over the inputs; `ld( i )` yields input i of the
+// first output (input i - K*r of output r).
+template< int K, int NT, int R, class LD >
+__device__ __forceinline__ void dn_accumulate( const float ( &c )[ NT ],
+	f4 ( &acc )[ R ], LD&& ld )
+{
+#pragma unroll
+	for( int r = 0; r < R; r++ )
+	{
+		acc[ r ] = (f4) 0.0f;
+	}
+
+	dn_static_for< NT + ( R - 1 ) * K >( [&]( auto ic )
+	{
+		constexpr int i = decltype( ic )::value;
+		dn_feed< K, NT, R, i >( c, acc, ld( i ));
+	} );
+}
+
+// ---------------------------------------------------------------------
+// H pass
+// ---------------------------------------------------------------------
+
+template< int K, int NT, int R >
+__global__ void __launch_bounds__( 256 ) k_dnh( const DnHParams P )
+{
+	constexpr int NT1 = 64 * R;                // resize outputs per wave
+	constexpr int NIN = K * ( NT1 - 1 ) + NT;  // input pixels per wave
+	constexpr int NDMA = ( NIN + 63 ) / 64;
+	constexpr int SEG = NT1 - 6;               // FIR outputs per wave
+
+	__shared__ __attribute__(( aligned( 16 ))) f4 sS[ 4 ][ NDMA * 64 ];
+	__shared__ __attribute__(( aligned( 16 ))) f4 sT[ 4 ][ NT1 ];
+	const int tid = threadIdx.x;
+	const int lane = tid & 63;
+	const int wave = __builtin_amdgcn_readfirstlane( tid >> 6 );
+
+	// the (uniform) coefficients: scalar loads, SGPR operands of the multiplies
+	float c[ NT ];
+#pragma unroll
+	for( int t = 0; t < NT; t++ )
+	{
+		c[ t ] = P.A.coef[ t ];
+	}
+
+	const float f0 = P.A.coef[ NT ], f1 = P.A.coef[ NT + 1 ],
+		f2 = P.A.coef[ NT + 2 ], f3 = P.A.coef[ NT + 3 ];
+
+	const int y = P.row_lo + blockIdx.y * 4 + wave;
+
+	if( y >= P.row_hi )
+	{
+		return;
+	}
+
+	const int X0 = blockIdx.x * SEG - 3;  // first resize output of this wave
+	const int in0 = K * X0 + P.A.c0;      // its first input pixel
+
+	// ---- source row segment -> LDS (lane-linear DMA, clamped columns)
+	const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+		(void*) ( P.src + (long) y * P.src_ss ), 0, 0x7fffffff, 0x00020000 );
+
+#pragma unroll
+	for( int q = 0; q < NDMA; q++ )
+	{
+		const int i = q * 64 + lane;
+
+		if(( q + 1 ) * 64 <= NIN || i < NIN )
+		{
+			const int gx = dn_clampi( in0 + i, P.A.in_len - 1 );
+			__builtin_amdgcn_raw_ptr_buffer_load_lds( rsrc,
+				(ldsptr) ( &sS[ wave ][ q * 64 ]), 16, gx * 16, 0, 0, 0 );
+		}
+	}
+
+	asm volatile( "s_waitcnt vmcnt(0)" ::: "memory" );
+
+	// ---- resize: R consecutive outputs per lane
+	{
+		const f4* base = &sS[ wave ][ K * R * lane ];
+		f4 acc[ R ];
+		dn_accumulate< K, NT, R >( c, acc,
+			[&]( const int i ) { return( base[ i ]); } );
+
+#pragma unroll
+		for( int r = 0; r < R; r++ )
+		{
+			sT[ wave ][ R * lane + r ] = acc[ r ];
+		}
+	}
+
+	// ---- correction FIR along x, coalesced stores
+	const int olast = P.A.out_len - 1;
+	float* drow = P.dst + (long) y * P.dst_ss;
+
+#pragma unroll
+	for( int q = 0; q < R; q++ )
+	{
+		const int n = q * 64 + lane;
+		const int x = X0 + n;
+
+		if( n >= 3 && n < NT1 - 3 && x <= olast )
+		{
+			const f4* t = &sT[ wave ][ -X0 ];
+			f4 a = f0 * t[ x ];
+			a = a + f1 * ( t[ dn_clampi( x + 1, olast )] +
+				t[ dn_clampi( x - 1, olast )]);
+			a = a + f2 * ( t[ dn_clampi( x + 2, olast )] +
+				t[ dn_clampi( x - 2, olast )]);
+			a = a + f3 * ( t[ dn_clampi( x + 3, olast )] +
+				t[ dn_clampi( x - 3, olast )]);
+			*(f4*) ( drow + (long) x * 4 ) = a;
+		}
+	}
+}
+
+// ---------------------------------------------------------------------
+// V pass
+// ---------------------------------------------------------------------
+
+template< int K, int NT, int R >
+__global__ void __launch_bounds__( 256 )
+__attribute__(( amdgpu_waves_per_eu( 4, 4 ))) k_dnv( const DnVParams P )
+{
+	const int tid = threadIdx.x;
+	const int lane = tid & 63;
+	const int wave = __builtin_amdgcn_readfirstlane( tid >> 6 );
+
+	float c[ NT ];
+#pragma unroll
+	for( int t = 0; t < NT; t++ )
+	{
+		c[ t ] = P.A.coef[ t ];
+	}
+
+	const int g = P.g_lo + blockIdx.y * 4 + wave; // group of R output rows
+	const int x = blockIdx.x * 64 + lane;
+
+	if( g >= P.g_hi )
+	{
+		return;
+	}
+
+	const int j0 = g * R;
+	const int r0 = K * j0 + P.A.c0; // first input row of output j0
+	const int row_b = (int) P.src_ss * 4;
+	const int xb = dn_clampi( x, P.width - 1 ) * 16;
+
+	// rows are addressed relative to the first one needed so that the scalar
+	// offsets stay small for any image size
+	const int rbase = dn_clampi( r0, P.A.in_len - 1 );
+	const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+		(void*) ( P.src + (long) rbase * P.src_ss ), 0, 0x7fffffff,
+		0x00020000 );
+
+	auto ld = [&]( const int i )
+	{
+		const int row = dn_clampi( r0 + i, P.A.in_len - 1 ) - rbase;
+		return( __builtin_bit_cast( f4, __builtin_amdgcn_raw_buffer_load_b128(
+			rsrc, xb, row * row_b, 0 )));
+	};
+
+	// explicit two-stage register pipeline: batch b+1 is in flight while
+	// batch b is consumed (left alone, hipcc hoists all the loads and spills)
+	constexpr int NI = NT + ( R - 1 ) * K;
+	constexpr int BS = 6;
+	constexpr int NB = ( NI + BS - 1 ) / BS;
+	f4 buf[ 2 ][ BS ];
+	f4 acc[ R ];
+#pragma unroll
+	for( int r = 0; r < R; r++ )
+	{
+		acc[ r ] = (f4) 0.0f;
+	}
+
+	dn_static_for< BS >( [&]( auto jc )
+	{
+		constexpr int j = decltype( jc )::value;
+		buf[ 0 ][ j ] = ld( j );
+	} );
+
+	dn_static_for< NB >( [&]( auto bc )
+	{
+		constexpr int b = decltype( bc )::value;
+
+		if constexpr( b + 1 < NB )
+		{
+			dn_static_for< BS >( [&]( auto jc )
+			{
+				constexpr int j = decltype( jc )::value;
+
+				if constexpr(( b + 1 ) * BS + j < NI )
+				{
+					buf[ ( b + 1 ) & 1 ][ j ] = ld(( b + 1 ) * BS + j );
+				}
+			} );
+		}
+
+		// the memory clobbers pin the loads of batch b+1 between the compute
+		// of batch b-1 and of batch b (hipcc otherwise issues all the loads
+		// up front and spills them)
+		asm volatile( "" ::: "memory" );
+		__builtin_amdgcn_sched_barrier( 0 );
+		dn_static_for< BS >( [&]( auto jc )
+		{
+			constexpr int j = decltype( jc )::value;
+			constexpr int i = b * BS + j;
+
+			if constexpr( i < NI )
+			{
+				dn_feed< K, NT, R, i >( c, acc, buf[ b & 1 ][ j ]);
+				// keep the products of one input together (the scheduler
+				// otherwise hoists every multiply of the batch)
+				__builtin_amdgcn_sched_barrier( 0 );
+			}
+		} );
+		asm volatile( "" ::: "memory" );
+	} );
+
+	if( x < P.width )
+	{
+#pragma unroll
+		for( int r = 0; r < R; r++ )
+		{
+			if( j0 + r < P.A.out_len )
+			{
+				*(f4*) ( P.dst + (long) ( j0 + r ) * P.dst_ss + (long) x * 4 ) =
+					acc[ r ];
+			}
+		}
+	}
+}
+
+__global__ void __launch_bounds__( 256 ) k_dnvf( const DnFParams P )
+{
+	const int x = blockIdx.x * 64 + ( threadIdx.x & 63 );
+	const int y = P.row_lo + blockIdx.y * 4 + ( threadIdx.x >> 6 );
+
+	if( x >= P.width || y >= P.row_hi )
+	{
+		return;
+	}
+
+	const int last = P.rows - 1;
+	const float* s = P.src + (long) x * 4;
+	auto T = [&]( const int r )
+	{
+		return( *(const f4*) ( s + (long) dn_clampi( r, last ) * P.ss ));
+	};
+
+	f4 a = P.fir[ 0 ] * T( y );
+	a = a + P.fir[ 1 ] * ( T( y + 1 ) + T( y - 1 ));
+	a = a + P.fir[ 2 ] * ( T( y + 2 ) + T( y - 2 ));
+	a = a + P.fir[ 3 ] * ( T( y + 3 ) + T( y - 3 ));
+	*(f4*) ( P.dst + (long) ( y - P.dst_row0 ) * P.ss + (long) x * 4 ) = a;
+}
+
+// ---------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------
+
+struct DnAxis
+{
+	int K, NT, c0, in_len, out_len;
+	float* d_coef;
+};
+
+struct DnData
+{
+	bool hok, vok;
+	DnAxis h, v;
+	float* t1;   // V pass: resized rows before the correction filter
+	std::vector< void* > allocs;
+};
+
+static bool dn_supported( int K, int NT )
+{
+	return(( K == 2 && NT == 24 ) || ( K == 3 && NT == 38 ));
+}
+
+// Recognises "regular resize + 7-tap correction filter" and uploads its taps.
+static int dn_match( const LAxis& ax, DnData* D, DnAxis& A, bool& ok )
+{
+	ok = false;
+
+	if( ax.ops.size() != 2 )
+	{
+		return( AVIRHIP_OK );
+	}
+
+	const LOp& g = ax.ops[ 0 ];
+	const LOp& f = ax.ops[ 1 ];
+
+	if( g.type != OP_GATHER || g.view != VIEW_CLAMP || g.out_len < 8 ||
+		f.type != OP_FIR || f.view != VIEW_CLAMP || f.rf != 1 || f.e != 0 ||
+		f.lat != 3 || f.in_len != g.out_len || f.out_len != g.out_len ||
+		(int) f.h_flt.size() < 4 )
+	{
+		return( AVIRHIP_OK );
+	}
+
+	const int K = g.h_start[ 1 ] - g.h_start[ 0 ];
+	const int NT = g.maxtaps;
+
+	if( !dn_supported( K, NT ))
+	{
+		return( AVIRHIP_OK );
+	}
+
+	for( int j = 0; j < g.out_len; j++ )
+	{
+		if( g.h_ntaps[ j ] != NT ||
+			g.h_start[ j ] != g.h_start[ 0 ] + K * j ||
+			memcmp( &g.h_coef[ (size_t) j * NT ], &g.h_coef[ 0 ],
+			NT * sizeof( float )) != 0 )
+		{
+			return( AVIRHIP_OK );
+		}
+	}
+
+	float hc[ DN_MAXNT + 4 ];
+	memcpy( hc, &g.h_coef[ 0 ], NT * sizeof( float ));
+	memcpy( hc + NT, &f.h_flt[ 0 ], 4 * sizeof( float ));
+	void* q = nullptr;
+	AVIRHIP_HIPCHECK( hipMalloc( &q, sizeof( hc )));
+	D -> allocs.push_back( q );
+	AVIRHIP_HIPCHECK( hipMemcpy( q, hc, ( NT + 4 ) * sizeof( float ),
+		hipMemcpyHostToDevice ));
+	A.K = K; A.NT = NT; A.c0 = g.h_start[ 0 ];
+	A.in_len = g.in_len; A.out_len = g.out_len;
+	A.d_coef = (float*) q;
+	ok = true;
+	return( AVIRHIP_OK );
+}
+
+int dn_prepare( avirhip_plan* p, void** out )
+{
+	*out = nullptr;
+
+	if( p -> is_lancir || p -> ch != 4 )
+	{
+		return( AVIRHIP_OK );
+	}
+
+	DnData* D = new DnData();
+	D -> hok = D -> vok = false;
+	D -> t1 = nullptr;
+	int rc = dn_match( p -> h, D, D -> h, D -> hok );
+
+	if( rc == 0 )
+	{
+		rc = dn_match( p -> v, D, D -> v, D -> vok );
+	}
+
+	if( rc != 0 || ( !D -> hok && !D -> vok ))
+	{
+		dn_release( D );
+		return( rc );
+	}
+
+	*out = D;
+	return( AVIRHIP_OK );
+}
+
+void dn_release( void* d )
+{
+	DnData* D = (DnData*) d;
+
+	if( D == nullptr )
+	{
+		return;
+	}
+
+	for( size_t i = 0; i < D -> allocs.size(); i++ )
+	{
+		(void) hipFree( D -> allocs[ i ]);
+	}
+
+	delete D;
+}
+
+bool dn_has_h( const void* d ) { return( d != nullptr && ((const DnData*) d ) -> hok ); }
+bool dn_has_v( const void* d ) { return( d != nullptr && ((const DnData*) d ) -> vok ); }
+
+static DnAxisP axis_params( const DnAxis& A )
+{
+	DnAxisP P;
+	P.K = A.K; P.NT = A.NT; P.c0 = A.c0;
+	P.in_len = A.in_len; P.out_len = A.out_len; P.coef = A.d_coef;
+	return( P );
+}
+
+// source rows [a, b) -> FltBuf rows [a, b)
+int dn_run_h( void* d, const float* src, long src_ss, float* flt, long flt_ss,
+	int a, int b, hipStream_t st )
+{
+	const DnData* D = (const DnData*) d;
+
+	if( b <= a )
+	{
+		return( AVIRHIP_OK );
+	}
+
+	DnHParams P;
+	P.A = axis_params( D -> h );
+	P.src = src; P.src_ss = src_ss; P.dst = flt; P.dst_ss = flt_ss;
+	P.row_lo = a; P.row_hi = b;
+	const int R = 3;
+	const int seg = 64 * R - 6;
+	const dim3 grid(( D -> h.out_len + seg - 1 ) / seg, ( b - a + 3 ) / 4 );
+
+	if( D -> h.K == 3 )
+	{
+		hipLaunchKernelGGL(( k_dnh< 3, 38, 3 > ), grid, dim3( 256 ), 0, st, P );
+	}
+	else
+	{
+		hipLaunchKernelGGL(( k_dnh< 2, 24, 3 > ), grid, dim3( 256 ), 0, st, P );
+	}
+
+	AVIRHIP_HIPCHECK( hipGetLastError() );
+	return( AVIRHIP_OK );
+}
+
+// FltBuf [in_len][width] -> destination rows [row0, row1)
+int dn_run_v( void* d, const float* flt, long flt_ss, int width, float* dst,
+	int row0, int row1, hipStream_t st )
+{
+	DnData* D = (DnData*) d;
+
+	if( row1 <= row0 )
+	{
+		return( AVIRHIP_OK );
+	}
+
+	const int olen = D -> v.out_len;
+
+	if( D -> t1 == nullptr )
+	{
+		void* q = nullptr;
+		AVIRHIP_HIPCHECK( hipMalloc( &q, (size_t) olen * width * 16 ));
+		D -> allocs.push_back( q );
+		D -> t1 = (float*) q;
+	}
+
+	const int R = 4;
+	const int ta = std::max( row0 - 3, 0 );
+	const int tb = std::min( row1 + 3, olen ); // T1 rows [ta, tb)
+
+	DnVParams P;
+	P.A = axis_params( D -> v );
+	P.src = flt; P.src_ss = flt_ss;
+	P.dst = D -> t1; P.dst_ss = (long) width * 4;
+	P.width = width;
+	P.g_lo = ta / R;
+	P.g_hi = ( tb + R - 1 ) / R;
+	const dim3 grid(( width + 63 ) / 64, ( P.g_hi - P.g_lo + 3 ) / 4 );
+
+	if( D -> v.K == 3 )
+	{
+		hipLaunchKernelGGL(( k_dnv< 3, 38, 4 > ), grid, dim3( 256 ), 0, st, P );
+	}
+	else
+	{
+		hipLaunchKernelGGL(( k_dnv< 2, 24, 4 > ), grid, dim3( 256 ), 0, st, P );
+	}
+
+	AVIRHIP_HIPCHECK( hipGetLastError() );
+
+	DnFParams F;
+	F.src = D -> t1; F.dst = dst; F.ss = (long) width * 4;
+	F.width = width; F.rows = olen;
+	F.row_lo = row0; F.row_hi = row1; F.dst_row0 = row0;
+	F.fir = D -> v.d_coef + D -> v.NT;
+	const dim3 gf(( width + 63 ) / 64, ( row1 - row0 + 3 ) / 4 );
+	hipLaunchKernelGGL( k_dnvf, gf, dim3( 256 ), 0, st, F );
+	AVIRHIP_HIPCHECK( hipGetLastError() );
+	return( AVIRHIP_OK );
+}
+
+} // namespace avirhip

@@ -336,6 +336,7 @@ struct FusedData
 	TileGeom hpass; // path 2, pass 1 (H chain only)
 	TileGeom vpass; // path 2, pass 2 (V chain only)
 	float* fltbuf;  // path 2 intermediate [src_h][new_w] pixels
+	void* dn;       // dn.hip: specialised passes of path 2 (integer downsizing)
 	std::vector< void* > allocs;
 };
 
@@ -544,6 +545,7 @@ int fused_prepare( avirhip_plan* p )
 
 	FusedData* F = new FusedData();
 	F -> fltbuf = nullptr;
+	F -> dn = nullptr;
 	F -> fused.ok = F -> hpass.ok = F -> vpass.ok = false;
 	p -> fused = F;
 
@@ -564,7 +566,16 @@ int fused_prepare( avirhip_plan* p )
 		return( rc );
 	}
 
-	const bool two = ( F -> hpass.ok && F -> vpass.ok );
+	if( rc == 0 ) rc = dn_prepare( p, &F -> dn );
+
+	if( rc != 0 )
+	{
+		fused_release( p );
+		return( rc );
+	}
+
+	const bool two = (( F -> hpass.ok || dn_has_h( F -> dn )) &&
+		( F -> vpass.ok || dn_has_v( F -> dn )));
 	p -> fused_ok = ( F -> fused.ok ? 2 : 0 ) | ( two ? 1 : 0 );
 
 	// Upsizing (both axes): the intermediate is the big image -> keep it in
@@ -597,6 +608,7 @@ void fused_release( avirhip_plan* p )
 		(void) hipFree( F -> allocs[ i ]);
 	}
 
+	dn_release( F -> dn );
 	delete F;
 	p -> fused = nullptr;
 }
@@ -710,12 +722,20 @@ int fused_run( avirhip_plan* p, int mode, const float* src, long src_stride,
 		F -> fltbuf = (float*) q;
 	}
 
-	int rc = launch_tiles( p, F -> hpass, true, false, src, src_stride,
-		F -> fltbuf, dss, 0, a, b + 1, st );
+	int rc = ( dn_has_h( F -> dn ) ?
+		dn_run_h( F -> dn, src, src_stride, F -> fltbuf, dss, a, b + 1, st ) :
+		launch_tiles( p, F -> hpass, true, false, src, src_stride,
+		F -> fltbuf, dss, 0, a, b + 1, st ));
 
 	if( rc != 0 )
 	{
 		return( rc );
+	}
+
+	if( dn_has_v( F -> dn ))
+	{
+		return( dn_run_v( F -> dn, F -> fltbuf, dss, p -> new_w, dst, row0,
+			row1, st ));
 	}
 
 	return( launch_tiles( p, F -> vpass, false, true, F -> fltbuf, dss, dst,

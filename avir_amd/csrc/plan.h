@@ -148,6 +148,16 @@ void fused_release( avirhip_plan* p );
 int fused_run( avirhip_plan* p, int mode, const float* src, long src_stride,
 	float* dst, int row0, int row1, hipStream_t st );
 
+// dn.hip: integer-ratio downsizing passes used by the two-pass tiled path
+int dn_prepare( avirhip_plan* p, void** out );
+void dn_release( void* d );
+bool dn_has_h( const void* d );
+bool dn_has_v( const void* d );
+int dn_run_h( void* d, const float* src, long src_ss, float* flt, long flt_ss,
+	int a, int b, hipStream_t st );
+int dn_run_v( void* d, const float* flt, long flt_ss, int width, float* dst,
+	int row0, int row1, hipStream_t st );
+
 // up2.hip: specialised exact-2x RGBA kernel (path 4)
 int up2_prepare( avirhip_plan* p );
 void up2_release( avirhip_plan* p );

@@ -258,6 +258,48 @@ def test_band_execution_matches_full():
                                  "path %d band [%d,%d)" % (path, a, b))
 
 
+DOWN_INT = [
+    # (sw, sh, nw, nh): 3x, 2x, mixed 2x/3x, a dn axis next to a generic one,
+    # sizes around the 186-output segment and the 4-row group boundaries
+    (300, 201, 100, 67), (640, 480, 320, 240), (1116, 90, 372, 30),
+    (1119, 93, 373, 31), (1122, 96, 374, 32), (60, 1200, 20, 400),
+    (384, 216, 192, 72), (384, 216, 128, 108), (300, 200, 100, 131),
+    (301, 200, 150, 100), (24, 24, 8, 8), (48, 30, 24, 10),
+    (1920, 1080, 640, 360),
+]
+
+
+@pytest.mark.parametrize("bits", [8, 16])
+@pytest.mark.parametrize("sw,sh,nw,nh", DOWN_INT)
+def test_avir_integer_downsizing_passes(sw, sh, nw, nh, bits):
+    """dn.hip (regular resize + correction filter, K = 2 and 3) inside the
+    two-pass path, forced and as the automatic choice."""
+    src = rb.lcg_f32((sh, sw, 4), seed=99 + sw)
+    want = _checker_avir(src, nw, nh, resbits=bits)
+    _assert_same(_run_avir(src, nw, nh, resbits=bits), want, "auto path")
+    _assert_same(_run_avir(src, nw, nh, resbits=bits, path=abi.PATH_TILED),
+                 want, "two-pass path")
+
+
+def test_avir_integer_downsizing_bands():
+    import ctypes as C
+    lib = abi.load()
+    for (sw, sh, nw, nh) in [(640, 431, 320, 144), (300, 600, 100, 200)]:
+        src = rb.lcg_f32((sh, sw, 4), seed=78)
+        r = avir_amd.CImageResizer(16)
+        full = r.resize(src, nw, nh)
+        p = r.plan(sw, sh, nw, nh, 4)
+        abi.check(lib.avirhip_plan_set_path(p, abi.PATH_TILED), "set_path")
+        for g in (2, 3, 7):
+            cuts = [nh * i // g for i in range(g + 1)]
+            for a, b in zip(cuts[:-1], cuts[1:]):
+                band = np.empty((b - a, nw, 4), np.float32)
+                abi.check(lib.avirhip_resize_band(
+                    p, src.ctypes.data, abi.MEM_HOST, band.ctypes.data,
+                    abi.MEM_HOST, a, b, None), "band")
+                _assert_same(band, full[a:b], "band [%d,%d)" % (a, b))
+
+
 def test_zero_sized_and_errors():
     r = avir_amd.CImageResizer(8)
     dst = np.full((4, 5, 3), 7, np.uint8)
