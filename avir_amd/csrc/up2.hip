@@ -56,9 +56,6 @@ typedef unsigned u2 __attribute__(( ext_vector_type( 2 )));
 #define U2_NT ( U2_TW * 2 ) // threads per workgroup: one per half pixel
 #ifndef U2_RB
 #define U2_RB 8   // source rows per marching step (8 or 16)
-#ifndef U2_BPC
-#define U2_BPC 8 // resident workgroups per CU the launch is sized for (TW 64)
-#endif
 #endif
 #define U2_SW ( U2_TW / 2 + 18 ) // S tile width (px)
 #define U2_CW ( U2_TW / 2 + 12 ) // C tile width (px)
@@ -678,24 +675,44 @@ int up2_run( avirhip_plan* p, const float* src, long src_stride, float* dst,
 	P.srow_lo = row0; P.srow_hi = row1;
 	P.nstrips = ( p -> new_w + U2_TW - 1 ) / U2_TW;
 
-	// Chunk height. A chunk of cq source rows costs cq + 18 marching steps (6
-	// preload + 12 warm-up) in units of U2_RB, so cq = U2_RB*k - 18 wastes
-	// nothing. The chip holds 256 CUs x 4 resident workgroups; size the chunks
-	// so that all work items fit in a whole number of such rounds (a partly
-	// filled last round leaves CUs idle), preferring the fewest rounds whose
-	// chunks are still >= 62 rows (warm-up <= ~1/4 of the horizontal work).
-	const int slots = 256 * ( U2_TW == 32 ? 12 : ( U2_TW == 64 ? U2_BPC : 4 ));
+	// Chunk height. A chunk of cq source rows costs (cq + 18) / U2_RB marching
+	// steps (6 rows of preload + 12 of warm-up), so cq = U2_RB*k - 18 wastes
+	// nothing. The kernel is VALU-bound and a CU shares its VALUs among its
+	// resident workgroups (up to 8), so a launch whose items are all resident
+	// at once takes about
+	//     m * k / thr( m ),   m = ceil( items / 256 CUs )
+	// step-times -- the most loaded CU finishes last, and thr is the measured
+	// VALU throughput of a CU running m workgroups (cq sweeps of cfg2 and cfg3,
+	// profiles/r01_up2_chunk_sweep.txt). Few tall chunks waste little warm-up
+	// work, many short ones balance and fill the CUs; launches of more than
+	// 8 x 256 items run in partial rounds and measured ~6 % worse than their
+	// step count.
 	int cq = 0;
-
-	for( int rounds = 1; rounds <= 8 && cq == 0; rounds++ )
 	{
-		const int nch = std::max( 1, rounds * slots / P.nstrips );
-		int c = ( p -> src_h + nch - 1 ) / nch;
-		c = (( c + 18 + U2_RB - 1 ) / U2_RB ) * U2_RB - 18;
+		static const double thr[ 9 ] = { 1.0, 0.3, 0.57, 0.8, 0.9, 0.9, 0.9,
+			0.97, 1.0 };
+		const int rows = ( row1 - row0 + 1 ) / 2 + 1; // source rows of the band
+		double best = -1.0;
 
-		if( c >= 62 || rounds == 8 )
+		for( int k = 10; k <= 64; k++ )
 		{
-			cq = std::max( c, 62 );
+			const int c = U2_RB * k - 18;
+			const long nch = ( rows + c - 1 ) / c;
+			const long items = nch * P.nstrips;
+			const long m = ( items + 255 ) / 256;
+			const double cost = ( m <= 8 ? (double) m * k / thr[ m ] :
+				(double) items * k / 256.0 * 1.06 );
+
+			if( best < 0.0 || cost < best )
+			{
+				best = cost;
+				cq = c;
+			}
+
+			if( nch == 1 )
+			{
+				break;
+			}
 		}
 	}
 
