@@ -58,7 +58,8 @@ class PlanDesc(C.Structure):
                 ("channels", C.c_int32),
                 ("in_type", C.c_int32), ("out_type", C.c_int32),
                 ("h", Axis), ("v", Axis),
-                ("tr_mul", C.c_double), ("pk_out", C.c_double)]
+                ("tr_mul", C.c_double), ("pk_out", C.c_double),
+                ("use_srgb_gamma", C.c_int32), ("alpha_index", C.c_int32)]
 
 
 class LancirPos(C.Structure):

@@ -419,7 +419,7 @@ static int ensure_scratch( avirhip_plan* p )
 	int rc;
 	void* q;
 
-	if( p -> in_type != AVIRHIP_F32 && p -> packed == nullptr )
+	if(( p -> in_type != AVIRHIP_F32 || p -> gamma ) && p -> packed == nullptr )
 	{
 		if(( rc = dev_alloc( p, (size_t) p -> src_w * p -> src_h * p -> ch *
 			sizeof( float ), &q )) != 0 ) return( rc );
@@ -585,6 +585,16 @@ static int exec_device( avirhip_plan* p, const void* src, void* dst,
 	const float* fsrc = (const float*) src;
 	long sstride = p -> src_stride;
 
+	if( p -> gamma )
+	{
+		if(( rc = launch_pack_gamma( src, p -> in_type, p -> packed,
+			p -> src_w, p -> src_h, p -> ch, p -> src_stride,
+			p -> alpha_index, p -> d_srgb_tbl, st )) != 0 ) return( rc );
+
+		fsrc = p -> packed;
+		sstride = (long) p -> src_w * p -> ch;
+	}
+	else
 	if( p -> in_type != AVIRHIP_F32 )
 	{
 		if(( rc = launch_pack( src, p -> in_type, p -> packed, p -> src_w,
@@ -594,6 +604,9 @@ static int exec_device( avirhip_plan* p, const void* src, void* dst,
 		sstride = (long) p -> src_w * p -> ch;
 	}
 
+	// float output is the vertical pass' in-place result (avir.h:4956-4979):
+	// with gamma it stays linear, only the other output types are
+	// de-linearised in the epilogue
 	float* fdst = ( p -> out_type == AVIRHIP_F32 ? (float*) dst :
 		p -> resbuf );
 
@@ -630,7 +643,7 @@ static int exec_device( avirhip_plan* p, const void* src, void* dst,
 	{
 		rc = launch_epilogue( fdst, dst, p -> out_type,
 			(long) ( row1 - row0 ) * p -> new_w * p -> ch, p -> tr_mul,
-			p -> pk_out, st );
+			p -> pk_out, p -> gamma, p -> ch, p -> alpha_index, st );
 	}
 
 	return( rc );
@@ -741,6 +754,7 @@ static avirhip_plan* new_plan()
 	p -> stage_src = nullptr; p -> stage_dst = nullptr;
 	p -> stage_src_bytes = 0; p -> stage_dst_bytes = 0;
 	p -> tr_mul = 1.0; p -> pk_out = 0.0;
+	p -> gamma = 0; p -> alpha_index = -1; p -> d_srgb_tbl = nullptr;
 	p -> l_out_mul = 1.0f; p -> l_clamp = 0.0f; p -> l_unity = 1;
 	(void) hipGetDevice( &p -> device );
 	return( p );
@@ -826,12 +840,22 @@ int avirhip_plan_create( const avirhip_plan_desc* d, avirhip_plan** out )
 	p -> ch = d -> channels;
 	p -> in_type = d -> in_type; p -> out_type = d -> out_type;
 	p -> tr_mul = d -> tr_mul; p -> pk_out = d -> pk_out;
+	p -> gamma = ( d -> use_srgb_gamma ? 1 : 0 );
+	p -> alpha_index = ( d -> channels == 4 ? d -> alpha_index : -1 );
 
 	int rc = lower_axis( d -> h, d -> src_w, d -> new_w, p -> h );
 
 	if( rc == 0 ) rc = lower_axis( d -> v, d -> src_h, d -> new_h, p -> v );
 	if( rc == 0 ) rc = upload_axis( p, p -> h );
 	if( rc == 0 ) rc = upload_axis( p, p -> v );
+
+	if( rc == 0 && p -> gamma )
+	{
+		std::vector< float > tbl( 256 );
+		srgb_u8_table( tbl.data() );
+		rc = upload( p, tbl, &p -> d_srgb_tbl );
+	}
+
 	if( rc == 0 ) rc = fused_prepare( p );
 	if( rc == 0 ) rc = up2_prepare( p );
 

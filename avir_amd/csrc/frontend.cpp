@@ -20,7 +20,7 @@ struct avirhip_resizer
 	AvirPlanner* planner;
 	std::mutex mtx;
 	typedef std::tuple< int, int, int, int, int, int, double, double, double,
-		int, int, int > Key;
+		int, int, int, int, int > Key;
 	std::map< Key, avirhip_plan* > cache;
 };
 
@@ -143,7 +143,7 @@ int avirhip_resizer_build_desc( avirhip_resizer* r, int src_w, int src_h,
 
 	if( S == nullptr )
 	{
-		return( V.UseSRGBGamma ? AVIRHIP_EUNSUPPORTED : AVIRHIP_EINVAL );
+		return( AVIRHIP_EINVAL );
 	}
 
 	*out = &S -> d;
@@ -176,7 +176,8 @@ int avirhip_resizer_get_plan( avirhip_resizer* r, int src_w, int src_h,
 	}
 
 	const avirhip_resizer::Key key( src_w, src_h, src_scanline_size, new_w,
-		new_h, el_count_io, k, V.ox, V.oy, V.BuildMode, in_type, out_type );
+		new_h, el_count_io, k, V.ox, V.oy, V.BuildMode, in_type, out_type,
+		( V.UseSRGBGamma ? 1 : 0 ), V.AlphaIndex );
 
 	std::lock_guard< std::mutex > lock( r -> mtx );
 	auto it = r -> cache.find( key );

@@ -11,6 +11,8 @@
 // is bit-identical to the reference's scalar float path.
 
 #include "plan.h"
+#include <stdio.h>
+#include <stdlib.h>
 
 namespace avirhip {
 
@@ -266,6 +268,150 @@ int launch_pack( const void* src, int in_type, float* dst, int w, int h,
 	return( AVIRHIP_OK );
 }
 
+// ---- sRGB gamma (UseSRGBGamma). The reference approximates the 2.4 and 1/2.4
+// powers with a rational polynomial / nested square roots evaluated in DOUBLE
+// from a float argument (pow24_sRGB avir.h:162-175, pow24i_sRGB 187-198); IEEE
+// double +, *, / and sqrt are correctly rounded on gfx950 as on the CPU, and
+// -ffp-contract=off keeps the operation order, so the stages are bit-exact.
+
+__host__ __device__ __forceinline__ double srgb_pow24( const double x )
+{
+	const double x2 = x * x;
+	const double x3 = x2 * x;
+	const double x4 = x2 * x2;
+
+	return( 0.0985766365536824 + 0.839474952656502 * x2 +
+		0.363287814061725 * x3 - 0.0125559718896615 /
+		( 0.12758338921578 + 0.290283465468235 * x ) -
+		0.231757513261358 * x - 0.0395365717969074 * x4 );
+}
+
+__device__ __forceinline__ double srgb_pow24i( const double x )
+{
+	const double sx = sqrt( x );
+	const double ssx = sqrt( sx );
+	const double sssx = sqrt( ssx );
+
+	return( 0.000213364515060263 + 0.0149409239419218 * x +
+		0.433973412731747 * sx + ssx * ( 0.659628181609715 * sssx -
+		0.0380957908841466 - 0.0706476137208521 * sx ));
+}
+
+// convertSRGB2Lin< float, Tin >, avir.h:206-219 (float arithmetic around the
+// double polynomial)
+__device__ __forceinline__ float srgb_to_lin( const float s0, const float m )
+{
+	const float s = s0 * m;
+	const float a = 0.055f;
+
+	if( s <= 0.04045f )
+	{
+		return( s / 12.92f );
+	}
+
+	return( (float) srgb_pow24( (double) (( s + a ) / ( 1.0f + a ))));
+}
+
+// convertLin2SRGB< float >, avir.h:301-312
+__device__ __forceinline__ float lin_to_srgb( const float s )
+{
+	const float a = 0.055f;
+
+	if( s <= 0.0031308f )
+	{
+		return( 12.92f * s );
+	}
+
+	return(( 1.0f + a ) * (float) srgb_pow24i( (double) s ) - a );
+}
+
+// The uint8_t specialisation of convertSRGB2Lin (avir.h:229-291) is a table of
+// 256 literals. They are the double-precision evaluation of the same
+// approximation, written with 7 significant digits: regenerate them that way
+// (tests/test_oracle.py checks all 256 against the reference).
+void srgb_u8_table( float* tbl )
+{
+	for( int i = 0; i < 256; i++ )
+	{
+		const double s = (double) i * ( 1.0 / 255.0 );
+		const double a = 0.055;
+		const double v = ( s <= 0.04045 ? s / 12.92 :
+			srgb_pow24(( s + a ) / ( 1.0 + a )));
+
+		char buf[ 64 ];
+		snprintf( buf, sizeof( buf ), "%.7g", v );
+		tbl[ i ] = strtof( buf, nullptr );
+	}
+}
+
+// packScanline with gamma, avir.h:2841-2930: colour channels are linearised,
+// the alpha channel (4-channel pixels, AlphaIndex 0 or 3) is only scaled by
+// InGammaMult.
+template< typename Tin >
+__global__ void __launch_bounds__( 256 ) k_pack_gamma( const Tin* src,
+	float* dst, int row_elems, int h, long src_stride, int ch,
+	int alpha_index, float gm, const float* tbl )
+{
+	const int x = blockIdx.x * blockDim.x + threadIdx.x;
+	const int y = blockIdx.y;
+
+	if( x >= row_elems || y >= h )
+	{
+		return;
+	}
+
+	const Tin v = src[ (long) y * src_stride + x ];
+	const int c = x % ch;
+	float r;
+
+	if( c == alpha_index )
+	{
+		r = (float) v * gm;
+	}
+	else
+	if( sizeof( Tin ) == 1 )
+	{
+		r = tbl[ (int) v ];
+	}
+	else
+	{
+		r = srgb_to_lin( (float) v, gm );
+	}
+
+	dst[ (long) y * row_elems + x ] = r;
+}
+
+int launch_pack_gamma( const void* src, int in_type, float* dst, int w, int h,
+	int ch, long src_stride, int alpha_index, const float* tbl,
+	hipStream_t st )
+{
+	const int re = w * ch;
+	const dim3 grd(( re + 255 ) / 256, h );
+	// InGammaMult, avir.h:4744-4754
+	const float gm = (float) ( in_type == AVIRHIP_U8 ? 1.0 / 255.0 :
+		( in_type == AVIRHIP_U16 ? 1.0 / 65535.0 : 1.0 ));
+
+	if( in_type == AVIRHIP_U8 )
+		hipLaunchKernelGGL( k_pack_gamma< uint8_t >, grd, dim3( 256 ), 0, st,
+			(const uint8_t*) src, dst, re, h, src_stride, ch, alpha_index,
+			gm, tbl );
+	else if( in_type == AVIRHIP_U16 )
+		hipLaunchKernelGGL( k_pack_gamma< uint16_t >, grd, dim3( 256 ), 0,
+			st, (const uint16_t*) src, dst, re, h, src_stride, ch,
+			alpha_index, gm, tbl );
+	else if( in_type == AVIRHIP_F64 )
+		hipLaunchKernelGGL( k_pack_gamma< double >, grd, dim3( 256 ), 0, st,
+			(const double*) src, dst, re, h, src_stride, ch, alpha_index,
+			gm, tbl );
+	else
+		hipLaunchKernelGGL( k_pack_gamma< float >, grd, dim3( 256 ), 0, st,
+			(const float*) src, dst, re, h, src_stride, ch, alpha_index,
+			gm, tbl );
+
+	AVIRHIP_HIPCHECK( hipGetLastError() );
+	return( AVIRHIP_OK );
+}
+
 // avir::round, avir.h:130-135 (biased, via int cast).
 __device__ __forceinline__ float avir_round( const float d )
 {
@@ -275,9 +421,12 @@ __device__ __forceinline__ float avir_round( const float d )
 
 // CImageResizerDithererDefINL::dither (avir.h:4392-4419) + unpackScanline
 // (avir.h:3155-3215): round, clamp, optional bit-depth truncation, C cast.
+// With gamma, applySRGBGamma (avir.h:2982-3068) runs first: colour channels are
+// de-linearised and scaled by OutGammaMult, the alpha channel only scaled.
 template< typename Tout, bool IsInt >
 __global__ void __launch_bounds__( 256 ) k_epilogue( const float* res,
-	Tout* dst, long n, int use_tr, float tr_mul, float tr_muli, float pk_out )
+	Tout* dst, long n, int use_tr, float tr_mul, float tr_muli, float pk_out,
+	int gamma, int ch, int alpha_index, float ogm )
 {
 	const long i = (long) blockIdx.x * blockDim.x + threadIdx.x;
 
@@ -287,6 +436,18 @@ __global__ void __launch_bounds__( 256 ) k_epilogue( const float* res,
 	}
 
 	float v = res[ i ];
+
+	if( gamma )
+	{
+		if( (int) ( i % ch ) == alpha_index )
+		{
+			v = v * ogm;
+		}
+		else
+		{
+			v = lin_to_srgb( v ) * ogm;
+		}
+	}
 
 	if( IsInt )
 	{
@@ -306,26 +467,34 @@ __global__ void __launch_bounds__( 256 ) k_epilogue( const float* res,
 }
 
 int launch_epilogue( const float* res, void* dst, int out_type, long n,
-	double tr_mul, double pk_out, hipStream_t st )
+	double tr_mul, double pk_out, int gamma, int ch, int alpha_index,
+	hipStream_t st )
 {
 	const dim3 grd( (unsigned) (( n + 255 ) / 256 ));
 	const int use_tr = ( tr_mul != 1.0 );
 	const float trm = (float) tr_mul;
 	const float trmi = (float) ( 1.0 / tr_mul );
 	const float pk = (float) pk_out;
+	// OutGammaMult, avir.h:4756-4763
+	const float ogm = (float) ( out_type == AVIRHIP_U8 ? 255.0 :
+		( out_type == AVIRHIP_U16 ? 65535.0 : 1.0 ));
 
 	if( out_type == AVIRHIP_U8 )
 		hipLaunchKernelGGL(( k_epilogue< uint8_t, true > ), grd, dim3( 256 ),
-			0, st, res, (uint8_t*) dst, n, use_tr, trm, trmi, pk );
+			0, st, res, (uint8_t*) dst, n, use_tr, trm, trmi, pk, gamma, ch,
+			alpha_index, ogm );
 	else if( out_type == AVIRHIP_U16 )
 		hipLaunchKernelGGL(( k_epilogue< uint16_t, true > ), grd, dim3( 256 ),
-			0, st, res, (uint16_t*) dst, n, use_tr, trm, trmi, pk );
+			0, st, res, (uint16_t*) dst, n, use_tr, trm, trmi, pk, gamma, ch,
+			alpha_index, ogm );
 	else if( out_type == AVIRHIP_F64 )
 		hipLaunchKernelGGL(( k_epilogue< double, false > ), grd, dim3( 256 ),
-			0, st, res, (double*) dst, n, use_tr, trm, trmi, pk );
+			0, st, res, (double*) dst, n, use_tr, trm, trmi, pk, gamma, ch,
+			alpha_index, ogm );
 	else
 		hipLaunchKernelGGL(( k_epilogue< float, false > ), grd, dim3( 256 ),
-			0, st, res, (float*) dst, n, use_tr, trm, trmi, pk );
+			0, st, res, (float*) dst, n, use_tr, trm, trmi, pk, gamma, ch,
+			alpha_index, ogm );
 
 	AVIRHIP_HIPCHECK( hipGetLastError() );
 	return( AVIRHIP_OK );

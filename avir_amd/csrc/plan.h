@@ -95,6 +95,8 @@ struct avirhip_plan
 	int src_w, src_h, src_stride, new_w, new_h, new_stride, ch;
 	int in_type, out_type;
 	double tr_mul, pk_out;
+	int gamma, alpha_index; // sRGB gamma stages (avir.h:2841-2930, 2982-3068)
+	float* d_srgb_tbl;      // 256-entry uint8 linearisation table (gamma plans)
 	avirhip::LAxis h, v;
 	// LANCIR
 	avirhip::LancirAxisDev lv, lh;
@@ -132,11 +134,16 @@ size_t dtype_size( int t );
 // generic.hip
 int launch_pack( const void* src, int in_type, float* dst, int w, int h,
 	int ch, long src_stride, hipStream_t st );
+int launch_pack_gamma( const void* src, int in_type, float* dst, int w, int h,
+	int ch, long src_stride, int alpha_index, const float* tbl,
+	hipStream_t st );
+void srgb_u8_table( float* tbl );
 int launch_op( const LOp& op, int ch, bool x_is_idx, const Surf& in,
 	const Surf& out, int scan0, int scan1, int idx0, int idx1,
 	hipStream_t st );
 int launch_epilogue( const float* res, void* dst, int out_type, long n,
-	double tr_mul, double pk_out, hipStream_t st );
+	double tr_mul, double pk_out, int gamma, int ch, int alpha_index,
+	hipStream_t st );
 int launch_lancir_generic( const avirhip_plan* p, const void* src, void* dst,
 	float* tmp, int row0, int row1, hipStream_t st );
 

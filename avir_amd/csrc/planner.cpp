@@ -1413,13 +1413,6 @@ DescStore* AvirPlanner::build( int sw, int sh, int sstride, int nw, int nh,
 		return( nullptr );
 	}
 
-	if( vars.UseSRGBGamma )
-	{
-		set_error( "planner: sRGB gamma (avir.h:162-310) is outside the "
-			"built scope" );
-		return( nullptr );
-	}
-
 	AvirPlannerImpl& I = *impl;
 
 	// Steps and offsets, avir.h:4709-4736.
@@ -1449,23 +1442,32 @@ DescStore* AvirPlanner::build( int sw, int sh, int sstride, int nw, int nh,
 		ky = -k;
 	}
 
-	// Output multiplier, avir.h:4740-4782 (no gamma).
+	// Output multiplier, avir.h:4740-4782. With sRGB gamma the range
+	// conversion happens in the gamma stages (InGammaMult / OutGammaMult) and
+	// the filters keep unity gain.
 	const bool inFloat = ( in_type >= AVIRHIP_F32 );
 	const bool outFloat = ( out_type >= AVIRHIP_F32 );
 	double outMul;
 
-	if( outFloat )
+	if( vars.UseSRGBGamma )
 	{
 		outMul = 1.0;
 	}
 	else
 	{
-		outMul = ( out_type == AVIRHIP_U8 ? 255.0 : 65535.0 );
-	}
+		if( outFloat )
+		{
+			outMul = 1.0;
+		}
+		else
+		{
+			outMul = ( out_type == AVIRHIP_U8 ? 255.0 : 65535.0 );
+		}
 
-	if( !inFloat )
-	{
-		outMul /= ( in_type == AVIRHIP_U8 ? 255.0 : 65535.0 );
+		if( !inFloat )
+		{
+			outMul /= ( in_type == AVIRHIP_U8 ? 255.0 : 65535.0 );
+		}
 	}
 
 	if( sstride < 1 )
@@ -1611,6 +1613,8 @@ DescStore* AvirPlanner::build( int sw, int sh, int sstride, int nw, int nh,
 	d.in_type = in_type; d.out_type = out_type;
 	d.tr_mul = 1.0;
 	d.pk_out = 0.0;
+	d.use_srgb_gamma = ( vars.UseSRGBGamma ? 1 : 0 );
+	d.alpha_index = vars.AlphaIndex;
 
 	if( !outFloat )
 	{

@@ -19,9 +19,9 @@
  * (detected; zero-copy).
  *
  * Differences by design: there is NO CPU execution path -- if the library
- * cannot run the call (no gfx950 device, or a feature outside the built scope
- * such as UseSRGBGamma) resizeImage() throws std::runtime_error instead of
- * silently computing elsewhere. Only the float pipeline is provided
+ * cannot run the call (no gfx950 device, or a request outside the built
+ * scope) resizeImage() throws std::runtime_error instead of silently computing
+ * elsewhere. UseSRGBGamma / AlphaIndex are honoured (bit-exact gamma stages). Only the float pipeline is provided
  * (fpclass_def<float>, the reference's default).
  */
 #ifndef AVIR_HIP_AVIR_H

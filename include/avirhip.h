@@ -124,6 +124,15 @@ typedef struct avirhip_plan_desc {
 	 * float/double output. */
 	double tr_mul;            /* TrMul (1.0: no bit-depth truncation) */
 	double pk_out;            /* PkOut: 255 or 65535 */
+	/* sRGB gamma (CImageResizerVars::UseSRGBGamma / AlphaIndex, avir.h:2526-2527):
+	 * the source is linearised while it is packed (packScanline gamma branch,
+	 * avir.h:2841-2930, convertSRGB2Lin 206-291) and the result de-linearised
+	 * before the dither/unpack stage (applySRGBGamma, avir.h:2982-3068,
+	 * convertLin2SRGB 301-312); the alpha channel (index 0 or 3 of 4-channel
+	 * pixels, -1 = none) is only scaled. As in the reference, float32 output
+	 * is the vertical pass' in-place result and stays linear (avir.h:4956-4979). */
+	int32_t use_srgb_gamma;
+	int32_t alpha_index;
 } avirhip_plan_desc;
 
 /* ---------------------------------------------------------------------
@@ -242,7 +251,7 @@ void avirhip_params_preset(int preset, avirhip_params* out);
 /* The caller-settable part of CImageResizerVars (avir.h:2516-2547). */
 typedef struct avirhip_vars {
 	double ox, oy;
-	int32_t UseSRGBGamma; /* must be 0: gamma is outside the built scope */
+	int32_t UseSRGBGamma; /* non-zero: sRGB gamma linearisation (avir.h:2526) */
 	int32_t AlphaIndex;
 	int32_t BuildMode;    /* -1 = automatic */
 	int32_t RndSeed;

@@ -10,11 +10,12 @@
  * with -ffp-contract=off.
  *
  * Parity: PINNED against oracle/_ref (the real reference) and the golden
- * hashes of SURVEY.md 8(c) by tests/test_oracle.py. sRGB gamma and the
- * error-diffusion ditherer are not restated (out of scope).
+ * hashes of SURVEY.md 8(c) by tests/test_oracle.py. The sRGB gamma stages are
+ * restated too; the error-diffusion ditherer is not (out of scope).
  */
 #include "oracle.h"
 #include <math.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -1774,6 +1775,91 @@ static size_t tsize( int t )
 }
 
 /* resizeImage, avir.h:4680-5092. */
+/* ---- sRGB gamma stages (CImageResizerVars::UseSRGBGamma) ------------- */
+
+static int g_gamma = 0;
+static int g_alpha = -1;
+
+/* UseSRGBGamma / AlphaIndex of the following oracle_avir_resize() calls. */
+void oracle_set_gamma( int use, int alpha_index )
+{
+	g_gamma = use;
+	g_alpha = alpha_index;
+}
+
+/* pow24_sRGB, avir.h:162-175: double arithmetic from a float argument. */
+static double srgb_pow24( double x )
+{
+	const double x2 = x * x;
+	const double x3 = x2 * x;
+	const double x4 = x2 * x2;
+
+	return( 0.0985766365536824 + 0.839474952656502 * x2 +
+		0.363287814061725 * x3 - 0.0125559718896615 /
+		( 0.12758338921578 + 0.290283465468235 * x ) -
+		0.231757513261358 * x - 0.0395365717969074 * x4 );
+}
+
+/* pow24i_sRGB, avir.h:187-198. */
+static double srgb_pow24i( double x )
+{
+	const double sx = sqrt( x );
+	const double ssx = sqrt( sx );
+	const double sssx = sqrt( ssx );
+
+	return( 0.000213364515060263 + 0.0149409239419218 * x +
+		0.433973412731747 * sx + ssx * ( 0.659628181609715 * sssx -
+		0.0380957908841466 - 0.0706476137208521 * sx ));
+}
+
+/* convertSRGB2Lin<float,Tin>, avir.h:206-219. */
+static float srgb_to_lin( float s0, float m )
+{
+	const float s = s0 * m;
+	const float a = 0.055f;
+
+	if( s <= 0.04045f )
+	{
+		return( s / 12.92f );
+	}
+
+	return( (float) srgb_pow24( (double) (( s + a ) / ( 1.0f + a ))));
+}
+
+/* convertLin2SRGB<float>, avir.h:301-312. */
+static float lin_to_srgb( float s )
+{
+	const float a = 0.055f;
+
+	if( s <= 0.0031308f )
+	{
+		return( 12.92f * s );
+	}
+
+	return(( 1.0f + a ) * (float) srgb_pow24i( (double) s ) - a );
+}
+
+/* The uint8_t specialisation of convertSRGB2Lin is a table of 256 literals
+ * (avir.h:229-291): the double-precision evaluation of the approximation
+ * written with 7 significant digits. Regenerated here; test_oracle.py checks
+ * every entry against the reference's table. */
+void oracle_srgb_u8_table( float* tbl )
+{
+	int i;
+
+	for( i = 0; i < 256; i++ )
+	{
+		const double s = (double) i * ( 1.0 / 255.0 );
+		const double a = 0.055;
+		const double v = ( s <= 0.04045 ? s / 12.92 :
+			srgb_pow24(( s + a ) / ( 1.0 + a )));
+
+		char buf[ 64 ];
+		snprintf( buf, sizeof( buf ), "%.7g", v );
+		tbl[ i ] = strtof( buf, NULL );
+	}
+}
+
 int oracle_avir_resize( const void* src, int sw, int sh, int sstride,
 	void* dst, int nw, int nh, int ch, double k, int in_type, int out_type,
 	int resbits, int srcbits, const double* params, double ox0, double oy0,
@@ -1796,6 +1882,9 @@ int oracle_avir_resize( const void* src, int sw, int sh, int sstride,
 	float* bp[ 3 ];
 	float* resbuf = NULL;
 	int neww_e;
+	float ingm = 1.0f, outgm = 1.0f;
+	float srgbtbl[ 256 ];
+	const int alpha = ( ch == 4 ? g_alpha : -1 );
 
 	if( ch < 1 || ch > 4 || in_type < 0 || in_type > 3 || out_type < 0 ||
 		out_type > 3 )
@@ -1859,18 +1948,33 @@ int oracle_avir_resize( const void* src, int sw, int sh, int sstride,
 	isinfloat = ( in_type >= ORACLE_F32 );
 	isoutfloat = ( out_type >= ORACLE_F32 );
 
-	if( isoutfloat )
+	/* avir.h:4740-4782 */
+	if( g_gamma )
 	{
+		ingm = (float) ( isinfloat ? 1.0 :
+			1.0 / ( in_type == ORACLE_U8 ? 255.0 : 65535.0 ));
+
+		outgm = (float) ( isoutfloat ? 1.0 :
+			( out_type == ORACLE_U8 ? 255.0 : 65535.0 ));
+
 		outmul = 1.0;
+		oracle_srgb_u8_table( srgbtbl );
 	}
 	else
 	{
-		outmul = ( out_type == ORACLE_U8 ? 255.0 : 65535.0 );
-	}
+		if( isoutfloat )
+		{
+			outmul = 1.0;
+		}
+		else
+		{
+			outmul = ( out_type == ORACLE_U8 ? 255.0 : 65535.0 );
+		}
 
-	if( !isinfloat )
-	{
-		outmul /= ( in_type == ORACLE_U8 ? 255.0 : 65535.0 );
+		if( !isinfloat )
+		{
+			outmul /= ( in_type == ORACLE_U8 ? 255.0 : 65535.0 );
+		}
 	}
 
 	neww_e = nw * ch;
@@ -1942,10 +2046,29 @@ int oracle_avir_resize( const void* src, int sw, int sh, int sstride,
 
 	for( i = 0; i < sh; i++ )
 	{
-		/* packScanline, avir.h:2777-2840 */
+		/* packScanline, avir.h:2777-2840; gamma branch 2841-2930 */
 		for( j = 0; j < sw * ch; j++ )
 		{
-			bp[ 0 ][ j ] = load_in( src, (size_t) i * sstride + j, in_type );
+			const float v = load_in( src, (size_t) i * sstride + j, in_type );
+
+			if( !g_gamma )
+			{
+				bp[ 0 ][ j ] = v;
+			}
+			else
+			if( j % ch == alpha )
+			{
+				bp[ 0 ][ j ] = v * ingm;
+			}
+			else
+			if( in_type == ORACLE_U8 )
+			{
+				bp[ 0 ][ j ] = srgbtbl[ (int) v ];
+			}
+			else
+			{
+				bp[ 0 ][ j ] = srgb_to_lin( v, ingm );
+			}
 		}
 
 		bp[ 2 ] = &fltbuf_[ (size_t) i * neww_e ];
@@ -2018,6 +2141,9 @@ int oracle_avir_resize( const void* src, int sw, int sh, int sstride,
 	bp[ 0 ] = bufs + V.bufoffs[ 0 ];
 	bp[ 1 ] = bufs + V.buflen[ 0 ] + V.bufoffs[ 1 ];
 
+	/* float output is written in place by the vertical pass and returned as
+	 * is, avir.h:4956-4979 -- with gamma it therefore stays LINEAR (only the
+	 * other output types pass through applySRGBGamma) */
 	if( out_type != ORACLE_F32 )
 	{
 		resbuf = (float*) xalloc( sizeof( float ) * (size_t) neww_e * nh );
@@ -2043,6 +2169,22 @@ int oracle_avir_resize( const void* src, int sw, int sh, int sstride,
 			(float*) dst + i * ch );
 
 		run_steps( &S, &V, bp, neww_e );
+	}
+
+	if( resbuf != NULL && g_gamma )
+	{
+		/* applySRGBGamma, avir.h:2982-3068 */
+		for( j = 0; j < nh * neww_e; j++ )
+		{
+			if( j % ch == alpha )
+			{
+				resbuf[ j ] = resbuf[ j ] * outgm;
+			}
+			else
+			{
+				resbuf[ j ] = lin_to_srgb( resbuf[ j ]) * outgm;
+			}
+		}
 	}
 
 	if( resbuf != NULL )

@@ -31,12 +31,19 @@ extern "C" {
  * (avir.h:4680-5092). `params` = 8 doubles {CorrFltAlpha, CorrFltLen,
  * IntFltAlpha, IntFltCutoff, IntFltLen, LPFltAlpha, LPFltBaseLen,
  * LPFltCutoffMult} or NULL for CImageResizerParamsDef. Returns 0, or <0 on an
- * unsupported request (sRGB gamma is not restated). `mode_h`/`mode_v`, if not
- * NULL, receive the build modes selected per axis. */
+ * unsupported request. `mode_h`/`mode_v`, if not NULL, receive the build modes
+ * selected per axis. */
 int oracle_avir_resize( const void* src, int sw, int sh, int sstride,
 	void* dst, int nw, int nh, int ch, double k, int in_type, int out_type,
 	int resbits, int srcbits, const double* params, double ox, double oy,
 	int build_mode, int* mode_h, int* mode_v );
+
+/* CImageResizerVars::UseSRGBGamma / AlphaIndex (avir.h:2526-2527) of the
+ * following oracle_avir_resize() calls; default off / -1. */
+void oracle_set_gamma( int use, int alpha_index );
+
+/* The regenerated uint8_t linearisation table (avir.h:229-291). */
+void oracle_srgb_u8_table( float* tbl );
 
 /* avir::CLancIR::resizeImage<Tin,Tout>() (lancir.h:386-713), x86-64 SSE2
  * summation order. Returns NewHeight, or 0 on a parameter error. */

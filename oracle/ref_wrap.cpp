@@ -89,6 +89,11 @@ void fillParams( avir::CImageResizerParams& P, const double* p )
 	}
 }
 
+/* CImageResizerVars::UseSRGBGamma / AlphaIndex of the following
+ * ref_avir_resize calls (set by ref_set_gamma; test harness only). */
+int g_use_gamma = 0;
+int g_alpha_index = -1;
+
 template< class R, typename Tin, typename Tout >
 void doResizeT( const void* src, int sw, int sh, int sstride, void* dst,
 	int nw, int nh, int ch, double k, int resbits, int srcbits,
@@ -99,6 +104,8 @@ void doResizeT( const void* src, int sw, int sh, int sstride, void* dst,
 	R r( resbits, srcbits, P );
 	avir::CImageResizerVars V;
 	V.ox = ox; V.oy = oy; V.BuildMode = build_mode;
+	V.UseSRGBGamma = ( g_use_gamma != 0 );
+	V.AlphaIndex = g_alpha_index;
 	CRefThreadPool pool( threads );
 	if( threads > 1 ) V.ThreadPool = &pool;
 	r.resizeImage( (const Tin*) src, sw, sh, sstride, (Tout*) dst, nw, nh,
@@ -270,6 +277,23 @@ extern "C" {
 
 /* avir::CImageResizer<fpclass>::resizeImage<Tin,Tout>() on the CPU.
  * variant 0 = fpclass_def<float> (the parity oracle), 1 = fpclass_float4. */
+/* UseSRGBGamma / AlphaIndex for subsequent ref_avir_resize() calls. */
+void ref_set_gamma( int use, int alpha_index )
+{
+	g_use_gamma = use;
+	g_alpha_index = alpha_index;
+}
+
+/* The uint8_t specialisation of avir::convertSRGB2Lin (the 256-entry literal
+ * table, avir.h:229-291), for checking the regenerated tables against it. */
+void ref_srgb_u8_table( float* out )
+{
+	for( int i = 0; i < 256; i++ )
+	{
+		out[ i ] = avir::convertSRGB2Lin< float >( (unsigned char) i, 1.0f );
+	}
+}
+
 int ref_avir_resize( const void* src, int sw, int sh, int sstride, void* dst,
 	int nw, int nh, int ch, double k, int in_type, int out_type, int resbits,
 	int srcbits, const double* params, double ox, double oy, int build_mode,

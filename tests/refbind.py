@@ -45,6 +45,10 @@ def ref():
             C.c_int, C.c_int, C.c_double, C.c_int, C.c_int, C.c_int, C.c_int,
             C.POINTER(C.c_double), C.c_double, C.c_double, C.c_int, C.c_int,
             C.c_int]
+        lib.ref_set_gamma.restype = None
+        lib.ref_set_gamma.argtypes = [C.c_int, C.c_int]
+        lib.ref_srgb_u8_table.restype = None
+        lib.ref_srgb_u8_table.argtypes = [C.c_void_p]
         lib.ref_lancir_resize.restype = C.c_int
         lib.ref_lancir_resize.argtypes = [
             C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int,
@@ -79,6 +83,10 @@ def orc():
             C.c_int, C.c_int, C.c_double, C.c_int, C.c_int, C.c_int, C.c_int,
             C.POINTER(C.c_double), C.c_double, C.c_double, C.c_int,
             C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        lib.oracle_set_gamma.restype = None
+        lib.oracle_set_gamma.argtypes = [C.c_int, C.c_int]
+        lib.oracle_srgb_u8_table.restype = None
+        lib.oracle_srgb_u8_table.argtypes = [C.c_void_p]
         lib.oracle_lancir_resize.restype = C.c_int
         lib.oracle_lancir_resize.argtypes = [
             C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int,
@@ -132,25 +140,34 @@ def _avir_call(fn, extra, src, nw, nh, k, out_dtype, resbits, srcbits, params,
 
 def ref_avir(src, nw, nh, k=0.0, out_dtype=None, resbits=8, srcbits=0,
              params=None, ox=0.0, oy=0.0, build_mode=-1, threads=1, variant=0,
-             sstride=0):
-    """avir::CImageResizer<>::resizeImage on the CPU; src is (H, W, C)."""
+             sstride=0, gamma=False, alpha=-1):
+    """avir::CImageResizer<>::resizeImage on the CPU; src is (H, W, C).
+    gamma/alpha = CImageResizerVars::UseSRGBGamma / AlphaIndex."""
     out_dtype = src.dtype if out_dtype is None else out_dtype
-    rc, dst = _avir_call(ref().ref_avir_resize, (threads, variant), src, nw,
-                         nh, k, out_dtype, resbits, srcbits, params, ox, oy,
-                         build_mode, sstride)
+    ref().ref_set_gamma(1 if gamma else 0, alpha)
+    try:
+        rc, dst = _avir_call(ref().ref_avir_resize, (threads, variant), src,
+                             nw, nh, k, out_dtype, resbits, srcbits, params,
+                             ox, oy, build_mode, sstride)
+    finally:
+        ref().ref_set_gamma(0, -1)
     assert rc == 0, rc
     return dst
 
 
 def orc_avir(src, nw, nh, k=0.0, out_dtype=None, resbits=8, srcbits=0,
              params=None, ox=0.0, oy=0.0, build_mode=-1, sstride=0,
-             return_modes=False):
+             return_modes=False, gamma=False, alpha=-1):
     out_dtype = src.dtype if out_dtype is None else out_dtype
     mh, mv = C.c_int(-9), C.c_int(-9)
-    rc, dst = _avir_call(orc().oracle_avir_resize,
-                         (C.byref(mh), C.byref(mv)), src, nw, nh, k,
-                         out_dtype, resbits, srcbits, params, ox, oy,
-                         build_mode, sstride)
+    orc().oracle_set_gamma(1 if gamma else 0, alpha)
+    try:
+        rc, dst = _avir_call(orc().oracle_avir_resize,
+                             (C.byref(mh), C.byref(mv)), src, nw, nh, k,
+                             out_dtype, resbits, srcbits, params, ox, oy,
+                             build_mode, sstride)
+    finally:
+        orc().oracle_set_gamma(0, -1)
     assert rc == 0, rc
     if return_modes:
         return dst, (mh.value, mv.value)

@@ -66,9 +66,12 @@ def test_error_paths_report_messages():
     lib.avirhip_vars_default(C.byref(v))
     v.UseSRGBGamma = 1
     d = C.POINTER(abi.PlanDesc)()
-    rc = lib.avirhip_resizer_build_desc(r, 8, 8, 0, 4, 4, 3, 0.0, C.byref(v),
+    v.AlphaIndex = 3
+    rc = lib.avirhip_resizer_build_desc(r, 8, 8, 0, 4, 4, 4, 0.0, C.byref(v),
                                         abi.U8, abi.U8, C.byref(d))
-    assert rc == -4 and b"gamma" in lib.avirhip_last_error()
+    assert rc == 0 and d.contents.use_srgb_gamma == 1
+    assert d.contents.alpha_index == 3
+    lib.avirhip_plan_desc_free(d)
     rc = lib.avirhip_resizer_build_desc(r, 8, 8, 0, 4, 4, 5, 0.0, None,
                                         abi.U8, abi.U8, C.byref(d))
     assert rc == -1

@@ -53,6 +53,8 @@ def _run_avir(src, nw, nh, resbits=8, out_dtype=None, build_mode=-1, k=0.0,
     v = avir_amd.CImageResizerVars()
     v.BuildMode = build_mode
     v.ox, v.oy = kw.get("ox", 0.0), kw.get("oy", 0.0)
+    v.UseSRGBGamma = 1 if kw.get("gamma", False) else 0
+    v.AlphaIndex = kw.get("alpha", -1)
     h, w, ch = src.shape
     out_dtype = np.dtype(out_dtype or src.dtype)
     if path:
@@ -300,16 +302,51 @@ def test_avir_integer_downsizing_bands():
                 _assert_same(band, full[a:b], "band [%d,%d)" % (a, b))
 
 
+GAMMA_GPU = [
+    # (sw, sh, nw, nh, ch, in dtype, out dtype, alpha)
+    (37, 21, 74, 42, 4, np.uint8, np.uint8, -1),
+    (37, 21, 74, 42, 4, np.uint8, np.uint8, 3),
+    (40, 30, 25, 17, 4, np.uint8, np.uint16, 0),
+    (40, 30, 61, 47, 3, np.uint8, np.uint8, -1),
+    (33, 20, 20, 31, 1, np.uint16, np.uint8, -1),
+    (33, 20, 50, 31, 2, np.uint16, np.uint16, -1),
+    (64, 48, 100, 77, 4, np.float32, np.float32, 3),
+    (64, 48, 128, 96, 4, np.float32, np.float32, -1),
+    (64, 48, 21, 16, 3, np.float32, np.uint8, -1),
+    (30, 30, 45, 45, 4, np.float64, np.float64, 0),
+    (50, 40, 50, 40, 4, np.uint8, np.float32, -1),
+    (300, 200, 100, 67, 4, np.uint8, np.uint8, 3),
+]
+
+
+@pytest.mark.parametrize("sw,sh,nw,nh,ch,tin,tout,alpha", GAMMA_GPU)
+def test_avir_srgb_gamma(sw, sh, nw, nh, ch, tin, tout, alpha):
+    """UseSRGBGamma / AlphaIndex (avir.h:2526-2527): linearising pack stage
+    and de-linearising epilogue, bit-exact for every I/O type -- including the
+    reference's float32-output-stays-linear behaviour (avir.h:4956-4979)."""
+    if tin == np.uint8:
+        src = rb.lcg_u8((sh, sw, ch), seed=5 + sw)
+    elif tin == np.uint16:
+        src = rb.lcg_u8((sh, sw, ch * 2), seed=5 + sw).view(
+            np.uint16).reshape(sh, sw, ch).copy()
+    else:
+        src = rb.lcg_f32((sh, sw, ch), seed=5 + sw).astype(tin)
+    for bits in (8, 16):
+        want = _checker_avir(src, nw, nh, out_dtype=tout, resbits=bits,
+                             gamma=True, alpha=alpha)
+        got = _run_avir(src, nw, nh, out_dtype=tout, resbits=bits,
+                        gamma=True, alpha=alpha)
+        _assert_same(got, want, "gamma bits %d" % bits)
+
+
 def test_zero_sized_and_errors():
     r = avir_amd.CImageResizer(8)
     dst = np.full((4, 5, 3), 7, np.uint8)
     r.resizeImage(np.zeros((0,), np.uint8), 0, 0, 0, dst, 5, 4, 3, 0.0)
     # avir.h:4686-4692 zero-fills NewWidth*NewHeight ELEMENTS only
     assert dst.reshape(-1)[:20].sum() == 0 and dst.reshape(-1)[20:].min() == 7
-    v = avir_amd.CImageResizerVars()
-    v.UseSRGBGamma = 1
     with pytest.raises(avir_amd.AvirHipError):
-        r.resize(np.zeros((8, 8, 3), np.uint8), 4, 4, aVars=v)
+        r.resize(np.zeros((8, 8, 5), np.uint8), 4, 4)  # 5 channels
 
 
 # ---- LANCIR ----
