@@ -41,6 +41,9 @@
 #define protected public
 #include "avir.h"
 #include "avir_float4_sse.h"
+#if defined( REF_SIMD ) && defined( __AVX__ )
+#include "avir_float8_avx.h"
+#endif
 #include "lancir.h"
 #undef private
 #undef protected
@@ -145,6 +148,9 @@ int doResize( const void* src, int sw, int sh, int sstride, void* dst,
 
 typedef avir::CImageResizer< avir::fpclass_def< float > > RDef;
 typedef avir::CImageResizer< avir::fpclass_float4 > RF4;
+#if defined( REF_SIMD ) && defined( __AVX__ )
+typedef avir::CImageResizer< avir::fpclass_float8_dil > RF8;
+#endif
 
 /* ---- plan dump ---- */
 
@@ -276,7 +282,9 @@ void dumpAxis( DumpStore& S, RDef::CFilterSteps& Steps,
 extern "C" {
 
 /* avir::CImageResizer<fpclass>::resizeImage<Tin,Tout>() on the CPU.
- * variant 0 = fpclass_def<float> (the parity oracle), 1 = fpclass_float4. */
+ * variant 0 = fpclass_def<float> (the parity oracle), 1 = fpclass_float4
+ * (SSE), 2 = fpclass_float8_dil (AVX, de-interleaved; only in the REF_SIMD
+ * speed build, which is a CPU-baseline timing aid and not a parity oracle). */
 /* UseSRGBGamma / AlphaIndex for subsequent ref_avir_resize() calls. */
 void ref_set_gamma( int use, int alpha_index )
 {
@@ -299,6 +307,15 @@ int ref_avir_resize( const void* src, int sw, int sh, int sstride, void* dst,
 	int srcbits, const double* params, double ox, double oy, int build_mode,
 	int threads, int variant )
 {
+#if defined( REF_SIMD ) && defined( __AVX__ )
+	if( variant == 2 )
+	{
+		return( doResize< RF8 >( src, sw, sh, sstride, dst, nw, nh, ch, k,
+			in_type, out_type, resbits, srcbits, params, ox, oy, build_mode,
+			threads ));
+	}
+#endif
+
 	if( variant == 1 )
 	{
 		return( doResize< RF4 >( src, sw, sh, sstride, dst, nw, nh, ch, k,

@@ -16,6 +16,7 @@ from avir_amd import abi
 
 _ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 REF_PATH = os.path.join(_ROOT, "oracle", "_ref", "libavir_ref.so")
+REF_SIMD_PATH = os.path.join(_ROOT, "oracle", "_ref", "libavir_ref_simd.so")
 ORC_PATH = os.path.join(_ROOT, "oracle", "liboracle.so")
 
 _DT = {np.dtype(np.uint8): abi.U8, np.dtype(np.uint16): abi.U16,
@@ -33,6 +34,30 @@ def have_ref():
 
 def have_orc():
     return os.path.exists(ORC_PATH)
+
+
+def have_ref_simd():
+    return os.path.exists(REF_SIMD_PATH)
+
+
+_ref_simd = None
+
+
+def ref_avir_simd(src, nw, nh, variant, threads=1, resbits=16):
+    """The reference built for speed (-O3 -mavx2 -mfma): variant 1 =
+    fpclass_float4 (SSE), 2 = fpclass_float8_dil (AVX). CPU-baseline timing
+    only -- not a parity oracle (FMA contraction, de-interleaved order)."""
+    global _ref_simd
+    if _ref_simd is None:
+        lib = C.CDLL(REF_SIMD_PATH)
+        lib.ref_avir_resize.restype = C.c_int
+        lib.ref_avir_resize.argtypes = ref().ref_avir_resize.argtypes
+        _ref_simd = lib
+    rc, dst = _avir_call(_ref_simd.ref_avir_resize, (threads, variant), src,
+                         nw, nh, 0.0, src.dtype, resbits, 0, None, 0.0, 0.0,
+                         -1, 0)
+    assert rc == 0, rc
+    return dst
 
 
 def ref():
