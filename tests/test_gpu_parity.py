@@ -302,6 +302,23 @@ def test_avir_integer_downsizing_bands():
                 _assert_same(band, full[a:b], "band [%d,%d)" % (a, b))
 
 
+def test_dc_gain_constant_image():
+    """a constant image must come out constant on every
+    execution path and ratio class. The reference's own DC error is 6e-8 ..
+    3e-7 for integer ratios and 5.6e-5 for fractional phases (its bank
+    filters are not renormalised per phase), hence 1e-4 here; bit parity with
+    the reference is asserted by the other tests."""
+    for (sw, sh, nw, nh) in [(64, 48, 128, 96), (64, 48, 100, 77),
+                             (300, 200, 100, 67), (120, 90, 80, 60)]:
+        src = np.full((sh, sw, 4), 0.625, np.float32)
+        for path in (0, abi.PATH_GENERIC, abi.PATH_TILED, abi.PATH_FUSED):
+            got = _run_avir(src, nw, nh, resbits=16, path=path)
+            assert np.abs(got - 0.625).max() < 1e-4, (sw, sh, nw, nh, path)
+    out = avir_amd.CLancIR().resize(np.full((48, 64, 4), 0.625, np.float32),
+                                    128, 96)
+    assert np.abs(out - 0.625).max() < 1e-6
+
+
 GAMMA_GPU = [
     # (sw, sh, nw, nh, ch, in dtype, out dtype, alpha)
     (37, 21, 74, 42, 4, np.uint8, np.uint8, -1),
