@@ -288,8 +288,12 @@ def main():
             "kernels_per_step": {1: 5, 2: 2, 3: 1, 4: 1}.get(path)}
 
     if world > 1:
-        out["band_gather"] = band_gather(lib, plan, src, dev, world, rank, dist,
-                                         torch)
+        # secondary measurement: must never take the headline line down
+        try:
+            out["band_gather"] = band_gather(lib, plan, src, dev, world, rank,
+                                             dist, torch)
+        except Exception as e:  # noqa: BLE001
+            out["band_gather"] = {"error": "%s: %s" % (type(e).__name__, e)}
 
     if rank == 0 and world == 1 and not args.no_cpu:
         # the drop-in call as a host program makes it: host pointers in and

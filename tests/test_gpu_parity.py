@@ -302,6 +302,72 @@ def test_avir_integer_downsizing_bands():
                 _assert_same(band, full[a:b], "band [%d,%d)" % (a, b))
 
 
+@pytest.mark.parametrize("sw,sh,nw,nh", [(64, 48, 128, 96), (300, 201, 100, 67),
+                                         (64, 48, 100, 77), (120, 90, 80, 60)])
+@pytest.mark.parametrize("pad", [4, 3])
+def test_avir_padded_source_rows(sw, sh, nw, nh, pad):
+    """SrcScanlineSize > SrcWidth*ElCount (avir.h:4791-4794): rows with a
+    16-byte-aligned pitch stay on the fast paths, the odd pitch falls back."""
+    ch = 4
+    ss = sw * ch + pad
+    buf = rb.lcg_f32((sh, ss), seed=sw + pad)
+    src = np.ascontiguousarray(buf[:, :sw * ch]).reshape(sh, sw, ch)
+    want = _checker_avir(src, nw, nh, resbits=16)
+    r = avir_amd.CImageResizer(16)
+    dst = np.empty((nh, nw, ch), np.float32)
+    r.resizeImage(buf, sw, sh, ss, dst, nw, nh, ch, 0.0)
+    _assert_same(dst, want, "padded rows, host pointers")
+    import torch
+    dbuf = torch.from_numpy(buf).to("cuda:0")
+    ddst = torch.empty((nh, nw, ch), dtype=torch.float32, device="cuda:0")
+    r.resizeImage(dbuf, sw, sh, ss, ddst, nw, nh, ch, 0.0)
+    torch.cuda.synchronize()
+    _assert_same(ddst.cpu().numpy(), want, "padded rows, device pointers")
+
+
+def test_avir_unaligned_device_pointers():
+    """Device buffers that are only 4-byte aligned: the vectorised paths
+    refuse and the call still completes bit-exactly on the generic path."""
+    import torch
+    for (sw, sh, nw, nh) in [(64, 48, 128, 96), (120, 90, 40, 30)]:
+        src = rb.lcg_f32((sh, sw, 4), seed=3)
+        want = _checker_avir(src, nw, nh, resbits=16)
+        big = torch.zeros(sh * sw * 4 + 1, dtype=torch.float32, device="cuda:0")
+        big[1:] = torch.from_numpy(src.reshape(-1)).to("cuda:0")
+        out = torch.zeros(nh * nw * 4 + 1, dtype=torch.float32, device="cuda:0")
+        r = avir_amd.CImageResizer(16)
+        r.resizeImage(big[1:], sw, sh, 0, out[1:], nw, nh, 4, 0.0)
+        torch.cuda.synchronize()
+        _assert_same(out[1:].cpu().numpy().reshape(nh, nw, 4), want,
+                     "unaligned device pointers")
+
+
+@pytest.mark.parametrize("k,ox,oy", [(0.5, 0.0, 0.0), (-0.5, 0.25, -0.125),
+                                     (1.7, 0.0, 0.0), (-2.0, 0.5, 0.5),
+                                     (3.0, 0.0, 0.0)])
+def test_avir_explicit_step_and_offsets(k, ox, oy):
+    """k > 0 (centred), k < 0 (not centred) and CImageResizerVars::ox/oy
+    (avir.h:4714-4736)."""
+    src = rb.lcg_f32((60, 80, 4), seed=17)
+    nw, nh = max(1, int(80 / abs(k))), max(1, int(60 / abs(k)))
+    want = _checker_avir(src, nw, nh, resbits=16, k=k, ox=ox, oy=oy)
+    got = _run_avir(src, nw, nh, resbits=16, k=k, ox=ox, oy=oy)
+    _assert_same(got, want, "k=%g" % k)
+
+
+@pytest.mark.parametrize("preset", ["ulr", "lr", "low", "high", "ultra"])
+def test_avir_parameter_presets(preset):
+    """CImageResizerParams presets (avir.h:2262-2464) change every filter."""
+    src = rb.lcg_f32((40, 56, 4), seed=23)
+    P = avir_amd.CImageResizerParams(preset)
+    params = [P.CorrFltAlpha, P.CorrFltLen, P.IntFltAlpha, P.IntFltCutoff,
+              P.IntFltLen, P.LPFltAlpha, P.LPFltBaseLen, P.LPFltCutoffMult]
+    for (nw, nh) in [(112, 80), (37, 29)]:
+        want = _checker_avir(src, nw, nh, resbits=16, params=params)
+        got = avir_amd.CImageResizer(16, 0, P).resize(src, nw, nh)
+        _assert_same(got, want, "preset %s" % preset)
+
+
 def test_dc_gain_constant_image():
     """a constant image must come out constant on every
     execution path and ratio class. The reference's own DC error is 6e-8 ..
