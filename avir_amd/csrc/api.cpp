@@ -419,14 +419,16 @@ static int ensure_scratch( avirhip_plan* p )
 	int rc;
 	void* q;
 
-	if(( p -> in_type != AVIRHIP_F32 || p -> gamma ) && p -> packed == nullptr )
+	if(( p -> in_type != AVIRHIP_F32 || p -> gamma || p -> ch != p -> io_ch ) &&
+		p -> packed == nullptr )
 	{
 		if(( rc = dev_alloc( p, (size_t) p -> src_w * p -> src_h * p -> ch *
 			sizeof( float ), &q )) != 0 ) return( rc );
 		p -> packed = (float*) q;
 	}
 
-	if( p -> out_type != AVIRHIP_F32 && p -> resbuf == nullptr )
+	if(( p -> out_type != AVIRHIP_F32 || p -> ch != p -> io_ch ) &&
+		p -> resbuf == nullptr )
 	{
 		if(( rc = dev_alloc( p, (size_t) p -> new_w * p -> new_h * p -> ch *
 			sizeof( float ), &q )) != 0 ) return( rc );
@@ -588,17 +590,18 @@ static int exec_device( avirhip_plan* p, const void* src, void* dst,
 	if( p -> gamma )
 	{
 		if(( rc = launch_pack_gamma( src, p -> in_type, p -> packed,
-			p -> src_w, p -> src_h, p -> ch, p -> src_stride,
+			p -> src_w, p -> src_h, p -> io_ch, p -> ch, p -> src_stride,
 			p -> alpha_index, p -> d_srgb_tbl, st )) != 0 ) return( rc );
 
 		fsrc = p -> packed;
 		sstride = (long) p -> src_w * p -> ch;
 	}
 	else
-	if( p -> in_type != AVIRHIP_F32 )
+	if( p -> in_type != AVIRHIP_F32 || p -> ch != p -> io_ch )
 	{
 		if(( rc = launch_pack( src, p -> in_type, p -> packed, p -> src_w,
-			p -> src_h, p -> ch, p -> src_stride, st )) != 0 ) return( rc );
+			p -> src_h, p -> io_ch, p -> ch, p -> src_stride, st )) != 0 )
+			return( rc );
 
 		fsrc = p -> packed;
 		sstride = (long) p -> src_w * p -> ch;
@@ -607,8 +610,10 @@ static int exec_device( avirhip_plan* p, const void* src, void* dst,
 	// float output is the vertical pass' in-place result (avir.h:4956-4979):
 	// with gamma it stays linear, only the other output types are
 	// de-linearised in the epilogue
-	float* fdst = ( p -> out_type == AVIRHIP_F32 ? (float*) dst :
-		p -> resbuf );
+	const bool direct = ( p -> out_type == AVIRHIP_F32 &&
+		p -> ch == p -> io_ch );
+
+	float* fdst = ( direct ? (float*) dst : p -> resbuf );
 
 	const int path = ( p -> path != 0 ? p -> path : p -> auto_path );
 	rc = 1;
@@ -639,11 +644,12 @@ static int exec_device( avirhip_plan* p, const void* src, void* dst,
 
 	if( rc != 0 ) return( rc );
 
-	if( p -> out_type != AVIRHIP_F32 )
+	if( !direct )
 	{
 		rc = launch_epilogue( fdst, dst, p -> out_type,
-			(long) ( row1 - row0 ) * p -> new_w * p -> ch, p -> tr_mul,
-			p -> pk_out, p -> gamma, p -> ch, p -> alpha_index, st );
+			(long) ( row1 - row0 ) * p -> new_w * p -> io_ch, p -> tr_mul,
+			p -> pk_out, ( p -> gamma && p -> out_type != AVIRHIP_F32 ),
+			p -> io_ch, p -> ch, p -> alpha_index, st );
 	}
 
 	return( rc );
@@ -690,12 +696,12 @@ static int exec_any( avirhip_plan* p, const void* src, int src_mem, void* dst,
 	const void* dsrc = src;
 	void* ddst = dst;
 	const size_t src_bytes = ( (size_t) ( p -> src_h - 1 ) * p -> src_stride +
-		(size_t) p -> src_w * p -> ch ) * dtype_size( p -> in_type );
+		(size_t) p -> src_w * p -> io_ch ) * dtype_size( p -> in_type );
 	const size_t row_bytes = (size_t) p -> new_stride *
 		dtype_size( p -> out_type );
 	const size_t dst_bytes = ( row1 > row0 ?
 		(size_t) ( row1 - row0 - 1 ) * row_bytes + (size_t) p -> new_w *
-		p -> ch * dtype_size( p -> out_type ) : 0 );
+		p -> io_ch * dtype_size( p -> out_type ) : 0 );
 
 	if( src_mem == AVIRHIP_MEM_HOST )
 	{
@@ -755,6 +761,7 @@ static avirhip_plan* new_plan()
 	p -> stage_src_bytes = 0; p -> stage_dst_bytes = 0;
 	p -> tr_mul = 1.0; p -> pk_out = 0.0;
 	p -> gamma = 0; p -> alpha_index = -1; p -> d_srgb_tbl = nullptr;
+	p -> ch = 0; p -> io_ch = 0;
 	p -> l_out_mul = 1.0f; p -> l_clamp = 0.0f; p -> l_unity = 1;
 	(void) hipGetDevice( &p -> device );
 	return( p );
@@ -838,6 +845,7 @@ int avirhip_plan_create( const avirhip_plan_desc* d, avirhip_plan** out )
 	p -> new_w = d -> new_w; p -> new_h = d -> new_h;
 	p -> new_stride = d -> new_w * d -> channels;
 	p -> ch = d -> channels;
+	p -> io_ch = d -> channels;
 	p -> in_type = d -> in_type; p -> out_type = d -> out_type;
 	p -> tr_mul = d -> tr_mul; p -> pk_out = d -> pk_out;
 	p -> gamma = ( d -> use_srgb_gamma ? 1 : 0 );
@@ -856,8 +864,26 @@ int avirhip_plan_create( const avirhip_plan_desc* d, avirhip_plan** out )
 		rc = upload( p, tbl, &p -> d_srgb_tbl );
 	}
 
+	// 1-3 channel pixels: channels are independent, so executing them as
+	// RGBA with zero padding (written by the pack stage, dropped by the
+	// epilogue) is bit-identical and opens the RGBA fast paths -- 4/3 of the
+	// arithmetic on kernels several times faster than the generic ones.
+	if( rc == 0 && p -> io_ch < 4 )
+	{
+		p -> ch = 4;
+	}
+
 	if( rc == 0 ) rc = fused_prepare( p );
 	if( rc == 0 ) rc = up2_prepare( p );
+
+	if( rc == 0 && p -> ch != p -> io_ch && p -> auto_path == 1 )
+	{
+		// no fast path for this plan: run the generic kernels unpadded
+		fused_release( p );
+		up2_release( p );
+		p -> ch = p -> io_ch;
+		p -> fused_ok = 0;
+	}
 
 	if( rc != 0 )
 	{
@@ -942,6 +968,7 @@ int avirhip_lancir_plan_create( const avirhip_lancir_desc* d,
 	p -> new_stride = ( d -> new_stride_elems < 1 ?
 		d -> new_w * d -> channels : d -> new_stride_elems );
 	p -> ch = d -> channels;
+	p -> io_ch = d -> channels;
 	p -> in_type = d -> in_type; p -> out_type = d -> out_type;
 	p -> l_out_mul = d -> out_mul; p -> l_clamp = d -> clamp;
 	p -> l_unity = d -> is_unity_mul;

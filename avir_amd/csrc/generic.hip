@@ -231,38 +231,43 @@ int launch_op( const LOp& op, int ch, bool x_is_idx, const Surf& in,
 }
 
 // packScanline, avir.h:2777-2840 (no-gamma branch): (float) cast per element.
+// Pixels of `ch` channels are written with `ech` >= ch channels, the extra
+// ones zero (the reference pads its SIMD lanes the same way, avir.h:2932-2971).
 template< typename Tin >
 __global__ void __launch_bounds__( 256 ) k_pack( const Tin* src, float* dst,
-	int row_elems, int h, long src_stride )
+	int row_elems, int h, long src_stride, int ch, int ech )
 {
 	const int x = blockIdx.x * blockDim.x + threadIdx.x;
 	const int y = blockIdx.y;
 
 	if( x < row_elems && y < h )
 	{
-		dst[ (long) y * row_elems + x ] =
-			(float) src[ (long) y * src_stride + x ];
+		const int px = x / ech;
+		const int c = x - px * ech;
+
+		dst[ (long) y * row_elems + x ] = ( c < ch ?
+			(float) src[ (long) y * src_stride + px * ch + c ] : 0.0f );
 	}
 }
 
 int launch_pack( const void* src, int in_type, float* dst, int w, int h,
-	int ch, long src_stride, hipStream_t st )
+	int ch, int ech, long src_stride, hipStream_t st )
 {
-	const int re = w * ch;
+	const int re = w * ech;
 	const dim3 grd(( re + 255 ) / 256, h );
 
 	if( in_type == AVIRHIP_U8 )
 		hipLaunchKernelGGL( k_pack< uint8_t >, grd, dim3( 256 ), 0, st,
-			(const uint8_t*) src, dst, re, h, src_stride );
+			(const uint8_t*) src, dst, re, h, src_stride, ch, ech );
 	else if( in_type == AVIRHIP_U16 )
 		hipLaunchKernelGGL( k_pack< uint16_t >, grd, dim3( 256 ), 0, st,
-			(const uint16_t*) src, dst, re, h, src_stride );
+			(const uint16_t*) src, dst, re, h, src_stride, ch, ech );
 	else if( in_type == AVIRHIP_F64 )
 		hipLaunchKernelGGL( k_pack< double >, grd, dim3( 256 ), 0, st,
-			(const double*) src, dst, re, h, src_stride );
+			(const double*) src, dst, re, h, src_stride, ch, ech );
 	else
 		hipLaunchKernelGGL( k_pack< float >, grd, dim3( 256 ), 0, st,
-			(const float*) src, dst, re, h, src_stride );
+			(const float*) src, dst, re, h, src_stride, ch, ech );
 
 	AVIRHIP_HIPCHECK( hipGetLastError() );
 	return( AVIRHIP_OK );
@@ -349,7 +354,7 @@ void srgb_u8_table( float* tbl )
 // InGammaMult.
 template< typename Tin >
 __global__ void __launch_bounds__( 256 ) k_pack_gamma( const Tin* src,
-	float* dst, int row_elems, int h, long src_stride, int ch,
+	float* dst, int row_elems, int h, long src_stride, int ch, int ech,
 	int alpha_index, float gm, const float* tbl )
 {
 	const int x = blockIdx.x * blockDim.x + threadIdx.x;
@@ -360,32 +365,37 @@ __global__ void __launch_bounds__( 256 ) k_pack_gamma( const Tin* src,
 		return;
 	}
 
-	const Tin v = src[ (long) y * src_stride + x ];
-	const int c = x % ch;
-	float r;
+	const int px = x / ech;
+	const int c = x - px * ech;
+	float r = 0.0f;
 
-	if( c == alpha_index )
+	if( c < ch )
 	{
-		r = (float) v * gm;
-	}
-	else
-	if( sizeof( Tin ) == 1 )
-	{
-		r = tbl[ (int) v ];
-	}
-	else
-	{
-		r = srgb_to_lin( (float) v, gm );
+		const Tin v = src[ (long) y * src_stride + px * ch + c ];
+
+		if( c == alpha_index )
+		{
+			r = (float) v * gm;
+		}
+		else
+		if( sizeof( Tin ) == 1 )
+		{
+			r = tbl[ (int) v ];
+		}
+		else
+		{
+			r = srgb_to_lin( (float) v, gm );
+		}
 	}
 
 	dst[ (long) y * row_elems + x ] = r;
 }
 
 int launch_pack_gamma( const void* src, int in_type, float* dst, int w, int h,
-	int ch, long src_stride, int alpha_index, const float* tbl,
+	int ch, int ech, long src_stride, int alpha_index, const float* tbl,
 	hipStream_t st )
 {
-	const int re = w * ch;
+	const int re = w * ech;
 	const dim3 grd(( re + 255 ) / 256, h );
 	// InGammaMult, avir.h:4744-4754
 	const float gm = (float) ( in_type == AVIRHIP_U8 ? 1.0 / 255.0 :
@@ -393,20 +403,20 @@ int launch_pack_gamma( const void* src, int in_type, float* dst, int w, int h,
 
 	if( in_type == AVIRHIP_U8 )
 		hipLaunchKernelGGL( k_pack_gamma< uint8_t >, grd, dim3( 256 ), 0, st,
-			(const uint8_t*) src, dst, re, h, src_stride, ch, alpha_index,
-			gm, tbl );
+			(const uint8_t*) src, dst, re, h, src_stride, ch, ech,
+			alpha_index, gm, tbl );
 	else if( in_type == AVIRHIP_U16 )
 		hipLaunchKernelGGL( k_pack_gamma< uint16_t >, grd, dim3( 256 ), 0,
-			st, (const uint16_t*) src, dst, re, h, src_stride, ch,
+			st, (const uint16_t*) src, dst, re, h, src_stride, ch, ech,
 			alpha_index, gm, tbl );
 	else if( in_type == AVIRHIP_F64 )
 		hipLaunchKernelGGL( k_pack_gamma< double >, grd, dim3( 256 ), 0, st,
-			(const double*) src, dst, re, h, src_stride, ch, alpha_index,
-			gm, tbl );
+			(const double*) src, dst, re, h, src_stride, ch, ech,
+			alpha_index, gm, tbl );
 	else
 		hipLaunchKernelGGL( k_pack_gamma< float >, grd, dim3( 256 ), 0, st,
-			(const float*) src, dst, re, h, src_stride, ch, alpha_index,
-			gm, tbl );
+			(const float*) src, dst, re, h, src_stride, ch, ech,
+			alpha_index, gm, tbl );
 
 	AVIRHIP_HIPCHECK( hipGetLastError() );
 	return( AVIRHIP_OK );
@@ -426,7 +436,7 @@ __device__ __forceinline__ float avir_round( const float d )
 template< typename Tout, bool IsInt >
 __global__ void __launch_bounds__( 256 ) k_epilogue( const float* res,
 	Tout* dst, long n, int use_tr, float tr_mul, float tr_muli, float pk_out,
-	int gamma, int ch, int alpha_index, float ogm )
+	int gamma, int ch, int ech, int alpha_index, float ogm )
 {
 	const long i = (long) blockIdx.x * blockDim.x + threadIdx.x;
 
@@ -435,11 +445,14 @@ __global__ void __launch_bounds__( 256 ) k_epilogue( const float* res,
 		return;
 	}
 
-	float v = res[ i ];
+	// `res` holds ech >= ch channels per pixel (padding dropped here)
+	const long px = i / ch;
+	const int c = (int) ( i - px * ch );
+	float v = res[ px * ech + c ];
 
 	if( gamma )
 	{
-		if( (int) ( i % ch ) == alpha_index )
+		if( c == alpha_index )
 		{
 			v = v * ogm;
 		}
@@ -467,8 +480,8 @@ __global__ void __launch_bounds__( 256 ) k_epilogue( const float* res,
 }
 
 int launch_epilogue( const float* res, void* dst, int out_type, long n,
-	double tr_mul, double pk_out, int gamma, int ch, int alpha_index,
-	hipStream_t st )
+	double tr_mul, double pk_out, int gamma, int ch, int ech,
+	int alpha_index, hipStream_t st )
 {
 	const dim3 grd( (unsigned) (( n + 255 ) / 256 ));
 	const int use_tr = ( tr_mul != 1.0 );
@@ -482,19 +495,19 @@ int launch_epilogue( const float* res, void* dst, int out_type, long n,
 	if( out_type == AVIRHIP_U8 )
 		hipLaunchKernelGGL(( k_epilogue< uint8_t, true > ), grd, dim3( 256 ),
 			0, st, res, (uint8_t*) dst, n, use_tr, trm, trmi, pk, gamma, ch,
-			alpha_index, ogm );
+			ech, alpha_index, ogm );
 	else if( out_type == AVIRHIP_U16 )
 		hipLaunchKernelGGL(( k_epilogue< uint16_t, true > ), grd, dim3( 256 ),
 			0, st, res, (uint16_t*) dst, n, use_tr, trm, trmi, pk, gamma, ch,
-			alpha_index, ogm );
+			ech, alpha_index, ogm );
 	else if( out_type == AVIRHIP_F64 )
 		hipLaunchKernelGGL(( k_epilogue< double, false > ), grd, dim3( 256 ),
 			0, st, res, (double*) dst, n, use_tr, trm, trmi, pk, gamma, ch,
-			alpha_index, ogm );
+			ech, alpha_index, ogm );
 	else
 		hipLaunchKernelGGL(( k_epilogue< float, false > ), grd, dim3( 256 ),
 			0, st, res, (float*) dst, n, use_tr, trm, trmi, pk, gamma, ch,
-			alpha_index, ogm );
+			ech, alpha_index, ogm );
 
 	AVIRHIP_HIPCHECK( hipGetLastError() );
 	return( AVIRHIP_OK );

@@ -92,7 +92,10 @@ struct avirhip_plan
 {
 	int is_lancir;
 	int device;
-	int src_w, src_h, src_stride, new_w, new_h, new_stride, ch;
+	int src_w, src_h, src_stride, new_w, new_h, new_stride;
+	int ch;    // channels the kernels execute with (4 when 1-3 channel pixels
+	           // are padded so that the RGBA fast paths apply)
+	int io_ch; // channels of the caller's buffers (ElCountIO)
 	int in_type, out_type;
 	double tr_mul, pk_out;
 	int gamma, alpha_index; // sRGB gamma stages (avir.h:2841-2930, 2982-3068)
@@ -132,18 +135,19 @@ void set_error( const char* fmt, ... );
 size_t dtype_size( int t );
 
 // generic.hip
+// `ch` = channels in `src`, `ech` >= ch = channels written (zero padded)
 int launch_pack( const void* src, int in_type, float* dst, int w, int h,
-	int ch, long src_stride, hipStream_t st );
+	int ch, int ech, long src_stride, hipStream_t st );
 int launch_pack_gamma( const void* src, int in_type, float* dst, int w, int h,
-	int ch, long src_stride, int alpha_index, const float* tbl,
+	int ch, int ech, long src_stride, int alpha_index, const float* tbl,
 	hipStream_t st );
 void srgb_u8_table( float* tbl );
 int launch_op( const LOp& op, int ch, bool x_is_idx, const Surf& in,
 	const Surf& out, int scan0, int scan1, int idx0, int idx1,
 	hipStream_t st );
 int launch_epilogue( const float* res, void* dst, int out_type, long n,
-	double tr_mul, double pk_out, int gamma, int ch, int alpha_index,
-	hipStream_t st );
+	double tr_mul, double pk_out, int gamma, int ch, int ech,
+	int alpha_index, hipStream_t st );
 int launch_lancir_generic( const avirhip_plan* p, const void* src, void* dst,
 	float* tmp, int row0, int row1, hipStream_t st );
 

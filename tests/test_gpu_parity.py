@@ -368,6 +368,35 @@ def test_avir_parameter_presets(preset):
         _assert_same(got, want, "preset %s" % preset)
 
 
+@pytest.mark.parametrize("ch", [1, 2, 3])
+@pytest.mark.parametrize("sw,sh,nw,nh", [(64, 48, 128, 96), (300, 201, 100, 67),
+                                         (64, 48, 100, 77), (120, 90, 60, 45),
+                                         (257, 129, 64, 300)])
+def test_avir_few_channels_take_the_rgba_fast_paths(sw, sh, nw, nh, ch):
+    """1-3 channel pixels are executed as zero-padded RGBA (pack stage pads,
+    epilogue drops): same bits as the reference, on the fast kernels."""
+    lib = abi.load()
+    for dt in (np.uint8, np.float32):
+        src = (rb.lcg_u8((sh, sw, ch), seed=ch + sw) if dt == np.uint8 else
+               rb.lcg_f32((sh, sw, ch), seed=ch + sw))
+        want = _checker_avir(src, nw, nh, resbits=8)
+        r = avir_amd.CImageResizer(8)
+        _assert_same(r.resize(src, nw, nh), want, "auto path")
+        p = r.plan(sw, sh, nw, nh, ch, 0.0, None, rb._DT[src.dtype],
+                   rb._DT[src.dtype])
+        auto = lib.avirhip_plan_get_path(p)
+        if sw == 300:
+            # plans without a filtered upsample (small images at 8 bits pick
+            # build modes the tiled kernels refuse) must not stay generic
+            assert auto in (abi.PATH_TILED, abi.PATH_FUSED, abi.PATH_UP2)
+        for path in (abi.PATH_GENERIC, abi.PATH_TILED):
+            if path == abi.PATH_TILED and auto == abi.PATH_GENERIC:
+                continue
+            abi.check(lib.avirhip_plan_set_path(p, path), "set_path")
+            _assert_same(r.resize(src, nw, nh), want, "path %d" % path)
+        abi.check(lib.avirhip_plan_set_path(p, 0), "set_path")
+
+
 def test_dc_gain_constant_image():
     """a constant image must come out constant on every
     execution path and ratio class. The reference's own DC error is 6e-8 ..
