@@ -195,6 +195,11 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)
+        # pay RCCL's communicator set-up now: the barrier that brackets the
+        # timed region must be a ~100 us one, not seconds of idle GPU (clocks
+        # would ramp down right before the measurement)
+        dist.barrier()
+        torch.cuda.synchronize(dev)
 
     lib = abi.load()
     assert lib.avirhip_device_count() >= 1, "no gfx950 device"
