@@ -250,9 +250,72 @@ __global__ void __launch_bounds__( 256 ) k_pack( const Tin* src, float* dst,
 	}
 }
 
+// ech == 4: one thread per pixel, one 16-byte store (the element-wise kernel
+// above spends an integer division and a 4-byte store per float)
+template< typename Tin, int CH >
+__global__ void __launch_bounds__( 256 ) k_pack_px( const Tin* src,
+	float* dst, int w, int h, long src_stride )
+{
+	const int x = blockIdx.x * blockDim.x + threadIdx.x;
+	const int y = blockIdx.y;
+
+	if( x >= w || y >= h )
+	{
+		return;
+	}
+
+	const Tin* s = src + (long) y * src_stride + (long) x * CH;
+	float v[ 4 ] = { 0.0f, 0.0f, 0.0f, 0.0f };
+#pragma unroll
+	for( int c = 0; c < CH; c++ )
+	{
+		v[ c ] = (float) s[ c ];
+	}
+
+	typedef float f4v __attribute__(( ext_vector_type( 4 )));
+	f4v o; o.x = v[ 0 ]; o.y = v[ 1 ]; o.z = v[ 2 ]; o.w = v[ 3 ];
+	*(f4v*) ( dst + ( (long) y * w + x ) * 4 ) = o;
+}
+
+template< typename Tin >
+static void launch_pack_px( const void* src, float* dst, int w, int h, int ch,
+	long src_stride, hipStream_t st )
+{
+	const dim3 grd(( w + 255 ) / 256, h );
+	const Tin* s = (const Tin*) src;
+
+	switch( ch )
+	{
+		case 1: hipLaunchKernelGGL(( k_pack_px< Tin, 1 > ), grd, dim3( 256 ),
+			0, st, s, dst, w, h, src_stride ); break;
+		case 2: hipLaunchKernelGGL(( k_pack_px< Tin, 2 > ), grd, dim3( 256 ),
+			0, st, s, dst, w, h, src_stride ); break;
+		case 3: hipLaunchKernelGGL(( k_pack_px< Tin, 3 > ), grd, dim3( 256 ),
+			0, st, s, dst, w, h, src_stride ); break;
+		default: hipLaunchKernelGGL(( k_pack_px< Tin, 4 > ), grd, dim3( 256 ),
+			0, st, s, dst, w, h, src_stride ); break;
+	}
+}
+
 int launch_pack( const void* src, int in_type, float* dst, int w, int h,
 	int ch, int ech, long src_stride, hipStream_t st )
 {
+	if( ech == 4 )
+	{
+		if( in_type == AVIRHIP_U8 )
+			launch_pack_px< uint8_t >( src, dst, w, h, ch, src_stride, st );
+		else if( in_type == AVIRHIP_U16 )
+			launch_pack_px< uint16_t >( src, dst, w, h, ch, src_stride, st );
+		else if( in_type == AVIRHIP_F64 )
+			launch_pack_px< double >( src, dst, w, h, ch, src_stride, st );
+		else
+			launch_pack_px< float >( src, dst, w, h, ch, src_stride, st );
+
+		AVIRHIP_HIPCHECK( hipGetLastError() );
+		return( AVIRHIP_OK );
+	}
+
+
 	const int re = w * ech;
 	const dim3 grd(( re + 255 ) / 256, h );
 
@@ -479,6 +542,76 @@ __global__ void __launch_bounds__( 256 ) k_epilogue( const float* res,
 	dst[ i ] = (Tout) v;
 }
 
+// ech == 4, no gamma: one thread per pixel, one 16-byte load; 4-channel uint8
+// pixels leave as one 32-bit store
+template< typename Tout, bool IsInt, int CH >
+__global__ void __launch_bounds__( 256 ) k_epilogue_px( const float* res,
+	Tout* dst, long npx, int use_tr, float tr_mul, float tr_muli,
+	float pk_out )
+{
+	const long i = (long) blockIdx.x * blockDim.x + threadIdx.x;
+
+	if( i >= npx )
+	{
+		return;
+	}
+
+	typedef float f4v __attribute__(( ext_vector_type( 4 )));
+	const f4v r = *(const f4v*) ( res + i * 4 );
+	float v[ 4 ] = { r.x, r.y, r.z, r.w };
+	Tout o[ 4 ];
+#pragma unroll
+	for( int c = 0; c < CH; c++ )
+	{
+		float t = v[ c ];
+
+		if( IsInt )
+		{
+			t = ( use_tr ? avir_round( t * tr_muli ) * tr_mul :
+				avir_round( t ));
+
+			t = ( t < 0.0f ? 0.0f : ( t > pk_out ? pk_out : t ));
+		}
+
+		o[ c ] = (Tout) t;
+	}
+
+	if( CH == 4 && sizeof( Tout ) == 1 )
+	{
+		*(uint32_t*) ( dst + i * 4 ) = (uint32_t) o[ 0 ] |
+			( (uint32_t) o[ 1 ] << 8 ) | ( (uint32_t) o[ 2 ] << 16 ) |
+			( (uint32_t) o[ 3 ] << 24 );
+	}
+	else
+	{
+#pragma unroll
+		for( int c = 0; c < CH; c++ )
+		{
+			dst[ i * CH + c ] = o[ c ];
+		}
+	}
+}
+
+template< typename Tout, bool IsInt >
+static void launch_epilogue_px( const float* res, void* dst, long npx, int ch,
+	int use_tr, float trm, float trmi, float pk, hipStream_t st )
+{
+	const dim3 grd( (unsigned) (( npx + 255 ) / 256 ));
+	Tout* d = (Tout*) dst;
+
+	switch( ch )
+	{
+		case 1: hipLaunchKernelGGL(( k_epilogue_px< Tout, IsInt, 1 > ), grd,
+			dim3( 256 ), 0, st, res, d, npx, use_tr, trm, trmi, pk ); break;
+		case 2: hipLaunchKernelGGL(( k_epilogue_px< Tout, IsInt, 2 > ), grd,
+			dim3( 256 ), 0, st, res, d, npx, use_tr, trm, trmi, pk ); break;
+		case 3: hipLaunchKernelGGL(( k_epilogue_px< Tout, IsInt, 3 > ), grd,
+			dim3( 256 ), 0, st, res, d, npx, use_tr, trm, trmi, pk ); break;
+		default: hipLaunchKernelGGL(( k_epilogue_px< Tout, IsInt, 4 > ), grd,
+			dim3( 256 ), 0, st, res, d, npx, use_tr, trm, trmi, pk ); break;
+	}
+}
+
 int launch_epilogue( const float* res, void* dst, int out_type, long n,
 	double tr_mul, double pk_out, int gamma, int ch, int ech,
 	int alpha_index, hipStream_t st )
@@ -491,6 +624,27 @@ int launch_epilogue( const float* res, void* dst, int out_type, long n,
 	// OutGammaMult, avir.h:4756-4763
 	const float ogm = (float) ( out_type == AVIRHIP_U8 ? 255.0 :
 		( out_type == AVIRHIP_U16 ? 65535.0 : 1.0 ));
+
+	if( ech == 4 && !gamma && ( (uintptr_t) dst & 3 ) == 0 )
+	{
+		const long npx = n / ch;
+
+		if( out_type == AVIRHIP_U8 )
+			launch_epilogue_px< uint8_t, true >( res, dst, npx, ch, use_tr,
+				trm, trmi, pk, st );
+		else if( out_type == AVIRHIP_U16 )
+			launch_epilogue_px< uint16_t, true >( res, dst, npx, ch, use_tr,
+				trm, trmi, pk, st );
+		else if( out_type == AVIRHIP_F64 )
+			launch_epilogue_px< double, false >( res, dst, npx, ch, use_tr,
+				trm, trmi, pk, st );
+		else
+			launch_epilogue_px< float, false >( res, dst, npx, ch, use_tr,
+				trm, trmi, pk, st );
+
+		AVIRHIP_HIPCHECK( hipGetLastError() );
+		return( AVIRHIP_OK );
+	}
 
 	if( out_type == AVIRHIP_U8 )
 		hipLaunchKernelGGL(( k_epilogue< uint8_t, true > ), grd, dim3( 256 ),
