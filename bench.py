@@ -35,30 +35,48 @@ ALGO_BYTES = (SRC_W * SRC_H + NEW_W * NEW_H) * CH * 4
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s
 
 # The other BASELINE.json configs (parity-test cases; `--workload` times them
-# for DESIGN.md, the driver's line is always cfg3): name -> (api, sw, sh, nw, nh)
-OTHER = {"cfg2": ("avir", 1920, 1080, 3840, 2160),
-         "cfg4": ("avir", 3840, 2160, 1280, 720),
-         "cfg5": ("lancir", 3840, 2160, 7680, 4320),
-         "nonint": ("avir", 1920, 1080, 2500, 1400)}
+# for DESIGN.md, the driver's line is always cfg3):
+# name -> (api, sw, sh, nw, nh, channels, dtype, resbits)
+OTHER = {"cfg1": ("avir", 640, 480, 1024, 768, 3, "u8", 8),
+         "cfg2": ("avir", 1920, 1080, 3840, 2160, 4, "f32", 16),
+         "cfg3": ("avir", 3840, 2160, 7680, 4320, 4, "f32", 16),
+         "cfg4": ("avir", 3840, 2160, 1280, 720, 4, "f32", 16),
+         "cfg5": ("lancir", 3840, 2160, 7680, 4320, 4, "f32", 16),
+         "nonint": ("avir", 1920, 1080, 2500, 1400, 4, "f32", 16),
+         # the one timing the reference's README publishes (README.md:157-162:
+         # 245 ms on 1 thread, 74 ms on 8 threads of an i7-7700K)
+         "readme": ("avir", 5184, 3456, 1920, 1280, 3, "u8", 8)}
 
 
-def time_other(name, steps, warmup, path, settle_ms=300.0):
-    """Times one of the non-headline configs (device-resident RGBA f32)."""
+def _workload_src(name):
+    import numpy as np
+    from tests import refbind as rb
+    api, sw, sh, nw, nh, ch, dt, bits = OTHER[name]
+    if dt == "u8":
+        return rb.lcg_u8((sh, sw, ch))
+    return rb.lcg_f32((sh, sw, ch))
+
+
+def time_other(name, steps, warmup, path, settle_ms=300.0, quiet=False):
+    """Times one of the non-headline configs (device-resident)."""
     import torch
     import avir_amd
     from avir_amd import abi
     from tests import refbind as rb
-    api, sw, sh, nw, nh = OTHER[name]
+    api, sw, sh, nw, nh, ch, dt, bits = OTHER[name]
     lib = abi.load()
     dev = torch.device("cuda", 0)
-    src = torch.from_numpy(rb.lcg_f32((sh, sw, 4))).to(dev)
-    dst = torch.empty((nh, nw, 4), dtype=torch.float32, device=dev)
+    src_np = _workload_src(name)
+    src = torch.from_numpy(src_np).to(dev)
+    dst = torch.empty((nh, nw, ch), dtype=src.dtype, device=dev)
+    tcode = abi.U8 if dt == "u8" else abi.F32
+    esz = 1 if dt == "u8" else 4
     if api == "avir":
-        obj = avir_amd.CImageResizer(16)
-        plan = obj.plan(sw, sh, nw, nh, 4)
+        obj = avir_amd.CImageResizer(bits)
+        plan = obj.plan(sw, sh, nw, nh, ch, 0.0, None, tcode, tcode)
     else:
         obj = avir_amd.CLancIR()
-        plan = obj.plan(sw, sh, nw, nh, 4)
+        plan = obj.plan(sw, sh, nw, nh, ch)
     if path:
         abi.check(lib.avirhip_plan_set_path(plan, path), "set_path")
     st = torch.cuda.current_stream(dev).cuda_stream
@@ -81,12 +99,66 @@ def time_other(name, steps, warmup, path, settle_ms=300.0):
     e1.record()
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / steps
-    algo = (sw * sh + nw * nh) * 16
-    print(json.dumps({"workload": name, "api": api, "ms_per_step": round(ms, 4),
-                      "value": round(nw * nh / 1e6 / (ms * 1e-3), 1),
-                      "unit": "Mpixels/s", "path": lib.avirhip_plan_get_path(plan),
-                      "roofline_frac": round(algo / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                      "fnv1a64": rb.fnv(dst.cpu().numpy())}), flush=True)
+    algo = (sw * sh + nw * nh) * ch * esz
+    out = {"workload": name, "api": api, "ms_per_step": round(ms, 4),
+           "value": round(nw * nh / 1e6 / (ms * 1e-3), 1),
+           "unit": "Mpixels/s", "path": lib.avirhip_plan_get_path(plan),
+           "algorithmic_gbs": round(algo / (ms * 1e-3) / 1e9, 1),
+           "roofline_frac": round(algo / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+           "fnv1a64": rb.fnv(dst.cpu().numpy())}
+    if not quiet:
+        print(json.dumps(out), flush=True)
+    return out, src_np, dst.cpu().numpy()
+
+
+def report(steps, warmup, settle_ms):
+    """The table BASELINE.md 4.5 asks for: every config, the reference on the
+    host CPU (1 thread and all threads, bounded samples) beside the GPU, with
+    the max ULP distance between the two outputs. Markdown on stdout."""
+    import numpy as np
+    from tests import refbind as rb
+    nthreads = os.cpu_count() or 1
+    rows = []
+    for name in ("cfg1", "cfg2", "cfg3", "cfg4", "cfg5", "nonint", "readme"):
+        api, sw, sh, nw, nh, ch, dt, bits = OTHER[name]
+        g, src_np, got = time_other(name, steps, warmup, 0, settle_ms, True)
+
+        def cpu(threads):
+            ts, res = [], None
+            budget = time.perf_counter() + 4.0
+            while len(ts) < 3 and (not ts or time.perf_counter() < budget):
+                t0 = time.perf_counter()
+                if api == "avir":
+                    res = rb.ref_avir(src_np, nw, nh, resbits=bits,
+                                      threads=threads)
+                else:
+                    res = rb.ref_lancir(src_np, nw, nh)
+                ts.append(time.perf_counter() - t0)
+            return min(ts) * 1e3, res
+        c1, want = cpu(1)
+        cn = cpu(nthreads)[0] if api == "avir" else None
+        if got.dtype == np.float32:
+            a = got.view(np.int32).astype(np.int64)
+            b = want.view(np.int32).astype(np.int64)
+            ulp = int(np.abs(a - b).max())
+        else:
+            ulp = int(np.abs(got.astype(np.int64) - want.astype(np.int64)).max())
+        rows.append((name, "%dx%d->%dx%d %s x%d" % (sw, sh, nw, nh, dt, ch),
+                     "CImageResizer<>(%d)" % bits if api == "avir" else "CLancIR",
+                     c1, cn, g, ulp))
+    mp = lambda r: OTHER[r[0]][3] * OTHER[r[0]][4] / 1e6
+    print("| config | shape | reference (CPU, -O2 -ffp-contract=off) | CPU 1 thread ms "
+          "(Mpix/s) | CPU %d threads ms (Mpix/s) | GPU ms | GPU Mpix/s | "
+          "algorithmic GB/s | %% of 8 TB/s | exec path | max ULP / LSB vs "
+          "reference |" % nthreads)
+    print("|---|---|---|---|---|---|---|---|---|---|---|")
+    for r in rows:
+        name, shape, what, c1, cn, g, ulp = r
+        print("| %s | %s | %s | %.1f (%.1f) | %s | %.4f | %.0f | %.0f | %.1f | %d | %d |" % (
+            name, shape, what, c1, mp(r) / (c1 * 1e-3),
+            "%.1f (%.1f)" % (cn, mp(r) / (cn * 1e-3)) if cn else "n/a (no MT)",
+            g["ms_per_step"], g["value"], g["algorithmic_gbs"],
+            g["roofline_frac"] * 100, g["path"], ulp))
 
 
 def cpu_baseline(src_np, threads):
@@ -169,10 +241,17 @@ def main():
                     help="0 auto, 1 generic, 2 two-pass, 3 fused tile, 4 up2 (A/B)")
     ap.add_argument("--no-cpu", action="store_true",
                     help="skip the CPU baseline leg")
+    ap.add_argument("--report", action="store_true",
+                    help="print the all-configs CPU-vs-GPU markdown table "
+                         "(BASELINE.md section 4, item 5)")
     ap.add_argument("--workload", default="cfg3",
                     help="cfg3 (the headline, default) or one of: "
                          + ", ".join(sorted(OTHER)))
     args = ap.parse_args()
+
+    if args.report:
+        report(args.steps, args.warmup, args.settle_ms)
+        return
 
     if args.workload != "cfg3":
         time_other(args.workload, args.steps, args.warmup, args.path,
