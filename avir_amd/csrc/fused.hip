@@ -27,16 +27,20 @@
 
 #include "plan.h"
 #include <algorithm>
+#include <string.h>
+#include <stdio.h>
 
 namespace avirhip {
 
 typedef float f4 __attribute__(( ext_vector_type( 4 )));
+typedef __attribute__(( address_space( 3 ))) void* tile_ldsptr;
 
 #define MAXCHAIN 3
 
 struct TOp
 {
 	int type;
+	int rowfast;    // ALONG_X gather with a lane stride > 1 px (see run_op)
 	int out_len;    // logical output length (producer-side clamp range)
 	int zero_above; // consumer is a zero-stuffed view: outputs with a logical
 	                // index above this are stored as 0 (INT_MAX: none)
@@ -63,6 +67,9 @@ struct TileParams
 	int dst_row0;                  // row index stored at dst
 	int srow_lo, srow_hi;          // store mask on the final-axis index
 	int maxA, maxB, maxC;          // LDS carve (pixels, pixels, floats)
+#ifdef U2_DBG
+	unsigned long long* clk;       // [blocks][8] phase timestamps (debug build)
+#endif
 };
 
 // Every buffer in LDS holds the *extended* index range its consumer touches:
@@ -105,13 +112,52 @@ __device__ __forceinline__ void run_op( const TOp& op, const f4* in,
 
 		const int tot = on * mt;
 
-		for( int i = tid; i < tot; i += 256 )
+		if( olo >= 0 && olo + on <= op.out_len )
 		{
-			const int j = i / mt;
-			const int t = i - j * mt;
-			const int ge = clampi( olo + j, olast );
-			cfl[ i ] = ( t < op.maxtaps ?
-				op.coef[ (long) ge * op.maxtaps + t ] : 0.0f );
+			// interior tile: its coefficient rows are one contiguous block of
+			// the (16-byte-row) table -> LDS-DMA, 1 KiB per wave-instruction,
+			// all in flight at once
+			const int wave = __builtin_amdgcn_readfirstlane( tid >> 6 );
+			const int lane = tid & 63;
+			const __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc(
+				(void*) ( op.coef + (long) olo * mt ), 0, 0x7fffffff,
+				0x00020000 );
+
+			for( int q0 = wave * 64; q0 * 4 < tot; q0 += 256 )
+			{
+				if(( q0 + lane ) * 4 < tot )
+				{
+					__builtin_amdgcn_raw_ptr_buffer_load_lds( rc,
+						(tile_ldsptr) ( cfl + q0 * 4 ), 16, ( q0 + lane ) * 16,
+						0, 0, 0 );
+				}
+			}
+
+			asm volatile( "s_waitcnt vmcnt(0)" ::: "memory" );
+		}
+		else
+		{
+			// edge tile: rows clamp individually
+			for( int i = tid; i < tot; i += 256 )
+			{
+				const int j = i / mt;
+				const int t = i - j * mt;
+				const int ge = clampi( olo + j, olast );
+				cfl[ i ] = op.coef[ (long) ge * mt + t ];
+			}
+		}
+
+		__syncthreads();
+	}
+	else
+	{
+		// FIR taps -> LDS once (read from global memory inside the tap loop
+		// they cost a dependent vector load per tap and output)
+		const int tid = ty * 32 + tx;
+
+		if( tid <= op.lat )
+		{
+			cfl[ tid ] = op.flt[ tid ];
 		}
 
 		__syncthreads();
@@ -122,9 +168,23 @@ __device__ __forceinline__ void run_op( const TOp& op, const f4* in,
 	const int ny = ( ALONG_X ? other_n : on );
 	const int istep = ( ALONG_X ? 1 : ipitch );
 
-	for( int y = ty; y < ny; y += 8 )
+	// Thread -> output mapping. Default: lanes run along x (32 wide), which
+	// is conflict-free when neighbouring outputs read neighbouring inputs.
+	// A downsizing gather along x reads with a stride of k > 1 pixels between
+	// lanes and its 128-bit LDS reads collide k-fold; there (op.rowfast) the
+	// 16 lanes of an LDS access group take 16 ROWS at the same x instead:
+	// with odd row pitches every group hits 16 distinct bank quads, and the
+	// coefficient read of a group is a broadcast.
+	const bool rowfast = ( ALONG_X && !TO_GLOBAL && op.rowfast != 0 );
+	const int tid_ = ty * 32 + tx;
+	const int ybeg = ( rowfast ? ( tid_ & 15 ) : ty );
+	const int ystep = ( rowfast ? 16 : 8 );
+	const int xbeg = ( rowfast ? ( tid_ >> 4 ) : tx );
+	const int xstep = ( rowfast ? 16 : 32 );
+
+	for( int y = ybeg; y < ny; y += ystep )
 	{
-		for( int x = tx; x < nx; x += 32 )
+		for( int x = xbeg; x < nx; x += xstep )
 		{
 			const int n = ( ALONG_X ? x : y );     // output index in tile
 			const int o = ( ALONG_X ? y : x );     // position on other axis
@@ -136,12 +196,12 @@ __device__ __forceinline__ void run_op( const TOp& op, const f4* in,
 			{
 				const int cp = op.rf * ( clampi( g, olast ) - op.e ) - ilo;
 				const f4* c = base + cp * istep;
-				acc = op.flt[ 0 ] * c[ 0 ];
+				acc = cfl[ 0 ] * c[ 0 ];
 
 				for( int i = 1; i <= op.lat; i++ )
 				{
 					const f4 s = c[ i * istep ] + c[ -i * istep ];
-					acc = acc + op.flt[ i ] * s;
+					acc = acc + cfl[ i ] * s;
 				}
 			}
 			else
@@ -238,58 +298,100 @@ __global__ void __launch_bounds__( 256 ) k_tile( const TileParams P )
 	const int row_lo = vr[ 0 ], rows = vr[ 1 ];
 	const int tx = threadIdx.x;
 	const int ty = threadIdx.y;
+	const int cp = cols | 1; // row pitches in LDS are odd (see run_op)
+#ifdef U2_DBG
+	int dbg_n = 0;
+#define TILE_STAMP() do { __syncthreads(); if( tx == 0 && ty == 0 && \
+	P.clk != nullptr && dbg_n < 8 ) P.clk[ blockIdx.x * 8 + dbg_n++ ] = \
+	wall_clock64(); } while( 0 )
+#else
+#define TILE_STAMP() do {} while( 0 )
+#endif
+	TILE_STAMP();
 
-	// source tile -> LDS (16 B per lane, contiguous along x), extended range:
-	// coordinates clamp to the image, zero-stuffed tails read 0
-	for( int y = ty; y < rows; y += 8 )
+	// source tile -> LDS by LDS-DMA (buffer_load_dwordx4 ... lds: no staging
+	// registers, every piece of the tile in flight at once), extended range:
+	// coordinates clamp to the image. One instruction moves 64 consecutive
+	// pixels of a row; rows are dealt to the four waves.
 	{
-		const int gy = row_lo + y;
-		const float* sp = P.src + (long) clampi( gy, P.src_h - 1 ) * P.src_ss;
+		const int tid = ty * 32 + tx;
+		const int wave = __builtin_amdgcn_readfirstlane( tid >> 6 );
+		const int lane = tid & 63;
 
-		for( int x = tx; x < cols; x += 32 )
+		for( int y = wave; y < rows; y += 4 )
 		{
-			const int gx = col_lo + x;
-			f4 v = *(const f4*) ( sp + (long) clampi( gx, P.src_w - 1 ) * 4 );
+			const int gy = clampi( row_lo + y, P.src_h - 1 );
+			const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+				(void*) ( P.src + (long) gy * P.src_ss ), 0, 0x7fffffff,
+				0x00020000 );
 
-			if( gx > P.xzero_above || gy > P.yzero_above )
+			for( int x0 = 0; x0 < cols; x0 += 64 )
 			{
-				v = (f4) 0.0f;
+				if( x0 + lane < cols )
+				{
+					const int gx = clampi( col_lo + x0 + lane, P.src_w - 1 );
+					__builtin_amdgcn_raw_ptr_buffer_load_lds( rs,
+						(tile_ldsptr) ( bufA + y * cp + x0 ), 16, gx * 16,
+						0, 0, 0 );
+				}
 			}
+		}
 
-			bufA[ y * cols + x ] = v;
+		asm volatile( "s_waitcnt vmcnt(0)" ::: "memory" );
+		__syncthreads();
+
+		// zero-stuffed first views: their tail reads 0 (rare: the tile must
+		// reach beyond the last replicated sample)
+		if( col_lo + cols - 1 > P.xzero_above ||
+			row_lo + rows - 1 > P.yzero_above )
+		{
+			for( int y = ty; y < rows; y += 8 )
+			{
+				for( int x = tx; x < cols; x += 32 )
+				{
+					if( col_lo + x > P.xzero_above ||
+						row_lo + y > P.yzero_above )
+					{
+						bufA[ y * cp + x ] = (f4) 0.0f;
+					}
+				}
+			}
 		}
 	}
 
 	__syncthreads();
+	TILE_STAMP();
 
 	f4* cur = bufA;
 	f4* oth = bufB;
 	int ilo = col_lo;
-	int ipitch = cols;
+	int ipitch = cp;
 
 	for( int s = 0; s < P.nh; s++ )
 	{
 		const int olo = hr[ ( s + 1 ) * 2 ];
 		const int on = hr[ ( s + 1 ) * 2 + 1 ];
+		const int op_ = on | 1;
 
 		if( s == P.nh - 1 && P.nv == 0 )
 		{
-			run_op< true, true >( P.hop[ s ], cur, ipitch, ilo, oth, on, olo,
+			run_op< true, true >( P.hop[ s ], cur, ipitch, ilo, oth, op_, olo,
 				on, rows, cfl, sti, P, row_lo );
 		}
 		else
 		{
-			run_op< true, false >( P.hop[ s ], cur, ipitch, ilo, oth, on, olo,
+			run_op< true, false >( P.hop[ s ], cur, ipitch, ilo, oth, op_, olo,
 				on, rows, cfl, sti, P, row_lo );
 		}
 
 		__syncthreads();
+		TILE_STAMP();
 		f4* t = cur; cur = oth; oth = t;
 		ilo = olo;
-		ipitch = on;
+		ipitch = op_;
 	}
 
-	// after the H chain the tile is [rows][tcols]
+	// after the H chain the tile is [rows][tcols], row pitch ipitch
 	const int tcol_lo = ( P.nh > 0 ? hr[ P.nh * 2 ] : col_lo );
 	const int tcols = ( P.nh > 0 ? hr[ P.nh * 2 + 1 ] : cols );
 	ilo = row_lo;
@@ -301,16 +403,17 @@ __global__ void __launch_bounds__( 256 ) k_tile( const TileParams P )
 
 		if( s == P.nv - 1 )
 		{
-			run_op< false, true >( P.vop[ s ], cur, tcols, ilo, oth, tcols,
+			run_op< false, true >( P.vop[ s ], cur, ipitch, ilo, oth, ipitch,
 				olo, on, tcols, cfl, sti, P, tcol_lo );
 		}
 		else
 		{
-			run_op< false, false >( P.vop[ s ], cur, tcols, ilo, oth, tcols,
+			run_op< false, false >( P.vop[ s ], cur, ipitch, ilo, oth, ipitch,
 				olo, on, tcols, cfl, sti, P, tcol_lo );
 		}
 
 		__syncthreads();
+		TILE_STAMP();
 		f4* t = cur; cur = oth; oth = t;
 		ilo = olo;
 	}
@@ -337,6 +440,11 @@ struct FusedData
 	TileGeom vpass; // path 2, pass 2 (V chain only)
 	float* fltbuf;  // path 2 intermediate [src_h][new_w] pixels
 	void* dn;       // dn.hip: specialised passes of path 2 (integer downsizing)
+	// coefficient tables of the GATHER ops re-laid with a row stride of
+	// (maxtaps+3)&~3 floats: 16-byte rows, so a tile's block of rows is one
+	// contiguous LDS-DMA transfer
+	const float* hpad[ MAXCHAIN ];
+	const float* vpad[ MAXCHAIN ];
 	std::vector< void* > allocs;
 };
 
@@ -438,17 +546,18 @@ static int make_geom( avirhip_plan* p, FusedData* F, bool useh, bool usev,
 		G.nty, vm );
 
 	// stage regions alternate A, B, A, ...: S | H ops | V ops (last -> global)
+	// (row pitches in LDS are made odd: | 1)
 	std::vector< long > reg;
-	reg.push_back( (long) hm[ 0 ] * vm[ 0 ]);
+	reg.push_back( (long) ( hm[ 0 ] | 1 ) * vm[ 0 ]);
 
 	for( int s = 1; s <= nh; s++ )
 	{
-		reg.push_back( (long) hm[ s ] * vm[ 0 ]);
+		reg.push_back( (long) ( hm[ s ] | 1 ) * vm[ 0 ]);
 	}
 
 	for( int s = 1; s <= nv; s++ )
 	{
-		reg.push_back( (long) hm[ nh ] * vm[ s ]);
+		reg.push_back( (long) ( hm[ nh ] | 1 ) * vm[ s ]);
 	}
 
 	reg.pop_back(); // the last stage writes to global memory
@@ -460,7 +569,7 @@ static int make_geom( avirhip_plan* p, FusedData* F, bool useh, bool usev,
 		else mA = std::max( mA, reg[ i ]);
 	}
 
-	long mC = 4, mS = 2;
+	long mC = 16, mS = 2; // mC >= 12: FIR taps of the longest decimating filter
 
 	for( int s = 0; s < nh; s++ )
 	{
@@ -549,15 +658,65 @@ int fused_prepare( avirhip_plan* p )
 	F -> fused.ok = F -> hpass.ok = F -> vpass.ok = false;
 	p -> fused = F;
 
+	for( int a = 0; a < 2; a++ )
+	{
+		const LAxis& ax = ( a == 0 ? p -> h : p -> v );
+		const float** pad = ( a == 0 ? F -> hpad : F -> vpad );
+
+		for( size_t i = 0; i < ax.ops.size(); i++ )
+		{
+			const LOp& o = ax.ops[ i ];
+			pad[ i ] = nullptr;
+
+			if( o.type != OP_GATHER )
+			{
+				continue;
+			}
+
+			const int mt = ( o.maxtaps + 3 ) & ~3;
+			std::vector< float > t( (size_t) o.out_len * mt, 0.0f );
+
+			for( int j = 0; j < o.out_len; j++ )
+			{
+				memcpy( &t[ (size_t) j * mt ], &o.h_coef[ (size_t) j *
+					o.maxtaps ], o.maxtaps * sizeof( float ));
+			}
+
+			void* q = nullptr;
+			hipError_t e = hipMalloc( &q, t.size() * sizeof( float ));
+
+			if( e == hipSuccess )
+			{
+				F -> allocs.push_back( q );
+				e = hipMemcpy( q, t.data(), t.size() * sizeof( float ),
+					hipMemcpyHostToDevice );
+			}
+
+			if( e != hipSuccess )
+			{
+				set_error( "tiled path: coefficient upload failed: %s",
+					hipGetErrorString( e ));
+				fused_release( p );
+				return( AVIRHIP_EHIP );
+			}
+
+			pad[ i ] = (const float*) q;
+		}
+	}
+
 	static const int cf[][ 2 ] = { { 32, 64 }, { 32, 32 }, { 64, 32 },
 		{ 32, 16 }, { 64, 16 }, { 16, 16 }, { 16, 8 }, { 8, 8 } };
 	static const int ch[][ 2 ] = { { 64, 8 }, { 128, 4 }, { 64, 4 }, { 32, 4 },
 		{ 32, 2 }, { 16, 2 }, { 8, 1 } };
+	// downsizing H pass: 16-row tiles (run_op's row-fast lane mapping)
+	static const int chd[][ 2 ] = { { 32, 16 }, { 16, 16 }, { 64, 8 }, { 32, 8 },
+		{ 32, 4 }, { 16, 2 }, { 8, 1 } };
 	static const int cv[][ 2 ] = { { 32, 32 }, { 64, 16 }, { 32, 16 },
 		{ 32, 8 }, { 16, 8 }, { 16, 4 }, { 8, 4 } };
 
 	int rc = pick_geom( p, F, true, true, cf, 8, F -> fused );
-	if( rc == 0 ) rc = pick_geom( p, F, true, false, ch, 7, F -> hpass );
+	if( rc == 0 ) rc = pick_geom( p, F, true, false,
+		( p -> src_w > p -> new_w ? chd : ch ), 7, F -> hpass );
 	if( rc == 0 ) rc = pick_geom( p, F, false, true, cv, 7, F -> vpass );
 
 	if( rc != 0 )
@@ -618,18 +777,20 @@ static int zero_above_of( const LOp& consumer )
 	return( consumer.view == VIEW_ZS ? consumer.zs_mmax : 0x7fffffff );
 }
 
-static void fill_ops( const LAxis& ax, int n, TOp* out )
+static void fill_ops( const LAxis& ax, int n, TOp* out,
+	const float* const* pad )
 {
 	for( int i = 0; i < n; i++ )
 	{
 		const LOp& o = ax.ops[ i ];
 		out[ i ].type = o.type;
+		out[ i ].rowfast = ( o.type == OP_GATHER && o.in_len > o.out_len );
 		out[ i ].out_len = o.out_len;
 		out[ i ].zero_above = ( i + 1 < n ? zero_above_of( ax.ops[ i + 1 ]) :
 			0x7fffffff );
 		out[ i ].rf = o.rf; out[ i ].lat = o.lat; out[ i ].e = o.e;
 		out[ i ].flt = o.d_flt; out[ i ].start = o.d_start;
-		out[ i ].ntaps = o.d_ntaps; out[ i ].coef = o.d_coef;
+		out[ i ].ntaps = o.d_ntaps; out[ i ].coef = pad[ i ];
 		out[ i ].maxtaps = o.maxtaps;
 	}
 }
@@ -648,8 +809,9 @@ static int launch_tiles( avirhip_plan* p, const TileGeom& G, bool useh,
 	TileParams P;
 	P.nh = ( useh ? (int) p -> h.ops.size() : 0 );
 	P.nv = ( usev ? (int) p -> v.ops.size() : 0 );
-	fill_ops( p -> h, P.nh, P.hop );
-	fill_ops( p -> v, P.nv, P.vop );
+	const FusedData* FD = (const FusedData*) p -> fused;
+	fill_ops( p -> h, P.nh, P.hop, FD -> hpad );
+	fill_ops( p -> v, P.nv, P.vop, FD -> vpad );
 	P.hrng = G.d_hrng; P.vrng = G.d_vrng;
 	P.ntx = G.ntx; P.nty = G.nty;
 	P.ty0 = a / G.th;
@@ -668,8 +830,53 @@ static int launch_tiles( avirhip_plan* p, const TileGeom& G, bool useh,
 	AVIRHIP_HIPCHECK( hipFuncSetAttribute( (const void*) k_tile,
 		hipFuncAttributeMaxDynamicSharedMemorySize, (int) G.lds ));
 
+#ifdef U2_DBG
+	static unsigned long long* dclk = nullptr;
+	static int calls = 0;
+
+	if( dclk == nullptr )
+	{
+		(void) hipMalloc( &dclk, 65536 * 64 );
+		(void) hipMemset( dclk, 0, 65536 * 64 );
+	}
+
+	P.clk = ( ntiles <= 65536 ? dclk : nullptr );
+#endif
 	hipLaunchKernelGGL( k_tile, dim3( ntiles ), dim3( 32, 8 ), G.lds, st, P );
 	AVIRHIP_HIPCHECK( hipGetLastError() );
+#ifdef U2_DBG
+	if( ++calls == 40 || calls == 41 )
+	{
+		std::vector< unsigned long long > h( (size_t) ntiles * 8 );
+		(void) hipStreamSynchronize( st );
+		(void) hipMemcpy( h.data(), dclk, h.size() * 8, hipMemcpyDeviceToHost );
+		double ph[ 8 ] = { 0 };
+		unsigned long long t0 = ~0ULL, t1 = 0;
+		const int np = 1 + 1 + P.nh + P.nv;
+
+		for( int b = 0; b < ntiles; b++ )
+		{
+			for( int k = 1; k < np; k++ )
+			{
+				ph[ k ] += (double) ( h[ b * 8 + k ] - h[ b * 8 + k - 1 ]);
+			}
+
+			t0 = std::min( t0, h[ b * 8 ]);
+			t1 = std::max( t1, h[ b * 8 + np - 1 ]);
+		}
+
+		fprintf( stderr, "k_tile nh=%d nv=%d tiles=%d lds=%zu span %.1f us; "
+			"mean per tile (us): load %.2f", P.nh, P.nv, ntiles, G.lds,
+			(double) ( t1 - t0 ) / 100.0, ph[ 1 ] / ntiles / 100.0 );
+
+		for( int k = 2; k < np; k++ )
+		{
+			fprintf( stderr, " | op%d %.2f", k - 2, ph[ k ] / ntiles / 100.0 );
+		}
+
+		fprintf( stderr, "\n" );
+	}
+#endif
 	return( AVIRHIP_OK );
 }
 
