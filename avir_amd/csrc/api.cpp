@@ -587,22 +587,45 @@ static int exec_device( avirhip_plan* p, const void* src, void* dst,
 	const float* fsrc = (const float*) src;
 	long sstride = p -> src_stride;
 
-	if( p -> gamma )
-	{
-		if(( rc = launch_pack_gamma( src, p -> in_type, p -> packed,
-			p -> src_w, p -> src_h, p -> io_ch, p -> ch, p -> src_stride,
-			p -> alpha_index, p -> d_srgb_tbl, st )) != 0 ) return( rc );
+	const int path = ( p -> path != 0 ? p -> path : p -> auto_path );
 
-		fsrc = p -> packed;
-		sstride = (long) p -> src_w * p -> ch;
+	// integer sources on the tiled paths: the tile loader converts and pads
+	// them itself, the float copy of the source (pack pass) is skipped
+	const bool raw = ( !p -> gamma && ( path == 2 || path == 3 ) &&
+		( p -> in_type == AVIRHIP_U8 || p -> in_type == AVIRHIP_U16 ) &&
+		p -> ch == 4 && fused_takes_raw( p, path ));
+
+	bool packed_done = false;
+	auto do_pack = [&]() -> int
+	{
+		if( packed_done )
+		{
+			return( AVIRHIP_OK );
+		}
+
+		packed_done = true;
+
+		if( p -> gamma )
+		{
+			return( launch_pack_gamma( src, p -> in_type, p -> packed,
+				p -> src_w, p -> src_h, p -> io_ch, p -> ch, p -> src_stride,
+				p -> alpha_index, p -> d_srgb_tbl, st ));
+		}
+
+		return( launch_pack( src, p -> in_type, p -> packed, p -> src_w,
+			p -> src_h, p -> io_ch, p -> ch, p -> src_stride, st ));
+	};
+
+	const bool need_pack = ( p -> gamma || p -> in_type != AVIRHIP_F32 ||
+		p -> ch != p -> io_ch );
+
+	if( need_pack && !raw )
+	{
+		if(( rc = do_pack()) != 0 ) return( rc );
 	}
-	else
-	if( p -> in_type != AVIRHIP_F32 || p -> ch != p -> io_ch )
-	{
-		if(( rc = launch_pack( src, p -> in_type, p -> packed, p -> src_w,
-			p -> src_h, p -> io_ch, p -> ch, p -> src_stride, st )) != 0 )
-			return( rc );
 
+	if( need_pack )
+	{
 		fsrc = p -> packed;
 		sstride = (long) p -> src_w * p -> ch;
 	}
@@ -615,7 +638,6 @@ static int exec_device( avirhip_plan* p, const void* src, void* dst,
 
 	float* fdst = ( direct ? (float*) dst : p -> resbuf );
 
-	const int path = ( p -> path != 0 ? p -> path : p -> auto_path );
 	rc = 1;
 
 	if( path >= 2 && path <= 4 )
@@ -625,8 +647,15 @@ static int exec_device( avirhip_plan* p, const void* src, void* dst,
 			rc = up2_run( p, fsrc, sstride, fdst, row0, row1, st );
 		}
 		else
+		if( raw )
 		{
-			rc = fused_run( p, path, fsrc, sstride, fdst, row0, row1, st );
+			rc = fused_run( p, path, src, p -> in_type, p -> io_ch,
+				p -> src_stride, fdst, row0, row1, st );
+		}
+		else
+		{
+			rc = fused_run( p, path, fsrc, AVIRHIP_F32, 4, sstride, fdst,
+				row0, row1, st );
 		}
 
 		if( rc == 1 && p -> path != 0 )
@@ -635,6 +664,12 @@ static int exec_device( avirhip_plan* p, const void* src, void* dst,
 				path );
 			return( AVIRHIP_EUNSUPPORTED );
 		}
+	}
+
+	if( rc == 1 && need_pack )
+	{
+		if(( rc = do_pack()) != 0 ) return( rc );
+		rc = 1;
 	}
 
 	if( rc == 1 )

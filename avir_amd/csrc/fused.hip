@@ -60,7 +60,8 @@ struct TileParams
 	const int* hrng; // [ntx][nh+1][2] (lo, count); [.][nh] = tile columns
 	const int* vrng; // [nty][nv+1][2]
 	int ntx, nty, ty0; // ty0: first tile row launched (bands)
-	const float* src; long src_ss; // floats per source row
+	const void* src; long src_ss;  // elements per source row
+	int src_type, src_ch;          // AVIRHIP_F32/4: float RGBA; U8/U16: raw image
 	int src_w, src_h;              // extent of `src` (clamp range of the load)
 	int xzero_above, yzero_above;  // zero-stuffed first views (INT_MAX: none)
 	float* dst; long dst_ss;       // floats per destination row
@@ -271,6 +272,53 @@ __device__ __forceinline__ void run_op( const TOp& op, const f4* in,
 	}
 }
 
+// Tile load straight from the caller's integer image: the (float) cast and
+// the zero padding to 4 channels of the pack stage (packScanline,
+// avir.h:2777-2840) happen here, so no float copy of the source ever exists.
+// Four 64-pixel pieces per trip: their loads are in flight together.
+template< typename Tin >
+__device__ __forceinline__ void load_raw_tile( const TileParams& P, f4* bufA,
+	const int cp, const int row_lo, const int rows, const int col_lo,
+	const int cols, const int wave, const int lane )
+{
+	const int ch = P.src_ch;
+
+	for( int y = wave; y < rows; y += 4 )
+	{
+		const int gy = clampi( row_lo + y, P.src_h - 1 );
+		const Tin* row = (const Tin*) P.src + (long) gy * P.src_ss;
+
+		for( int x0 = 0; x0 < cols; x0 += 256 )
+		{
+			float v[ 4 ][ 4 ];
+#pragma unroll
+			for( int u = 0; u < 4; u++ )
+			{
+				const int x = x0 + u * 64 + lane;
+				const Tin* s = row + (long) clampi( col_lo + x, P.src_w - 1 ) * ch;
+#pragma unroll
+				for( int c = 0; c < 4; c++ )
+				{
+					v[ u ][ c ] = ( c < ch && x < cols ? (float) s[ c ] : 0.0f );
+				}
+			}
+#pragma unroll
+			for( int u = 0; u < 4; u++ )
+			{
+				const int x = x0 + u * 64 + lane;
+
+				if( x < cols )
+				{
+					f4 o;
+					o.x = v[ u ][ 0 ]; o.y = v[ u ][ 1 ];
+					o.z = v[ u ][ 2 ]; o.w = v[ u ][ 3 ];
+					bufA[ y * cp + x ] = o;
+				}
+			}
+		}
+	}
+}
+
 __global__ void __launch_bounds__( 256 ) k_tile( const TileParams P )
 {
 	extern __shared__ __attribute__(( aligned( 16 ))) char smem[];
@@ -318,23 +366,39 @@ __global__ void __launch_bounds__( 256 ) k_tile( const TileParams P )
 		const int wave = __builtin_amdgcn_readfirstlane( tid >> 6 );
 		const int lane = tid & 63;
 
-		for( int y = wave; y < rows; y += 4 )
+		if( P.src_type == AVIRHIP_F32 )
 		{
-			const int gy = clampi( row_lo + y, P.src_h - 1 );
-			const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
-				(void*) ( P.src + (long) gy * P.src_ss ), 0, 0x7fffffff,
-				0x00020000 );
-
-			for( int x0 = 0; x0 < cols; x0 += 64 )
+			for( int y = wave; y < rows; y += 4 )
 			{
-				if( x0 + lane < cols )
+				const int gy = clampi( row_lo + y, P.src_h - 1 );
+				const __amdgpu_buffer_rsrc_t rs =
+					__builtin_amdgcn_make_buffer_rsrc( (void*) (
+					(const float*) P.src + (long) gy * P.src_ss ), 0,
+					0x7fffffff, 0x00020000 );
+
+				for( int x0 = 0; x0 < cols; x0 += 64 )
 				{
-					const int gx = clampi( col_lo + x0 + lane, P.src_w - 1 );
-					__builtin_amdgcn_raw_ptr_buffer_load_lds( rs,
-						(tile_ldsptr) ( bufA + y * cp + x0 ), 16, gx * 16,
-						0, 0, 0 );
+					if( x0 + lane < cols )
+					{
+						const int gx = clampi( col_lo + x0 + lane,
+							P.src_w - 1 );
+						__builtin_amdgcn_raw_ptr_buffer_load_lds( rs,
+							(tile_ldsptr) ( bufA + y * cp + x0 ), 16, gx * 16,
+							0, 0, 0 );
+					}
 				}
 			}
+		}
+		else
+		if( P.src_type == AVIRHIP_U8 )
+		{
+			load_raw_tile< uint8_t >( P, bufA, cp, row_lo, rows, col_lo, cols,
+				wave, lane );
+		}
+		else
+		{
+			load_raw_tile< uint16_t >( P, bufA, cp, row_lo, rows, col_lo,
+				cols, wave, lane );
 		}
 
 		asm volatile( "s_waitcnt vmcnt(0)" ::: "memory" );
@@ -796,8 +860,8 @@ static void fill_ops( const LAxis& ax, int n, TOp* out,
 }
 
 static int launch_tiles( avirhip_plan* p, const TileGeom& G, bool useh,
-	bool usev, const float* src, long src_ss, float* dst, long dst_ss,
-	int dst_row0, int a, int b, hipStream_t st )
+	bool usev, const void* src, int src_type, int src_ch, long src_ss,
+	float* dst, long dst_ss, int dst_row0, int a, int b, hipStream_t st )
 {
 	// [a, b) = range on the y extent (output rows, or source rows for an
 	// H-only pass)
@@ -817,6 +881,7 @@ static int launch_tiles( avirhip_plan* p, const TileGeom& G, bool useh,
 	P.ty0 = a / G.th;
 	const int ty1 = ( b - 1 ) / G.th;
 	P.src = src; P.src_ss = src_ss;
+	P.src_type = src_type; P.src_ch = src_ch;
 	// extent of the array at `src`: the source image, or FltBuf [src_h][new_w]
 	P.src_w = ( useh ? p -> src_w : p -> new_w );
 	P.src_h = p -> src_h;
@@ -881,8 +946,18 @@ static int launch_tiles( avirhip_plan* p, const TileGeom& G, bool useh,
 }
 
 // mode 3: fused; mode 2: two-pass.
-int fused_run( avirhip_plan* p, int mode, const float* src, long src_stride,
-	float* dst, int row0, int row1, hipStream_t st )
+bool fused_takes_raw( const avirhip_plan* p, int mode )
+{
+	const FusedData* F = (const FusedData*) p -> fused;
+
+	// the integer-ratio H pass (dn.hip) loads float rows by DMA
+	return( F != nullptr && ( mode == 3 || ( mode == 2 &&
+		!dn_has_h( F -> dn ))));
+}
+
+int fused_run( avirhip_plan* p, int mode, const void* src, int src_type,
+	int src_ch, long src_stride, float* dst, int row0, int row1,
+	hipStream_t st )
 {
 	FusedData* F = (FusedData*) p -> fused;
 
@@ -892,18 +967,32 @@ int fused_run( avirhip_plan* p, int mode, const float* src, long src_stride,
 		return( 1 );
 	}
 
-	if(( (uintptr_t) src & 15 ) || ( (uintptr_t) dst & 15 ) ||
-		( src_stride & 3 ))
+	if( src_type == AVIRHIP_F32 )
 	{
-		return( 1 ); // tiled paths need 16-byte aligned rows
+		if( src_ch != 4 || ( (uintptr_t) src & 15 ) || ( src_stride & 3 ))
+		{
+			return( 1 ); // DMA tile loads need 16-byte aligned float rows
+		}
+	}
+	else
+	if(( src_type != AVIRHIP_U8 && src_type != AVIRHIP_U16 ) ||
+		!fused_takes_raw( p, mode ) ||
+		( src_type == AVIRHIP_U16 && ( (uintptr_t) src & 1 )))
+	{
+		return( 1 );
+	}
+
+	if( (uintptr_t) dst & 15 )
+	{
+		return( 1 );
 	}
 
 	const long dss = (long) p -> new_w * 4;
 
 	if( mode == 3 )
 	{
-		return( launch_tiles( p, F -> fused, true, true, src, src_stride,
-			dst, dss, row0, row0, row1, st ));
+		return( launch_tiles( p, F -> fused, true, true, src, src_type, src_ch,
+			src_stride, dst, dss, row0, row0, row1, st ));
 	}
 
 	// two-pass: which FltBuf rows does the band need?
@@ -930,9 +1019,10 @@ int fused_run( avirhip_plan* p, int mode, const float* src, long src_stride,
 	}
 
 	int rc = ( dn_has_h( F -> dn ) ?
-		dn_run_h( F -> dn, src, src_stride, F -> fltbuf, dss, a, b + 1, st ) :
-		launch_tiles( p, F -> hpass, true, false, src, src_stride,
-		F -> fltbuf, dss, 0, a, b + 1, st ));
+		dn_run_h( F -> dn, (const float*) src, src_stride, F -> fltbuf, dss,
+		a, b + 1, st ) :
+		launch_tiles( p, F -> hpass, true, false, src, src_type, src_ch,
+		src_stride, F -> fltbuf, dss, 0, a, b + 1, st ));
 
 	if( rc != 0 )
 	{
@@ -945,8 +1035,8 @@ int fused_run( avirhip_plan* p, int mode, const float* src, long src_stride,
 			row1, st ));
 	}
 
-	return( launch_tiles( p, F -> vpass, false, true, F -> fltbuf, dss, dst,
-		dss, row0, row0, row1, st ));
+	return( launch_tiles( p, F -> vpass, false, true, F -> fltbuf,
+		AVIRHIP_F32, 4, dss, dst, dss, row0, row0, row1, st ));
 }
 
 } // namespace avirhip

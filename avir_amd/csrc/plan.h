@@ -156,8 +156,14 @@ int fused_prepare( avirhip_plan* p );
 void fused_release( avirhip_plan* p );
 // Runs path `mode` (2 = two-pass tiled, 3 = fused). Returns 1 when the call
 // cannot take a tiled path (e.g. unaligned rows) and the generic path should.
-int fused_run( avirhip_plan* p, int mode, const float* src, long src_stride,
-	float* dst, int row0, int row1, hipStream_t st );
+// `src_type` / `src_ch`: element type and channel count of the array at `src`
+// (AVIRHIP_F32 and 4: a float RGBA image; AVIRHIP_U8 / AVIRHIP_U16 with 1-4
+// channels: the caller's integer image, converted and padded by the tile
+// loader itself -- no pack pass). `src_stride` in elements of that type.
+int fused_run( avirhip_plan* p, int mode, const void* src, int src_type,
+	int src_ch, long src_stride, float* dst, int row0, int row1,
+	hipStream_t st );
+bool fused_takes_raw( const avirhip_plan* p, int mode );
 
 // dn.hip: integer-ratio downsizing passes used by the two-pass tiled path
 int dn_prepare( avirhip_plan* p, void** out );

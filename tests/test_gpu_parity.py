@@ -325,6 +325,39 @@ def test_avir_padded_source_rows(sw, sh, nw, nh, pad):
     _assert_same(ddst.cpu().numpy(), want, "padded rows, device pointers")
 
 
+@pytest.mark.parametrize("dt", [np.uint8, np.uint16])
+@pytest.mark.parametrize("ch", [3, 4])
+def test_avir_integer_sources_load_raw_tiles(dt, ch):
+    """uint8 / uint16 sources on the tiled paths are converted by the tile
+    loader itself (no pack pass): padded row pitches, odd byte alignment, row
+    bands."""
+    lib = abi.load()
+    for (sw, sh, nw, nh) in [(301, 203, 100, 67), (131, 97, 200, 150),
+                             (300, 200, 111, 74)]:
+        pad = 5
+        ss = sw * ch + pad
+        u = rb.lcg_u8((sh, ss * (2 if dt == np.uint16 else 1)), seed=sw)
+        buf = u.view(dt).reshape(sh, ss)
+        src = np.ascontiguousarray(buf[:, :sw * ch]).reshape(sh, sw, ch)
+        want = _checker_avir(src, nw, nh, resbits=16)
+        r = avir_amd.CImageResizer(16)
+        dst = np.empty((nh, nw, ch), dt)
+        r.resizeImage(buf, sw, sh, ss, dst, nw, nh, ch, 0.0)
+        _assert_same(dst, want, "raw tiles %dx%d" % (sw, sh))
+        p = r.plan(sw, sh, nw, nh, ch, 0.0, None, rb._DT[np.dtype(dt)],
+                   rb._DT[np.dtype(dt)], ss)
+        for path in (abi.PATH_TILED, abi.PATH_FUSED):
+            abi.check(lib.avirhip_plan_set_path(p, path), "set_path")
+            r.resizeImage(buf, sw, sh, ss, dst, nw, nh, ch, 0.0)
+            _assert_same(dst, want, "raw tiles path %d" % path)
+            band = np.empty((nh - nh // 3, nw, ch), dt)
+            abi.check(lib.avirhip_resize_band(
+                p, buf.ctypes.data, abi.MEM_HOST, band.ctypes.data,
+                abi.MEM_HOST, nh // 3, nh, None), "band")
+            _assert_same(band, want[nh // 3:], "raw tiles band")
+        abi.check(lib.avirhip_plan_set_path(p, 0), "set_path")
+
+
 def test_avir_unaligned_device_pointers():
     """Device buffers that are only 4-byte aligned: the vectorised paths
     refuse and the call still completes bit-exactly on the generic path."""
