@@ -430,6 +430,23 @@ def test_avir_few_channels_take_the_rgba_fast_paths(sw, sh, nw, nh, ch):
         abi.check(lib.avirhip_plan_set_path(p, 0), "set_path")
 
 
+def test_large_frames_beyond_the_headline_size():
+    """8K -> 16K (2.1 GB destination: 32-bit element offsets overflow here if
+    any kernel used them) and a 3x downsizing of an 8K frame, against the
+    reference on all host threads."""
+    import torch
+    nthr = min(64, os.cpu_count() or 1)
+    for (sw, sh, nw, nh) in [(7680, 4320, 15360, 8640), (7680, 4320, 2560, 1440)]:
+        src = rb.lcg_f32((sh, sw, 4), seed=2024)
+        want = rb.ref_avir(src, nw, nh, resbits=16, threads=nthr) \
+            if rb.have_ref() else rb.orc_avir(src, nw, nh, resbits=16)
+        dsrc = torch.from_numpy(src).to("cuda:0")
+        got = avir_amd.CImageResizer(16).resize(dsrc, nw, nh)
+        torch.cuda.synchronize()
+        _assert_same(got.cpu().numpy(), want, "%dx%d" % (nw, nh))
+        del got, dsrc, want
+
+
 def test_dc_gain_constant_image():
     """a constant image must come out constant on every
     execution path and ratio class. The reference's own DC error is 6e-8 ..
