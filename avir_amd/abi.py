@@ -121,6 +121,8 @@ PROTOTYPES = {
     "avirhip_plan_get_path": (_I, [_VP]),
     "avirhip_resize": (_I, [_VP, _VP, _I, _VP, _I, _VP]),
     "avirhip_resize_band": (_I, [_VP, _VP, _I, _VP, _I, _I, _I, _VP]),
+    "avirhip_resize_sharded": (_I, [_VP, _I, C.POINTER(C.c_int), _VP, _VP, _I,
+                                 C.POINTER(_D), C.POINTER(_D)]),
     "avirhip_time_resize": (_I, [_VP, _VP, _VP, _I, _VP, C.POINTER(_D)]),
     "avirhip_params_preset": (None, [_I, C.POINTER(Params)]),
     "avirhip_vars_default": (None, [C.POINTER(Vars)]),

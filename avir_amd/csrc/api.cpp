@@ -7,7 +7,9 @@
 #include <stdarg.h>
 #include <stdio.h>
 #include <string.h>
+#include <stdlib.h>
 #include <algorithm>
+#include <chrono>
 
 namespace avirhip {
 
@@ -794,6 +796,8 @@ static avirhip_plan* new_plan()
 	p -> packed = nullptr; p -> resbuf = nullptr; p -> lres = nullptr;
 	p -> stage_src = nullptr; p -> stage_dst = nullptr;
 	p -> stage_src_bytes = 0; p -> stage_dst_bytes = 0;
+	p -> shard_band = nullptr; p -> shard_band_bytes = 0;
+	p -> shard_src = nullptr; p -> shard_src_bytes = 0;
 	p -> tr_mul = 1.0; p -> pk_out = 0.0;
 	p -> gamma = 0; p -> alpha_index = -1; p -> d_srgb_tbl = nullptr;
 	p -> ch = 0; p -> io_ch = 0;
@@ -889,7 +893,29 @@ int avirhip_plan_create( const avirhip_plan_desc* d, avirhip_plan** out )
 	int rc = lower_axis( d -> h, d -> src_w, d -> new_w, p -> h );
 
 	if( rc == 0 ) rc = lower_axis( d -> v, d -> src_h, d -> new_h, p -> v );
-	if( rc == 0 ) rc = upload_axis( p, p -> h );
+	if( rc == 0 ) rc = finalize_avir_plan( p );
+
+	if( rc != 0 )
+	{
+		avirhip_plan_destroy( p );
+		return( rc );
+	}
+
+	*out = p;
+	return( AVIRHIP_OK );
+}
+
+} // extern "C"
+
+namespace avirhip {
+
+// Device side of an AVIR plan whose axes are lowered (host vectors filled):
+// uploads, channel padding decision, fast-path preparation -- on the current
+// device. Shared by plan creation and by the per-device replicas of
+// avirhip_resize_sharded.
+int finalize_avir_plan( avirhip_plan* p )
+{
+	int rc = upload_axis( p, p -> h );
 	if( rc == 0 ) rc = upload_axis( p, p -> v );
 
 	if( rc == 0 && p -> gamma )
@@ -920,14 +946,250 @@ int avirhip_plan_create( const avirhip_plan_desc* d, avirhip_plan** out )
 		p -> fused_ok = 0;
 	}
 
+	return( rc );
+}
+
+static int finalize_lancir_plan( avirhip_plan* p )
+{
+	int rc = AVIRHIP_OK;
+	LancirAxisDev* ax[ 2 ] = { &p -> lv, &p -> lh };
+
+	for( int i = 0; i < 2 && rc == 0; i++ )
+	{
+		LancirAxisDev& L = *ax[ i ];
+		if( rc == 0 ) rc = upload( p, L.h_flt, &L.d_flt );
+		if( rc == 0 ) rc = upload( p, L.h_start, &L.d_start );
+		if( rc == 0 ) rc = upload( p, L.h_fidx, &L.d_fidx );
+	}
+
+	if( rc == 0 ) rc = fused_prepare( p );
+	if( rc == 0 ) rc = lanc2_prepare( p );
+	return( rc );
+}
+
+// A replica of plan `s` on device `device` (same tables, its own uploads,
+// scratch and fast-path state).
+static int clone_plan( const avirhip_plan* s, int device, avirhip_plan** out )
+{
+	AVIRHIP_HIPCHECK( hipSetDevice( device ));
+	avirhip_plan* q = new_plan();
+	q -> is_lancir = s -> is_lancir;
+	q -> src_w = s -> src_w; q -> src_h = s -> src_h;
+	q -> src_stride = s -> src_stride;
+	q -> new_w = s -> new_w; q -> new_h = s -> new_h;
+	q -> new_stride = s -> new_stride;
+	q -> ch = s -> io_ch; q -> io_ch = s -> io_ch;
+	q -> in_type = s -> in_type; q -> out_type = s -> out_type;
+	q -> tr_mul = s -> tr_mul; q -> pk_out = s -> pk_out;
+	q -> gamma = s -> gamma; q -> alpha_index = s -> alpha_index;
+	q -> l_out_mul = s -> l_out_mul; q -> l_clamp = s -> l_clamp;
+	q -> l_unity = s -> l_unity;
+	q -> h = s -> h; q -> v = s -> v;     // host vectors; device pointers are
+	q -> lv = s -> lv; q -> lh = s -> lh; // replaced by the uploads below
+	q -> path = s -> path;
+
+	const int rc = ( s -> is_lancir ? finalize_lancir_plan( q ) :
+		finalize_avir_plan( q ));
+
 	if( rc != 0 )
 	{
-		avirhip_plan_destroy( p );
+		avirhip_plan_destroy( q );
 		return( rc );
 	}
 
-	*out = p;
+	*out = q;
 	return( AVIRHIP_OK );
+}
+
+static int grow( avirhip_plan* p, void** buf, size_t* have, size_t need )
+{
+	if( *have < need )
+	{
+		void* q;
+		const int rc = dev_alloc( p, need, &q );
+		if( rc != 0 ) return( rc );
+		*buf = q;
+		*have = need;
+	}
+
+	return( AVIRHIP_OK );
+}
+
+} // namespace avirhip
+
+extern "C" {
+
+/* one frame, contiguous output-row bands, one band per
+ * entry of `devices`, stitched into `dst`. Bands are computed with global
+ * indices, so the stitched frame is bit-identical to avirhip_resize(). */
+int avirhip_resize_sharded( avirhip_plan* p, int n_gpus, const int* devices,
+	const void* src, void* dst, int gather_root, double* t_compute_ms,
+	double* t_gather_ms )
+{
+	if( p == nullptr || n_gpus < 1 || src == nullptr || dst == nullptr ||
+		( devices == nullptr && n_gpus > 1 ) || gather_root < 0 ||
+		gather_root >= n_gpus )
+	{
+		set_error( "resize_sharded: bad arguments" );
+		return( AVIRHIP_EINVAL );
+	}
+
+	int ndev = 0;
+	AVIRHIP_HIPCHECK( hipGetDeviceCount( &ndev ));
+	const int src_mem = avirhip_resolve_mem( src, AVIRHIP_MEM_AUTO );
+	const int dst_mem = avirhip_resolve_mem( dst, AVIRHIP_MEM_AUTO );
+	int src_dev = -1;
+
+	if( src_mem == AVIRHIP_MEM_DEVICE )
+	{
+		hipPointerAttribute_t at;
+		AVIRHIP_HIPCHECK( hipPointerGetAttributes( &at, src ));
+		src_dev = at.device;
+	}
+
+	const bool force_replica =
+		( getenv( "AVIRHIP_SHARDED_FORCE_REPLICA" ) != nullptr );
+
+	const size_t esz_in = dtype_size( p -> in_type );
+	const size_t esz_out = dtype_size( p -> out_type );
+	const size_t src_bytes = ( (size_t) ( p -> src_h - 1 ) * p -> src_stride +
+		(size_t) p -> src_w * p -> io_ch ) * esz_in;
+	const size_t row_bytes = (size_t) p -> new_stride * esz_out;
+	int keep = 0;
+	(void) hipGetDevice( &keep );
+	std::vector< avirhip_plan* > pl( n_gpus );
+	std::vector< int > r0( n_gpus ), r1( n_gpus );
+	std::vector< char* > band( n_gpus );
+	int rc = AVIRHIP_OK;
+	const auto t0 = std::chrono::steady_clock::now();
+
+	// ---- compute: every band on its device's default stream
+	for( int g = 0; g < n_gpus && rc == 0; g++ )
+	{
+		const int d = ( devices != nullptr ? devices[ g ] : p -> device );
+
+		if( d < 0 || d >= ndev )
+		{
+			set_error( "resize_sharded: device %d does not exist", d );
+			rc = AVIRHIP_EINVAL;
+			break;
+		}
+
+		avirhip_plan* q = nullptr;
+
+		if( d == p -> device && !force_replica )
+		{
+			q = p;
+		}
+		else
+		{
+			for( size_t i = 0; i < p -> replicas.size(); i++ )
+			{
+				if( p -> replicas[ i ] -> device == d )
+				{
+					q = p -> replicas[ i ];
+				}
+			}
+
+			if( q == nullptr )
+			{
+				if(( rc = clone_plan( p, d, &q )) != 0 ) break;
+				p -> replicas.push_back( q );
+			}
+		}
+
+		pl[ g ] = q;
+		r0[ g ] = (int) ( (long) p -> new_h * g / n_gpus );
+		r1[ g ] = (int) ( (long) p -> new_h * ( g + 1 ) / n_gpus );
+		AVIRHIP_HIPCHECK( hipSetDevice( d ));
+
+		// the source where this device can read it
+		const void* s = src;
+		int smem = src_mem;
+
+		if( src_mem == AVIRHIP_MEM_DEVICE && src_dev != d )
+		{
+			if(( rc = grow( q, &q -> shard_src, &q -> shard_src_bytes,
+				src_bytes )) != 0 ) break;
+
+			AVIRHIP_HIPCHECK( hipMemcpyPeerAsync( q -> shard_src, d, src,
+				src_dev, src_bytes, nullptr ));
+			s = q -> shard_src;
+		}
+
+		// bands that share a device (and plan) lie one after another in that
+		// plan's band buffer: room for the whole frame covers every split
+		if(( rc = grow( q, &q -> shard_band, &q -> shard_band_bytes,
+			(size_t) p -> new_h * row_bytes + 16 )) != 0 ) break;
+
+		band[ g ] = (char*) q -> shard_band + (size_t) r0[ g ] * row_bytes;
+		rc = exec_any( q, s, smem, band[ g ], AVIRHIP_MEM_DEVICE, r0[ g ],
+			r1[ g ], nullptr );
+	}
+
+	for( int g = 0; g < n_gpus && rc == 0; g++ )
+	{
+		AVIRHIP_HIPCHECK( hipSetDevice( pl[ g ] -> device ));
+		AVIRHIP_HIPCHECK( hipStreamSynchronize( nullptr ));
+	}
+
+	const auto t1 = std::chrono::steady_clock::now();
+
+	// ---- gather: band buffers -> dst (peer copies over xGMI, or D2H)
+	int dst_dev = -1;
+
+	if( rc == 0 && dst_mem == AVIRHIP_MEM_DEVICE )
+	{
+		hipPointerAttribute_t at;
+		AVIRHIP_HIPCHECK( hipPointerGetAttributes( &at, dst ));
+		dst_dev = at.device;
+	}
+
+	for( int g = 0; g < n_gpus && rc == 0; g++ )
+	{
+		const size_t bb = (size_t) ( r1[ g ] - r0[ g ]) * row_bytes;
+		char* to = (char*) dst + (size_t) r0[ g ] * row_bytes;
+		AVIRHIP_HIPCHECK( hipSetDevice( pl[ g ] -> device ));
+
+		if( bb == 0 )
+		{
+			continue;
+		}
+
+		if( dst_mem == AVIRHIP_MEM_DEVICE )
+		{
+			AVIRHIP_HIPCHECK( hipMemcpyPeerAsync( to, dst_dev, band[ g ],
+				pl[ g ] -> device, bb, nullptr ));
+		}
+		else
+		{
+			AVIRHIP_HIPCHECK( hipMemcpyAsync( to, band[ g ], bb,
+				hipMemcpyDeviceToHost, nullptr ));
+		}
+	}
+
+	for( int g = 0; g < n_gpus && rc == 0; g++ )
+	{
+		AVIRHIP_HIPCHECK( hipSetDevice( pl[ g ] -> device ));
+		AVIRHIP_HIPCHECK( hipStreamSynchronize( nullptr ));
+	}
+
+	const auto t2 = std::chrono::steady_clock::now();
+	(void) hipSetDevice( keep );
+
+	if( t_compute_ms != nullptr )
+	{
+		*t_compute_ms = std::chrono::duration< double, std::milli >(
+			t1 - t0 ).count();
+	}
+
+	if( t_gather_ms != nullptr )
+	{
+		*t_gather_ms = std::chrono::duration< double, std::milli >(
+			t2 - t1 ).count();
+	}
+
+	return( rc );
 }
 
 static int lower_lancir_axis( avirhip_plan* p, const avirhip_lancir_axis& a,
@@ -962,10 +1224,6 @@ static int lower_lancir_axis( avirhip_plan* p, const avirhip_lancir_axis& a,
 		L.h_fidx[ j ] = a.pos[ j ].flt_index;
 	}
 
-	int rc;
-	if(( rc = upload( p, L.h_flt, &L.d_flt )) != 0 ) return( rc );
-	if(( rc = upload( p, L.h_start, &L.d_start )) != 0 ) return( rc );
-	if(( rc = upload( p, L.h_fidx, &L.d_fidx )) != 0 ) return( rc );
 	return( AVIRHIP_OK );
 }
 
@@ -1010,8 +1268,7 @@ int avirhip_lancir_plan_create( const avirhip_lancir_desc* d,
 
 	int rc = lower_lancir_axis( p, d -> v, p -> lv );
 	if( rc == 0 ) rc = lower_lancir_axis( p, d -> h, p -> lh );
-	if( rc == 0 ) rc = fused_prepare( p );
-	if( rc == 0 ) rc = lanc2_prepare( p );
+	if( rc == 0 ) rc = finalize_lancir_plan( p );
 
 	if( rc != 0 )
 	{
@@ -1030,6 +1287,12 @@ void avirhip_plan_destroy( avirhip_plan* p )
 		return;
 	}
 
+	for( size_t i = 0; i < p -> replicas.size(); i++ )
+	{
+		avirhip_plan_destroy( p -> replicas[ i ]);
+	}
+
+	p -> replicas.clear();
 	fused_release( p );
 	up2_release( p );
 	lanc2_release( p );

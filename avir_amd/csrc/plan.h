@@ -119,6 +119,11 @@ struct avirhip_plan
 	float* resbuf;  // float result before the integer / f64 epilogue
 	float* lres;    // LANCIR: float result rows before the output stage
 	std::vector< float* > hbuf, vbuf; // per-op outputs
+	// avirhip_resize_sharded: replicas of this plan on other devices, and the
+	// per-replica band / source buffers
+	std::vector< avirhip_plan* > replicas;
+	void* shard_band; size_t shard_band_bytes;
+	void* shard_src; size_t shard_src_bytes;
 	void* stage_src; // host-pointer staging
 	void* stage_dst;
 	size_t stage_src_bytes, stage_dst_bytes;
@@ -133,6 +138,7 @@ void set_error( const char* fmt, ... );
 		return( AVIRHIP_EHIP ); } } while( 0 )
 
 size_t dtype_size( int t );
+int finalize_avir_plan( avirhip_plan* p ); // api.cpp
 
 // generic.hip
 // `ch` = channels in `src`, `ech` >= ch = channels written (zero padded)

@@ -215,6 +215,23 @@ int avirhip_resize(avirhip_plan* plan, const void* src, int src_mem,
 int avirhip_resize_band(avirhip_plan* plan, const void* src, int src_mem,
 	void* dst_band, int dst_mem, int row0, int row1, void* stream);
 
+/* One frame sharded over several devices of THIS process:
+ * the destination rows are split into `n_gpus` contiguous bands, band g is
+ * computed on device `devices[g]` (a replica of the plan is created there on
+ * first use; `devices` == NULL or repeated entries run the bands one after
+ * another on the same device) and the bands are stitched into `dst` -- peer
+ * copies over xGMI when `dst` is device memory, device-to-host copies
+ * otherwise. `src`/`dst` are whole images, host or device memory (detected).
+ * The stitched frame is bit-identical to avirhip_resize(). `gather_root` is
+ * the index of the band whose device should hold `dst` when the caller
+ * allocates it there (informational; `dst` is used where it is). The two
+ * optional outputs receive the wall time of the compute and gather phases.
+ * The multi-PROCESS form of the same sharding (one process per GPU, RCCL) is
+ * avirhip_resize_band + avir_amd/sharding.py. */
+int avirhip_resize_sharded(avirhip_plan* plan, int n_gpus, const int* devices,
+	const void* src, void* dst, int gather_root, double* t_compute_ms,
+	double* t_gather_ms);
+
 /* Timing aid for bench.py: runs `iters` executions on device buffers and
  * returns the average duration in milliseconds measured with HIP events on
  * `stream` (the stream the kernels are launched on). */

@@ -501,6 +501,59 @@ def test_avir_srgb_gamma(sw, sh, nw, nh, ch, tin, tout, alpha):
         _assert_same(got, want, "gamma bits %d" % bits)
 
 
+@pytest.mark.parametrize("force_replica", [False, True])
+def test_single_process_sharded_resize(force_replica, monkeypatch):
+    """avirhip_resize_sharded: bands on the devices of one
+    process, stitched by peer / D2H copies. On the 1-GPU box every band runs
+    on device 0; AVIRHIP_SHARDED_FORCE_REPLICA makes each band use a cloned
+    plan and the peer-copy code, as a second device would."""
+    import ctypes as C
+    import torch
+    lib = abi.load()
+    if force_replica:
+        monkeypatch.setenv("AVIRHIP_SHARDED_FORCE_REPLICA", "1")
+    for (sw, sh, nw, nh, ch, dt) in [(300, 200, 600, 400, 4, np.float32),
+                                     (301, 203, 100, 67, 3, np.uint8),
+                                     (64, 48, 100, 77, 4, np.float32)]:
+        src = (rb.lcg_u8((sh, sw, ch), seed=8) if dt == np.uint8 else
+               rb.lcg_f32((sh, sw, ch), seed=8))
+        r = avir_amd.CImageResizer(16)
+        want = r.resize(src, nw, nh)
+        code = rb._DT[np.dtype(dt)]
+        p = r.plan(sw, sh, nw, nh, ch, 0.0, None, code, code)
+        tc, tg = C.c_double(), C.c_double()
+        for n in (1, 3, 8):
+            devs = (C.c_int * n)(*([0] * n))
+            # host buffers
+            dst = np.zeros((nh, nw, ch), dt)
+            abi.check(lib.avirhip_resize_sharded(
+                p, n, devs, src.ctypes.data, dst.ctypes.data, 0,
+                C.byref(tc), C.byref(tg)), "sharded host")
+            _assert_same(dst, want, "sharded host n=%d" % n)
+            # device buffers
+            dsrc = torch.from_numpy(src).to("cuda:0")
+            ddst = torch.zeros((nh, nw, ch), dtype=dsrc.dtype, device="cuda:0")
+            abi.check(lib.avirhip_resize_sharded(
+                p, n, devs, dsrc.data_ptr(), ddst.data_ptr(), 0,
+                C.byref(tc), C.byref(tg)), "sharded device")
+            torch.cuda.synchronize()
+            _assert_same(ddst.cpu().numpy(), want, "sharded device n=%d" % n)
+            assert tc.value > 0.0 and tg.value >= 0.0
+    lp = avir_amd.CLancIR()
+    src = rb.lcg_f32((60, 80, 4), seed=9)
+    want = lp.resize(src, 160, 120)
+    p = lp.plan(80, 60, 160, 120, 4)
+    dst = np.zeros((120, 160, 4), np.float32)
+    devs = (C.c_int * 4)(0, 0, 0, 0)
+    abi.check(lib.avirhip_resize_sharded(p, 4, devs, src.ctypes.data,
+                                         dst.ctypes.data, 0, None, None),
+              "sharded lancir")
+    _assert_same(dst, want, "sharded lancir")
+    bad = (C.c_int * 2)(0, 99)
+    assert lib.avirhip_resize_sharded(p, 2, bad, src.ctypes.data,
+                                      dst.ctypes.data, 0, None, None) != 0
+
+
 def test_zero_sized_and_errors():
     r = avir_amd.CImageResizer(8)
     dst = np.full((4, 5, 3), 7, np.uint8)
