@@ -241,6 +241,9 @@ def main():
                     help="0 auto, 1 generic, 2 two-pass, 3 fused tile, 4 up2 (A/B)")
     ap.add_argument("--no-cpu", action="store_true",
                     help="skip the CPU baseline leg")
+    ap.add_argument("--backend", default="nccl",
+                    help="torch.distributed backend for --gpus > 1 (nccl = "
+                         "RCCL; gloo only for dry runs of the rank logic)")
     ap.add_argument("--report", action="store_true",
                     help="print the all-configs CPU-vs-GPU markdown table "
                          "(BASELINE.md section 4, item 5)")
@@ -268,12 +271,18 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    # one rank per GPU; a dry run of the multi-rank path on a box with fewer
+    # GPUs than ranks (--backend gloo) shares devices
+    local = local % max(1, torch.cuda.device_count())
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
 
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(args.backend)
         # pay RCCL's communicator set-up now: the barrier that brackets the
         # timed region must be a ~100 us one, not seconds of idle GPU (clocks
         # would ramp down right before the measurement)
