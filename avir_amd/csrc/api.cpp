@@ -5,6 +5,7 @@
 
 #include "plan.h"
 #include <stdarg.h>
+#include <stdint.h>
 #include <stdio.h>
 #include <string.h>
 #include <stdlib.h>
@@ -730,6 +731,47 @@ static int exec_any( avirhip_plan* p, const void* src, int src_mem, void* dst,
 	}
 
 	hipStream_t st = (hipStream_t) stream;
+
+	// Calls on one plan share its scratch buffers: serialise them (the
+	// reference allows concurrent resizeImage() calls on one object). The
+	// only scratch-free case, device-resident float RGBA through the
+	// single-launch 2x kernels, skips this.
+	const int xpath = ( p -> path != 0 ? p -> path : p -> auto_path );
+	const bool scratch_free = ( xpath == 4 && p -> in_type == AVIRHIP_F32 &&
+		p -> out_type == AVIRHIP_F32 && p -> ch == p -> io_ch &&
+		!p -> gamma && src_mem == AVIRHIP_MEM_DEVICE &&
+		dst_mem == AVIRHIP_MEM_DEVICE &&
+		// ... and only when the 2x kernel cannot refuse the call and fall
+		// back to the generic kernels (which use scratch)
+		(( (uintptr_t) src | (uintptr_t) dst ) & 15 ) == 0 &&
+		( p -> src_stride & 3 ) == 0 &&
+		(long) p -> src_stride * 4 < ( 1L << 22 ) &&
+		(long) p -> new_w * 16 < ( 1L << 22 ));
+
+	std::unique_lock< std::mutex > guard( p -> exec_mtx, std::defer_lock );
+
+	if( !scratch_free )
+	{
+		guard.lock();
+
+		if( p -> last_done == nullptr )
+		{
+			AVIRHIP_HIPCHECK( hipEventCreateWithFlags( &p -> last_done,
+				hipEventDisableTiming ));
+		}
+		else
+		{
+			AVIRHIP_HIPCHECK( hipStreamWaitEvent( st, p -> last_done, 0 ));
+		}
+	}
+
+	struct Done
+	{
+		avirhip_plan* p; hipStream_t st; bool on;
+		~Done() { if( on && p -> last_done != nullptr )
+			(void) hipEventRecord( p -> last_done, st ); }
+	} done = { p, st, !scratch_free };
+
 	const void* dsrc = src;
 	void* ddst = dst;
 	const size_t src_bytes = ( (size_t) ( p -> src_h - 1 ) * p -> src_stride +
@@ -797,6 +839,7 @@ static avirhip_plan* new_plan()
 	p -> stage_src = nullptr; p -> stage_dst = nullptr;
 	p -> stage_src_bytes = 0; p -> stage_dst_bytes = 0;
 	p -> shard_band = nullptr; p -> shard_band_bytes = 0;
+	p -> last_done = nullptr;
 	p -> shard_src = nullptr; p -> shard_src_bytes = 0;
 	p -> tr_mul = 1.0; p -> pk_out = 0.0;
 	p -> gamma = 0; p -> alpha_index = -1; p -> d_srgb_tbl = nullptr;
@@ -1293,6 +1336,12 @@ void avirhip_plan_destroy( avirhip_plan* p )
 	}
 
 	p -> replicas.clear();
+
+	if( p -> last_done != nullptr )
+	{
+		(void) hipEventDestroy( p -> last_done );
+	}
+
 	fused_release( p );
 	up2_release( p );
 	lanc2_release( p );

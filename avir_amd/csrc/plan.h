@@ -19,6 +19,7 @@
 #include <stdint.h>
 #include <string>
 #include <vector>
+#include <mutex>
 #include "../../include/avirhip.h"
 
 namespace avirhip {
@@ -124,6 +125,12 @@ struct avirhip_plan
 	std::vector< avirhip_plan* > replicas;
 	void* shard_band; size_t shard_band_bytes;
 	void* shard_src; size_t shard_src_bytes;
+	// A plan owns scratch buffers (packed source, float result, FltBuf, op
+	// outputs, staging): calls that use them are serialised -- host side by
+	// the mutex, device side by making every call's stream wait for the
+	// previous call's completion event.
+	std::mutex exec_mtx;
+	hipEvent_t last_done;
 	void* stage_src; // host-pointer staging
 	void* stage_dst;
 	size_t stage_src_bytes, stage_dst_bytes;

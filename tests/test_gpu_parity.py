@@ -554,6 +554,43 @@ def test_single_process_sharded_resize(force_replica, monkeypatch):
                                       dst.ctypes.data, 0, None, None) != 0
 
 
+def test_concurrent_calls_on_one_object():
+    """The reference allows concurrent resizeImage() calls on one object
+    (README.md:83-85). Calls that share a cached plan share its scratch
+    buffers and are serialised inside the library: threads on different
+    streams must all get the right answer."""
+    import threading
+    import torch
+    src8 = rb.lcg_u8((203, 301, 3), seed=12)
+    want8 = _checker_avir(src8, 100, 67, resbits=8)
+    srcf = rb.lcg_f32((200, 300, 4), seed=13)
+    wantf = _checker_avir(srcf, 130, 87, resbits=8)
+    r = avir_amd.CImageResizer(8)
+    errs = []
+
+    def worker(i):
+        try:
+            torch.cuda.set_device(0)
+            st = torch.cuda.Stream()
+            with torch.cuda.stream(st):
+                for _ in range(10):
+                    if i % 2 == 0:
+                        d = torch.from_numpy(src8).to("cuda:0")
+                        o = r.resize(d, 100, 67)
+                        st.synchronize()
+                        _assert_same(o.cpu().numpy(), want8, "thread %d u8" % i)
+                    else:
+                        o = r.resize(srcf, 130, 87)
+                        _assert_same(o, wantf, "thread %d f32 host" % i)
+        except Exception as e:  # noqa: BLE001
+            errs.append(e)
+
+    ts = [threading.Thread(target=worker, args=(i,)) for i in range(6)]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    assert not errs, errs[0]
+
+
 def test_zero_sized_and_errors():
     r = avir_amd.CImageResizer(8)
     dst = np.full((4, 5, 3), 7, np.uint8)
