@@ -13,14 +13,17 @@
 //                     FltBuf, then V chain only). Chosen for downsizing, where
 //                     FltBuf is small and a fused tile's halo would be huge.
 //
-// gfx950 mapping: a workgroup is 256 threads = 4 wave64; lanes run along the
-// image x axis in every stage, so global loads/stores of a wave are contiguous
-// 16-byte-per-lane segments and LDS accesses of a lane group are consecutive
-// 16-byte slots (conflict-free ds_read_b128 / ds_write_b128). Per-tile filter
-// coefficient rows are staged into LDS once per stage (coalesced) and then
-// read as broadcast / 48-byte-stride b128 words. Tiles are dealt to workgroups
-// so that consecutive tiles (which share halo rows/columns) land on the same
-// XCD and hit in its private L2.
+// gfx950 mapping: a workgroup is 256 threads = 4 wave64. The source tile and
+// the tile's block of coefficient rows (tables re-laid with 16-byte rows) are
+// fetched by LDS-DMA (buffer_load_dwordx4 ... lds), every piece in flight at
+// once; uint8 / uint16 sources are converted and padded to RGBA by the loader
+// itself. Every LDS buffer holds the *extended* range its consumer reads (the
+// producer fills the replicated / zero-stuffed slots), so the tap loops have
+// no clamps. Lanes run along the image x axis -- contiguous 16-byte global
+// accesses, conflict-free ds_read_b128 -- except in a downsizing gather along
+// x, where the 16 lanes of an LDS access group take 16 rows at one x (see
+// run_op). Tiles are dealt to workgroups so that consecutive tiles (which
+// share halo rows/columns) land on the same XCD and hit in its private L2.
 //
 // Arithmetic contract: -ffp-contract=off, separate mul/add in the reference's
 // tap order, sums started from +0.0f (see generic.hip) => bit-identical.
