@@ -736,8 +736,20 @@ static int exec_any( avirhip_plan* p, const void* src, int src_mem, void* dst,
 	// reference allows concurrent resizeImage() calls on one object). The
 	// only scratch-free case, device-resident float RGBA through the
 	// single-launch 2x kernels, skips this.
+	const size_t src_bytes = ( (size_t) ( p -> src_h - 1 ) * p -> src_stride +
+		(size_t) p -> src_w * p -> io_ch ) * dtype_size( p -> in_type );
+	const size_t row_bytes = (size_t) p -> new_stride *
+		dtype_size( p -> out_type );
+	const size_t dst_bytes = ( row1 > row0 ?
+		(size_t) ( row1 - row0 - 1 ) * row_bytes + (size_t) p -> new_w *
+		p -> io_ch * dtype_size( p -> out_type ) : 0 );
+	const bool overlap = ( src_mem == AVIRHIP_MEM_DEVICE &&
+		dst_mem == AVIRHIP_MEM_DEVICE &&
+		(const char*) src < (const char*) dst + dst_bytes &&
+		(const char*) dst < (const char*) src + src_bytes );
+
 	const int xpath = ( p -> path != 0 ? p -> path : p -> auto_path );
-	const bool scratch_free = ( xpath == 4 && p -> in_type == AVIRHIP_F32 &&
+	const bool scratch_free = ( !overlap && xpath == 4 && p -> in_type == AVIRHIP_F32 &&
 		p -> out_type == AVIRHIP_F32 && p -> ch == p -> io_ch &&
 		!p -> gamma && src_mem == AVIRHIP_MEM_DEVICE &&
 		dst_mem == AVIRHIP_MEM_DEVICE &&
@@ -774,13 +786,6 @@ static int exec_any( avirhip_plan* p, const void* src, int src_mem, void* dst,
 
 	const void* dsrc = src;
 	void* ddst = dst;
-	const size_t src_bytes = ( (size_t) ( p -> src_h - 1 ) * p -> src_stride +
-		(size_t) p -> src_w * p -> io_ch ) * dtype_size( p -> in_type );
-	const size_t row_bytes = (size_t) p -> new_stride *
-		dtype_size( p -> out_type );
-	const size_t dst_bytes = ( row1 > row0 ?
-		(size_t) ( row1 - row0 - 1 ) * row_bytes + (size_t) p -> new_w *
-		p -> io_ch * dtype_size( p -> out_type ) : 0 );
 
 	if( src_mem == AVIRHIP_MEM_HOST )
 	{
@@ -795,6 +800,26 @@ static int exec_any( avirhip_plan* p, const void* src, int src_mem, void* dst,
 
 		AVIRHIP_HIPCHECK( hipMemcpyAsync( p -> stage_src, src, src_bytes,
 			hipMemcpyHostToDevice, st ));
+		dsrc = p -> stage_src;
+	}
+
+	// NewBuf may alias SrcBuf (avir.h:4650-4652: allowed when the result is
+	// not larger). The reference survives that because it has consumed the
+	// source into FltBuf before it writes; the kernels here read the source
+	// while they write, so an overlapping device source is copied aside first.
+	if( overlap )
+	{
+		if( p -> stage_src_bytes < src_bytes )
+		{
+			void* q;
+			int rc = dev_alloc( p, src_bytes, &q );
+			if( rc != 0 ) return( rc );
+			p -> stage_src = q;
+			p -> stage_src_bytes = src_bytes;
+		}
+
+		AVIRHIP_HIPCHECK( hipMemcpyAsync( p -> stage_src, src, src_bytes,
+			hipMemcpyDeviceToDevice, st ));
 		dsrc = p -> stage_src;
 	}
 

@@ -554,6 +554,24 @@ def test_single_process_sharded_resize(force_replica, monkeypatch):
                                       dst.ctypes.data, 0, None, None) != 0
 
 
+def test_in_place_device_resize():
+    """NewBuf may alias SrcBuf when the result is not larger
+    (avir.h:4650-4652); with device buffers the library copies the
+    overlapping source aside first."""
+    import torch
+    for (sw, sh, nw, nh) in [(300, 200, 100, 67), (120, 90, 80, 60),
+                             (64, 48, 64, 48)]:
+        src = rb.lcg_f32((sh, sw, 4), seed=41)
+        want = _checker_avir(src, nw, nh, resbits=16)
+        buf = torch.from_numpy(src.reshape(-1).copy()).to("cuda:0")
+        r = avir_amd.CImageResizer(16)
+        out = buf[:nh * nw * 4]
+        r.resizeImage(buf, sw, sh, 0, out, nw, nh, 4, 0.0)
+        torch.cuda.synchronize()
+        _assert_same(out.cpu().numpy().reshape(nh, nw, 4), want,
+                     "in place %dx%d" % (sw, sh))
+
+
 def test_concurrent_calls_on_one_object():
     """The reference allows concurrent resizeImage() calls on one object
     (README.md:83-85). Calls that share a cached plan share its scratch
