@@ -21,10 +21,10 @@
 //           columns), R = 3 resize outputs per lane (lane stride R*K pixels is
 //           bank-conflict free for K = 3), T -> LDS, FIR7 along x, coalesced
 //           store into FltBuf. Waves are autonomous: no barrier in the loop.
-//   k_dnv   one lane per pixel column, R = 4 resize outputs per lane, rows
-//           streamed from FltBuf (L2/MALL resident: it is the small image) as
-//           coalesced 1-KiB wave loads; no LDS at all.
-//   k_dnvf  FIR7 along y over the (small) resized image.
+//   k_dnv   one lane per pixel column, 8 final rows per lane: the 14 resize
+//           rows they need accumulate in registers from FltBuf rows streamed
+//           as coalesced 1-KiB wave loads (L2/MALL resident: it is the small
+//           image), then the FIR7 along y runs over the registers; no LDS.
 
 #include "plan.h"
 #include <algorithm>
@@ -59,17 +59,10 @@ struct DnVParams
 {
 	DnAxisP A;
 	const float* src; long src_ss; // FltBuf
-	float* dst; long dst_ss;       // T1 [out_len][width]
+	float* dst; long dst_ss;       // destination band, row dst_row0 at dst
 	int width;                     // pixels per row
-	int g_lo, g_hi;                // output groups (of R rows) to process
-};
-
-struct DnFParams
-{
-	const float* src; float* dst; long ss; // both [rows][width] pixels
-	int width, rows;
-	int row_lo, row_hi, dst_row0;  // rows to store; row stored at dst
-	const float* fir;              // 4 taps
+	int g_lo, g_hi;                // output groups (of RO rows) to process
+	int row_lo, row_hi, dst_row0;  // rows to store
 };
 
 __device__ __forceinline__ int dn_clampi( int i, int hi )
@@ -249,10 +242,16 @@ __global__ void __launch_bounds__( 256 ) k_dnh( const DnHParams P )
 // V pass
 // ---------------------------------------------------------------------
 
-template< int K, int NT, int R >
+// RO final rows per lane: RO + 6 resize rows T[j0 .. j0+RO+5], j0 = g*RO - 3,
+// accumulate in registers from one pass over NT + (RO+5)*K source rows; the
+// correction filter then runs over them in registers too. T rows outside the
+// array are copies of the edge rows (the reference replicates the resize
+// OUTPUT there, avir.h:3227-3239), not resizes of replicated input.
+template< int K, int NT, int RO >
 __global__ void __launch_bounds__( 256 )
 __attribute__(( amdgpu_waves_per_eu( 4, 4 ))) k_dnv( const DnVParams P )
 {
+	constexpr int R = RO + 6;
 	const int tid = threadIdx.x;
 	const int lane = tid & 63;
 	const int wave = __builtin_amdgcn_readfirstlane( tid >> 6 );
@@ -264,7 +263,10 @@ __attribute__(( amdgpu_waves_per_eu( 4, 4 ))) k_dnv( const DnVParams P )
 		c[ t ] = P.A.coef[ t ];
 	}
 
-	const int g = P.g_lo + blockIdx.y * 4 + wave; // group of R output rows
+	const float f0 = P.A.coef[ NT ], f1 = P.A.coef[ NT + 1 ],
+		f2 = P.A.coef[ NT + 2 ], f3 = P.A.coef[ NT + 3 ];
+
+	const int g = P.g_lo + blockIdx.y * 4 + wave; // group of RO output rows
 	const int x = blockIdx.x * 64 + lane;
 
 	if( g >= P.g_hi )
@@ -272,8 +274,8 @@ __attribute__(( amdgpu_waves_per_eu( 4, 4 ))) k_dnv( const DnVParams P )
 		return;
 	}
 
-	const int j0 = g * R;
-	const int r0 = K * j0 + P.A.c0; // first input row of output j0
+	const int j0 = g * RO - 3;      // first resize row held
+	const int r0 = K * j0 + P.A.c0; // its first input row
 	const int row_b = (int) P.src_ss * 4;
 	const int xb = dn_clampi( x, P.width - 1 ) * 16;
 
@@ -348,42 +350,48 @@ __attribute__(( amdgpu_waves_per_eu( 4, 4 ))) k_dnv( const DnVParams P )
 		asm volatile( "" ::: "memory" );
 	} );
 
+	// resize rows outside [0, out_len) are copies of the edge rows
+	const int olast = P.A.out_len - 1;
+
+	dn_static_for< R - 1 >( [&]( auto rc )
+	{
+		constexpr int r = R - 2 - decltype( rc )::value; // R-2 .. 0
+
+		if( j0 + r < 0 )
+		{
+			acc[ r ] = acc[ r + 1 ];
+		}
+	} );
+
+	dn_static_for< R - 1 >( [&]( auto rc )
+	{
+		constexpr int r = 1 + decltype( rc )::value; // 1 .. R-1
+
+		if( j0 + r > olast )
+		{
+			acc[ r ] = acc[ r - 1 ];
+		}
+	} );
+
+	// correction FIR along y (doFilter, avir.h:3748-3866) and store
 	if( x < P.width )
 	{
-#pragma unroll
-		for( int r = 0; r < R; r++ )
+		dn_static_for< RO >( [&]( auto qc )
 		{
-			if( j0 + r < P.A.out_len )
+			constexpr int q = decltype( qc )::value;
+			const int y = j0 + 3 + q;
+
+			if( y >= P.row_lo && y < P.row_hi )
 			{
-				*(f4*) ( P.dst + (long) ( j0 + r ) * P.dst_ss + (long) x * 4 ) =
-					acc[ r ];
+				f4 a = f0 * acc[ q + 3 ];
+				a = a + f1 * ( acc[ q + 4 ] + acc[ q + 2 ]);
+				a = a + f2 * ( acc[ q + 5 ] + acc[ q + 1 ]);
+				a = a + f3 * ( acc[ q + 6 ] + acc[ q ]);
+				*(f4*) ( P.dst + (long) ( y - P.dst_row0 ) * P.dst_ss +
+					(long) x * 4 ) = a;
 			}
-		}
+		} );
 	}
-}
-
-__global__ void __launch_bounds__( 256 ) k_dnvf( const DnFParams P )
-{
-	const int x = blockIdx.x * 64 + ( threadIdx.x & 63 );
-	const int y = P.row_lo + blockIdx.y * 4 + ( threadIdx.x >> 6 );
-
-	if( x >= P.width || y >= P.row_hi )
-	{
-		return;
-	}
-
-	const int last = P.rows - 1;
-	const float* s = P.src + (long) x * 4;
-	auto T = [&]( const int r )
-	{
-		return( *(const f4*) ( s + (long) dn_clampi( r, last ) * P.ss ));
-	};
-
-	f4 a = P.fir[ 0 ] * T( y );
-	a = a + P.fir[ 1 ] * ( T( y + 1 ) + T( y - 1 ));
-	a = a + P.fir[ 2 ] * ( T( y + 2 ) + T( y - 2 ));
-	a = a + P.fir[ 3 ] * ( T( y + 3 ) + T( y - 3 ));
-	*(f4*) ( P.dst + (long) ( y - P.dst_row0 ) * P.ss + (long) x * 4 ) = a;
 }
 
 // ---------------------------------------------------------------------
@@ -400,7 +408,6 @@ struct DnData
 {
 	bool hok, vok;
 	DnAxis h, v;
-	float* t1;   // V pass: resized rows before the correction filter
 	std::vector< void* > allocs;
 };
 
@@ -475,7 +482,6 @@ int dn_prepare( avirhip_plan* p, void** out )
 
 	DnData* D = new DnData();
 	D -> hok = D -> vok = false;
-	D -> t1 = nullptr;
 	int rc = dn_match( p -> h, D, D -> h, D -> hok );
 
 	if( rc == 0 )
@@ -564,47 +570,26 @@ int dn_run_v( void* d, const float* flt, long flt_ss, int width, float* dst,
 		return( AVIRHIP_OK );
 	}
 
-	const int olen = D -> v.out_len;
-
-	if( D -> t1 == nullptr )
-	{
-		void* q = nullptr;
-		AVIRHIP_HIPCHECK( hipMalloc( &q, (size_t) olen * width * 16 ));
-		D -> allocs.push_back( q );
-		D -> t1 = (float*) q;
-	}
-
-	const int R = 4;
-	const int ta = std::max( row0 - 3, 0 );
-	const int tb = std::min( row1 + 3, olen ); // T1 rows [ta, tb)
-
+	const int RO = 8;
 	DnVParams P;
 	P.A = axis_params( D -> v );
 	P.src = flt; P.src_ss = flt_ss;
-	P.dst = D -> t1; P.dst_ss = (long) width * 4;
+	P.dst = dst; P.dst_ss = (long) width * 4;
 	P.width = width;
-	P.g_lo = ta / R;
-	P.g_hi = ( tb + R - 1 ) / R;
+	P.g_lo = row0 / RO;
+	P.g_hi = ( row1 - 1 ) / RO + 1;
+	P.row_lo = row0; P.row_hi = row1; P.dst_row0 = row0;
 	const dim3 grid(( width + 63 ) / 64, ( P.g_hi - P.g_lo + 3 ) / 4 );
 
 	if( D -> v.K == 3 )
 	{
-		hipLaunchKernelGGL(( k_dnv< 3, 38, 4 > ), grid, dim3( 256 ), 0, st, P );
+		hipLaunchKernelGGL(( k_dnv< 3, 38, 8 > ), grid, dim3( 256 ), 0, st, P );
 	}
 	else
 	{
-		hipLaunchKernelGGL(( k_dnv< 2, 24, 4 > ), grid, dim3( 256 ), 0, st, P );
+		hipLaunchKernelGGL(( k_dnv< 2, 24, 8 > ), grid, dim3( 256 ), 0, st, P );
 	}
 
-	AVIRHIP_HIPCHECK( hipGetLastError() );
-
-	DnFParams F;
-	F.src = D -> t1; F.dst = dst; F.ss = (long) width * 4;
-	F.width = width; F.rows = olen;
-	F.row_lo = row0; F.row_hi = row1; F.dst_row0 = row0;
-	F.fir = D -> v.d_coef + D -> v.NT;
-	const dim3 gf(( width + 63 ) / 64, ( row1 - row0 + 3 ) / 4 );
-	hipLaunchKernelGGL( k_dnvf, gf, dim3( 256 ), 0, st, F );
 	AVIRHIP_HIPCHECK( hipGetLastError() );
 	return( AVIRHIP_OK );
 }
