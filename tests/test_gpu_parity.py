@@ -135,6 +135,78 @@ def test_avir_exact_2x_marching_kernel(sw, sh, bits):
         _assert_same(got, want, "up2 %dx%d mode %d" % (sw, sh, mode))
 
 
+def test_avir_exact_2x_random_shapes_agree_with_generic_kernels():
+    """60 random exact-2x geometries (sizes around every strip / chunk / ring
+    boundary of the marching kernels): k_up2 and k_lanc2 against the generic
+    per-op kernels of the same library, and a subset against the reference."""
+    import torch
+    lib = abi.load()
+    rng = np.random.RandomState(20260925)
+    for i in range(60):
+        sw = int(rng.choice([rng.randint(1, 40), rng.randint(40, 400),
+                             rng.choice([31, 32, 33, 63, 64, 65, 127, 128, 129])]))
+        sh = int(rng.choice([rng.randint(1, 40), rng.randint(40, 400),
+                             rng.choice([7, 8, 9, 15, 16, 17, 61, 62, 63, 134, 135])]))
+        src = rb.lcg_f32((sh, sw, 4), seed=1000 + i)
+        dsrc = torch.from_numpy(src).to("cuda:0")
+        for obj in (avir_amd.CImageResizer(16), avir_amd.CLancIR()):
+            p = obj.plan(sw, sh, 2 * sw, 2 * sh, 4)
+            outs = []
+            if lib.avirhip_plan_set_path(p, abi.PATH_UP2) != 0:
+                # small frames: the planner picked a build mode whose plan is
+                # not the one the marching kernel implements
+                assert not isinstance(obj, avir_amd.CLancIR)
+                continue
+            for path in (abi.PATH_UP2, abi.PATH_GENERIC):
+                abi.check(lib.avirhip_plan_set_path(p, path), "set_path")
+                outs.append(obj.resize(dsrc, 2 * sw, 2 * sh).cpu().numpy())
+            abi.check(lib.avirhip_plan_set_path(p, 0), "set_path")
+            _assert_same(outs[0], outs[1], "%s %dx%d" % (type(obj).__name__,
+                                                          sw, sh))
+        if i % 10 == 0:
+            _assert_same(outs[0], rb.ref_lancir(src, 2 * sw, 2 * sh)
+                         if rb.have_ref() else rb.orc_lancir(src, 2 * sw, 2 * sh),
+                         "lancir vs reference %dx%d" % (sw, sh))
+
+
+def test_avir_random_geometries_fast_paths_agree_with_generic_kernels():
+    """120 random geometries, 1-4 channels, u8 and f32: whatever fast path the
+    library picks (tiles, integer-ratio passes, padded channels, raw integer
+    tile loads) against its own generic per-op kernels; every tenth against
+    the reference."""
+    import torch
+    lib = abi.load()
+    rng = np.random.RandomState(777)
+    for i in range(120):
+        sw, sh = int(rng.randint(8, 420)), int(rng.randint(8, 300))
+        kind = i % 4
+        if kind == 0:      # integer downsizing
+            nw, nh = max(4, sw // int(rng.choice([2, 3]))), \
+                max(4, sh // int(rng.choice([2, 3])))
+            sw, sh = nw * (sw // nw), nh * (sh // nh)
+        else:
+            nw, nh = int(rng.randint(4, 500)), int(rng.randint(4, 400))
+        ch = int(rng.choice([1, 2, 3, 4, 4]))
+        dt = np.uint8 if rng.rand() < 0.4 else np.float32
+        src = (rb.lcg_u8((sh, sw, ch), seed=i) if dt == np.uint8 else
+               rb.lcg_f32((sh, sw, ch), seed=i))
+        bits = int(rng.choice([8, 16]))
+        r = avir_amd.CImageResizer(bits)
+        code = rb._DT[np.dtype(dt)]
+        p = r.plan(sw, sh, nw, nh, ch, 0.0, None, code, code)
+        auto = lib.avirhip_plan_get_path(p)
+        got = r.resize(src, nw, nh)
+        if auto != abi.PATH_GENERIC:
+            abi.check(lib.avirhip_plan_set_path(p, abi.PATH_GENERIC), "set_path")
+            _assert_same(got, r.resize(src, nw, nh),
+                         "#%d %dx%d->%dx%d ch%d path %d" % (i, sw, sh, nw, nh,
+                                                            ch, auto))
+            abi.check(lib.avirhip_plan_set_path(p, 0), "set_path")
+        if i % 10 == 0:
+            _assert_same(got, _checker_avir(src, nw, nh, resbits=bits),
+                         "#%d vs reference" % i)
+
+
 def test_avir_exact_2x_other_io_types():
     """u8 / u16 / f64 I/O around the 2x kernel (pack + epilogue kernels)."""
     for tin, tout in [(np.uint8, np.uint8), (np.uint8, np.float32),
