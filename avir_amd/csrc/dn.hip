@@ -50,7 +50,10 @@ struct DnAxisP
 struct DnHParams
 {
 	DnAxisP A;
-	const float* src; long src_ss; // floats per source row
+	const void* src; long src_ss;  // elements per source row
+	int src_type, src_ch;          // AVIRHIP_F32 / 4: float RGBA rows (LDS-DMA);
+	                               // AVIRHIP_U8 / _U16, 1-4 channels: the
+	                               // caller's image, converted by the loader
 	float* dst; long dst_ss;       // FltBuf, floats per row
 	int row_lo, row_hi;            // source rows to process
 };
@@ -145,6 +148,38 @@ __device__ __forceinline__ void dn_accumulate( const float ( &c )[ NT ],
 // H pass
 // ---------------------------------------------------------------------
 
+// one row segment of an integer image -> float RGBA pixels in LDS (the cast
+// and the channel padding of packScanline, avir.h:2777-2840); all loads of
+// the segment are issued before the first conversion
+template< typename Tin, int NQ >
+__device__ __forceinline__ void dn_load_raw( const Tin* row, const int ch,
+	const int in0, const int in_len, const int nin, const int lane, f4* dst )
+{
+	Tin v[ NQ ][ 4 ];
+#pragma unroll
+	for( int q = 0; q < NQ; q++ )
+	{
+		const Tin* s = row + (long) dn_clampi( in0 + q * 64 + lane,
+			in_len - 1 ) * ch;
+#pragma unroll
+		for( int c = 0; c < 4; c++ )
+		{
+			v[ q ][ c ] = ( c < ch ? s[ c ] : (Tin) 0 );
+		}
+	}
+#pragma unroll
+	for( int q = 0; q < NQ; q++ )
+	{
+		if( q * 64 + lane < nin )
+		{
+			f4 o;
+			o.x = (float) v[ q ][ 0 ]; o.y = (float) v[ q ][ 1 ];
+			o.z = (float) v[ q ][ 2 ]; o.w = (float) v[ q ][ 3 ];
+			dst[ q * 64 + lane ] = o;
+		}
+	}
+}
+
 template< int K, int NT, int R >
 __global__ void __launch_bounds__( 256 ) k_dnh( const DnHParams P )
 {
@@ -180,21 +215,38 @@ __global__ void __launch_bounds__( 256 ) k_dnh( const DnHParams P )
 	const int X0 = blockIdx.x * SEG - 3;  // first resize output of this wave
 	const int in0 = K * X0 + P.A.c0;      // its first input pixel
 
-	// ---- source row segment -> LDS (lane-linear DMA, clamped columns)
-	const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
-		(void*) ( P.src + (long) y * P.src_ss ), 0, 0x7fffffff, 0x00020000 );
+	// ---- source row segment -> LDS (clamped columns): lane-linear DMA for
+	// float RGBA rows; integer rows are converted (and padded to 4 channels)
+	// here, so no float copy of the source image is ever made
+	if( P.src_type == AVIRHIP_F32 )
+	{
+		const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+			(void*) ( (const float*) P.src + (long) y * P.src_ss ), 0,
+			0x7fffffff, 0x00020000 );
 
 #pragma unroll
-	for( int q = 0; q < NDMA; q++ )
-	{
-		const int i = q * 64 + lane;
-
-		if(( q + 1 ) * 64 <= NIN || i < NIN )
+		for( int q = 0; q < NDMA; q++ )
 		{
-			const int gx = dn_clampi( in0 + i, P.A.in_len - 1 );
-			__builtin_amdgcn_raw_ptr_buffer_load_lds( rsrc,
-				(ldsptr) ( &sS[ wave ][ q * 64 ]), 16, gx * 16, 0, 0, 0 );
+			const int i = q * 64 + lane;
+
+			if(( q + 1 ) * 64 <= NIN || i < NIN )
+			{
+				const int gx = dn_clampi( in0 + i, P.A.in_len - 1 );
+				__builtin_amdgcn_raw_ptr_buffer_load_lds( rsrc,
+					(ldsptr) ( &sS[ wave ][ q * 64 ]), 16, gx * 16, 0, 0, 0 );
+			}
 		}
+	}
+	else
+	if( P.src_type == AVIRHIP_U8 )
+	{
+		dn_load_raw< uint8_t, NDMA >( (const uint8_t*) P.src + (long) y *
+			P.src_ss, P.src_ch, in0, P.A.in_len, NIN, lane, sS[ wave ]);
+	}
+	else
+	{
+		dn_load_raw< uint16_t, NDMA >( (const uint16_t*) P.src + (long) y *
+			P.src_ss, P.src_ch, in0, P.A.in_len, NIN, lane, sS[ wave ]);
 	}
 
 	asm volatile( "s_waitcnt vmcnt(0)" ::: "memory" );
@@ -528,8 +580,8 @@ static DnAxisP axis_params( const DnAxis& A )
 }
 
 // source rows [a, b) -> FltBuf rows [a, b)
-int dn_run_h( void* d, const float* src, long src_ss, float* flt, long flt_ss,
-	int a, int b, hipStream_t st )
+int dn_run_h( void* d, const void* src, int src_type, int src_ch, long src_ss,
+	float* flt, long flt_ss, int a, int b, hipStream_t st )
 {
 	const DnData* D = (const DnData*) d;
 
@@ -541,6 +593,7 @@ int dn_run_h( void* d, const float* src, long src_ss, float* flt, long flt_ss,
 	DnHParams P;
 	P.A = axis_params( D -> h );
 	P.src = src; P.src_ss = src_ss; P.dst = flt; P.dst_ss = flt_ss;
+	P.src_type = src_type; P.src_ch = src_ch;
 	P.row_lo = a; P.row_hi = b;
 	const int R = 3;
 	const int seg = 64 * R - 6;

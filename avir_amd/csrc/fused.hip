@@ -951,11 +951,8 @@ static int launch_tiles( avirhip_plan* p, const TileGeom& G, bool useh,
 // mode 3: fused; mode 2: two-pass.
 bool fused_takes_raw( const avirhip_plan* p, int mode )
 {
-	const FusedData* F = (const FusedData*) p -> fused;
-
-	// the integer-ratio H pass (dn.hip) loads float rows by DMA
-	return( F != nullptr && ( mode == 3 || ( mode == 2 &&
-		!dn_has_h( F -> dn ))));
+	// every loader of the tiled paths converts integer sources itself
+	return( p -> fused != nullptr && ( mode == 2 || mode == 3 ));
 }
 
 int fused_run( avirhip_plan* p, int mode, const void* src, int src_type,
@@ -1022,8 +1019,8 @@ int fused_run( avirhip_plan* p, int mode, const void* src, int src_type,
 	}
 
 	int rc = ( dn_has_h( F -> dn ) ?
-		dn_run_h( F -> dn, (const float*) src, src_stride, F -> fltbuf, dss,
-		a, b + 1, st ) :
+		dn_run_h( F -> dn, src, src_type, src_ch, src_stride, F -> fltbuf,
+		dss, a, b + 1, st ) :
 		launch_tiles( p, F -> hpass, true, false, src, src_type, src_ch,
 		src_stride, F -> fltbuf, dss, 0, a, b + 1, st ));
 

@@ -183,8 +183,8 @@ int dn_prepare( avirhip_plan* p, void** out );
 void dn_release( void* d );
 bool dn_has_h( const void* d );
 bool dn_has_v( const void* d );
-int dn_run_h( void* d, const float* src, long src_ss, float* flt, long flt_ss,
-	int a, int b, hipStream_t st );
+int dn_run_h( void* d, const void* src, int src_type, int src_ch, long src_ss,
+	float* flt, long flt_ss, int a, int b, hipStream_t st );
 int dn_run_v( void* d, const float* flt, long flt_ss, int width, float* dst,
 	int row0, int row1, hipStream_t st );
 
