@@ -112,6 +112,27 @@ __device__ __forceinline__ Taps load_taps( const float* p )
 	return( t );
 }
 
+// f0..3 and fe0..11 only (the transposed vertical phase needs no fo)
+struct TapsE
+{
+	f16 a, b;
+	__device__ __forceinline__ f2 pr( const f16& v, int i ) const
+		{ f2 r; r.x = v[ 2 * i ]; r.y = v[ 2 * i + 1 ]; return( r ); }
+	__device__ __forceinline__ f2 f( int i ) const { return( pr( a, i )); }
+	__device__ __forceinline__ f2 fe( int i ) const
+		{ return( i < 4 ? pr( a, 4 + i ) : pr( b, i - 4 )); }
+};
+
+__device__ __forceinline__ TapsE load_taps_e( const float* p )
+{
+	TapsE t;
+	asm volatile( "s_load_dwordx16 %0, %2, 0x0\n\t"
+		"s_load_dwordx16 %1, %2, 0x40\n\t"
+		"s_waitcnt lgkmcnt(0)"
+		: "=&s"( t.a ), "=&s"( t.b ) : "s"( p ) : "memory" );
+	return( t );
+}
+
 __device__ __forceinline__ f8 load_f8( const float* p )
 {
 	f8 t;
@@ -126,6 +147,17 @@ __device__ __forceinline__ f4 tmul( const f2 t, const f4 v )
 	const f2 lo = t * v.lo;
 	const f2 hi = t * v.hi;
 	return( __builtin_shufflevector( lo, hi, 0, 1, 2, 3 ));
+}
+
+// The thread index, recomputed from the lane id: per-lane addresses derived
+// from it inside a phase need no registers while the other phases run (the
+// compiler cannot see through the asm, so it cannot keep them alive either).
+__device__ __forceinline__ int fresh_tid( const int wave )
+{
+	int l;
+	asm volatile( "v_mbcnt_lo_u32_b32 %0, -1, 0\n\t"
+		"v_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"( l ));
+	return( l + wave * 64 );
 }
 
 __device__ __forceinline__ int clampi( int i, int hi )
@@ -159,6 +191,13 @@ __device__ __forceinline__ int clampi( int i, int hi )
 
 #define U2_TPL ( U2_RB * ( U2_TW / 2 ) + 8 ) // px per T plane, incl. the 128-B skew
 
+// VT ("vertical transposed"): when the bank phase is bit-symmetric (fo[t] ==
+// fe[11-t], true for every parameter preset), the product fe[t]*C2[m] belongs to
+// BOTH even(m+3-t) and odd(m-9+t). The vertical phase then keeps 24 running
+// sums per thread instead of a 13-row window: each new C2 row costs 12
+// multiplies + 24 adds instead of 24 + 24, every sum still receives its
+// products in ascending tap order from a +0 start => same bits.
+template< bool VT >
 __global__ void __launch_bounds__( U2_NT )
 __attribute__(( amdgpu_waves_per_eu( 4, 4 ))) k_up2( const Up2Params P )
 {
@@ -223,12 +262,16 @@ __attribute__(( amdgpu_waves_per_eu( 4, 4 ))) k_up2( const Up2Params P )
 		0x7fffffff, 0x00020000 );
 
 	f2 tw[ 8 ];  // ring of the last T values of this column   (slot u & 7)
-	f2 cw[ 16 ]; // ring of the last C2 values of this column  (slot u & 15)
+	f2 cw[ VT ? 1 : 16 ]; // ring of the last C2 values of this column (slot u & 15)
+	f2 ea[ VT ? 12 : 1 ]; // VT: running sums of the even output rows (slot q % 12)
+	f2 oa[ VT ? 12 : 1 ]; // VT: running sums of the odd output rows  (slot q % 12)
 
 #pragma unroll
 	for( int i = 0; i < 8; i++ ) tw[ i ] = (f2) 0.0f;
 #pragma unroll
-	for( int i = 0; i < 16; i++ ) cw[ i ] = (f2) 0.0f;
+	for( int i = 0; i < ( VT ? 1 : 16 ); i++ ) cw[ i ] = (f2) 0.0f;
+#pragma unroll
+	for( int i = 0; i < ( VT ? 12 : 1 ); i++ ) ea[ i ] = oa[ i ] = (f2) 0.0f;
 
 	// ---- source tiles: LDS-DMA (buffer_load_dwordx4 ... lds), HBM -> LDS
 	// without passing through registers. One instruction moves whole pixels
@@ -240,15 +283,18 @@ __attribute__(( amdgpu_waves_per_eu( 4, 4 ))) k_up2( const Up2Params P )
 	constexpr int NDMA = U2_RB / RPI;
 	static_assert( RPI >= 1 && U2_RB % RPI == 0, "S tile / DMA geometry" );
 
-	const int pr_r = tid / U2_SW;
-	const int pr_sx = clampi( qx0 - 9 + ( tid - pr_r * U2_SW ), P.sw - 1 );
-	const bool pr_on = ( tid < RPI * U2_SW );
-	const int pr_voff = pr_r * srow_b + pr_sx * 16;
 	typedef __attribute__(( address_space( 3 ))) void* ldsptr;
-	const int wave_b = __builtin_amdgcn_readfirstlane( tid >> 6 ) * 1024;
+	const int wave = __builtin_amdgcn_readfirstlane( tid >> 6 );
+	const int wave_b = wave * 1024;
 
 	auto prefetch = [&]( const int ub )
 	{
+		const int tid = ( VT ? fresh_tid( wave ) : (int) threadIdx.x );
+		const int pr_r = tid / U2_SW;
+		const int pr_sx = clampi( qx0 - 9 + ( tid - pr_r * U2_SW ), P.sw - 1 );
+		const bool pr_on = ( tid < RPI * U2_SW );
+		const int pr_voff = pr_r * srow_b + pr_sx * 16;
+
 		if( !pr_on )
 		{
 			return;
@@ -303,27 +349,33 @@ __attribute__(( amdgpu_waves_per_eu( 4, 4 ))) k_up2( const Up2Params P )
 		}
 	};
 
-	// One marching step of U2_RB source rows. R0 = ring phase of its first
-	// row (compile-time), so every ring access below is a fixed register.
-	auto march = [&]( auto R0C, const int ub, const bool more,
-		const bool more2 )
+	// the same without a lane condition (no control flow inside a vertical
+	// step: basic-block boundaries let the compiler sink accumulation chains
+	// across them): lanes past the tile's end redo its last pixel
+	auto h1_iter_nb = [&]( const int k, const f2 ( &h )[ 4 ])
 	{
-		constexpr int R0 = decltype( R0C )::value;
+		const int tid = fresh_tid( wave );
+		const int i = (( k + 1 ) * U2_NT <= CN ? tid + k * U2_NT :
+			min( tid + k * U2_NT, CN - 1 ));
+		const int r = (int) ((unsigned) i / U2_CW );
+		const f4* s = &sS[ i + r * ( U2_SW - U2_CW )];
+		const f4 s0 = s[ 0 ], s1 = s[ 1 ], s2 = s[ 2 ], s3 = s[ 3 ];
+		const f4 s4 = s[ 4 ], s5 = s[ 5 ], s6 = s[ 6 ];
+		f4 a = tmul( h[ 0 ], s3 );
+		a = a + tmul( h[ 1 ], s4 + s2 );
+		a = a + tmul( h[ 2 ], s5 + s1 );
+		a = a + tmul( h[ 3 ], s6 + s0 );
+		sC[ i ] = a;
+	};
 
-		// ======== interval B: H2 of this step, while the S tile of the next
-		// step lands in sS (nobody reads sS in this interval: H1 of this step
-		// ran inside the previous vertical phase). The DMA is complete
-		// (vmcnt) before the closing barrier.
-		if( more && U2_ON( 8 ))
-		{
-			prefetch( ub + U2_RB );
-		}
-
+	// ---- H2: T[2q], T[2q+1] from the 13-px window C[qq .. qq+12], one source
+	// pixel (two whole output pixels) per thread and iteration
+	auto h2_phase = [&]()
+	{
 		if( U2_ON( 2 ))
 		{
-			// ---- H2: T[2q], T[2q+1] from the 13-px window C[qq .. qq+12], one
-			// source pixel (two whole output pixels) per thread and iteration
 			const Taps H = load_taps( P.coef );
+			const int tid = ( VT ? fresh_tid( wave ) : (int) threadIdx.x );
 			const int qq = tid & ( U2_TW / 2 - 1 );
 
 			for( int r = tid / ( U2_TW / 2 ); r < U2_RB;
@@ -333,6 +385,43 @@ __attribute__(( amdgpu_waves_per_eu( 4, 4 ))) k_up2( const Up2Params P )
 				f4 e = (f4) 0.0f;
 				f4 o = (f4) 0.0f;
 				f4 w[ 13 ];
+
+				if( VT )
+				{
+					// the window in three parts of 5 + 4 + 4 pixels: the
+					// transposed vertical phase keeps 64 registers live
+					// across this phase
+#pragma unroll
+					for( int t = 0; t < 5; t++ ) w[ t ] = c[ t ];
+#pragma unroll
+					for( int t = 0; t < 4; t++ )
+					{
+						e = e + tmul( H.fe( t ), w[ t ]);
+						o = o + tmul( H.fo( t ), w[ t + 1 ]);
+					}
+
+					__builtin_amdgcn_sched_barrier( 0 );
+#pragma unroll
+					for( int t = 5; t < 9; t++ ) w[ t ] = c[ t ];
+#pragma unroll
+					for( int t = 4; t < 8; t++ )
+					{
+						e = e + tmul( H.fe( t ), w[ t ]);
+						o = o + tmul( H.fo( t ), w[ t + 1 ]);
+					}
+
+					__builtin_amdgcn_sched_barrier( 0 );
+#pragma unroll
+					for( int t = 9; t < 13; t++ ) w[ t ] = c[ t ];
+#pragma unroll
+					for( int t = 8; t < 12; t++ )
+					{
+						e = e + tmul( H.fe( t ), w[ t ]);
+						o = o + tmul( H.fo( t ), w[ t + 1 ]);
+					}
+				}
+				else
+				{
 #pragma unroll
 				for( int t = 0; t < 7; t++ ) w[ t ] = c[ t ];
 #pragma unroll
@@ -353,11 +442,32 @@ __attribute__(( amdgpu_waves_per_eu( 4, 4 ))) k_up2( const Up2Params P )
 					e = e + tmul( H.fe( t ), w[ t ]);
 					o = o + tmul( H.fo( t ), w[ t + 1 ]);
 				}
+				}
 
 				sT[ r * ( U2_TW / 2 ) + qq ] = e;
 				sT[ U2_TPL + r * ( U2_TW / 2 ) + qq ] = o;
 			}
 		}
+
+	};
+
+	// One marching step of U2_RB source rows. R0 = ring phase of its first
+	// row (compile-time), so every ring access below is a fixed register.
+	auto march = [&]( auto R0C, const int ub, const bool more,
+		const bool more2 )
+	{
+		constexpr int R0 = decltype( R0C )::value;
+
+		// ======== interval B: H2 of this step, while the S tile of the next
+		// step lands in sS (nobody reads sS in this interval: H1 of this step
+		// ran inside the previous vertical phase). The DMA is complete
+		// (vmcnt) before the closing barrier.
+		if( more && U2_ON( 8 ))
+		{
+			prefetch( ub + U2_RB );
+		}
+
+		h2_phase();
 
 		U2_SYNC();
 
@@ -493,24 +603,256 @@ __attribute__(( amdgpu_waves_per_eu( 4, 4 ))) k_up2( const Up2Params P )
 
 	U2_SYNC();
 
-	// the ring period is 16 rows: 16 / U2_RB marching steps per trip
-	for( int sb = 0; sb < nsteps; sb += 16 )
+	if constexpr( VT )
 	{
-#if U2_RB == 16
-		march( std::integral_constant< int, 0 >(), u0 + sb, sb + 16 < nsteps,
-			sb + 32 < nsteps );
-#else
-		march( std::integral_constant< int, 0 >(), u0 + sb, sb + 8 < nsteps,
-			sb + 16 < nsteps );
+		// ---- transposed vertical phase. Ring phase g of a row: tw slot g & 7,
+		// running sums even( q ) / odd( q ) in slot q % 12 with q counted so that
+		// the row of phase g carries C2 index m = g (mod 12): the product
+		// fe[t]*C2[m] goes to even( m+3-t ) and odd( m-9+t ); even( m+3 ) and
+		// odd( m+2 ) start on this row (0 + product), even( m-8 ) and
+		// odd( m-9 ) are complete after it: output rows y0 + 2 and y0 + 1.
+		// MODE 2: first 24 rows of the chunk (row j = g of the chunk: sums of
+		// rows before the chunk are neither updated nor stored). One code
+		// variant per ring phase: whether a row is stored is one scalar bit
+		// test, and lanes right of the image carry an out-of-range buffer
+		// offset (the hardware drops their stores).
+		static_assert( !VT || U2_RB == 8, "VT marching period is 3 x 8 rows" );
+		void* const dbase = (void*) ( P.dst +
+			(long) ( qy0 * 2 - P.dst_row0 ) * P.dst_ss );
 
-		if( sb + 8 >= nsteps )
+		auto vstep_t = [&]( auto R0C, auto MODEC, const int ub,
+			const bool more )
 		{
-			break;
-		}
+			constexpr int R0 = decltype( R0C )::value;
+			constexpr int MODE = decltype( MODEC )::value;
+			const TapsE V = load_taps_e( P.coef + 64 );
+			// the horizontal FIR taps stay in SGPRs too (16 + 4 pairs in all)
+			f2 hv[ 4 ];
+			{
+				const f8 HF = load_f8( P.coef );
+#pragma unroll
+				for( int t = 0; t < 4; t++ )
+				{
+					hv[ t ].x = HF[ t * 2 ];
+					hv[ t ].y = HF[ t * 2 + 1 ];
+				}
+			}
 
-		march( std::integral_constant< int, 8 >(), u0 + sb + 8,
-			sb + 16 < nsteps, sb + 24 < nsteps );
+			const int yb = ( ub - 9 ) * 2;
+			int so = ( yb - qy0 * 2 ) * drow_b; // scalar byte offset of row yb
+			const int tid = fresh_tid( wave );
+			const int hf = tid & 1;
+			const int col = tid >> 1;
+			const int xo = qx0 * 2 + col;
+			const int dlane_v = ( xo < P.nw ? ( xo * 4 + hf * 2 ) * 4 :
+				(int) 0x80000000u );
+			const f2* sT2 = (const f2*) sT +
+				((( col & 1 ) * U2_TPL + ( col >> 1 )) * 2 + hf );
+			// rows yb + 1 .. yb + 16 that lie in [ylo, yhi)
+			const int rlo = min( max( ylo - ( yb + 1 ), 0 ), 2 * U2_RB );
+			const int rhi = min( max( yhi - ( yb + 1 ), 0 ), 2 * U2_RB );
+			const unsigned rmask = __builtin_amdgcn_readfirstlane(
+				(( 1u << rhi ) - 1u ) & ~(( 1u << rlo ) - 1u ));
+
+			tw[ R0 & 7 ] = sT2[ 0 ];
+#pragma unroll
+			for( int rr = 0; rr < U2_RB; rr++ )
+			{
+				const int g = R0 + rr; // ring phase of this row (0..23)
+
+				if( rr + 1 < U2_RB )
+				{
+					tw[ ( g + 1 ) & 7 ] = sT2[ ( rr + 1 ) * U2_TW ];
+				}
+
+				f2 c2 = V.f( 0 ) * tw[ ( g - 3 ) & 7 ];
+				c2 = c2 + V.f( 1 ) * ( tw[ ( g - 2 ) & 7 ] +
+					tw[ ( g - 4 ) & 7 ]);
+				c2 = c2 + V.f( 2 ) * ( tw[ ( g - 1 ) & 7 ] +
+					tw[ ( g - 5 ) & 7 ]);
+				c2 = c2 + V.f( 3 ) * ( tw[ g & 7 ] + tw[ ( g - 6 ) & 7 ]);
+
+				if( U2_ON( 4 ))
+				{
+#pragma unroll
+					for( int t = 0; t < 12; t += 2 )
+					{
+						// in the chunk's first rows (MODE 2, row j = g): even
+						// sums wanted for t <= j - 6, odd sums for t >= 18 - j
+						const bool we0 = ( MODE != 2 || t <= g - 6 );
+						const bool wo0 = ( MODE != 2 || t >= 18 - g );
+						const bool we1 = ( MODE != 2 || t + 1 <= g - 6 );
+						const bool wo1 = ( MODE != 2 || t + 1 >= 18 - g );
+						f2 p0, p1;
+
+						if( we0 || wo0 ) p0 = V.fe( t ) * c2;
+						if( we1 || wo1 ) p1 = V.fe( t + 1 ) * c2;
+
+						__builtin_amdgcn_sched_barrier( 0 );
+
+						if( we0 )
+						{
+							f2& a = ea[ ( g + 3 - t + 24 ) % 12 ];
+							a = ( t == 0 ? (f2) 0.0f : a ) + p0;
+						}
+
+						if( wo0 )
+						{
+							f2& a = oa[ ( g + 3 + t ) % 12 ];
+							a = a + p0;
+						}
+
+						if( we1 )
+						{
+							f2& a = ea[ ( g + 2 - t + 24 ) % 12 ];
+							a = a + p1;
+						}
+
+						if( wo1 )
+						{
+							f2& a = oa[ ( g + 4 + t ) % 12 ];
+							a = ( t + 1 == 11 ? (f2) 0.0f : a ) + p1;
+						}
+
+						__builtin_amdgcn_sched_barrier( 0 );
+					}
+
+					// pin the 24 sums here: the instruction-selection DAG is
+					// free to postpone an add until its sum is next used (a
+					// row later), keeping the product alive instead -- that
+					// spilled ~300 registers
+					asm volatile( "" : "+v"( ea[ 0 ]), "+v"( ea[ 1 ]),
+						"+v"( ea[ 2 ]), "+v"( ea[ 3 ]), "+v"( ea[ 4 ]),
+						"+v"( ea[ 5 ]), "+v"( ea[ 6 ]), "+v"( ea[ 7 ]),
+						"+v"( ea[ 8 ]), "+v"( ea[ 9 ]), "+v"( ea[ 10 ]),
+						"+v"( ea[ 11 ]));
+					asm volatile( "" : "+v"( oa[ 0 ]), "+v"( oa[ 1 ]),
+						"+v"( oa[ 2 ]), "+v"( oa[ 3 ]), "+v"( oa[ 4 ]),
+						"+v"( oa[ 5 ]), "+v"( oa[ 6 ]), "+v"( oa[ 7 ]),
+						"+v"( oa[ 8 ]), "+v"( oa[ 9 ]), "+v"( oa[ 10 ]),
+						"+v"( oa[ 11 ]));
+
+					const f2 od = oa[ ( g + 3 ) % 12 ]; // odd( m-9 ): row y0 + 1
+					const f2 ed = ea[ ( g + 4 ) % 12 ]; // even( m-8 ): row y0 + 2
+
+					if( MODE != 2 || g >= 17 )
+					{
+						// bit k of rmask: row yb + 1 + k is stored by this item.
+						// No branches (they would let the compiler sink whole
+						// accumulation chains into them): an unwanted row goes
+						// through a zero-length view of the destination, whose
+						// range check drops the store.
+						if( U2_ON( 1 ) || od.x == 1234.5f )
+						{
+							__builtin_amdgcn_raw_buffer_store_b64(
+								__builtin_bit_cast( u2, od ),
+								__builtin_amdgcn_make_buffer_rsrc( dbase, 0,
+								( rmask & ( 1u << ( 2 * rr )) ? 0x7fffffff : 0 ),
+								0x00020000 ), dlane_v, so + drow_b, U2_STAUX );
+						}
+
+						if( U2_ON( 1 ) || ed.y == 1234.5f )
+						{
+							__builtin_amdgcn_raw_buffer_store_b64(
+								__builtin_bit_cast( u2, ed ),
+								__builtin_amdgcn_make_buffer_rsrc( dbase, 0,
+								( rmask & ( 2u << ( 2 * rr )) ? 0x7fffffff : 0 ),
+								0x00020000 ), dlane_v, so + 2 * drow_b, U2_STAUX );
+						}
+					}
+				}
+
+				so += 2 * drow_b;
+
+				// ---- H1 of the next step, one iteration
+				// (unconditional: after the chunk's last step it works on
+				// stale tiles and nobody reads its result)
+				if( rr % H1EVERY == 0 && rr / H1EVERY < NH1 && U2_ON( 2 ))
+				{
+					h1_iter_nb( rr / H1EVERY, hv );
+				}
+			}
+		};
+
+		typedef std::integral_constant< int, 0 > I0;
+		typedef std::integral_constant< int, 1 > I1;
+		typedef std::integral_constant< int, 2 > I2;
+		typedef std::integral_constant< int, 8 > I8;
+		typedef std::integral_constant< int, 16 > I16;
+
+		// one marching step: interval B = {DMA of the next S tile, H2 of this
+		// step}, interval A = {V of this step, H1 of the next} (see march)
+		auto march_t = [&]( auto R0C, auto RAMPC, const int sb )
+		{
+			const int ub = u0 + sb;
+			const bool more = ( sb + U2_RB < nsteps );
+
+			if( more && U2_ON( 8 ))
+			{
+				prefetch( ub + U2_RB );
+			}
+
+			h2_phase();
+			U2_SYNC();
+
+			if( decltype( RAMPC )::value )
+			{
+				vstep_t( R0C, I2(), ub, more );
+			}
+			else
+			{
+				vstep_t( R0C, I1(), ub, more );
+			}
+
+			U2_SYNC();
+		};
+
+		// the chunk's first 24 rows (nsteps >= 24: cq >= 6), then the period
+		// of 24 rows = 3 steps per trip
+		march_t( I0(), std::true_type(), 0 );
+		march_t( I8(), std::true_type(), 8 );
+		march_t( I16(), std::true_type(), 16 );
+
+		for( int sb = 24; sb < nsteps; sb += 24 )
+		{
+			march_t( I0(), std::false_type(), sb );
+
+			if( sb + 8 >= nsteps )
+			{
+				break;
+			}
+
+			march_t( I8(), std::false_type(), sb + 8 );
+
+			if( sb + 16 >= nsteps )
+			{
+				break;
+			}
+
+			march_t( I16(), std::false_type(), sb + 16 );
+		}
+	}
+	else
+	{
+		// the ring period is 16 rows: 16 / U2_RB marching steps per trip
+		for( int sb = 0; sb < nsteps; sb += 16 )
+		{
+#if U2_RB == 16
+			march( std::integral_constant< int, 0 >(), u0 + sb, sb + 16 < nsteps,
+				sb + 32 < nsteps );
+#else
+			march( std::integral_constant< int, 0 >(), u0 + sb, sb + 8 < nsteps,
+				sb + 16 < nsteps );
+
+			if( sb + 8 >= nsteps )
+			{
+				break;
+			}
+
+			march( std::integral_constant< int, 8 >(), u0 + sb + 8,
+				sb + 16 < nsteps, sb + 24 < nsteps );
 #endif
+		}
 	}
 
 #ifdef U2_DBG
@@ -585,6 +927,7 @@ struct Up2Data
 {
 	Up2Axis h, v;
 	float* d_coef;
+	bool vsym; // vertical bank phase bit-symmetric: fo[t] == fe[11-t]
 };
 
 int up2_prepare( avirhip_plan* p )
@@ -625,6 +968,14 @@ int up2_prepare( avirhip_plan* p )
 		AVIRHIP_HIPCHECK( hipMemcpy( q, hc, sizeof( hc ),
 			hipMemcpyHostToDevice ));
 		D -> d_coef = (float*) q;
+		D -> vsym = true;
+
+		for( int t = 0; t < 12; t++ )
+		{
+			D -> vsym &= ( memcmp( &D -> v.fo[ t ], &D -> v.fe[ 11 - t ],
+				sizeof( float )) == 0 );
+		}
+
 		p -> up2 = D;
 		p -> fused_ok |= 4;
 		p -> auto_path = 4;
@@ -750,14 +1101,25 @@ int up2_run( avirhip_plan* p, const float* src, long src_stride, float* dst,
 	{
 		int nb = -1;
 		(void) hipOccupancyMaxActiveBlocksPerMultiprocessor( &nb,
-			(const void*) k_up2, U2_NT, 0 );
+			(const void*) k_up2< false >, U2_NT, 0 );
 		fprintf( stderr, "k_up2: %d items (strips %d, cq %d), occupancy API "
 			"%d workgroups/CU\n", items, P.nstrips, P.cq, nb );
 	}
 
 	const char* pad = getenv( "AVIRHIP_UP2_LDSPAD" ); // residency experiments
-	hipLaunchKernelGGL( k_up2, dim3( items ), dim3( U2_NT ),
-		( pad != nullptr ? atoi( pad ) : 0 ), st, P );
+	const int ldspad = ( pad != nullptr ? atoi( pad ) : 0 );
+	static const bool novt = ( getenv( "AVIRHIP_UP2_NOVT" ) != nullptr );
+
+	if( U2_RB == 8 && D -> vsym && !novt )
+	{
+		hipLaunchKernelGGL( k_up2< U2_RB == 8 >, dim3( items ), dim3( U2_NT ),
+			ldspad, st, P );
+	}
+	else
+	{
+		hipLaunchKernelGGL( k_up2< false >, dim3( items ), dim3( U2_NT ),
+			ldspad, st, P );
+	}
 	AVIRHIP_HIPCHECK( hipGetLastError() );
 #ifdef U2_DBG
 	if( ++dclk_calls == 60 && items <= 8192 )
