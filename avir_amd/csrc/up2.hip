@@ -99,8 +99,19 @@ struct Taps
 	}
 };
 
-__device__ __forceinline__ Taps load_taps( const float* p )
+// (forces a wave-uniform pointer into an SGPR pair: under register pressure
+// the compiler may otherwise hand the asm a VGPR pair)
+__device__ __forceinline__ const float* sgpr_ptr( const float* p )
 {
+	const unsigned long long a = (unsigned long long) p;
+	const unsigned lo = __builtin_amdgcn_readfirstlane( (unsigned) a );
+	const unsigned hi = __builtin_amdgcn_readfirstlane( (unsigned) ( a >> 32 ));
+	return( (const float*) (( (unsigned long long) hi << 32 ) | lo ));
+}
+
+__device__ __forceinline__ Taps load_taps( const float* p0 )
+{
+	const float* const p = sgpr_ptr( p0 );
 	Taps t;
 	asm volatile( "s_load_dwordx16 %0, %4, 0x0\n\t"
 		"s_load_dwordx16 %1, %4, 0x40\n\t"
@@ -123,8 +134,9 @@ struct TapsE
 		{ return( i < 4 ? pr( a, 4 + i ) : pr( b, i - 4 )); }
 };
 
-__device__ __forceinline__ TapsE load_taps_e( const float* p )
+__device__ __forceinline__ TapsE load_taps_e( const float* p0 )
 {
+	const float* const p = sgpr_ptr( p0 );
 	TapsE t;
 	asm volatile( "s_load_dwordx16 %0, %2, 0x0\n\t"
 		"s_load_dwordx16 %1, %2, 0x40\n\t"
@@ -133,8 +145,9 @@ __device__ __forceinline__ TapsE load_taps_e( const float* p )
 	return( t );
 }
 
-__device__ __forceinline__ f8 load_f8( const float* p )
+__device__ __forceinline__ f8 load_f8( const float* p0 )
 {
+	const float* const p = sgpr_ptr( p0 );
 	f8 t;
 	asm volatile( "s_load_dwordx8 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)"
 		: "=&s"( t ) : "s"( p ) : "memory" );

@@ -297,6 +297,8 @@ def main():
 
     src_np = rb.lcg_f32((SRC_H, SRC_W, CH))  # SURVEY.md 8(c) generator
     src = torch.from_numpy(src_np).to(dev)
+    if os.environ.get("AVIRHIP_BENCH_FILL") == "zero":
+        src.zero_()  # power experiment only (the parity field then says false)
     dst = torch.empty((NEW_H, NEW_W, CH), dtype=torch.float32, device=dev)
 
     rz = avir_amd.CImageResizer(16)
