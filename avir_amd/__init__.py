@@ -33,6 +33,18 @@ def _is_torch(x):
     return type(x).__module__.startswith("torch")
 
 
+def _numel(x):
+    return int(x.numel()) if _is_torch(x) else int(x.size)
+
+
+def _need(x, n, what):
+    """A short buffer would become a silent out-of-bounds copy or device
+    write inside the library: refuse it here."""
+    if _numel(x) < n:
+        raise ValueError("%s holds %d elements, the call needs %d"
+                         % (what, _numel(x), n))
+
+
 def _buf(x):
     """-> (pointer, mem kind, dtype code, stream)"""
     if _is_torch(x):
@@ -74,15 +86,25 @@ class CImageResizerVars(abi.Vars):
 
 class CImageResizer(object):
     """avir::CImageResizer<> (avir.h:4609): `CImageResizer(aResBitDepth=8,
-    aSrcBitDepth=0, aParams=CImageResizerParamsDef())`."""
+    aSrcBitDepth=0, aParams=CImageResizerParamsDef())`. `aDitherer` stands
+    for the reference's third fpclass_def template parameter (avir.h:4569):
+    "def" = CImageResizerDithererDefINL, "errd" = CImageResizerDithererErrdINL
+    (README.md:135-142)."""
 
-    def __init__(self, aResBitDepth=8, aSrcBitDepth=0, aParams=None):
+    DITHERERS = {"def": abi.DITHER_DEF, "errd": abi.DITHER_ERRD}
+
+    def __init__(self, aResBitDepth=8, aSrcBitDepth=0, aParams=None,
+                 aDitherer="def"):
         self._lib = abi.load()
         self._h = C.c_void_p()
         abi.check(self._lib.avirhip_resizer_create(
             aResBitDepth, aSrcBitDepth,
             C.byref(aParams) if aParams is not None else None,
             C.byref(self._h)), "avirhip_resizer_create")
+        if aDitherer != "def":
+            abi.check(self._lib.avirhip_resizer_set_ditherer(
+                self._h, self.DITHERERS[aDitherer]),
+                "avirhip_resizer_set_ditherer")
 
     def __del__(self):
         h, self._h = getattr(self, "_h", None), None
@@ -95,6 +117,12 @@ class CImageResizer(object):
         the buffers' dtypes."""
         sp, sm, st, s1 = _buf(SrcBuf)
         dp, dm, dt, s2 = _buf(NewBuf)
+        if SrcWidth > 0 and SrcHeight > 0 and NewWidth > 0 and NewHeight > 0:
+            ss = SrcScanlineSize if SrcScanlineSize >= 1 else SrcWidth * ElCountIO
+            _need(SrcBuf, (SrcHeight - 1) * ss + SrcWidth * ElCountIO, "SrcBuf")
+            _need(NewBuf, NewWidth * NewHeight * ElCountIO, "NewBuf")
+        elif NewWidth > 0 and NewHeight > 0:
+            _need(NewBuf, NewWidth * NewHeight, "NewBuf")
         abi.check(self._lib.avirhip_resizer_resize(
             self._h, sp, sm, SrcWidth, SrcHeight, SrcScanlineSize, dp, dm,
             NewWidth, NewHeight, ElCountIO, float(k),
@@ -160,6 +188,13 @@ class CLancIR(object):
             return 0
         sp, sm, st, s1 = _buf(SrcBuf)
         dp, dm, dt, s2 = _buf(NewBuf)
+        if min(SrcWidth, SrcHeight, NewWidth, NewHeight, ElCount) > 0:
+            ss = aParams.SrcSSize if aParams is not None else 0
+            ns = aParams.NewSSize if aParams is not None else 0
+            ss = ss if ss >= 1 else SrcWidth * ElCount
+            ns = ns if ns >= 1 else NewWidth * ElCount
+            _need(SrcBuf, (SrcHeight - 1) * ss + SrcWidth * ElCount, "SrcBuf")
+            _need(NewBuf, (NewHeight - 1) * ns + NewWidth * ElCount, "NewBuf")
         rc = self._lib.avirhip_lancir_resize(
             self._h, sp, sm, SrcWidth, SrcHeight, dp, dm, NewWidth, NewHeight,
             ElCount, C.byref(aParams) if aParams is not None else None, st,

@@ -17,6 +17,7 @@ MEM_HOST, MEM_DEVICE = 0, 1
 STEP_FIR, STEP_UP_ZEROSTUFF, STEP_UP_FILTERED, STEP_RESIZE, STEP_RESIZE2 = range(5)
 STEP_NAMES = ["FIR", "UP_ZEROSTUFF", "UP_FILTERED", "RESIZE", "RESIZE2"]
 
+DITHER_DEF, DITHER_ERRD = 0, 1
 PATH_AUTO, PATH_GENERIC, PATH_TILED, PATH_FUSED, PATH_UP2 = 0, 1, 2, 3, 4
 
 _fp = C.POINTER(C.c_float)
@@ -59,7 +60,8 @@ class PlanDesc(C.Structure):
                 ("in_type", C.c_int32), ("out_type", C.c_int32),
                 ("h", Axis), ("v", Axis),
                 ("tr_mul", C.c_double), ("pk_out", C.c_double),
-                ("use_srgb_gamma", C.c_int32), ("alpha_index", C.c_int32)]
+                ("use_srgb_gamma", C.c_int32), ("alpha_index", C.c_int32),
+                ("dither", C.c_int32)]
 
 
 class LancirPos(C.Structure):
@@ -99,6 +101,17 @@ class Vars(C.Structure):
                 ("BuildMode", C.c_int32), ("RndSeed", C.c_int32)]
 
 
+class VarsBase(C.Structure):
+    _fields_ = [("ElCount", C.c_int32), ("ElCountIO", C.c_int32),
+                ("fppack", C.c_int32), ("fpalign", C.c_int32),
+                ("elalign", C.c_int32), ("packmode", C.c_int32),
+                ("BufLen", C.c_int32 * 2), ("BufOffs", C.c_int32 * 2),
+                ("k", C.c_double), ("o", C.c_double),
+                ("ResizeStep", C.c_int32), ("IsResize2", C.c_int32),
+                ("gamma_valid", C.c_int32),
+                ("InGammaMult", C.c_double), ("OutGammaMult", C.c_double)]
+
+
 class LancirParams(C.Structure):
     _fields_ = [("SrcSSize", C.c_int32), ("NewSSize", C.c_int32),
                 ("kx", C.c_double), ("ky", C.c_double),
@@ -128,12 +141,16 @@ PROTOTYPES = {
     "avirhip_vars_default": (None, [C.POINTER(Vars)]),
     "avirhip_resizer_create": (_I, [_I, _I, C.POINTER(Params), C.POINTER(_VP)]),
     "avirhip_resizer_destroy": (None, [_VP]),
+    "avirhip_resizer_set_ditherer": (_I, [_VP, _I]),
     "avirhip_resizer_build_desc": (_I, [_VP, _I, _I, _I, _I, _I, _I, _D,
                                         C.POINTER(Vars), _I, _I,
                                         C.POINTER(C.POINTER(PlanDesc))]),
     "avirhip_plan_desc_free": (None, [C.POINTER(PlanDesc)]),
     "avirhip_resizer_resize": (_I, [_VP, _VP, _I, _I, _I, _I, _VP, _I, _I, _I,
                                     _I, _D, C.POINTER(Vars), _I, _I, _VP]),
+    "avirhip_resizer_vars_base": (_I, [_VP, _I, _I, _I, _I, _I, _I, _D,
+                                       C.POINTER(Vars), _I, _I,
+                                       C.POINTER(VarsBase)]),
     "avirhip_resizer_get_plan": (_I, [_VP, _I, _I, _I, _I, _I, _I, _D,
                                       C.POINTER(Vars), _I, _I, C.POINTER(_VP)]),
     "avirhip_lancir_params_default": (None, [C.POINTER(LancirParams)]),

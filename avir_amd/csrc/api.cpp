@@ -559,8 +559,11 @@ static int run_generic( avirhip_plan* p, const float* src, long src_stride,
 static int exec_device( avirhip_plan* p, const void* src, void* dst,
 	int row0, int row1, hipStream_t st )
 {
-	int rc = ensure_scratch( p );
-	if( rc != 0 ) return( rc );
+	int rc;
+
+	// LANCIR: the exact-2x kernel needs no scratch; the generic kernels'
+	// intermediate is only allocated when they actually run
+	if( !p -> is_lancir && ( rc = ensure_scratch( p )) != 0 ) return( rc );
 
 	if( p -> is_lancir )
 	{
@@ -582,6 +585,8 @@ static int exec_device( avirhip_plan* p, const void* src, void* dst,
 				return( AVIRHIP_EUNSUPPORTED );
 			}
 		}
+
+		if(( rc = ensure_scratch( p )) != 0 ) return( rc );
 
 		return( launch_lancir_generic( p, src, dst, p -> resbuf, row0, row1,
 			st ));
@@ -682,6 +687,22 @@ static int exec_device( avirhip_plan* p, const void* src, void* dst,
 
 	if( rc != 0 ) return( rc );
 
+	if( !direct && p -> dither == AVIRHIP_DITHER_ERRD )
+	{
+		// recursive ditherer: whole frames only (exec_any refuses bands)
+		if( p -> errd_line == nullptr )
+		{
+			void* q;
+			if(( rc = dev_alloc( p, (size_t) 2 * p -> new_w * 4 *
+				sizeof( float ), &q )) != 0 ) return( rc );
+			p -> errd_line = (float*) q;
+		}
+
+		rc = launch_errd( fdst, dst, p -> out_type, p -> new_w, p -> new_h,
+			p -> io_ch, p -> ch, p -> tr_mul, p -> pk_out, p -> gamma,
+			p -> alpha_index, p -> errd_line, st );
+	}
+	else
 	if( !direct )
 	{
 		rc = launch_epilogue( fdst, dst, p -> out_type,
@@ -730,6 +751,14 @@ static int exec_any( avirhip_plan* p, const void* src, int src_mem, void* dst,
 		return( AVIRHIP_EINVAL );
 	}
 
+	if( !p -> is_lancir && p -> dither == AVIRHIP_DITHER_ERRD &&
+		( row0 != 0 || row1 != p -> new_h ))
+	{
+		set_error( "the error-diffusion ditherer is recursive over rows "
+			"(avir.h:4473-4480): row bands cannot be executed" );
+		return( AVIRHIP_EUNSUPPORTED );
+	}
+
 	hipStream_t st = (hipStream_t) stream;
 
 	// Calls on one plan share its scratch buffers: serialise them (the
@@ -749,7 +778,10 @@ static int exec_any( avirhip_plan* p, const void* src, int src_mem, void* dst,
 		(const char*) dst < (const char*) src + src_bytes );
 
 	const int xpath = ( p -> path != 0 ? p -> path : p -> auto_path );
-	const bool scratch_free = ( !overlap && xpath == 4 && p -> in_type == AVIRHIP_F32 &&
+	// (CLancIR is not thread-safe in the reference either, lancir.h:319-349:
+	// its plans always take the lock, and may allocate scratch under it)
+	const bool scratch_free = ( !p -> is_lancir && !overlap && xpath == 4 &&
+		p -> in_type == AVIRHIP_F32 &&
 		p -> out_type == AVIRHIP_F32 && p -> ch == p -> io_ch &&
 		!p -> gamma && src_mem == AVIRHIP_MEM_DEVICE &&
 		dst_mem == AVIRHIP_MEM_DEVICE &&
@@ -868,6 +900,7 @@ static avirhip_plan* new_plan()
 	p -> shard_src = nullptr; p -> shard_src_bytes = 0;
 	p -> tr_mul = 1.0; p -> pk_out = 0.0;
 	p -> gamma = 0; p -> alpha_index = -1; p -> d_srgb_tbl = nullptr;
+	p -> dither = AVIRHIP_DITHER_DEF; p -> errd_line = nullptr;
 	p -> ch = 0; p -> io_ch = 0;
 	p -> l_out_mul = 1.0f; p -> l_clamp = 0.0f; p -> l_unity = 1;
 	(void) hipGetDevice( &p -> device );
@@ -956,7 +989,22 @@ int avirhip_plan_create( const avirhip_plan_desc* d, avirhip_plan** out )
 	p -> in_type = d -> in_type; p -> out_type = d -> out_type;
 	p -> tr_mul = d -> tr_mul; p -> pk_out = d -> pk_out;
 	p -> gamma = ( d -> use_srgb_gamma ? 1 : 0 );
-	p -> alpha_index = ( d -> channels == 4 ? d -> alpha_index : -1 );
+	// the reference treats only AlphaIndex 0 and 3 of 4-channel pixels as an
+	// alpha channel (avir.h:2859/2874, 3002/3016); any other value gamma-
+	// converts all four channels
+	p -> alpha_index = ( d -> channels == 4 && ( d -> alpha_index == 0 ||
+		d -> alpha_index == 3 ) ? d -> alpha_index : -1 );
+
+	if( d -> dither != AVIRHIP_DITHER_DEF && d -> dither != AVIRHIP_DITHER_ERRD )
+	{
+		set_error( "unknown ditherer %d", d -> dither );
+		avirhip_plan_destroy( p );
+		return( AVIRHIP_EINVAL );
+	}
+
+	// float / double output skips the dither stage (avir.h:5002-5025)
+	p -> dither = ( d -> out_type == AVIRHIP_U8 || d -> out_type == AVIRHIP_U16 ?
+		d -> dither : AVIRHIP_DITHER_DEF );
 
 	int rc = lower_axis( d -> h, d -> src_w, d -> new_w, p -> h );
 
@@ -1050,6 +1098,7 @@ static int clone_plan( const avirhip_plan* s, int device, avirhip_plan** out )
 	q -> in_type = s -> in_type; q -> out_type = s -> out_type;
 	q -> tr_mul = s -> tr_mul; q -> pk_out = s -> pk_out;
 	q -> gamma = s -> gamma; q -> alpha_index = s -> alpha_index;
+	q -> dither = s -> dither;
 	q -> l_out_mul = s -> l_out_mul; q -> l_clamp = s -> l_clamp;
 	q -> l_unity = s -> l_unity;
 	q -> h = s -> h; q -> v = s -> v;     // host vectors; device pointers are

@@ -7,6 +7,7 @@
 #include "plan.h"
 #include "planner.h"
 #include <string.h>
+#include <algorithm>
 #include <map>
 #include <mutex>
 #include <tuple>
@@ -18,10 +19,12 @@ extern "C" int avirhip_resolve_mem( const void* ptr, int mem );
 struct avirhip_resizer
 {
 	AvirPlanner* planner;
+	int dither; // AVIRHIP_DITHER_*: fpclass::CDitherer of the mirrored object
 	std::mutex mtx;
 	typedef std::tuple< int, int, int, int, int, int, double, double, double,
-		int, int, int, int, int > Key;
+		int, int, int, int, int, int > Key;
 	std::map< Key, avirhip_plan* > cache;
+	std::map< Key, avirhip_vars_base > vbcache;
 };
 
 struct avirhip_lancir
@@ -106,7 +109,22 @@ int avirhip_resizer_create( int res_bit_depth, int src_bit_depth,
 
 	avirhip_resizer* r = new avirhip_resizer();
 	r -> planner = new AvirPlanner( res_bit_depth, src_bit_depth, P );
+	r -> dither = AVIRHIP_DITHER_DEF;
 	*out = r;
+	return( AVIRHIP_OK );
+}
+
+int avirhip_resizer_set_ditherer( avirhip_resizer* r, int dither )
+{
+	if( r == nullptr || ( dither != AVIRHIP_DITHER_DEF &&
+		dither != AVIRHIP_DITHER_ERRD ))
+	{
+		set_error( "set_ditherer: bad arguments" );
+		return( AVIRHIP_EINVAL );
+	}
+
+	std::lock_guard< std::mutex > lock( r -> mtx );
+	r -> dither = dither;
 	return( AVIRHIP_OK );
 }
 
@@ -146,6 +164,7 @@ int avirhip_resizer_build_desc( avirhip_resizer* r, int src_w, int src_h,
 		return( AVIRHIP_EINVAL );
 	}
 
+	S -> d.dither = r -> dither;
 	*out = &S -> d;
 	return( AVIRHIP_OK );
 }
@@ -177,7 +196,7 @@ int avirhip_resizer_get_plan( avirhip_resizer* r, int src_w, int src_h,
 
 	const avirhip_resizer::Key key( src_w, src_h, src_scanline_size, new_w,
 		new_h, el_count_io, k, V.ox, V.oy, V.BuildMode, in_type, out_type,
-		( V.UseSRGBGamma ? 1 : 0 ), V.AlphaIndex );
+		( V.UseSRGBGamma ? 1 : 0 ), V.AlphaIndex, r -> dither );
 
 	std::lock_guard< std::mutex > lock( r -> mtx );
 	auto it = r -> cache.find( key );
@@ -208,6 +227,163 @@ int avirhip_resizer_get_plan( avirhip_resizer* r, int src_w, int src_h,
 
 	r -> cache[ key ] = p;
 	*out = p;
+	return( AVIRHIP_OK );
+}
+
+// CImageResizerVarsBase after resizeImage() (avir.h:2473-2506), from the
+// vertical axis of the plan description. The coordinate pair (k, o) walks the
+// step list (an upsampling step scales both, a filter step divides them and
+// shifts o by its edge pixels); the two flip-flop scanline buffers must hold
+// the largest prefix and the largest length + suffix of every step that reads
+// or writes them (steps alternate between the buffers, the last one writes
+// the destination).
+static void fill_vars_base( const avirhip_plan_desc& d, double k0,
+	const avirhip_vars& V, avirhip_vars_base* out )
+{
+	avirhip_vars_base& B = *out;
+	memset( &B, 0, sizeof( B ));
+	B.ElCount = d.channels; B.ElCountIO = d.channels;
+	B.fppack = 1; B.fpalign = 4; B.elalign = 1; B.packmode = 0;
+
+	double k, o = V.oy;
+
+	if( k0 == 0.0 )
+	{
+		k = (double) d.src_h / d.new_h;
+		o += ( k - 1.0 ) * 0.5;
+	}
+	else
+	if( k0 > 0.0 )
+	{
+		k = k0;
+		o += ( k0 - 1.0 ) * 0.5;
+	}
+	else
+	{
+		k = -k0;
+	}
+
+	int maxpre[ 2 ] = { 0, 0 }, maxlen[ 2 ] = { 0, 0 };
+	const int n = d.v.n_steps;
+
+	for( int i = 0; i < n; i++ )
+	{
+		const avirhip_step& s = d.v.steps[ i ];
+		const int ib = i & 1;
+		const bool up = ( s.kind == AVIRHIP_STEP_UP_ZEROSTUFF ||
+			s.kind == AVIRHIP_STEP_UP_FILTERED );
+
+		if( up )
+		{
+			k *= s.resample_factor;
+			o *= s.resample_factor;
+		}
+		else
+		if( s.kind == AVIRHIP_STEP_FIR )
+		{
+			k /= s.resample_factor;
+			o /= s.resample_factor;
+			o += s.edge_pixel_count;
+		}
+		else
+		{
+			B.ResizeStep = i;
+			B.IsResize2 = ( s.kind == AVIRHIP_STEP_RESIZE2 ? 1 : 0 );
+		}
+
+		maxpre[ ib ] = std::max( maxpre[ ib ], s.in_prefix );
+		maxlen[ ib ] = std::max( maxlen[ ib ], s.in_len + s.in_suffix );
+
+		if( i + 1 < n )
+		{
+			const int ob = ib ^ 1;
+
+			if( up )
+			{
+				maxpre[ ob ] = std::max( maxpre[ ob ], s.out_prefix );
+				maxlen[ ob ] = std::max( maxlen[ ob ],
+					s.out_len + s.out_suffix );
+			}
+			else
+			{
+				maxlen[ ob ] = std::max( maxlen[ ob ], s.out_len );
+			}
+		}
+	}
+
+	for( int i = 0; i < 2; i++ )
+	{
+		B.BufLen[ i ] = ( maxpre[ i ] + maxlen[ i ]) * d.channels;
+		B.BufOffs[ i ] = maxpre[ i ] * d.channels;
+	}
+
+	B.k = k; B.o = o;
+	B.gamma_valid = ( V.UseSRGBGamma ? 1 : 0 );
+
+	if( V.UseSRGBGamma )
+	{
+		// avir.h:4744-4763
+		B.InGammaMult = ( d.in_type == AVIRHIP_U8 ? 1.0 / 255.0 :
+			( d.in_type == AVIRHIP_U16 ? 1.0 / 65535.0 : 1.0 ));
+
+		B.OutGammaMult = ( d.out_type == AVIRHIP_U8 ? 255.0 :
+			( d.out_type == AVIRHIP_U16 ? 65535.0 : 1.0 ));
+	}
+}
+
+int avirhip_resizer_vars_base( avirhip_resizer* r, int src_w, int src_h,
+	int src_scanline_size, int new_w, int new_h, int el_count_io, double k,
+	const avirhip_vars* vars, int in_type, int out_type,
+	avirhip_vars_base* out )
+{
+	if( r == nullptr || out == nullptr )
+	{
+		set_error( "vars_base: null argument" );
+		return( AVIRHIP_EINVAL );
+	}
+
+	const avirhip_vars& V = ( vars == nullptr ? g_defvars : *vars );
+
+	if( src_scanline_size < 1 )
+	{
+		src_scanline_size = src_w * el_count_io;
+	}
+
+	const avirhip_resizer::Key key( src_w, src_h, src_scanline_size, new_w,
+		new_h, el_count_io, k, V.ox, V.oy, V.BuildMode, in_type, out_type,
+		( V.UseSRGBGamma ? 1 : 0 ), V.AlphaIndex, 0 );
+
+	{
+		std::lock_guard< std::mutex > lock( r -> mtx );
+		auto it = r -> vbcache.find( key );
+
+		if( it != r -> vbcache.end() )
+		{
+			*out = it -> second;
+			return( AVIRHIP_OK );
+		}
+	}
+
+	avirhip_plan_desc* d = nullptr;
+	int rc = avirhip_resizer_build_desc( r, src_w, src_h, src_scanline_size,
+		new_w, new_h, el_count_io, k, &V, in_type, out_type, &d );
+
+	if( rc != 0 )
+	{
+		return( rc );
+	}
+
+	fill_vars_base( *d, k, V, out );
+	avirhip_plan_desc_free( d );
+
+	std::lock_guard< std::mutex > lock( r -> mtx );
+
+	if( r -> vbcache.size() >= 256 )
+	{
+		r -> vbcache.clear();
+	}
+
+	r -> vbcache[ key ] = *out;
 	return( AVIRHIP_OK );
 }
 

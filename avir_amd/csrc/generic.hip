@@ -668,6 +668,200 @@ int launch_epilogue( const float* res, void* dst, int out_type, long n,
 }
 
 // ---------------------------------------------------------------------
+// CImageResizerDithererErrdINL::dither (avir.h:4485-4525) + unpackScanline:
+// error diffusion, "recursive" in the reference's terms -- pixel p of row r
+// needs the quantisation noise of pixel p-1 of its own row and of pixels p-1,
+// p, p+1 of the row above. That is a wavefront with a lag of two pixels per
+// row: row r works on pixel t - 2r at step t. One workgroup, one thread per
+// row (up to 1024 rows in flight, passes of 1024 rows for taller frames), one
+// barrier per step; the diffusion value D[p-1] of a row is complete the
+// moment the row has processed pixel p and is handed to the row below through
+// a lane shuffle (LDS between waves, a global row between passes).
+//
+// Order of the float operations, per channel (all in the reference's order):
+//   v      = ( R[p] + D_above[p] ) + NoiseM1[p-1]          (no third term at p = 0)
+//   z0     = round( v * TrMulI ) * TrMul;  Noise = v - z0;  out = clamp( z0 )
+//   D[p-1] = (( 0 + Noise[p-2]*c3 ) + Noise[p-1]*c1 ) + Noise[p]*c2
+// with c1 = 0.364842, c2 = 0.207305, c3 = 0.063011 (float).
+// ---------------------------------------------------------------------
+
+template< typename Tout >
+__global__ void __launch_bounds__( 1024 ) k_errd( const float* res, Tout* dst,
+	const int w, const int h, const int ch, const int ech, const float tr_mul,
+	const float tr_muli, const float pk_out, const int gamma,
+	const int alpha_index, const float ogm, float* line )
+{
+	__shared__ float xch[ 2 ][ 16 ][ 4 ];
+	const int rr = threadIdx.x;
+	const int lane = rr & 63;
+	const int wave = rr >> 6;
+	const int nrows = blockDim.x;
+	const float c1 = (float) 0.364842;
+	const float c2 = (float) 0.207305;
+	const float c3 = (float) 0.063011;
+	int pass = 0;
+
+	for( int row0 = 0; row0 < h; row0 += nrows, pass++ )
+	{
+		const int row = row0 + rr;
+		const bool rowok = ( row < h );
+		// rows of this pass; its last row feeds the next pass through `line`
+		const int prow = min( nrows, h - row0 );
+		const bool feeds = ( rr == prow - 1 && row0 + nrows < h );
+		const float* const lin = line + (size_t) ( pass & 1 ) * w * 4;
+		float* const lout = line + (size_t) (( pass + 1 ) & 1 ) * w * 4;
+		const float* const rp = res + (size_t) row * w * ech;
+		Tout* const dp = dst + (size_t) row * w * ch;
+		float A[ 4 ], B[ 4 ], nm1[ 4 ], dout[ 4 ];
+#pragma unroll
+		for( int c = 0; c < 4; c++ )
+		{
+			A[ c ] = B[ c ] = nm1[ c ] = dout[ c ] = 0.0f;
+		}
+
+		const int nsteps = w + 2 * ( prow - 1 ) + 2;
+
+		for( int t = 0; t < nsteps; t++ )
+		{
+			const int p = t - 2 * rr;
+			float din[ 4 ];
+#pragma unroll
+			for( int c = 0; c < 4; c++ )
+			{
+				din[ c ] = __shfl_up( dout[ c ], 1 );
+			}
+
+			if( lane == 0 )
+			{
+#pragma unroll
+				for( int c = 0; c < 4; c++ )
+				{
+					if( wave > 0 )
+					{
+						din[ c ] = xch[( t + 1 ) & 1 ][ wave - 1 ][ c ];
+					}
+					else
+					if( pass > 0 && p >= 0 && p < w )
+					{
+						// written by another wave of this workgroup in the
+						// previous pass: read past the L1
+						din[ c ] = __hip_atomic_load( &lin[ p * 4 + c ],
+							__ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT );
+					}
+					else
+					{
+						din[ c ] = 0.0f;
+					}
+				}
+			}
+
+			if( rowok && p >= 0 && p < w )
+			{
+#pragma unroll
+				for( int c = 0; c < 4; c++ )
+				{
+					if( c < ch )
+					{
+						float v = rp[ (size_t) p * ech + c ];
+
+						if( gamma )
+						{
+							v = ( c == alpha_index ? v * ogm :
+								lin_to_srgb( v ) * ogm );
+						}
+
+						v = v + din[ c ];
+
+						if( p > 0 )
+						{
+							v = v + nm1[ c ];
+						}
+
+						const float z0 = avir_round( v * tr_muli ) * tr_mul;
+						const float noise = v - z0;
+						const float o = ( z0 < 0.0f ? 0.0f :
+							( z0 > pk_out ? pk_out : z0 ));
+
+						dp[ (size_t) p * ch + c ] = (Tout) o;
+						const float m1 = noise * c1;
+						dout[ c ] = A[ c ] + noise * c2; // D[p-1] complete
+						A[ c ] = B[ c ] + m1;            // D[p]: two of three
+						B[ c ] = 0.0f + noise * c3;      // D[p+1]: first term
+						nm1[ c ] = m1;
+					}
+				}
+			}
+			else
+			if( rowok && p == w )
+			{
+				// the last pixel's D has no right-hand neighbour term
+#pragma unroll
+				for( int c = 0; c < 4; c++ )
+				{
+					dout[ c ] = A[ c ];
+				}
+			}
+
+			if( feeds && p >= 1 && p <= w )
+			{
+#pragma unroll
+				for( int c = 0; c < 4; c++ )
+				{
+					lout[ ( p - 1 ) * 4 + c ] = dout[ c ];
+				}
+			}
+
+			if( lane == 63 )
+			{
+#pragma unroll
+				for( int c = 0; c < 4; c++ )
+				{
+					xch[ t & 1 ][ wave ][ c ] = dout[ c ];
+				}
+			}
+
+			__syncthreads();
+		}
+
+		__threadfence();
+		__syncthreads();
+	}
+}
+
+int launch_errd( const float* res, void* dst, int out_type, int w, int h,
+	int ch, int ech, double tr_mul, double pk_out, int gamma, int alpha_index,
+	float* line, hipStream_t st )
+{
+	const float trm = (float) tr_mul;
+	const float trmi = (float) ( 1.0 / tr_mul );
+	const float pk = (float) pk_out;
+	const float ogm = (float) ( out_type == AVIRHIP_U8 ? 255.0 : 65535.0 );
+	const int nt = std::min( 1024, (( h + 63 ) / 64 ) * 64 );
+
+	if( out_type == AVIRHIP_U8 )
+	{
+		hipLaunchKernelGGL(( k_errd< uint8_t > ), dim3( 1 ), dim3( nt ), 0, st,
+			res, (uint8_t*) dst, w, h, ch, ech, trm, trmi, pk, gamma,
+			alpha_index, ogm, line );
+	}
+	else
+	if( out_type == AVIRHIP_U16 )
+	{
+		hipLaunchKernelGGL(( k_errd< uint16_t > ), dim3( 1 ), dim3( nt ), 0, st,
+			res, (uint16_t*) dst, w, h, ch, ech, trm, trmi, pk, gamma,
+			alpha_index, ogm, line );
+	}
+	else
+	{
+		set_error( "error-diffusion dither: integer output types only" );
+		return( AVIRHIP_EINVAL );
+	}
+
+	AVIRHIP_HIPCHECK( hipGetLastError() );
+	return( AVIRHIP_OK );
+}
+
+// ---------------------------------------------------------------------
 // LANCIR generic kernels (lancir.h:541-710): vertical pass first into a float
 // intermediate [rows][SrcWidth], then the horizontal pass, then the output
 // stage. The dot product of one output pixel reproduces the lane structure of

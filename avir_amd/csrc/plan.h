@@ -100,6 +100,8 @@ struct avirhip_plan
 	int in_type, out_type;
 	double tr_mul, pk_out;
 	int gamma, alpha_index; // sRGB gamma stages (avir.h:2841-2930, 2982-3068)
+	int dither;             // AVIRHIP_DITHER_* (integer outputs only)
+	float* errd_line;       // error-diffusion rows handed between row blocks
 	float* d_srgb_tbl;      // 256-entry uint8 linearisation table (gamma plans)
 	avirhip::LAxis h, v;
 	// LANCIR
@@ -161,6 +163,9 @@ int launch_op( const LOp& op, int ch, bool x_is_idx, const Surf& in,
 int launch_epilogue( const float* res, void* dst, int out_type, long n,
 	double tr_mul, double pk_out, int gamma, int ch, int ech,
 	int alpha_index, hipStream_t st );
+int launch_errd( const float* res, void* dst, int out_type, int w, int h,
+	int ch, int ech, double tr_mul, double pk_out, int gamma, int alpha_index,
+	float* line, hipStream_t st );
 int launch_lancir_generic( const avirhip_plan* p, const void* src, void* dst,
 	float* tmp, int row0, int row1, hipStream_t st );
 

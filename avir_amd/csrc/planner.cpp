@@ -1615,6 +1615,7 @@ DescStore* AvirPlanner::build( int sw, int sh, int sstride, int nw, int nh,
 	d.pk_out = 0.0;
 	d.use_srgb_gamma = ( vars.UseSRGBGamma ? 1 : 0 );
 	d.alpha_index = vars.AlphaIndex;
+	d.dither = AVIRHIP_DITHER_DEF; // the front end fills in its ditherer
 
 	if( !outFloat )
 	{

@@ -88,6 +88,50 @@ int main()
 		printf( "lancir rc=%d %016llx\n", rc, (unsigned long long) fnv1a64(
 			OutF.data(), OutF.size() * sizeof( float )));
 
+		// error-diffusion dithering, exactly as the reference's README enables
+		// it (README.md:135-142)
+		typedef avir :: fpclass_def< float, float,
+			avir :: CImageResizerDithererErrdINL< float > > fpclass_dith;
+		avir :: CImageResizer< fpclass_dith > ImageResizerDith( 8 );
+		ImageResizerDith.resizeImage( In8.data(), 640, 480, 0, Out8.data(),
+			1024, 768, 3, 0 );
+
+		printf( "errd %016llx\n", (unsigned long long) fnv1a64( Out8.data(),
+			Out8.size() ));
+
+		// CImageResizerVarsBase is written back (avir.h:4663-4669)
+		avir :: CImageResizerVars Vars2;
+		Vars2.UseSRGBGamma = true;
+		std :: vector< uint8_t > OutS( 300 * 200 * 3 );
+		ImageResizer.resizeImage( In8.data(), 640, 480, 0, OutS.data(), 300,
+			200, 3, 0, &Vars2 );
+
+		printf( "vars %d %d %d %d %d %d %.17g %.17g %d %d %.17g %.17g\n",
+			Vars2.ElCount, Vars2.BufLen[ 0 ], Vars2.BufLen[ 1 ],
+			Vars2.BufOffs[ 0 ], Vars2.BufOffs[ 1 ], Vars2.ResizeStep, Vars2.k,
+			Vars2.o, (int) Vars2.IsResize2, Vars2.packmode, Vars2.InGammaMult,
+			Vars2.OutGammaMult );
+
+		// LANCIR's legacy 13-argument overload with padded scanlines
+		// (lancir.h:744-755)
+		std :: vector< float > InP( 480 * ( 640 * 4 + 8 ), 7.0f );
+		std :: vector< float > OutP( 300 * ( 400 * 4 + 12 ), 5.0f );
+
+		for( int y = 0; y < 480; y++ )
+		{
+			for( int x = 0; x < 640 * 4; x++ )
+			{
+				InP[ (size_t) y * ( 640 * 4 + 8 ) + x ] =
+					InF[ (size_t) y * 640 * 4 + x ];
+			}
+		}
+
+		const int rcl = LancIR.resizeImage( InP.data(), 640, 480, 640 * 4 + 8,
+			OutP.data(), 400, 300, 400 * 4 + 12, 4, 0.0, 0.0, 0.25, -0.5 );
+
+		printf( "lancir_legacy rc=%d %016llx\n", rcl, (unsigned long long)
+			fnv1a64( OutP.data(), OutP.size() * sizeof( float )));
+
 		// parameter error -> 0, like the reference
 		printf( "lancir_err rc=%d\n", LancIR.resizeImage( InF.data(), 640, 480,
 			OutF.data(), 0, 768, 4 ));

@@ -151,9 +151,31 @@ public:
 	}
 };
 
-/* avir.h:4569-4592 -- accepted for source compatibility. The device pipeline
- * is the interleaved float one, i.e. fpclass_def< float >. */
-template< typename afptype, typename afptypeatom = afptype >
+/* avir.h:4351-4427: the default ditherer (round + clamp, no dithering). Here
+ * a tag type: the rounding itself runs on the device (AVIRHIP_DITHER_DEF). */
+template< typename fptype >
+class CImageResizerDithererDefINL
+{
+public:
+	static bool isRecursive() { return( false ); }
+	static const int avirhip_dither = AVIRHIP_DITHER_DEF;
+};
+
+/* avir.h:4441-4537: error-diffusion dithering (AVIRHIP_DITHER_ERRD). */
+template< typename fptype >
+class CImageResizerDithererErrdINL :
+	public CImageResizerDithererDefINL< fptype >
+{
+public:
+	static bool isRecursive() { return( true ); }
+	static const int avirhip_dither = AVIRHIP_DITHER_ERRD;
+};
+
+/* avir.h:4569-4592. The device pipeline is the interleaved float one, i.e.
+ * fpclass_def< float >; `adith` selects the ditherer of integer outputs, as in
+ * the reference (README.md:135-142). */
+template< typename afptype, typename afptypeatom = afptype,
+	class adith = CImageResizerDithererDefINL< afptype > >
 class fpclass_def
 {
 public:
@@ -163,6 +185,7 @@ public:
 	static const int fpalign = sizeof( fptype );
 	static const int elalign = 1;
 	static const int packmode = 0;
+	typedef adith CDitherer;
 };
 
 namespace hipdetail {
@@ -212,6 +235,10 @@ public:
 
 		hipdetail :: check( avirhip_resizer_create( aResBitDepth,
 			aSrcBitDepth, &p, &h ), "avirhip_resizer_create" );
+
+		hipdetail :: check( avirhip_resizer_set_ditherer( h,
+			fpclass :: CDitherer :: avirhip_dither ),
+			"avirhip_resizer_set_ditherer" );
 	}
 
 	~CImageResizer()
@@ -251,6 +278,35 @@ public:
 			hipdetail :: dtype_of< Tin > :: v,
 			hipdetail :: dtype_of< Tout > :: v, nullptr ),
 			"avir::CImageResizer::resizeImage" );
+
+		if( aVars != nullptr && SrcWidth > 0 && SrcHeight > 0 &&
+			NewWidth > 0 && NewHeight > 0 )
+		{
+			// avir.h:4663-4669: the CImageResizerVarsBase part of *aVars is
+			// overwritten by the call
+			avirhip_vars_base b;
+
+			hipdetail :: check( avirhip_resizer_vars_base( h, SrcWidth,
+				SrcHeight, SrcScanlineSize, NewWidth, NewHeight, ElCountIO,
+				k, &v, hipdetail :: dtype_of< Tin > :: v,
+				hipdetail :: dtype_of< Tout > :: v, &b ),
+				"avirhip_resizer_vars_base" );
+
+			aVars -> BufLen[ 0 ] = b.BufLen[ 0 ];
+			aVars -> BufLen[ 1 ] = b.BufLen[ 1 ];
+			aVars -> BufOffs[ 0 ] = b.BufOffs[ 0 ];
+			aVars -> BufOffs[ 1 ] = b.BufOffs[ 1 ];
+			aVars -> k = b.k;
+			aVars -> o = b.o;
+			aVars -> ResizeStep = b.ResizeStep;
+			aVars -> IsResize2 = ( b.IsResize2 != 0 );
+
+			if( b.gamma_valid )
+			{
+				aVars -> InGammaMult = b.InGammaMult;
+				aVars -> OutGammaMult = b.OutGammaMult;
+			}
+		}
 	}
 
 private:

@@ -133,7 +133,17 @@ typedef struct avirhip_plan_desc {
 	 * is the vertical pass' in-place result and stays linear (avir.h:4956-4979). */
 	int32_t use_srgb_gamma;
 	int32_t alpha_index;
+	/* Ditherer of the integer-output stage -- the reference selects it with
+	 * the third template parameter of fpclass_def (avir.h:4569-4592):
+	 * AVIRHIP_DITHER_DEF = CImageResizerDithererDefINL (round + clamp,
+	 * avir.h:4351-4427), AVIRHIP_DITHER_ERRD = CImageResizerDithererErrdINL
+	 * (error diffusion along and across rows, avir.h:4441-4537; "recursive":
+	 * rows depend on each other, so such a plan cannot execute row bands). */
+	int32_t dither;
 } avirhip_plan_desc;
+
+#define AVIRHIP_DITHER_DEF 0
+#define AVIRHIP_DITHER_ERRD 1
 
 /* ---------------------------------------------------------------------
  * LANCIR plan description (CLancIR internals, lancir.h:840-1381).
@@ -183,8 +193,10 @@ const char* avirhip_last_error(void);
 const char* avirhip_version(void);
 
 /* Uploads an AVIR plan to the current device. The plan is immutable and may
- * be shared by threads; executions on one plan must use distinct streams or
- * be serialized by the caller (scratch is per plan). */
+ * be shared by threads: executions that need the plan's scratch buffers are
+ * serialised inside the library (a mutex on the host side, an event chain on
+ * the device side); device-resident float RGBA calls of the single-launch 2x
+ * kernels need no scratch and run concurrently. */
 int avirhip_plan_create(const avirhip_plan_desc* desc, avirhip_plan** out);
 int avirhip_lancir_plan_create(const avirhip_lancir_desc* desc,
 	avirhip_plan** out);
@@ -283,6 +295,10 @@ typedef struct avirhip_resizer avirhip_resizer;
 int avirhip_resizer_create(int res_bit_depth, int src_bit_depth,
 	const avirhip_params* params, avirhip_resizer** out);
 void avirhip_resizer_destroy(avirhip_resizer* r);
+/* Selects the ditherer class (fpclass::CDitherer, avir.h:4591) of every
+ * following resize of this object: AVIRHIP_DITHER_DEF (default) or
+ * AVIRHIP_DITHER_ERRD. */
+int avirhip_resizer_set_ditherer(avirhip_resizer* r, int dither);
 
 /* Host-only: runs the planner exactly as resizeImage() would for this call
  * and returns the plan description (owned by the library; release with
@@ -292,6 +308,27 @@ int avirhip_resizer_build_desc(avirhip_resizer* r, int src_w, int src_h,
 	const avirhip_vars* vars, int in_type, int out_type,
 	avirhip_plan_desc** out);
 void avirhip_plan_desc_free(avirhip_plan_desc* desc);
+
+/* The fields of CImageResizerVarsBase (avir.h:2473-2506) as resizeImage()
+ * leaves them in the caller's CImageResizerVars (avir.h:4663-4669): the
+ * vertical axis is planned last, so k, o, BufLen, BufOffs, ResizeStep and
+ * IsResize2 describe its step list. InGammaMult / OutGammaMult are only
+ * written when UseSRGBGamma is set (`gamma_valid`). */
+typedef struct avirhip_vars_base {
+	int32_t ElCount, ElCountIO, fppack, fpalign, elalign, packmode;
+	int32_t BufLen[2], BufOffs[2];
+	double k, o;
+	int32_t ResizeStep, IsResize2;
+	int32_t gamma_valid;
+	double InGammaMult, OutGammaMult;
+} avirhip_vars_base;
+
+/* Host-only (no GPU needed): what resizeImage() with these arguments writes
+ * back into *aVars. */
+int avirhip_resizer_vars_base(avirhip_resizer* r, int src_w, int src_h,
+	int src_scanline_size, int new_w, int new_h, int el_count_io, double k,
+	const avirhip_vars* vars, int in_type, int out_type,
+	avirhip_vars_base* out);
 
 /* resizeImage<Tin,Tout>(), avir.h:4680-4684. Plans are cached per geometry
  * inside the resizer. Zero-sized source => destination zero-filled

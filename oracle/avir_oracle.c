@@ -11,7 +11,8 @@
  *
  * Parity: PINNED against oracle/_ref (the real reference) and the golden
  * hashes of SURVEY.md 8(c) by tests/test_oracle.py. The sRGB gamma stages are
- * restated too; the error-diffusion ditherer is not (out of scope).
+ * restated too, and so is the error-diffusion ditherer
+ * (CImageResizerDithererErrdINL, avir.h:4441-4537; oracle_set_dither).
  */
 #include "oracle.h"
 #include <math.h>
@@ -1787,6 +1788,16 @@ void oracle_set_gamma( int use, int alpha_index )
 	g_alpha = alpha_index;
 }
 
+static int g_dither = 0;
+
+/* Ditherer class of the following oracle_avir_resize() calls: 0 =
+ * CImageResizerDithererDefINL (rounding only), 1 =
+ * CImageResizerDithererErrdINL (error diffusion), avir.h:4351-4537. */
+void oracle_set_dither( int kind )
+{
+	g_dither = kind;
+}
+
 /* pow24_sRGB, avir.h:162-175: double arithmetic from a float argument. */
 static double srgb_pow24( double x )
 {
@@ -2221,6 +2232,65 @@ int oracle_avir_resize( const void* src, int sw, int sh, int sstride,
 
 			pkout = (float) pkout0;
 
+			if( g_dither == 1 )
+			{
+				/* CImageResizerDithererErrdINL::dither, avir.h:4485-4525:
+				 * rows in order, one diffusion row `dith` of LenE + ElCount
+				 * floats (pointer past the first ElCount) kept between them */
+				const float trmul = (float) trmul0;
+				const float trmuli = (float) ( 1.0 / trmul0 );
+				const int lene = neww_e;
+				float* const dith0 = (float*) calloc( (size_t) lene + ch,
+					sizeof( float ));
+				float* const dith = dith0 + ch;
+				int y;
+
+				for( y = 0; y < nh; y++ )
+				{
+					float* const rs = &resbuf[ (size_t) y * lene ];
+
+					for( j = 0; j < lene; j++ )
+					{
+						rs[ j ] += dith[ j ];
+						dith[ j ] = 0.0f;
+					}
+
+					for( j = 0; j < lene - ch; j++ )
+					{
+						const float z0 = avir_round( rs[ j ] * trmuli ) * trmul;
+						const float noise = rs[ j ] - z0;
+						const float noisem1 = noise * (float) 0.364842;
+						rs[ j ] = ( z0 < 0.0f ? 0.0f :
+							( z0 > pkout ? pkout : z0 ));
+
+						rs[ j + ch ] += noisem1;
+						dith[ j - ch ] += noise * (float) 0.207305;
+						dith[ j ] += noisem1;
+						dith[ j + ch ] += noise * (float) 0.063011;
+					}
+
+					while( j < lene )
+					{
+						const float z0 = avir_round( rs[ j ] * trmuli ) * trmul;
+						const float noise = rs[ j ] - z0;
+						rs[ j ] = ( z0 < 0.0f ? 0.0f :
+							( z0 > pkout ? pkout : z0 ));
+
+						dith[ j - ch ] += noise * (float) 0.207305;
+						dith[ j ] += noise * (float) 0.364842;
+						j++;
+					}
+
+					for( j = 0; j < lene; j++ )
+					{
+						store_out( dst, (size_t) y * lene + j, out_type,
+							rs[ j ]);
+					}
+				}
+
+				free( dith0 );
+			}
+			else
 			if( trmul0 == 1.0 )
 			{
 				for( j = 0; j < nh * neww_e; j++ )

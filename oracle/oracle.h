@@ -41,6 +41,9 @@ int oracle_avir_resize( const void* src, int sw, int sh, int sstride,
 /* CImageResizerVars::UseSRGBGamma / AlphaIndex (avir.h:2526-2527) of the
  * following oracle_avir_resize() calls; default off / -1. */
 void oracle_set_gamma( int use, int alpha_index );
+/* 0 = CImageResizerDithererDefINL, 1 = CImageResizerDithererErrdINL
+ * (avir.h:4351-4537) for the following oracle_avir_resize() calls. */
+void oracle_set_dither( int kind );
 
 /* The regenerated uint8_t linearisation table (avir.h:229-291). */
 void oracle_srgb_u8_table( float* tbl );

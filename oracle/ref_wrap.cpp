@@ -148,6 +148,9 @@ int doResize( const void* src, int sw, int sh, int sstride, void* dst,
 
 typedef avir::CImageResizer< avir::fpclass_def< float > > RDef;
 typedef avir::CImageResizer< avir::fpclass_float4 > RF4;
+/* README.md:135-142: the error-diffusion ditherer */
+typedef avir::CImageResizer< avir::fpclass_def< float, float,
+	avir::CImageResizerDithererErrdINL< float > > > RErrd;
 #if defined( REF_SIMD ) && defined( __AVX__ )
 typedef avir::CImageResizer< avir::fpclass_float8_dil > RF8;
 #endif
@@ -284,7 +287,8 @@ extern "C" {
 /* avir::CImageResizer<fpclass>::resizeImage<Tin,Tout>() on the CPU.
  * variant 0 = fpclass_def<float> (the parity oracle), 1 = fpclass_float4
  * (SSE), 2 = fpclass_float8_dil (AVX, de-interleaved; only in the REF_SIMD
- * speed build, which is a CPU-baseline timing aid and not a parity oracle). */
+ * speed build, which is a CPU-baseline timing aid and not a parity oracle),
+ * 3 = fpclass_def<float,float,CImageResizerDithererErrdINL<float>>. */
 /* UseSRGBGamma / AlphaIndex for subsequent ref_avir_resize() calls. */
 void ref_set_gamma( int use, int alpha_index )
 {
@@ -302,6 +306,44 @@ void ref_srgb_u8_table( float* out )
 	}
 }
 
+/* The CImageResizerVarsBase fields resizeImage<uint8_t|float, same>() leaves
+ * in *aVars (avir.h:4663-4669), for checking the product's write-back:
+ * out[0..13] = ElCount, ElCountIO, fppack, fpalign, elalign, packmode,
+ * BufLen[0..1], BufOffs[0..1], k, o, ResizeStep, IsResize2; out[14..15] =
+ * InGammaMult, OutGammaMult (only meaningful with gamma). */
+int ref_avir_vars_base( int sw, int sh, int nw, int nh, int ch, double k,
+	int is_u8, int resbits, double ox, double oy, int build_mode, int gamma,
+	double* out )
+{
+	RDef r( resbits );
+	avir::CImageResizerVars V;
+	V.ox = ox; V.oy = oy; V.BuildMode = build_mode;
+	V.UseSRGBGamma = ( gamma != 0 );
+	V.InGammaMult = -1.0; V.OutGammaMult = -1.0;
+
+	if( is_u8 )
+	{
+		std::vector< uint8_t > a( (size_t) sw * sh * ch, 7 ),
+			b( (size_t) nw * nh * ch );
+		r.resizeImage( a.data(), sw, sh, 0, b.data(), nw, nh, ch, k, &V );
+	}
+	else
+	{
+		std::vector< float > a( (size_t) sw * sh * ch, 0.5f ),
+			b( (size_t) nw * nh * ch );
+		r.resizeImage( a.data(), sw, sh, 0, b.data(), nw, nh, ch, k, &V );
+	}
+
+	out[ 0 ] = V.ElCount; out[ 1 ] = V.ElCountIO; out[ 2 ] = V.fppack;
+	out[ 3 ] = V.fpalign; out[ 4 ] = V.elalign; out[ 5 ] = V.packmode;
+	out[ 6 ] = V.BufLen[ 0 ]; out[ 7 ] = V.BufLen[ 1 ];
+	out[ 8 ] = V.BufOffs[ 0 ]; out[ 9 ] = V.BufOffs[ 1 ];
+	out[ 10 ] = V.k; out[ 11 ] = V.o; out[ 12 ] = V.ResizeStep;
+	out[ 13 ] = V.IsResize2; out[ 14 ] = V.InGammaMult;
+	out[ 15 ] = V.OutGammaMult;
+	return( 0 );
+}
+
 int ref_avir_resize( const void* src, int sw, int sh, int sstride, void* dst,
 	int nw, int nh, int ch, double k, int in_type, int out_type, int resbits,
 	int srcbits, const double* params, double ox, double oy, int build_mode,
@@ -315,6 +357,13 @@ int ref_avir_resize( const void* src, int sw, int sh, int sstride, void* dst,
 			threads ));
 	}
 #endif
+
+	if( variant == 3 )
+	{
+		return( doResize< RErrd >( src, sw, sh, sstride, dst, nw, nh, ch, k,
+			in_type, out_type, resbits, srcbits, params, ox, oy, build_mode,
+			threads ));
+	}
 
 	if( variant == 1 )
 	{

@@ -84,6 +84,11 @@ def ref():
             C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double,
             C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double),
             C.c_double, C.c_double, C.c_int]
+        lib.ref_avir_vars_base.restype = C.c_int
+        lib.ref_avir_vars_base.argtypes = [
+            C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_int,
+            C.c_int, C.c_double, C.c_double, C.c_int, C.c_int,
+            C.POINTER(C.c_double)]
         lib.ref_avir_plan_free.restype = None
         lib.ref_avir_plan_free.argtypes = [C.POINTER(abi.PlanDesc)]
         lib.ref_lancir_plan_dump.restype = C.POINTER(abi.LancirDesc)
@@ -110,6 +115,8 @@ def orc():
             C.POINTER(C.c_int), C.POINTER(C.c_int)]
         lib.oracle_set_gamma.restype = None
         lib.oracle_set_gamma.argtypes = [C.c_int, C.c_int]
+        lib.oracle_set_dither.restype = None
+        lib.oracle_set_dither.argtypes = [C.c_int]
         lib.oracle_srgb_u8_table.restype = None
         lib.oracle_srgb_u8_table.argtypes = [C.c_void_p]
         lib.oracle_lancir_resize.restype = C.c_int
@@ -165,10 +172,13 @@ def _avir_call(fn, extra, src, nw, nh, k, out_dtype, resbits, srcbits, params,
 
 def ref_avir(src, nw, nh, k=0.0, out_dtype=None, resbits=8, srcbits=0,
              params=None, ox=0.0, oy=0.0, build_mode=-1, threads=1, variant=0,
-             sstride=0, gamma=False, alpha=-1):
+             sstride=0, gamma=False, alpha=-1, errd=False):
     """avir::CImageResizer<>::resizeImage on the CPU; src is (H, W, C).
-    gamma/alpha = CImageResizerVars::UseSRGBGamma / AlphaIndex."""
+    gamma/alpha = CImageResizerVars::UseSRGBGamma / AlphaIndex; errd = the
+    fpclass with CImageResizerDithererErrdINL (README.md:135-142)."""
     out_dtype = src.dtype if out_dtype is None else out_dtype
+    if errd:
+        variant = 3
     ref().ref_set_gamma(1 if gamma else 0, alpha)
     try:
         rc, dst = _avir_call(ref().ref_avir_resize, (threads, variant), src,
@@ -182,10 +192,11 @@ def ref_avir(src, nw, nh, k=0.0, out_dtype=None, resbits=8, srcbits=0,
 
 def orc_avir(src, nw, nh, k=0.0, out_dtype=None, resbits=8, srcbits=0,
              params=None, ox=0.0, oy=0.0, build_mode=-1, sstride=0,
-             return_modes=False, gamma=False, alpha=-1):
+             return_modes=False, gamma=False, alpha=-1, errd=False):
     out_dtype = src.dtype if out_dtype is None else out_dtype
     mh, mv = C.c_int(-9), C.c_int(-9)
     orc().oracle_set_gamma(1 if gamma else 0, alpha)
+    orc().oracle_set_dither(1 if errd else 0)
     try:
         rc, dst = _avir_call(orc().oracle_avir_resize,
                              (C.byref(mh), C.byref(mv)), src, nw, nh, k,
@@ -193,35 +204,50 @@ def orc_avir(src, nw, nh, k=0.0, out_dtype=None, resbits=8, srcbits=0,
                              build_mode, sstride)
     finally:
         orc().oracle_set_gamma(0, -1)
+        orc().oracle_set_dither(0)
     assert rc == 0, rc
     if return_modes:
         return dst, (mh.value, mv.value)
     return dst
 
 
-def _lancir_call(fn, src, nw, nh, out_dtype, kx, ky, ox, oy, la):
+def _lancir_call(fn, src, nw, nh, out_dtype, kx, ky, ox, oy, la, spad=0,
+                 npad=0):
+    """spad / npad: extra elements per source / destination row
+    (CLancIRParams::SrcSSize / NewSSize = width * channels + pad,
+    lancir.h:260-307). The padding is filled with a sentinel; the
+    destination's must survive the call."""
     src = np.ascontiguousarray(src)
     sh, sw, ch = src.shape
     out_dtype = np.dtype(src.dtype if out_dtype is None else out_dtype)
-    dst = np.zeros((nh, nw, ch), out_dtype)
+    ss = sw * ch + spad if spad else 0
+    ns = nw * ch + npad if npad else 0
+    if spad:
+        buf = np.full((sh, ss), 77, src.dtype)
+        buf[:, :sw * ch] = src.reshape(sh, sw * ch)
+        src = buf
+    dst = np.full((nh, ns if npad else nw * ch), 55, out_dtype)
     rc = fn(src.ctypes.data, sw, sh, dst.ctypes.data, nw, nh, ch,
-            _DT[src.dtype], _DT[out_dtype], 0, 0, float(kx), float(ky),
+            _DT[src.dtype], _DT[out_dtype], ss, ns, float(kx), float(ky),
             float(ox), float(oy), float(la))
+    if npad:
+        assert (dst[:, nw * ch:] == 55).all(), "row padding overwritten"
+    dst = np.ascontiguousarray(dst[:, :nw * ch]).reshape(nh, nw, ch)
     return rc, dst
 
 
 def ref_lancir(src, nw, nh, out_dtype=None, kx=0.0, ky=0.0, ox=0.0, oy=0.0,
-               la=3.0):
+               la=3.0, spad=0, npad=0):
     rc, dst = _lancir_call(ref().ref_lancir_resize, src, nw, nh, out_dtype,
-                           kx, ky, ox, oy, la)
+                           kx, ky, ox, oy, la, spad, npad)
     assert rc == nh, rc
     return dst
 
 
 def orc_lancir(src, nw, nh, out_dtype=None, kx=0.0, ky=0.0, ox=0.0, oy=0.0,
-               la=3.0):
+               la=3.0, spad=0, npad=0):
     rc, dst = _lancir_call(orc().oracle_lancir_resize, src, nw, nh, out_dtype,
-                           kx, ky, ox, oy, la)
+                           kx, ky, ox, oy, la, spad, npad)
     assert rc == nh, rc
     return dst
 

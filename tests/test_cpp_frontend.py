@@ -40,3 +40,22 @@ def test_reference_style_program_matches_reference():
     want = (rb.ref_avir if rb.have_ref() else rb.orc_avir)(
         src, 400, 300, resbits=8, params=ultra)
     assert got["ultra"] == rb.fnv(want)
+    # README.md:135-142: fpclass_def<float, float, CImageResizerDithererErrdINL<float>>
+    chk = rb.ref_avir if rb.have_ref() else rb.orc_avir
+    assert got["errd"] == rb.fnv(chk(rb.lcg_u8((480, 640, 3)), 1024, 768,
+                                     errd=True))
+    if rb.have_ref():
+        import ctypes as C
+        w = (C.c_double * 16)()
+        rb.ref().ref_avir_vars_base(640, 480, 300, 200, 3, 0.0, 1, 8, 0.0, 0.0,
+                                    -1, 1, w)
+        assert got["vars"] == "%d %d %d %d %d %d %.17g %.17g %d %d %.17g %.17g" % (
+            w[0], w[6], w[7], w[8], w[9], w[12], w[10], w[11], w[13], w[5],
+            w[14], w[15])
+    # lancir.h:744-755: legacy overload, SrcSSize / NewSSize / offsets
+    import numpy as np
+    lw = (rb.ref_lancir if rb.have_ref() else rb.orc_lancir)(
+        src, 400, 300, ox=0.25, oy=-0.5, spad=8, npad=12)
+    full = np.full((300, 400 * 4 + 12), 5.0, np.float32)
+    full[:, :1600] = lw.reshape(300, 1600)
+    assert got["lancir_legacy"] == "rc=300 " + rb.fnv(full)

@@ -797,3 +797,138 @@ def test_lancir_parameter_errors():
     b[:] = 1
     assert l.resizeImage(a, 0, 4, b, 8, 8, 4) == 8      # empty source
     assert not b.any()
+
+
+# ---- error-diffusion ditherer (CImageResizerDithererErrdINL, avir.h:4441-4537) ----
+
+ERRD = [
+    # (sw, sh, nw, nh, ch, in dtype, out dtype, ResBitDepth, gamma)
+    (64, 48, 100, 77, 3, np.uint8, np.uint8, 8, False),
+    (64, 48, 37, 21, 4, np.float32, np.uint8, 8, False),
+    (50, 40, 100, 80, 4, np.uint8, np.uint16, 16, False),
+    (50, 40, 99, 1, 1, np.uint16, np.uint8, 8, False),
+    (33, 20, 1, 7, 2, np.uint8, np.uint8, 8, False),
+    (64, 48, 100, 77, 4, np.uint8, np.uint8, 6, True),
+    (64, 48, 100, 77, 4, np.float32, np.uint16, 12, False),
+    (30, 90, 40, 150, 3, np.uint8, np.uint8, 8, True),
+    # more than one wave of rows, more than one pass of 1024 rows, rows of one
+    # pixel, exact 2x (marching kernel in front of the ditherer)
+    (40, 600, 30, 2100, 3, np.uint8, np.uint8, 8, False),
+    (20, 1100, 3, 1025, 4, np.uint8, np.uint8, 8, False),
+    (16, 700, 1, 1400, 1, np.uint8, np.uint16, 16, False),
+    (300, 200, 600, 400, 4, np.uint8, np.uint8, 8, False),
+]
+
+
+def _errd_src(sw, sh, ch, tin):
+    if tin == np.uint8:
+        return rb.lcg_u8((sh, sw, ch))
+    if tin == np.uint16:
+        return rb.lcg_u8((sh, sw, ch)).astype(np.uint16) * 257
+    return rb.lcg_f32((sh, sw, ch))
+
+
+@pytest.mark.parametrize("sw,sh,nw,nh,ch,tin,tout,bits,gamma", ERRD)
+def test_avir_error_diffusion_ditherer(sw, sh, nw, nh, ch, tin, tout, bits,
+                                       gamma):
+    """fpclass_def<float, float, CImageResizerDithererErrdINL<float>>
+    (README.md:135-142): the skewed-wavefront kernel against the reference's
+    serial ditherer, bit for bit; host and device buffers."""
+    import torch
+    src = _errd_src(sw, sh, ch, tin)
+    alpha = 3 if gamma and ch == 4 else -1
+    want = _checker_avir(src, nw, nh, out_dtype=tout, resbits=bits,
+                         gamma=gamma, alpha=alpha, errd=True)
+    r = avir_amd.CImageResizer(bits, aDitherer="errd")
+    v = avir_amd.CImageResizerVars()
+    v.UseSRGBGamma, v.AlphaIndex = (1 if gamma else 0), alpha
+    got = r.resize(src, nw, nh, out_dtype=np.dtype(tout), aVars=v)
+    _assert_same(got, want, "errd host")
+    if tin != np.uint16 and tout != np.uint16:
+        tt = {np.uint8: torch.uint8, np.float32: torch.float32}
+        d = r.resize(torch.from_numpy(src).cuda(), nw, nh,
+                     out_dtype=tt[tout], aVars=v)
+        _assert_same(d.cpu().numpy(), want, "errd device")
+    # the default ditherer of the same object type still rounds only
+    plain = avir_amd.CImageResizer(bits).resize(src, nw, nh,
+                                                out_dtype=np.dtype(tout),
+                                                aVars=v)
+    _assert_same(plain, _checker_avir(src, nw, nh, out_dtype=tout,
+                                      resbits=bits, gamma=gamma, alpha=alpha),
+                 "def ditherer")
+
+
+def test_error_diffusion_is_recursive_no_bands_and_float_output_unchanged():
+    lib = abi.load()
+    src = rb.lcg_u8((40, 50, 3))
+    r = avir_amd.CImageResizer(8, aDitherer="errd")
+    p = r.plan(50, 40, 80, 64, 3, in_type=abi.U8, out_type=abi.U8)
+    band = np.empty((32, 80, 3), np.uint8)
+    rc = lib.avirhip_resize_band(p, src.ctypes.data, abi.MEM_HOST,
+                                 band.ctypes.data, abi.MEM_HOST, 0, 32, None)
+    assert rc == -4 and b"recursive" in lib.avirhip_last_error()
+    f = r.resize(src, 80, 64, out_dtype=np.float32)
+    _assert_same(f, _checker_avir(src, 80, 64, out_dtype=np.float32),
+                 "float output skips the ditherer")
+
+
+def test_gamma_alpha_index_other_than_0_or_3_converts_every_channel():
+    """avir.h:2859/2874, 3002/3016: only AlphaIndex 0 and 3 name an alpha
+    channel; 1 or 2 gamma-convert all four channels."""
+    src = rb.lcg_u8((30, 40, 4))
+    for ai in (1, 2):
+        want = _checker_avir(src, 64, 50, gamma=True, alpha=ai)
+        got = _run_avir(src, 64, 50, gamma=True, alpha=ai)
+        _assert_same(got, want, "AlphaIndex %d" % ai)
+        _assert_same(got, _checker_avir(src, 64, 50, gamma=True, alpha=-1),
+                     "AlphaIndex %d == none" % ai)
+
+
+# ---- the reference's own published case (README.md:157-162) ----
+
+def test_readme_photo_case_golden_hashes():
+    """5184x3456 -> 1920x1280 RGB uint8, the only timing the reference
+    publishes; hashes of its output recorded by SURVEY.md 8(c)."""
+    src = rb.lcg_u8((3456, 5184, 3))
+    got = avir_amd.CImageResizer(8).resize(src, 1920, 1280)
+    assert rb.fnv(got) == "ef46dbcfc497d7af"
+    got = avir_amd.CLancIR().resize(src, 1920, 1280)
+    assert rb.fnv(got) == "1bea551bccca218d"
+
+
+# ---- LANCIR scanline sizes (CLancIRParams::SrcSSize / NewSSize) ----
+
+@pytest.mark.parametrize("tin,tout", [(np.float32, np.float32),
+                                      (np.uint8, np.uint8),
+                                      (np.uint8, np.float32),
+                                      (np.float32, np.uint8)])
+@pytest.mark.parametrize("sw,sh,nw,nh,ch,spad,npad", [
+    (37, 21, 74, 42, 4, 8, 12),    # exact 2x RGBA: k_lanc2, or its refusal
+    (37, 21, 74, 42, 4, 8, 0),     # (padded NewSSize) into the generic kernels
+    (37, 21, 74, 42, 4, 0, 4),
+    (64, 48, 100, 77, 3, 5, 0), (64, 48, 30, 20, 1, 0, 7),
+    (50, 40, 50, 40, 2, 3, 3), (300, 200, 100, 67, 4, 16, 32)])
+def test_lancir_scanline_sizes(sw, sh, nw, nh, ch, spad, npad, tin, tout):
+    """lancir.h:260-307: padded source and destination rows, host and device
+    buffers; the destination's padding must stay untouched."""
+    import torch
+    s = rb.lcg_u8((sh, sw, ch)) if tin == np.uint8 else rb.lcg_f32((sh, sw, ch))
+    want = (rb.ref_lancir if rb.have_ref() else rb.orc_lancir)(
+        s, nw, nh, out_dtype=tout, spad=spad, npad=npad)
+    ss = sw * ch + spad
+    ns = nw * ch + npad
+    sbuf = np.full((sh, ss), 77, s.dtype)
+    sbuf[:, :sw * ch] = s.reshape(sh, sw * ch)
+    P = avir_amd.CLancIRParams(ss if spad else 0, ns if npad else 0)
+    L = avir_amd.CLancIR()
+    for dev in (False, True):
+        dbuf = np.full((nh, ns), 55, tout)
+        if dev:
+            a, b = torch.from_numpy(sbuf).cuda(), torch.from_numpy(dbuf).cuda()
+            assert L.resizeImage(a, sw, sh, b, nw, nh, ch, P) == nh
+            dbuf = b.cpu().numpy()
+        else:
+            assert L.resizeImage(sbuf, sw, sh, dbuf, nw, nh, ch, P) == nh
+        assert (dbuf[:, nw * ch:] == 55).all(), "row padding overwritten"
+        _assert_same(np.ascontiguousarray(dbuf[:, :nw * ch]).reshape(nh, nw, ch),
+                     want, "lancir strides dev=%s" % dev)

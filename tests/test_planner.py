@@ -93,3 +93,43 @@ def test_io_types_and_bit_depths(it, ot):
         _check(120, 90, 200, 160, 3, in_type=it, out_type=ot, resbits=bits)
         _check(200, 160, 120, 90, 2, in_type=it, out_type=ot, resbits=bits,
                srcbits=8)
+
+
+@pytest.mark.skipif(not rb.have_ref(), reason="oracle/_ref not built")
+def test_vars_base_write_back_matches_reference():
+    """avir.h:4663-4669: resizeImage() overwrites the CImageResizerVarsBase
+    part of *aVars (ElCount .. packmode, BufLen, BufOffs, k, o, ResizeStep,
+    IsResize2, the gamma multipliers). The product computes the same values
+    from its plan description (host only)."""
+    import ctypes as C
+    lib = abi.load()
+    cases = [(64, 48, 128, 96, 4, 0.0, 0, 16, 0, 0, -1, 0),
+             (64, 48, 100, 77, 3, 0.0, 1, 8, 0, 0, -1, 0),
+             (300, 200, 100, 67, 4, 0.0, 0, 8, 0.25, -0.5, -1, 0),
+             (300, 200, 40, 31, 1, 0.0, 1, 8, 0, 0, -1, 1),
+             (90, 60, 120, 100, 2, 0.61, 0, 16, 0, 0, -1, 0),
+             (90, 60, 50, 40, 4, -2.5, 1, 8, 1.5, 0.75, -1, 1),
+             (37, 21, 74, 42, 4, 0.0, 0, 8, 0, 0, 0, 0),
+             (37, 21, 74, 42, 4, 0.0, 0, 8, 0, 0, 2, 0),
+             (16, 9, 5, 7, 2, 0.0, 0, 8, 0, 0, 3, 0)]
+    for (sw, sh, nw, nh, ch, k, u8, bits, ox, oy, mode, gamma) in cases:
+        want = (C.c_double * 16)()
+        assert rb.ref().ref_avir_vars_base(sw, sh, nw, nh, ch, k, u8, bits,
+                                           ox, oy, mode, gamma, want) == 0
+        r = C.c_void_p()
+        abi.check(lib.avirhip_resizer_create(bits, 0, None, C.byref(r)), "c")
+        v = abi.Vars()
+        lib.avirhip_vars_default(C.byref(v))
+        v.ox, v.oy, v.BuildMode, v.UseSRGBGamma = ox, oy, mode, gamma
+        b = abi.VarsBase()
+        t = abi.U8 if u8 else abi.F32
+        abi.check(lib.avirhip_resizer_vars_base(
+            r, sw, sh, 0, nw, nh, ch, k, C.byref(v), t, t, C.byref(b)), "vb")
+        lib.avirhip_resizer_destroy(r)
+        got = [b.ElCount, b.ElCountIO, b.fppack, b.fpalign, b.elalign,
+               b.packmode, b.BufLen[0], b.BufLen[1], b.BufOffs[0],
+               b.BufOffs[1], b.k, b.o, b.ResizeStep, b.IsResize2]
+        assert got == list(want)[:14], (sw, sh, nw, nh, got, list(want))
+        assert b.gamma_valid == gamma
+        if gamma:
+            assert [b.InGammaMult, b.OutGammaMult] == list(want)[14:16]
