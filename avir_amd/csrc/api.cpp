@@ -874,8 +874,23 @@ static int exec_any( avirhip_plan* p, const void* src, int src_mem, void* dst,
 
 	if( dst_mem == AVIRHIP_MEM_HOST )
 	{
-		AVIRHIP_HIPCHECK( hipMemcpyAsync( dst, ddst, dst_bytes,
-			hipMemcpyDeviceToHost, st ));
+		const size_t payload = (size_t) p -> new_w * p -> io_ch *
+			dtype_size( p -> out_type );
+
+		if( payload == row_bytes || row1 - row0 < 2 )
+		{
+			AVIRHIP_HIPCHECK( hipMemcpyAsync( dst, ddst, dst_bytes,
+				hipMemcpyDeviceToHost, st ));
+		}
+		else
+		{
+			// padded destination rows (CLancIRParams::NewSSize): the bytes
+			// between rows belong to the caller
+			AVIRHIP_HIPCHECK( hipMemcpy2DAsync( dst, row_bytes, ddst,
+				row_bytes, payload, (size_t) ( row1 - row0 ),
+				hipMemcpyDeviceToHost, st ));
+		}
+
 		AVIRHIP_HIPCHECK( hipStreamSynchronize( st ));
 	}
 	else
