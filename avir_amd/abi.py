@@ -137,6 +137,9 @@ PROTOTYPES = {
     "avirhip_resize_sharded": (_I, [_VP, _I, C.POINTER(C.c_int), _VP, _VP, _I,
                                  C.POINTER(_D), C.POINTER(_D)]),
     "avirhip_time_resize": (_I, [_VP, _VP, _VP, _I, _VP, C.POINTER(_D)]),
+    "avirhip_fill_lcg_u8": (None, [_VP, C.c_size_t, C.c_uint32]),
+    "avirhip_fill_lcg_f32": (None, [_VP, C.c_size_t, C.c_uint32]),
+    "avirhip_fnv1a64": (C.c_uint64, [_VP, C.c_size_t]),
     "avirhip_params_preset": (None, [_I, C.POINTER(Params)]),
     "avirhip_vars_default": (None, [C.POINTER(Vars)]),
     "avirhip_resizer_create": (_I, [_I, _I, C.POINTER(Params), C.POINTER(_VP)]),

@@ -39,6 +39,42 @@ static const avirhip_vars g_defvars = { 0.0, 0.0, 0, -1, -1, 0 };
 
 extern "C" {
 
+void avirhip_fill_lcg_u8( uint8_t* p, size_t n, uint32_t seed )
+{
+	uint32_t s = seed;
+
+	for( size_t i = 0; i < n; i++ )
+	{
+		s = s * 1664525u + 1013904223u;
+		p[ i ] = (uint8_t) ( s >> 24 );
+	}
+}
+
+void avirhip_fill_lcg_f32( float* p, size_t n, uint32_t seed )
+{
+	uint32_t s = seed;
+
+	for( size_t i = 0; i < n; i++ )
+	{
+		s = s * 1664525u + 1013904223u;
+		p[ i ] = (float) ( s >> 8 ) * ( 1.0f / 16777216.0f );
+	}
+}
+
+uint64_t avirhip_fnv1a64( const void* p, size_t n )
+{
+	const uint8_t* b = (const uint8_t*) p;
+	uint64_t h = 1469598103934665603ULL;
+
+	for( size_t i = 0; i < n; i++ )
+	{
+		h ^= b[ i ];
+		h *= 1099511628211ULL;
+	}
+
+	return( h );
+}
+
 void avirhip_params_preset( int preset, avirhip_params* p )
 {
 	if( p == nullptr )

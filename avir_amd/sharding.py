@@ -1,18 +1,31 @@
 """Multi-GPU plumbing for the resize hot path (torch.distributed; backend
-"nccl" == RCCL on ROCm, "gloo" in the CPU tests).
+"nccl" == RCCL on ROCm, "gloo" in the CPU tests and single-device dry runs).
 
 The path shards two ways:
-  * independent frames per rank -- no data-path collective (bench.py default);
   * one frame split into contiguous output-row bands, one per rank, computed
-    with avirhip_resize_band() (bit-identical to the rows of a full resize)
-    and stitched on a root rank with point-to-point sends over xGMI.
-Band heights differ by at most one row, so the stitch is a grouped
-isend/irecv rather than an equal-count gather."""
+    with avirhip_resize_band() (global indices => bit-identical to the rows of
+    a full resize) and stitched on a root rank with point-to-point transfers
+    over xGMI -- BASELINE.json configs[2], what `bench.py --gpus N` measures;
+  * independent frames per rank -- no data-path collective (reported beside it).
+
+Band heights differ by at most one row, so the stitch is send/recv rather than
+an equal-count gather. `BandPipeline` overlaps it with the compute: a band is
+cut into sub-bands, sub-band i travels (RCCL send on its own stream) while
+sub-band i+1 is being resized, the root posts all its receives before it
+computes its own band straight into the stitched frame, and two frame slots
+let frame f's transfers run under frame f+1's kernels."""
 
 
 def band_rows(new_h, world, rank):
     """Output rows [r0, r1) owned by `rank`."""
     return new_h * rank // world, new_h * (rank + 1) // world
+
+
+def sub_bands(r0, r1, nsub):
+    """Cuts [r0, r1) into at most `nsub` contiguous non-empty pieces."""
+    n = max(1, min(nsub, r1 - r0))
+    cuts = [r0 + (r1 - r0) * i // n for i in range(n + 1)]
+    return [(a, b) for a, b in zip(cuts[:-1], cuts[1:]) if b > a]
 
 
 def band_views(full, world):
@@ -21,26 +34,134 @@ def band_views(full, world):
     return [full[slice(*band_rows(h, world, r))] for r in range(world)]
 
 
+def _p2p_needs_host(dist, t):
+    """gloo moves host memory only: device tensors are staged (dry runs of the
+    rank logic on a box with fewer GPUs than ranks)."""
+    return dist.get_backend() == "gloo" and t.is_cuda
+
+
 def gather_bands(band, full, rank, world, dist, root=0):
     """Stitches the ranks' bands into `full` on `root` (full is None
-    elsewhere). One grouped batch of point-to-point operations."""
+    elsewhere). One grouped batch of point-to-point operations, after the
+    compute (the un-overlapped form; BandPipeline is the overlapped one)."""
     if world == 1:
         full.copy_(band)
         return
     if rank == root:
         parts = band_views(full, world)
         parts[root].copy_(band)
+        if _p2p_needs_host(dist, full):
+            tmp = {r: parts[r].cpu() for r in range(world) if r != root}
+            for w in [dist.irecv(tmp[r], r) for r in tmp]:
+                w.wait()
+            for r in tmp:
+                parts[r].copy_(tmp[r])
+            return
         ops = [dist.P2POp(dist.irecv, parts[r], r)
                for r in range(world) if r != root]
     else:
+        if _p2p_needs_host(dist, band):
+            dist.isend(band.cpu(), root).wait()
+            return
         ops = [dist.P2POp(dist.isend, band, root)]
     for w in dist.batch_isend_irecv(ops):
         w.wait()
 
 
+class BandPipeline(object):
+    """One frame per step(): this rank's band of the destination, sub-band by
+    sub-band, overlapped with its transfer to the root.
+
+    `resize_rows(dst_rows_tensor, a, b)` must enqueue the resize of output rows
+    [a, b) into `dst_rows_tensor` (shape (b-a, W, C)) on the current stream --
+    avirhip_resize_band() with a device destination. Frames alternate between
+    two slots; step() only waits for the transfers of the frame that used the
+    slot before (two frames ago), finish() drains everything. On the root,
+    frame(slot) is the stitched image of the last frame stepped into `slot`."""
+
+    def __init__(self, new_h, new_w, ch, dtype, device, rank, world, dist,
+                 resize_rows, nsub=4, root=0, slots=2):
+        import torch
+        self.rank, self.world, self.dist, self.root = rank, world, dist, root
+        self.resize_rows = resize_rows
+        self.new_h = new_h
+        self.r0, self.r1 = band_rows(new_h, world, rank)
+        self.subs = sub_bands(self.r0, self.r1, nsub)
+        self.nsub = nsub
+        self.slots = slots
+        self.pending = [[] for _ in range(slots)]
+        self.after = [[] for _ in range(slots)]  # host-staging copies (gloo)
+        self.nframe = 0
+        if rank == root:
+            self.full = [torch.empty((new_h, new_w, ch), dtype=dtype,
+                                     device=device) for _ in range(slots)]
+            self.band = None
+        else:
+            self.full = None
+            self.band = [torch.empty((self.r1 - self.r0, new_w, ch),
+                                     dtype=dtype, device=device)
+                         for _ in range(slots)]
+
+    def frame(self, slot):
+        return self.full[slot] if self.full is not None else None
+
+    def _wait(self, slot):
+        for w in self.pending[slot]:
+            w.wait()
+        self.pending[slot] = []
+        for fn in self.after[slot]:
+            fn()
+        self.after[slot] = []
+
+    def step(self):
+        """Enqueues one frame; returns the slot it used."""
+        dist, root = self.dist, self.root
+        slot = self.nframe % self.slots
+        self.nframe += 1
+        self._wait(slot)
+        if self.rank == root:
+            full = self.full[slot]
+            # every receive is posted before the root's own kernels start
+            for r in range(self.world):
+                if r == root:
+                    continue
+                a0, a1 = band_rows(self.new_h, self.world, r)
+                for (a, b) in sub_bands(a0, a1, self.nsub):
+                    view = full[a:b]
+                    if _p2p_needs_host(dist, view):
+                        tmp = view.cpu()
+                        self.pending[slot].append(dist.irecv(tmp, r))
+                        self.after[slot].append(
+                            lambda v=view, t=tmp: v.copy_(t))
+                    else:
+                        self.pending[slot].append(dist.irecv(view, r))
+            # the root's band goes straight into the stitched frame
+            for (a, b) in self.subs:
+                self.resize_rows(full[a:b], a, b)
+        else:
+            band = self.band[slot]
+            for (a, b) in self.subs:
+                view = band[a - self.r0:b - self.r0]
+                self.resize_rows(view, a, b)
+                # the send is ordered after the kernel just enqueued (RCCL
+                # waits for the current stream) and runs on RCCL's stream
+                # while the next sub-band is computed
+                if _p2p_needs_host(dist, view):
+                    self.pending[slot].append(dist.isend(view.cpu(), root))
+                else:
+                    self.pending[slot].append(dist.isend(view, root))
+        return slot
+
+    def finish(self):
+        for s in range(self.slots):
+            self._wait(s)
+
+
 def max_over_ranks(seconds, dist, device):
     """The bench contract: a step's time is the slowest rank's."""
     import torch
+    if dist.get_backend() == "gloo":
+        device = "cpu"
     t = torch.tensor([seconds], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())

@@ -9,16 +9,21 @@ roofline achieved by the dominant kernel.
 
 A "step" is one full resize of one synthetic 4K frame already resident in HBM
 (H pass + V pass). N > 1 (launched by torch.distributed.run, one rank per GPU)
-shards independent frames across ranks -- no data-path collective, weak
-scaling; value = frames * Mpix over the max-over-ranks wall time. After the
-timed region (never inside it) rank 0 also reports, in the same JSON line:
+is BASELINE.json configs[2]: the ONE frame is split into N contiguous output-row
+bands, one per GPU (every rank holds the source; bands are computed with global
+indices, bit-identical to the rows of a full resize), and stitched on rank 0
+with RCCL send/recv over xGMI, sub-band by sub-band under the kernels
+(avir_amd/sharding.py BandPipeline). `value` = stitched frames * Mpix over the
+max-over-ranks wall time (strong scaling). After the timed region (never inside
+it) rank 0 also reports, in the same JSON line:
   roofline      dominant-kernel launch duration from HIP events on the launch
                 stream -> algorithmic bytes / s against the 8 TB/s HBM peak
   cpu_baseline  the reference's own CPU path (oracle/_ref) timed on the host
                 cores, N == 1 only, bounded sample
-  band_gather   (N > 1) one frame split into N row bands, one band per GPU,
-                stitched on rank 0 with an RCCL gather over xGMI; compute and
-                gather timed separately
+  sharded       (N > 1) compute-only and gather-only rates of the same bands,
+                gather GB/s against the xGMI link peak, and the throughput of
+                independent frames per GPU (no collective) for comparison
+  sustained     the same step timed over >= 1 s (the default region is ms)
 """
 import argparse
 import ctypes as C
@@ -50,21 +55,22 @@ OTHER = {"cfg1": ("avir", 640, 480, 1024, 768, 3, "u8", 8),
          "readme": ("avir", 5184, 3456, 1920, 1280, 3, "u8", 8)}
 
 
+XGMI_LINK_GBS = 153.0  # per link, both directions (7 links per GPU)
+
+
 def _workload_src(name):
-    import numpy as np
-    from tests import refbind as rb
+    from avir_amd import synth
     api, sw, sh, nw, nh, ch, dt, bits = OTHER[name]
     if dt == "u8":
-        return rb.lcg_u8((sh, sw, ch))
-    return rb.lcg_f32((sh, sw, ch))
+        return synth.lcg_u8((sh, sw, ch))
+    return synth.lcg_f32((sh, sw, ch))
 
 
 def time_other(name, steps, warmup, path, settle_ms=300.0, quiet=False):
     """Times one of the non-headline configs (device-resident)."""
     import torch
     import avir_amd
-    from avir_amd import abi
-    from tests import refbind as rb
+    from avir_amd import abi, synth
     api, sw, sh, nw, nh, ch, dt, bits = OTHER[name]
     lib = abi.load()
     dev = torch.device("cuda", 0)
@@ -107,7 +113,7 @@ def time_other(name, steps, warmup, path, settle_ms=300.0, quiet=False):
            "unit": "Mpixels/s", "path": lib.avirhip_plan_get_path(plan),
            "algorithmic_gbs": round(algo / (ms * 1e-3) / 1e9, 1),
            "roofline_frac": round(algo / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-           "fnv1a64": rb.fnv(dst.cpu().numpy())}
+           "fnv1a64": synth.fnv(dst.cpu().numpy())}
     if not quiet:
         print(json.dumps(out), flush=True)
     return out, src_np, dst.cpu().numpy()
@@ -118,7 +124,7 @@ def report(steps, warmup, settle_ms):
     host CPU (1 thread and all threads, bounded samples) beside the GPU, with
     the max ULP distance between the two outputs. Markdown on stdout."""
     import numpy as np
-    from tests import refbind as rb
+    from oracle import bind as rb  # the checker: CPU baseline legs only
     nthreads = os.cpu_count() or 1
     rows = []
     for name in ("cfg1", "cfg2", "cfg3", "cfg4", "cfg5", "nonint", "readme"):
@@ -170,7 +176,7 @@ def cpu_baseline(src_np, threads):
     own SSE (fpclass_float4) and AVX (fpclass_float8_dil) classes built -O3
     -mavx2 -mfma, each on 1 thread and on all host threads through a
     std::thread CImageResizerThreadPool. `value` is the fastest of them."""
-    from tests import refbind as rb
+    from oracle import bind as rb  # the checker: CPU baseline legs only
     variants = []
     if rb.have_ref():
         kind = "reference"
@@ -246,6 +252,9 @@ def main():
     ap.add_argument("--backend", default="nccl",
                     help="torch.distributed backend for --gpus > 1 (nccl = "
                          "RCCL; gloo only for dry runs of the rank logic)")
+    ap.add_argument("--sub-bands", type=int, default=4,
+                    help="N > 1: sub-bands per rank (transfer of sub-band i "
+                         "overlaps the resize of sub-band i+1)")
     ap.add_argument("--report", action="store_true",
                     help="print the all-configs CPU-vs-GPU markdown table "
                          "(BASELINE.md section 4, item 5)")
@@ -267,8 +276,7 @@ def main():
     import torch
     import torch.distributed as dist
     import avir_amd
-    from avir_amd import abi
-    from tests import refbind as rb
+    from avir_amd import abi, synth
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -295,7 +303,7 @@ def main():
     assert lib.avirhip_device_count() >= 1, "no gfx950 device"
     abi.check(lib.avirhip_init(local), "avirhip_init")
 
-    src_np = rb.lcg_f32((SRC_H, SRC_W, CH))  # SURVEY.md 8(c) generator
+    src_np = synth.lcg_f32((SRC_H, SRC_W, CH))  # SURVEY.md 8(c) generator
     src = torch.from_numpy(src_np).to(dev)
     if os.environ.get("AVIRHIP_BENCH_FILL") == "zero":
         src.zero_()  # power experiment only (the parity field then says false)
@@ -307,11 +315,17 @@ def main():
         abi.check(lib.avirhip_plan_set_path(plan, args.path), "set_path")
     path = lib.avirhip_plan_get_path(plan)
     stream = torch.cuda.current_stream(dev).cuda_stream
+    mpix = NEW_W * NEW_H / 1e6
 
-    def step():
+    def full_frame():
         abi.check(lib.avirhip_resize(plan, src.data_ptr(), abi.MEM_DEVICE,
                                      dst.data_ptr(), abi.MEM_DEVICE, stream),
                   "avirhip_resize")
+
+    def resize_rows(rows, a, b):
+        abi.check(lib.avirhip_resize_band(
+            plan, src.data_ptr(), abi.MEM_DEVICE, rows.data_ptr(),
+            abi.MEM_DEVICE, a, b, stream), "avirhip_resize_band")
 
     def barrier():
         torch.cuda.synchronize(dev)
@@ -319,60 +333,105 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
+    def timed(step, steps, finish=None):
+        """Barrier, K steps, barrier: (max-over-ranks wall s, event ms/step)."""
+        barrier()
+        e0 = torch.cuda.Event(enable_timing=True)
+        e1 = torch.cuda.Event(enable_timing=True)
+        t0 = time.perf_counter()
+        e0.record()
+        for _ in range(steps):
+            step()
+        e1.record()
+        if finish is not None:
+            finish()
+        barrier()
+        t = time.perf_counter() - t0
+        if world > 1:
+            t = sharding.max_over_ranks(t, dist, dev)
+        return t, e0.elapsed_time(e1) / steps
+
+    pipe = None
+    sharded_error = None
+    if world > 1:
+        from avir_amd import sharding
+        try:
+            pipe = sharding.BandPipeline(NEW_H, NEW_W, CH, torch.float32, dev,
+                                         rank, world, dist, resize_rows,
+                                         nsub=args.sub_bands)
+            pipe.step()
+            pipe.finish()
+            barrier()
+        except Exception as e:  # noqa: BLE001 -- keep a headline line alive
+            sharded_error = "%s: %s" % (type(e).__name__, e)
+            pipe = None
+
+    step = full_frame if pipe is None else pipe.step
+    finish = None if pipe is None else pipe.finish
+
     # untimed run-in: steady-state clocks (a fresh process finds the GPU in its
     # low-power state; the first ~100 ms of load run at ramping clocks)
     t_settle = time.perf_counter()
     while (time.perf_counter() - t_settle) * 1e3 < args.settle_ms:
         for _ in range(50):
             step()
+        if finish is not None:
+            finish()
         torch.cuda.synchronize(dev)
     for _ in range(args.warmup):
         step()
-    barrier()
-    e0 = torch.cuda.Event(enable_timing=True)
-    e1 = torch.cuda.Event(enable_timing=True)
-    t0 = time.perf_counter()
-    e0.record()
-    for _ in range(args.steps):
-        step()
-    e1.record()
-    barrier()
-    t = time.perf_counter() - t0
+    if finish is not None:
+        finish()
 
-    if world > 1:
-        from avir_amd import sharding
-        t = sharding.max_over_ranks(t, dist, dev)
+    t, ev_ms = timed(step, args.steps, finish)
+    frames = args.steps if pipe is not None else world * args.steps
+    value = frames * mpix / t
 
-    ev_ms = e0.elapsed_time(e1) / args.steps  # kernel time on the launch stream
-    mpix = NEW_W * NEW_H / 1e6
-    value = world * args.steps * mpix / t
-
+    exec_path = {1: "generic per-step kernels",
+                 2: "LDS-tiled two-pass kernels",
+                 3: "LDS-tiled fused kernel",
+                 4: "exact-2x marching kernel (single launch)"
+                 }.get(path, str(path))
+    if world == 1:
+        shard = "one GPU, whole frame"
+    elif pipe is not None:
+        shard = ("row bands of ONE frame, one band per GPU (global indices), "
+                 "%d sub-bands each, stitched on rank 0 by RCCL send/recv "
+                 "over xGMI under the kernels; two frame slots"
+                 % args.sub_bands)
+    else:
+        shard = ("independent frames per GPU (band pipeline failed: %s)"
+                 % sharded_error)
     out = {
         "metric": "Mpixels/sec (output) for 4K->8K RGBA resize",
         "value": round(value, 1), "unit": "Mpixels/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "settle_ms": args.settle_ms,
         "ms_per_step": round(t / args.steps * 1e3, 4),
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "higher_is_better": True,
+        "scaling": "strong" if pipe is not None or world == 1 else "weak",
+        "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": "cfg3: 3840x2160->7680x4320 RGBA float32, "
                                "avir::CImageResizer<>(16), k=0, default params, "
                                "frame resident in HBM",
-                   "sharding": "independent frames per GPU (no data-path "
-                               "collective)",
-                   "exec_path": {1: "generic per-step kernels",
-                                 2: "LDS-tiled two-pass kernels",
-                                 3: "LDS-tiled fused kernel",
-                                 4: "exact-2x marching kernel (single launch)"
-                                 }.get(path, str(path))},
+                   "sharding": shard, "exec_path": exec_path},
     }
 
-    # parity spot check on the very buffer that was timed
+    # parity spot check on the very buffer that was timed (N > 1: the frame
+    # stitched on rank 0 in the last step)
     if rank == 0:
-        h = rb.fnv(dst.cpu().numpy())
+        got = dst if pipe is None else pipe.frame((pipe.nframe - 1) % pipe.slots)
+        h = synth.fnv(got.cpu().numpy())
         out["parity"] = {"fnv1a64": h, "golden": "38d7739587151f6e",
                          "ok": h == "38d7739587151f6e"}
 
+    # ---- roofline of the dominant kernel: whole-frame launches on this
+    # rank's stream (N > 1: measured after the headline, same plan)
+    if pipe is not None:
+        for _ in range(5):
+            full_frame()
+        _, ev_ms = timed(full_frame, max(20, min(args.steps, 200)))
     if rank == 0:
         achieved = ALGO_BYTES / (ev_ms * 1e-3) / 1e9
         out["roofline"] = {
@@ -385,12 +444,24 @@ def main():
             "kernels_per_step": {1: 5, 2: 2, 3: 1, 4: 1}.get(path)}
 
     if world > 1:
-        # secondary measurement: must never take the headline line down
+        # secondary measurements: must never take the headline line down
         try:
-            out["band_gather"] = band_gather(lib, plan, src, dev, world, rank,
-                                             dist, torch)
+            extra = sharded_extras(lib, plan, src, dst, dev, world, rank, dist,
+                                   torch, pipe, timed, full_frame, resize_rows,
+                                   mpix, max(20, min(args.steps, 100)))
+            if sharded_error:
+                extra["pipeline_error"] = sharded_error
+            out["sharded"] = extra
         except Exception as e:  # noqa: BLE001
-            out["band_gather"] = {"error": "%s: %s" % (type(e).__name__, e)}
+            out["sharded"] = {"error": "%s: %s" % (type(e).__name__, e)}
+
+    if rank == 0 and world == 1:
+        # a sustained figure: the default timed region is a few ms
+        n = max(args.steps, int(1.0 / max(t / args.steps, 1e-6)))
+        ts, _ = timed(full_frame, n)
+        out["sustained"] = {"steps": n, "seconds": round(ts, 3),
+                            "ms_per_step": round(ts / n * 1e3, 4),
+                            "value": round(n * mpix / ts, 1)}
 
     if rank == 0 and world == 1 and not args.no_cpu:
         # the drop-in call as a host program makes it: host pointers in and
@@ -410,7 +481,7 @@ def main():
             "value": round(mpix / min(ts[1:]), 1), "unit": "Mpixels/s",
             "note": "pageable host src/dst, H2D + kernel + D2H inside "
                     "avirhip_resize; 663.6 MB over PCIe",
-            "parity_ok": rb.fnv(hdst) == "38d7739587151f6e"}
+            "parity_ok": synth.fnv(hdst) == "38d7739587151f6e"}
         out["cpu_baseline"] = cpu_baseline(src_np, os.cpu_count() or 1)
 
     if rank == 0:
@@ -421,45 +492,41 @@ def main():
         dist.destroy_process_group()
 
 
-def band_gather(lib, plan, src, dev, world, rank, dist, torch, iters=20):
-    """One frame, N row bands, one band per GPU, stitched on rank 0 (RCCL over
-    xGMI; avir_amd/sharding.py). Bands are bit-identical to the rows of a
-    full-frame resize (tests/test_gpu_parity.py::
-    test_band_execution_matches_full)."""
-    from avir_amd import abi, sharding
+def sharded_extras(lib, plan, src, dst, dev, world, rank, dist, torch, pipe,
+                   timed, full_frame, resize_rows, mpix, iters):
+    """The pieces of the band-sharded frame, timed apart (compute
+    and gather must both be visible), and the no-collective alternative."""
+    from avir_amd import sharding
     r0, r1 = sharding.band_rows(NEW_H, world, rank)
     band = torch.empty((r1 - r0, NEW_W, CH), dtype=torch.float32, device=dev)
-    full = (torch.empty((NEW_H, NEW_W, CH), dtype=torch.float32, device=dev)
-            if rank == 0 else None)
-    stream = torch.cuda.current_stream(dev).cuda_stream
+    full = dst if rank == 0 else None
+    res = {"bytes_per_rank": int(band.numel() * 4)}
 
-    def compute():
-        abi.check(lib.avirhip_resize_band(
-            plan, src.data_ptr(), abi.MEM_DEVICE, band.data_ptr(),
-            abi.MEM_DEVICE, r0, r1, stream), "band")
-
-    def gather():
-        sharding.gather_bands(band, full, rank, world, dist)
-
-    compute(); gather()
-    torch.cuda.synchronize(dev); dist.barrier()
-    tc = tg = 0.0
-    for _ in range(iters):
-        t0 = time.perf_counter()
-        compute(); torch.cuda.synchronize(dev); dist.barrier()
-        t1 = time.perf_counter()
-        gather(); torch.cuda.synchronize(dev); dist.barrier()
-        t2 = time.perf_counter()
-        tc += t1 - t0
-        tg += t2 - t1
-    res = {"compute_ms": round(tc / iters * 1e3, 4),
-           "gather_ms": round(tg / iters * 1e3, 4),
-           "stitched_mpix_s": round(NEW_W * NEW_H / 1e6 / ((tc + tg) / iters), 1),
-           "compute_only_mpix_s": round(NEW_W * NEW_H / 1e6 / (tc / iters), 1),
-           "bytes_per_rank": int(band.numel() * 4)}
+    # bands computed, nothing sent: what the kernels alone sustain
+    t, _ = timed(lambda: resize_rows(band, r0, r1), iters)
+    res["compute_only"] = {"ms_per_frame": round(t / iters * 1e3, 4),
+                           "value": round(iters * mpix / t, 1)}
+    # the stitch alone (bands already computed), one grouped send/recv batch
+    sharding.gather_bands(band, full, rank, world, dist)
+    t, _ = timed(lambda: sharding.gather_bands(band, full, rank, world, dist),
+                 iters)
+    inbound = (NEW_H - (sharding.band_rows(NEW_H, world, 0)[1])) * NEW_W * CH * 4
+    gbs = inbound * iters / t / 1e9
+    res["gather_only"] = {
+        "ms_per_frame": round(t / iters * 1e3, 4),
+        "bytes_into_root": int(inbound), "achieved_gbs": round(gbs, 1),
+        "links": world - 1, "link_peak_gbs": XGMI_LINK_GBS,
+        "frac_of_links": round(gbs / ((world - 1) * XGMI_LINK_GBS), 4),
+        "note": "xGMI is point-to-point: the root receives over world-1 of its "
+                "7 links; 153 GB/s is a link's two-way peak (one way: half)"}
     if rank == 0:
-        from tests import refbind as rb
-        res["stitched_fnv1a64_ok"] = rb.fnv(full.cpu().numpy()) == "38d7739587151f6e"
+        res["gather_only"]["stitched_ok"] = (
+            __import__("avir_amd").synth.fnv(full.cpu().numpy())
+            == "38d7739587151f6e")
+    # independent frames per GPU, no data-path collective (weak scaling)
+    t, _ = timed(full_frame, iters)
+    res["independent_frames"] = {"ms_per_step": round(t / iters * 1e3, 4),
+                                 "value": round(world * iters * mpix / t, 1)}
     return res
 
 

@@ -250,6 +250,15 @@ int avirhip_resize_sharded(avirhip_plan* plan, int n_gpus, const int* devices,
 int avirhip_time_resize(avirhip_plan* plan, const void* src, void* dst,
 	int iters, void* stream, double* avg_ms);
 
+/* Synthetic-workload aids for bench.py / smoke (host only): the SURVEY.md
+ * 8(c) input generators -- u8: s = seed; per byte s = s*1664525 + 1013904223
+ * (uint32), v = s >> 24; f32: the same LCG, x = (s >> 8) * 2^-24 -- and the
+ * FNV-1a-64 hash the golden vectors are recorded with (offset basis
+ * 1469598103934665603, prime 1099511628211). */
+void avirhip_fill_lcg_u8(uint8_t* p, size_t n, uint32_t seed);
+void avirhip_fill_lcg_f32(float* p, size_t n, uint32_t seed);
+uint64_t avirhip_fnv1a64(const void* p, size_t n);
+
 /* ---------------------------------------------------------------------
  * Front-end mirror: the reference's host-side planner re-implemented inside
  * the library (double precision, -ffp-contract=off, same libm), so that a

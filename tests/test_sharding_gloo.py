@@ -24,7 +24,7 @@ def test_band_partition_covers_every_row_once():
             assert max(b - a for a, b in cuts) - min(b - a for a, b in cuts) <= 1
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, use_gpu=False):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -33,25 +33,76 @@ def _worker(rank, world, port, q):
         nw, nh = 180, 121
         whole = torch.from_numpy(rb.orc_avir(src, nw, nh, resbits=16))
         r0, r1 = sharding.band_rows(nh, world, rank)
-        band = whole[r0:r1].clone()           # this rank's share of the frame
-        full = torch.zeros_like(whole) if rank == 0 else None
+        dev = torch.device("cuda", 0) if use_gpu else torch.device("cpu")
+        if use_gpu:
+            # the product's band kernel feeds the stitch (both ranks share
+            # the one device of the GPU box)
+            import avir_amd
+            from avir_amd import abi
+            lib = abi.load()
+            abi.check(lib.avirhip_init(0), "init")
+            rz = avir_amd.CImageResizer(16)
+            plan = rz.plan(90, 60, nw, nh, 4)
+            dsrc = torch.from_numpy(src).to(dev)
+            st = torch.cuda.current_stream(dev).cuda_stream
+
+            def resize_rows(dst_rows, a, b):
+                abi.check(lib.avirhip_resize_band(
+                    plan, dsrc.data_ptr(), abi.MEM_DEVICE, dst_rows.data_ptr(),
+                    abi.MEM_DEVICE, a, b, st), "band")
+        else:
+            def resize_rows(dst_rows, a, b):
+                dst_rows.copy_(whole[a:b])
+
+        band = torch.empty((r1 - r0, nw, 4), dtype=torch.float32, device=dev)
+        resize_rows(band, r0, r1)             # this rank's share of the frame
+        full = (torch.zeros((nh, nw, 4), dtype=torch.float32, device=dev)
+                if rank == 0 else None)
         sharding.gather_bands(band, full, rank, world, dist)
-        t = sharding.max_over_ranks(1.0 + rank, dist, torch.device("cpu"))
+        t = sharding.max_over_ranks(1.0 + rank, dist, dev)
         ok = True
         if rank == 0:
-            ok = bool(torch.equal(full, whole))
+            ok = bool(torch.equal(full.cpu(), whole))
+        # the overlapped form: sub-bands, receives posted first, two frame
+        # slots; three frames so that a slot is reused
+        pipe = sharding.BandPipeline(nh, nw, 4, torch.float32, dev, rank,
+                                     world, dist, resize_rows, nsub=3)
+        slots = [pipe.step() for _ in range(3)]
+        pipe.finish()
+        if rank == 0:
+            for s in set(slots):
+                ok = ok and bool(torch.equal(pipe.frame(s).cpu(), whole))
         q.put((rank, ok, t))
     finally:
         dist.destroy_process_group()
 
 
+def test_sub_band_cuts():
+    for (r0, r1, n) in [(0, 10, 4), (5, 6, 4), (7, 7, 3), (0, 4320, 8)]:
+        subs = sharding.sub_bands(r0, r1, n)
+        assert [a for a, b in subs][1:] == [b for a, b in subs][:-1]
+        if r1 > r0:
+            assert subs[0][0] == r0 and subs[-1][1] == r1 and len(subs) <= n
+
+
 @pytest.mark.skipif(not rb.have_orc(), reason="oracle not built")
-def test_two_rank_band_gather_gloo():
-    world = 2
+@pytest.mark.parametrize("world", [2, 3])
+def test_band_gather_gloo(world):
+    _run_world(world, False)
+
+
+@pytest.mark.gpu
+def test_band_gather_gloo_with_device_bands():
+    """The same stitch fed by avirhip_resize_band() on the GPU box: two ranks
+    share its one device (gloo stages through host memory)."""
+    _run_world(2, True)
+
+
+def _run_world(world, use_gpu):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29500 + (os.getpid() % 2000)
-    procs = [ctx.Process(target=_worker, args=(r, world, port, q))
+    port = 29500 + (os.getpid() % 2000) + world
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, use_gpu))
              for r in range(world)]
     for p in procs:
         p.start()
@@ -61,4 +112,4 @@ def test_two_rank_band_gather_gloo():
         assert p.exitcode == 0
     for rank, ok, t in res:
         assert ok
-        assert t == 2.0  # max over ranks of (1 + rank)
+        assert t == float(world)  # max over ranks of (1 + rank)
