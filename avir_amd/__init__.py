@@ -188,7 +188,8 @@ class CLancIR(object):
             return 0
         sp, sm, st, s1 = _buf(SrcBuf)
         dp, dm, dt, s2 = _buf(NewBuf)
-        if min(SrcWidth, SrcHeight, NewWidth, NewHeight, ElCount) > 0:
+        if (min(SrcWidth, SrcHeight, NewWidth, NewHeight, ElCount) > 0
+                and sp != dp):  # SrcBuf == NewBuf is the library's error 0
             ss = aParams.SrcSSize if aParams is not None else 0
             ns = aParams.NewSSize if aParams is not None else 0
             ss = ss if ss >= 1 else SrcWidth * ElCount
