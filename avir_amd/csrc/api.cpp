@@ -1179,8 +1179,20 @@ int avirhip_resize_sharded( avirhip_plan* p, int n_gpus, const int* devices,
 		src_dev = at.device;
 	}
 
+	int dst_dev = -1;
+
+	if( dst_mem == AVIRHIP_MEM_DEVICE )
+	{
+		hipPointerAttribute_t at;
+		AVIRHIP_HIPCHECK( hipPointerGetAttributes( &at, dst ));
+		dst_dev = at.device;
+	}
+
 	const bool force_replica =
 		( getenv( "AVIRHIP_SHARDED_FORCE_REPLICA" ) != nullptr );
+	// test aid: always go through the band buffers + peer copies
+	const bool force_staged =
+		( getenv( "AVIRHIP_SHARDED_STAGED" ) != nullptr );
 
 	const size_t esz_in = dtype_size( p -> in_type );
 	const size_t esz_out = dtype_size( p -> out_type );
@@ -1249,6 +1261,43 @@ int avirhip_resize_sharded( avirhip_plan* p, int n_gpus, const int* devices,
 			s = q -> shard_src;
 		}
 
+		// A device destination the band's device can address (its own memory,
+		// or a peer's over xGMI): the kernels store the band straight into
+		// `dst` -- the transfer rides under the compute, there is no gather
+		// phase and no second pass over the band.
+		bool direct = false;
+
+		if( dst_mem == AVIRHIP_MEM_DEVICE && !force_staged )
+		{
+			if( d == dst_dev )
+			{
+				direct = true;
+			}
+			else
+			{
+				int can = 0;
+
+				if( hipDeviceCanAccessPeer( &can, d, dst_dev ) == hipSuccess &&
+					can )
+				{
+					const hipError_t pe = hipDeviceEnablePeerAccess( dst_dev, 0 );
+					direct = ( pe == hipSuccess ||
+						pe == hipErrorPeerAccessAlreadyEnabled );
+				}
+
+				(void) hipGetLastError();
+			}
+		}
+
+		if( direct )
+		{
+			band[ g ] = nullptr; // nothing to gather
+			rc = exec_any( q, s, smem, (char*) dst + (size_t) r0[ g ] *
+				row_bytes, AVIRHIP_MEM_DEVICE, r0[ g ], r1[ g ], nullptr );
+
+			continue;
+		}
+
 		// bands that share a device (and plan) lie one after another in that
 		// plan's band buffer: room for the whole frame covers every split
 		if(( rc = grow( q, &q -> shard_band, &q -> shard_band_bytes,
@@ -1267,15 +1316,8 @@ int avirhip_resize_sharded( avirhip_plan* p, int n_gpus, const int* devices,
 
 	const auto t1 = std::chrono::steady_clock::now();
 
-	// ---- gather: band buffers -> dst (peer copies over xGMI, or D2H)
-	int dst_dev = -1;
-
-	if( rc == 0 && dst_mem == AVIRHIP_MEM_DEVICE )
-	{
-		hipPointerAttribute_t at;
-		AVIRHIP_HIPCHECK( hipPointerGetAttributes( &at, dst ));
-		dst_dev = at.device;
-	}
+	// ---- gather: band buffers -> dst (peer copies over xGMI, or D2H) for
+	// the bands that could not be stored directly
 
 	for( int g = 0; g < n_gpus && rc == 0; g++ )
 	{
@@ -1283,7 +1325,7 @@ int avirhip_resize_sharded( avirhip_plan* p, int n_gpus, const int* devices,
 		char* to = (char*) dst + (size_t) r0[ g ] * row_bytes;
 		AVIRHIP_HIPCHECK( hipSetDevice( pl[ g ] -> device ));
 
-		if( bb == 0 )
+		if( bb == 0 || band[ g ] == nullptr )
 		{
 			continue;
 		}
