@@ -43,6 +43,7 @@ static int upload( avirhip_plan* p, const std::vector< T >& h, T** d )
 	void* q = nullptr;
 	AVIRHIP_HIPCHECK( hipMalloc( &q, h.size() * sizeof( T )));
 	p -> allocs.push_back( q );
+	p -> alloc_bytes += h.size() * sizeof( T );
 	AVIRHIP_HIPCHECK( hipMemcpy( q, h.data(), h.size() * sizeof( T ),
 		hipMemcpyHostToDevice ));
 
@@ -55,6 +56,7 @@ static int dev_alloc( avirhip_plan* p, size_t bytes, void** out )
 	void* q = nullptr;
 	AVIRHIP_HIPCHECK( hipMalloc( &q, bytes ));
 	p -> allocs.push_back( q );
+	p -> alloc_bytes += bytes;
 	*out = q;
 	return( AVIRHIP_OK );
 }
@@ -761,6 +763,23 @@ static int exec_any( avirhip_plan* p, const void* src, int src_mem, void* dst,
 
 	hipStream_t st = (hipStream_t) stream;
 
+	// A plan's tables and scratch live on the device it was created on: run
+	// there, whatever device the calling thread has current, and put the
+	// caller's device back on every way out.
+	struct DeviceGuard
+	{
+		int keep;
+		bool on;
+		DeviceGuard( int want ) : keep( 0 ), on( false )
+		{
+			if( hipGetDevice( &keep ) == hipSuccess && keep != want )
+			{
+				on = ( hipSetDevice( want ) == hipSuccess );
+			}
+		}
+		~DeviceGuard() { if( on ) (void) hipSetDevice( keep ); }
+	} devguard( p -> device );
+
 	// Calls on one plan share its scratch buffers: serialise them (the
 	// reference allows concurrent resizeImage() calls on one object). The
 	// only scratch-free case, device-resident float RGBA through the
@@ -905,7 +924,7 @@ static int exec_any( avirhip_plan* p, const void* src, int src_mem, void* dst,
 static avirhip_plan* new_plan()
 {
 	avirhip_plan* p = new avirhip_plan();
-	p -> is_lancir = 0; p -> device = 0;
+	p -> is_lancir = 0; p -> device = 0; p -> alloc_bytes = 0;
 	p -> path = 0; p -> fused_ok = 0; p -> auto_path = 1; p -> fused = nullptr; p -> up2 = nullptr; p -> lanc2 = nullptr;
 	p -> packed = nullptr; p -> resbuf = nullptr; p -> lres = nullptr;
 	p -> stage_src = nullptr; p -> stage_dst = nullptr;
@@ -1199,8 +1218,17 @@ int avirhip_resize_sharded( avirhip_plan* p, int n_gpus, const int* devices,
 	const size_t src_bytes = ( (size_t) ( p -> src_h - 1 ) * p -> src_stride +
 		(size_t) p -> src_w * p -> io_ch ) * esz_in;
 	const size_t row_bytes = (size_t) p -> new_stride * esz_out;
-	int keep = 0;
-	(void) hipGetDevice( &keep );
+
+	// the replica list and the per-replica band / source buffers are shared
+	// by every sharded call on this plan; the caller's current device comes
+	// back on every way out
+	std::lock_guard< std::mutex > shard_lock( p -> shard_mtx );
+	struct DeviceKeep
+	{
+		int keep;
+		DeviceKeep() : keep( 0 ) { (void) hipGetDevice( &keep ); }
+		~DeviceKeep() { (void) hipSetDevice( keep ); }
+	} devkeep;
 	std::vector< avirhip_plan* > pl( n_gpus );
 	std::vector< int > r0( n_gpus ), r1( n_gpus );
 	std::vector< char* > band( n_gpus );
@@ -1349,7 +1377,6 @@ int avirhip_resize_sharded( avirhip_plan* p, int n_gpus, const int* devices,
 	}
 
 	const auto t2 = std::chrono::steady_clock::now();
-	(void) hipSetDevice( keep );
 
 	if( t_compute_ms != nullptr )
 	{

@@ -7,6 +7,7 @@
 #include "plan.h"
 #include "planner.h"
 #include <string.h>
+#include <stdlib.h>
 #include <algorithm>
 #include <map>
 #include <mutex>
@@ -16,14 +17,106 @@ using namespace avirhip;
 
 extern "C" int avirhip_resolve_mem( const void* ptr, int mem );
 
+// Plans cached per geometry (and device), least recently used first out. A
+// thumbnailer resizes many geometries through one object: without a bound
+// every plan would keep its tables and full-frame scratch until the object
+// dies. Bounds: AVIRHIP_CACHE_PLANS plans (default 64) and AVIRHIP_CACHE_BYTES
+// of device memory (default 16 GiB). A plan is never dropped while a resize is
+// using it, nor after its handle was handed out by *_get_plan().
+template< class Key >
+struct PlanCache
+{
+	struct Entry
+	{
+		avirhip_plan* p;
+		unsigned long long tick;
+		int busy;    // resizes in flight on the host side
+		bool pinned; // handle given to the caller: owned until destruction
+	};
+
+	std::map< Key, Entry > m;
+	unsigned long long tick = 0;
+
+	Entry* find( const Key& k )
+	{
+		auto it = m.find( k );
+
+		if( it == m.end() )
+		{
+			return( nullptr );
+		}
+
+		it -> second.tick = ++tick;
+		return( &it -> second );
+	}
+
+	Entry* insert( const Key& k, avirhip_plan* p )
+	{
+		Entry e = { p, ++tick, 0, false };
+		Entry* r = &( m[ k ] = e );
+		trim( r );
+		return( r );
+	}
+
+	static size_t limit( const char* name, size_t def )
+	{
+		const char* v = getenv( name );
+		return( v != nullptr && atoll( v ) > 0 ? (size_t) atoll( v ) : def );
+	}
+
+	void trim( const Entry* keep )
+	{
+		static const size_t maxn = limit( "AVIRHIP_CACHE_PLANS", 64 );
+		static const size_t maxb = limit( "AVIRHIP_CACHE_BYTES",
+			(size_t) 16 << 30 );
+
+		while( true )
+		{
+			size_t bytes = 0;
+			auto victim = m.end();
+
+			for( auto it = m.begin(); it != m.end(); ++it )
+			{
+				bytes += it -> second.p -> alloc_bytes;
+
+				if( &it -> second != keep && it -> second.busy == 0 &&
+					!it -> second.pinned && ( victim == m.end() ||
+					it -> second.tick < victim -> second.tick ))
+				{
+					victim = it;
+				}
+			}
+
+			if(( m.size() <= maxn && bytes <= maxb ) || victim == m.end() )
+			{
+				return;
+			}
+
+			// (hipFree inside waits for the plan's queued work)
+			avirhip_plan_destroy( victim -> second.p );
+			m.erase( victim );
+		}
+	}
+
+	void clear()
+	{
+		for( auto& c : m )
+		{
+			avirhip_plan_destroy( c.second.p );
+		}
+
+		m.clear();
+	}
+};
+
 struct avirhip_resizer
 {
 	AvirPlanner* planner;
 	int dither; // AVIRHIP_DITHER_*: fpclass::CDitherer of the mirrored object
 	std::mutex mtx;
 	typedef std::tuple< int, int, int, int, int, int, double, double, double,
-		int, int, int, int, int, int > Key;
-	std::map< Key, avirhip_plan* > cache;
+		int, int, int, int, int, int, int > Key; // ..., ditherer, device
+	PlanCache< Key > cache;
 	std::map< Key, avirhip_vars_base > vbcache;
 };
 
@@ -31,8 +124,8 @@ struct avirhip_lancir
 {
 	std::mutex mtx;
 	typedef std::tuple< int, int, int, int, int, int, int, double, double,
-		double, double, double, int, int > Key;
-	std::map< Key, avirhip_plan* > cache;
+		double, double, double, int, int, int > Key; // ..., device
+	PlanCache< Key > cache;
 };
 
 static const avirhip_vars g_defvars = { 0.0, 0.0, 0, -1, -1, 0 };
@@ -171,11 +264,7 @@ void avirhip_resizer_destroy( avirhip_resizer* r )
 		return;
 	}
 
-	for( auto& c : r -> cache )
-	{
-		avirhip_plan_destroy( c.second );
-	}
-
+	r -> cache.clear();
 	delete r -> planner;
 	delete r;
 }
@@ -213,6 +302,82 @@ void avirhip_plan_desc_free( avirhip_plan_desc* d )
 	}
 }
 
+// Finds or builds the plan of a call. `pin`: the handle leaves the library
+// (never evicted); otherwise the entry is marked busy until release().
+static int resizer_acquire( avirhip_resizer* r, int src_w, int src_h,
+	int src_scanline_size, int new_w, int new_h, int el_count_io, double k,
+	const avirhip_vars* vars, int in_type, int out_type, bool pin,
+	avirhip_plan** out )
+{
+	const avirhip_vars& V = ( vars == nullptr ? g_defvars : *vars );
+
+	if( src_scanline_size < 1 )
+	{
+		src_scanline_size = src_w * el_count_io;
+	}
+
+	int dev = 0;
+	(void) hipGetDevice( &dev ); // a plan lives on the device it was made on
+
+	std::lock_guard< std::mutex > lock( r -> mtx );
+	const avirhip_resizer::Key key( src_w, src_h, src_scanline_size, new_w,
+		new_h, el_count_io, k, V.ox, V.oy, V.BuildMode, in_type, out_type,
+		( V.UseSRGBGamma ? 1 : 0 ), V.AlphaIndex, r -> dither, dev );
+
+	auto* e = r -> cache.find( key );
+
+	if( e == nullptr )
+	{
+		avirhip_plan_desc* d = nullptr;
+		int rc = avirhip_resizer_build_desc( r, src_w, src_h,
+			src_scanline_size, new_w, new_h, el_count_io, k, &V, in_type,
+			out_type, &d );
+
+		if( rc != 0 )
+		{
+			return( rc );
+		}
+
+		avirhip_plan* p = nullptr;
+		rc = avirhip_plan_create( d, &p );
+		avirhip_plan_desc_free( d );
+
+		if( rc != 0 )
+		{
+			return( rc );
+		}
+
+		e = r -> cache.insert( key, p );
+	}
+
+	if( pin )
+	{
+		e -> pinned = true;
+	}
+	else
+	{
+		e -> busy++;
+	}
+
+	*out = e -> p;
+	return( AVIRHIP_OK );
+}
+
+static void resizer_release( avirhip_resizer* r, avirhip_plan* p )
+{
+	std::lock_guard< std::mutex > lock( r -> mtx );
+
+	for( auto& c : r -> cache.m )
+	{
+		if( c.second.p == p )
+		{
+			c.second.busy--;
+		}
+	}
+
+	r -> cache.trim( nullptr ); // scratch may have grown during the call
+}
+
 int avirhip_resizer_get_plan( avirhip_resizer* r, int src_w, int src_h,
 	int src_scanline_size, int new_w, int new_h, int el_count_io, double k,
 	const avirhip_vars* vars, int in_type, int out_type, avirhip_plan** out )
@@ -223,47 +388,8 @@ int avirhip_resizer_get_plan( avirhip_resizer* r, int src_w, int src_h,
 		return( AVIRHIP_EINVAL );
 	}
 
-	const avirhip_vars& V = ( vars == nullptr ? g_defvars : *vars );
-
-	if( src_scanline_size < 1 )
-	{
-		src_scanline_size = src_w * el_count_io;
-	}
-
-	const avirhip_resizer::Key key( src_w, src_h, src_scanline_size, new_w,
-		new_h, el_count_io, k, V.ox, V.oy, V.BuildMode, in_type, out_type,
-		( V.UseSRGBGamma ? 1 : 0 ), V.AlphaIndex, r -> dither );
-
-	std::lock_guard< std::mutex > lock( r -> mtx );
-	auto it = r -> cache.find( key );
-
-	if( it != r -> cache.end() )
-	{
-		*out = it -> second;
-		return( AVIRHIP_OK );
-	}
-
-	avirhip_plan_desc* d = nullptr;
-	int rc = avirhip_resizer_build_desc( r, src_w, src_h, src_scanline_size,
-		new_w, new_h, el_count_io, k, &V, in_type, out_type, &d );
-
-	if( rc != 0 )
-	{
-		return( rc );
-	}
-
-	avirhip_plan* p = nullptr;
-	rc = avirhip_plan_create( d, &p );
-	avirhip_plan_desc_free( d );
-
-	if( rc != 0 )
-	{
-		return( rc );
-	}
-
-	r -> cache[ key ] = p;
-	*out = p;
-	return( AVIRHIP_OK );
+	return( resizer_acquire( r, src_w, src_h, src_scanline_size, new_w, new_h,
+		el_count_io, k, vars, in_type, out_type, true, out ));
 }
 
 // CImageResizerVarsBase after resizeImage() (avir.h:2473-2506), from the
@@ -387,7 +513,7 @@ int avirhip_resizer_vars_base( avirhip_resizer* r, int src_w, int src_h,
 
 	const avirhip_resizer::Key key( src_w, src_h, src_scanline_size, new_w,
 		new_h, el_count_io, k, V.ox, V.oy, V.BuildMode, in_type, out_type,
-		( V.UseSRGBGamma ? 1 : 0 ), V.AlphaIndex, 0 );
+		( V.UseSRGBGamma ? 1 : 0 ), V.AlphaIndex, 0, 0 );
 
 	{
 		std::lock_guard< std::mutex > lock( r -> mtx );
@@ -468,15 +594,17 @@ int avirhip_resizer_resize( avirhip_resizer* r, const void* src, int src_mem,
 	}
 
 	avirhip_plan* p = nullptr;
-	int rc = avirhip_resizer_get_plan( r, src_w, src_h, src_scanline_size,
-		new_w, new_h, el_count_io, k, vars, in_type, out_type, &p );
+	int rc = resizer_acquire( r, src_w, src_h, src_scanline_size, new_w,
+		new_h, el_count_io, k, vars, in_type, out_type, false, &p );
 
 	if( rc != 0 )
 	{
 		return( rc );
 	}
 
-	return( avirhip_resize( p, src, src_mem, dst, dst_mem, stream ));
+	rc = avirhip_resize( p, src, src_mem, dst, dst_mem, stream );
+	resizer_release( r, p );
+	return( rc );
 }
 
 void avirhip_lancir_params_default( avirhip_lancir_params* p )
@@ -508,11 +636,7 @@ void avirhip_lancir_destroy( avirhip_lancir* l )
 		return;
 	}
 
-	for( auto& c : l -> cache )
-	{
-		avirhip_plan_destroy( c.second );
-	}
-
+	l -> cache.clear();
 	delete l;
 }
 
@@ -557,16 +681,10 @@ void avirhip_lancir_desc_free( avirhip_lancir_desc* d )
 	}
 }
 
-int avirhip_lancir_get_plan( avirhip_lancir* l, int src_w, int src_h,
+static int lancir_acquire( avirhip_lancir* l, int src_w, int src_h,
 	int new_w, int new_h, int el_count, const avirhip_lancir_params* params,
-	int in_type, int out_type, avirhip_plan** out )
+	int in_type, int out_type, bool pin, avirhip_plan** out )
 {
-	if( l == nullptr || out == nullptr )
-	{
-		set_error( "lancir_get_plan: null argument" );
-		return( AVIRHIP_EINVAL );
-	}
-
 	avirhip_lancir_params P;
 
 	if( params == nullptr )
@@ -578,40 +696,79 @@ int avirhip_lancir_get_plan( avirhip_lancir* l, int src_w, int src_h,
 		P = *params;
 	}
 
+	int dev = 0;
+	(void) hipGetDevice( &dev );
+
 	const avirhip_lancir::Key key( src_w, src_h, new_w, new_h, el_count,
 		P.SrcSSize, P.NewSSize, P.kx, P.ky, P.ox, P.oy, P.la, in_type,
-		out_type );
+		out_type, dev );
 
 	std::lock_guard< std::mutex > lock( l -> mtx );
-	auto it = l -> cache.find( key );
+	auto* e = l -> cache.find( key );
 
-	if( it != l -> cache.end() )
+	if( e == nullptr )
 	{
-		*out = it -> second;
-		return( AVIRHIP_OK );
+		avirhip_lancir_desc* d = nullptr;
+		int rc = avirhip_lancir_build_desc( l, src_w, src_h, new_w, new_h,
+			el_count, &P, in_type, out_type, &d );
+
+		if( rc != 0 )
+		{
+			return( rc );
+		}
+
+		avirhip_plan* p = nullptr;
+		rc = avirhip_lancir_plan_create( d, &p );
+		avirhip_lancir_desc_free( d );
+
+		if( rc != 0 )
+		{
+			return( rc );
+		}
+
+		e = l -> cache.insert( key, p );
 	}
 
-	avirhip_lancir_desc* d = nullptr;
-	int rc = avirhip_lancir_build_desc( l, src_w, src_h, new_w, new_h,
-		el_count, &P, in_type, out_type, &d );
-
-	if( rc != 0 )
+	if( pin )
 	{
-		return( rc );
+		e -> pinned = true;
+	}
+	else
+	{
+		e -> busy++;
 	}
 
-	avirhip_plan* p = nullptr;
-	rc = avirhip_lancir_plan_create( d, &p );
-	avirhip_lancir_desc_free( d );
-
-	if( rc != 0 )
-	{
-		return( rc );
-	}
-
-	l -> cache[ key ] = p;
-	*out = p;
+	*out = e -> p;
 	return( AVIRHIP_OK );
+}
+
+static void lancir_release( avirhip_lancir* l, avirhip_plan* p )
+{
+	std::lock_guard< std::mutex > lock( l -> mtx );
+
+	for( auto& c : l -> cache.m )
+	{
+		if( c.second.p == p )
+		{
+			c.second.busy--;
+		}
+	}
+
+	l -> cache.trim( nullptr );
+}
+
+int avirhip_lancir_get_plan( avirhip_lancir* l, int src_w, int src_h,
+	int new_w, int new_h, int el_count, const avirhip_lancir_params* params,
+	int in_type, int out_type, avirhip_plan** out )
+{
+	if( l == nullptr || out == nullptr )
+	{
+		set_error( "lancir_get_plan: null argument" );
+		return( AVIRHIP_EINVAL );
+	}
+
+	return( lancir_acquire( l, src_w, src_h, new_w, new_h, el_count, params,
+		in_type, out_type, true, out ));
 }
 
 int avirhip_lancir_resize( avirhip_lancir* l, const void* src, int src_mem,
@@ -655,8 +812,8 @@ int avirhip_lancir_resize( avirhip_lancir* l, const void* src, int src_mem,
 	}
 
 	avirhip_plan* p = nullptr;
-	int rc = avirhip_lancir_get_plan( l, src_w, src_h, new_w, new_h, el_count,
-		params, in_type, out_type, &p );
+	int rc = lancir_acquire( l, src_w, src_h, new_w, new_h, el_count, params,
+		in_type, out_type, false, &p );
 
 	if( rc != 0 )
 	{
@@ -664,6 +821,7 @@ int avirhip_lancir_resize( avirhip_lancir* l, const void* src, int src_mem,
 	}
 
 	rc = avirhip_resize( p, src, src_mem, dst, dst_mem, stream );
+	lancir_release( l, p );
 	return( rc != 0 ? rc : new_h );
 }
 

@@ -1016,6 +1016,8 @@ int fused_run( avirhip_plan* p, int mode, const void* src, int src_type,
 			4 * sizeof( float )));
 		F -> allocs.push_back( q );
 		F -> fltbuf = (float*) q;
+		p -> alloc_bytes += (size_t) p -> src_h * p -> new_w * 4 *
+			sizeof( float );
 	}
 
 	int rc = ( dn_has_h( F -> dn ) ?

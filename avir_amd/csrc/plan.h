@@ -118,6 +118,7 @@ struct avirhip_plan
 
 	// scratch (device), lazily sized
 	std::vector< void* > allocs;
+	size_t alloc_bytes; // device bytes this plan holds (tables + scratch)
 	float* packed;  // source converted to float (non-f32 input)
 	float* resbuf;  // float result before the integer / f64 epilogue
 	float* lres;    // LANCIR: float result rows before the output stage
@@ -132,6 +133,7 @@ struct avirhip_plan
 	// the mutex, device side by making every call's stream wait for the
 	// previous call's completion event.
 	std::mutex exec_mtx;
+	std::mutex shard_mtx; // avirhip_resize_sharded: replicas, band buffers
 	hipEvent_t last_done;
 	void* stage_src; // host-pointer staging
 	void* stage_dst;

@@ -943,3 +943,41 @@ def test_lancir_scanline_sizes(sw, sh, nw, nh, ch, spad, npad, tin, tout):
         assert (dbuf[:, nw * ch:] == 55).all(), "row padding overwritten"
         _assert_same(np.ascontiguousarray(dbuf[:, :nw * ch]).reshape(nh, nw, ch),
                      want, "lancir strides dev=%s" % dev)
+
+
+def test_plan_cache_is_bounded():
+    """A thumbnailer-style caller: many geometries through one object. The
+    front-end caches keep the most recently used plans only (here 3, by
+    AVIRHIP_CACHE_PLANS) and give the evicted plans' device memory back;
+    results stay right when an evicted geometry comes round again."""
+    import subprocess
+    import sys
+    code = r'''
+import numpy as np, torch, avir_amd
+from avir_amd import abi, synth
+abi.check(abi.load().avirhip_init(0), "init")
+src = synth.lcg_u8((600, 800, 3))
+r, l = avir_amd.CImageResizer(8), avir_amd.CLancIR()
+first = {}
+torch.cuda.synchronize()
+free = []
+for rnd in range(3):
+    for i in range(12):
+        nw, nh = 300 + 37 * i, 200 + 29 * i
+        a = r.resize(src, nw, nh); b = l.resize(src, nw, nh)
+        k = (nw, nh)
+        if k in first:
+            assert np.array_equal(first[k][0], a) and np.array_equal(first[k][1], b)
+        else:
+            first[k] = (a, b)
+    torch.cuda.synchronize()
+    free.append(torch.cuda.mem_get_info()[0])
+# no growth from round to round: the caches hold 3 plans each, not 12
+assert abs(free[2] - free[1]) < 64 << 20, free
+print("OK", free)
+'''
+    env = dict(os.environ, AVIRHIP_CACHE_PLANS="3")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", code], cwd=root, env=env,
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "OK" in r.stdout, (r.stdout, r.stderr[-3000:])
