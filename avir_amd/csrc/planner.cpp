@@ -9,6 +9,33 @@
 // and its buffer bookkeeping (avir.h:5616-6127), the build-mode cost model
 // (avir.h:6206-6270), and LANCIR's normalised Lanczos phases (lancir.h:882-
 // 1351). Compiled with g++ -O2 -ffp-contract=off (no FMA contraction).
+//
+// DERIVED WORK NOTICE. Because bit-identical tables are the contract, the
+// numerical parts of this file follow the reference's algorithms statement by
+// statement (same formulas, same operation order): it is a derived work of
+// avir.h / lancir.h of AVIR v3.1 (https://github.com/avaneev/avir), which are
+// distributed under the MIT License:
+//
+//   Copyright (c) 2015-2025 Aleksey Vaneev
+//
+//   Permission is hereby granted, free of charge, to any person obtaining a
+//   copy of this software and associated documentation files (the
+//   "Software"), to deal in the Software without restriction, including
+//   without limitation the rights to use, copy, modify, merge, publish,
+//   distribute, sublicense, and/or sell copies of the Software, and to permit
+//   persons to whom the Software is furnished to do so, subject to the
+//   following conditions:
+//
+//   The above copyright notice and this permission notice shall be included
+//   in all copies or substantial portions of the Software.
+//
+//   THE SOFTWARE IS PROVIDED "AS IS", WITHOUT WARRANTY OF ANY KIND, EXPRESS
+//   OR IMPLIED, INCLUDING BUT NOT LIMITED TO THE WARRANTIES OF
+//   MERCHANTABILITY, FITNESS FOR A PARTICULAR PURPOSE AND NONINFRINGEMENT. IN
+//   NO EVENT SHALL THE AUTHORS OR COPYRIGHT HOLDERS BE LIABLE FOR ANY CLAIM,
+//   DAMAGES OR OTHER LIABILITY, WHETHER IN AN ACTION OF CONTRACT, TORT OR
+//   OTHERWISE, ARISING FROM, OUT OF OR IN CONNECTION WITH THE SOFTWARE OR THE
+//   USE OR OTHER DEALINGS IN THE SOFTWARE.
 
 #include "planner.h"
 #include <math.h>
