@@ -19,6 +19,7 @@ STEP_NAMES = ["FIR", "UP_ZEROSTUFF", "UP_FILTERED", "RESIZE", "RESIZE2"]
 
 DITHER_DEF, DITHER_ERRD = 0, 1
 PATH_AUTO, PATH_GENERIC, PATH_TILED, PATH_FUSED, PATH_UP2 = 0, 1, 2, 3, 4
+PATH_GPASS = 5
 
 _fp = C.POINTER(C.c_float)
 _ip = C.POINTER(C.c_int32)

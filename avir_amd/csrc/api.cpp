@@ -588,6 +588,24 @@ static int exec_device( avirhip_plan* p, const void* src, void* dst,
 			}
 		}
 
+		if( lpath == 5 || ( lpath == 4 && p -> path == 0 && gpass_ok( p )))
+		{
+			// general-ratio pass kernels (vertical pass first)
+			rc = gpass_run( p, (const float*) src, p -> src_stride,
+				(float*) dst, row0, row1, st );
+
+			if( rc != 1 )
+			{
+				return( rc );
+			}
+
+			if( p -> path != 0 )
+			{
+				set_error( "path 5 cannot run this call (unaligned buffers?)" );
+				return( AVIRHIP_EUNSUPPORTED );
+			}
+		}
+
 		if(( rc = ensure_scratch( p )) != 0 ) return( rc );
 
 		return( launch_lancir_generic( p, src, dst, p -> resbuf, row0, row1,
@@ -650,8 +668,14 @@ static int exec_device( avirhip_plan* p, const void* src, void* dst,
 
 	rc = 1;
 
-	if( path >= 2 && path <= 4 )
+	if( path >= 2 && path <= 5 )
 	{
+		if( path == 5 )
+		{
+			if( need_pack && ( rc = do_pack()) != 0 ) return( rc );
+			rc = gpass_run( p, fsrc, sstride, fdst, row0, row1, st );
+		}
+		else
 		if( path == 4 )
 		{
 			rc = up2_run( p, fsrc, sstride, fdst, row0, row1, st );
@@ -925,7 +949,7 @@ static avirhip_plan* new_plan()
 {
 	avirhip_plan* p = new avirhip_plan();
 	p -> is_lancir = 0; p -> device = 0; p -> alloc_bytes = 0;
-	p -> path = 0; p -> fused_ok = 0; p -> auto_path = 1; p -> fused = nullptr; p -> up2 = nullptr; p -> lanc2 = nullptr;
+	p -> path = 0; p -> fused_ok = 0; p -> auto_path = 1; p -> fused = nullptr; p -> up2 = nullptr; p -> lanc2 = nullptr; p -> gpass = nullptr;
 	p -> packed = nullptr; p -> resbuf = nullptr; p -> lres = nullptr;
 	p -> stage_src = nullptr; p -> stage_dst = nullptr;
 	p -> stage_src_bytes = 0; p -> stage_dst_bytes = 0;
@@ -1086,12 +1110,27 @@ int finalize_avir_plan( avirhip_plan* p )
 
 	if( rc == 0 ) rc = fused_prepare( p );
 	if( rc == 0 ) rc = up2_prepare( p );
+	if( rc == 0 ) rc = gpass_prepare( p );
+
+	if( rc == 0 && gpass_ok( p ))
+	{
+		p -> fused_ok |= 8;
+
+		// the pass kernels take every general ratio; exact 2x keeps its
+		// marching kernel, and {2, 3}-fold downsizing on both axes the
+		// integer-ratio passes of dn.hip
+		if( p -> auto_path != 4 && !fused_dn_both( p ))
+		{
+			p -> auto_path = 5;
+		}
+	}
 
 	if( rc == 0 && p -> ch != p -> io_ch && p -> auto_path == 1 )
 	{
 		// no fast path for this plan: run the generic kernels unpadded
 		fused_release( p );
 		up2_release( p );
+		gpass_release( p );
 		p -> ch = p -> io_ch;
 		p -> fused_ok = 0;
 	}
@@ -1114,6 +1153,17 @@ static int finalize_lancir_plan( avirhip_plan* p )
 
 	if( rc == 0 ) rc = fused_prepare( p );
 	if( rc == 0 ) rc = lanc2_prepare( p );
+	if( rc == 0 ) rc = gpass_prepare( p );
+
+	if( rc == 0 && gpass_ok( p ))
+	{
+		p -> fused_ok |= 8;
+
+		if( p -> auto_path != 4 )
+		{
+			p -> auto_path = 5;
+		}
+	}
 	return( rc );
 }
 
@@ -1503,6 +1553,7 @@ void avirhip_plan_destroy( avirhip_plan* p )
 	fused_release( p );
 	up2_release( p );
 	lanc2_release( p );
+	gpass_release( p );
 
 	for( size_t i = 0; i < p -> allocs.size(); i++ )
 	{
@@ -1514,7 +1565,7 @@ void avirhip_plan_destroy( avirhip_plan* p )
 
 int avirhip_plan_set_path( avirhip_plan* p, int path )
 {
-	if( p == nullptr || path < 0 || path > 4 )
+	if( p == nullptr || path < 0 || path > 5 )
 	{
 		set_error( "bad path" );
 		return( AVIRHIP_EINVAL );
@@ -1523,6 +1574,7 @@ int avirhip_plan_set_path( avirhip_plan* p, int path )
 	if(( path == 2 && !( p -> fused_ok & 1 )) ||
 		( path == 3 && !( p -> fused_ok & 2 )) ||
 		( path == 4 && !( p -> fused_ok & 4 )) ||
+		( path == 5 && !( p -> fused_ok & 8 )) ||
 		( p -> is_lancir && ( path == 2 || path == 3 )))
 	{
 		set_error( "path %d cannot run this plan", path );

@@ -820,6 +820,13 @@ int fused_prepare( avirhip_plan* p )
 	return( AVIRHIP_OK );
 }
 
+// Both axes of the two-pass path run dn.hip's integer-ratio kernels.
+bool fused_dn_both( const avirhip_plan* p )
+{
+	const FusedData* F = (const FusedData*) p -> fused;
+	return( F != nullptr && dn_has_h( F -> dn ) && dn_has_v( F -> dn ));
+}
+
 void fused_release( avirhip_plan* p )
 {
 	FusedData* F = (FusedData*) p -> fused;

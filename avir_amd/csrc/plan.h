@@ -115,6 +115,7 @@ struct avirhip_plan
 	void* fused;    // tiled-kernel private data
 	void* up2;      // exact-2x marching kernel private data (fused_ok bit 2)
 	void* lanc2;    // LANCIR exact-2x kernel private data (fused_ok bit 2)
+	void* gpass;    // general-ratio pass kernels, path 5 (fused_ok bit 3)
 
 	// scratch (device), lazily sized
 	std::vector< void* > allocs;
@@ -194,6 +195,14 @@ int dn_run_h( void* d, const void* src, int src_type, int src_ch, long src_ss,
 	float* flt, long flt_ss, int a, int b, hipStream_t st );
 int dn_run_v( void* d, const float* flt, long flt_ss, int width, float* dst,
 	int row0, int row1, hipStream_t st );
+
+// gpass.hip: general-ratio pass kernels (path 5), AVIR and LANCIR RGBA float
+int gpass_prepare( avirhip_plan* p );
+void gpass_release( avirhip_plan* p );
+bool gpass_ok( const avirhip_plan* p );
+int gpass_run( avirhip_plan* p, const float* src, long src_stride, float* dst,
+	int row0, int row1, hipStream_t st );
+bool fused_dn_both( const avirhip_plan* p );
 
 // up2.hip: specialised exact-2x RGBA kernel (path 4)
 int up2_prepare( avirhip_plan* p );

@@ -246,7 +246,8 @@ def main():
                          "sits at its lowest clock and DVFS needs tens of ms of "
                          "load to settle (0 = none)")
     ap.add_argument("--path", type=int, default=0,
-                    help="0 auto, 1 generic, 2 two-pass, 3 fused tile, 4 up2 (A/B)")
+                    help="0 auto, 1 generic, 2 two-pass, 3 fused tile, 4 up2, "
+                         "5 pass kernels (A/B)")
     ap.add_argument("--no-cpu", action="store_true",
                     help="skip the CPU baseline leg")
     ap.add_argument("--backend", default="nccl",
@@ -390,7 +391,8 @@ def main():
     exec_path = {1: "generic per-step kernels",
                  2: "LDS-tiled two-pass kernels",
                  3: "LDS-tiled fused kernel",
-                 4: "exact-2x marching kernel (single launch)"
+                 4: "exact-2x marching kernel (single launch)",
+                 5: "general-ratio pass kernels (H launch + V launch)"
                  }.get(path, str(path))
     if world == 1:
         shard = "one GPU, whole frame"
@@ -441,7 +443,7 @@ def main():
             "traffic": read_traffic(),
             "algorithmic_bytes": ALGO_BYTES,
             "kernel_ms": round(ev_ms, 4),
-            "kernels_per_step": {1: 5, 2: 2, 3: 1, 4: 1}.get(path)}
+            "kernels_per_step": {1: 5, 2: 2, 3: 1, 4: 1, 5: 2}.get(path)}
 
     if world > 1:
         # secondary measurements: must never take the headline line down

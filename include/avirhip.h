@@ -205,10 +205,11 @@ void avirhip_plan_destroy(avirhip_plan* plan);
 /* Plan tuning: force an execution path, for testing and A/B benchmarking.
  * 0 = automatic (fastest applicable), 1 = generic per-step kernels (every
  * plan), 2 = LDS-tiled two-pass kernels, 3 = LDS-tiled fused single launch,
- * 4 = specialised exact-2x RGBA marching kernel (single launch). Returns
- * AVIRHIP_EUNSUPPORTED if the path cannot run this plan. */
+ * 4 = specialised exact-2x RGBA marching kernel (single launch), 5 = the
+ * general-ratio pass kernels (one launch per axis, autonomous wavefronts).
+ * Returns AVIRHIP_EUNSUPPORTED if the path cannot run this plan. */
 int avirhip_plan_set_path(avirhip_plan* plan, int path);
-/* The path the next execution will take (1..4). */
+/* The path the next execution will take (1..5). */
 int avirhip_plan_get_path(const avirhip_plan* plan);
 
 /* Executes H pass + V pass (+ integer epilogue) of `plan`:

@@ -322,7 +322,8 @@ def test_band_execution_matches_full():
         r = avir_amd.CImageResizer(16)
         full = r.resize(src, nw, nh)
         p = r.plan(sw, sh, nw, nh, 4)
-        paths = [abi.PATH_GENERIC, abi.PATH_TILED, abi.PATH_FUSED]
+        paths = [abi.PATH_GENERIC, abi.PATH_TILED, abi.PATH_FUSED,
+                 abi.PATH_GPASS]
         if nw == 2 * sw and nh == 2 * sh:
             paths.append(abi.PATH_UP2)
         for path in paths:
@@ -981,3 +982,66 @@ print("OK", free)
     r = subprocess.run([sys.executable, "-c", code], cwd=root, env=env,
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "OK" in r.stdout, (r.stdout, r.stderr[-3000:])
+
+
+# ---- general-ratio pass kernels (path 5, gpass.hip) ----
+
+GPASS = [
+    # (sw, sh, nw, nh): upsizing (FIR7 then 12-tap gather), 1<k<2 (zero-stuffed
+    # gather then FIR7), k>=2 (long gather then FIR7), mixed axes, tiny, strips
+    # and blocks that end at every residue, one-pixel rows / columns
+    (64, 48, 100, 77), (37, 21, 80, 50), (640, 480, 1024, 768),
+    (300, 200, 301, 201), (100, 77, 64, 48), (1000, 700, 640, 480),
+    (300, 200, 100, 67), (640, 480, 200, 150), (257, 129, 64, 300),
+    (90, 300, 200, 120), (7, 5, 13, 11), (33, 65, 31, 67), (50, 40, 50, 40),
+    (1, 50, 3, 20), (100, 1, 37, 1), (129, 67, 513, 259), (1920, 1080, 2500, 1400),
+]
+
+
+@pytest.mark.parametrize("bits", [8, 16])
+@pytest.mark.parametrize("sw,sh,nw,nh", GPASS)
+def test_avir_pass_kernels(sw, sh, nw, nh, bits):
+    """Path 5 against the reference, bit for bit; plans whose chains are not
+    FIR7+gather / gather+FIR7 (tiny frames, deep downsizing) report that the
+    path cannot run them."""
+    src = rb.lcg_f32((sh, sw, 4), seed=sw * 7 + nh)
+    want = _checker_avir(src, nw, nh, resbits=bits)
+    try:
+        got = _run_avir(src, nw, nh, resbits=bits, path=abi.PATH_GPASS)
+    except avir_amd.AvirHipError as e:
+        assert "cannot run this plan" in str(e)
+        return
+    _assert_same(got, want, "gpass %dx%d->%dx%d b%d" % (sw, sh, nw, nh, bits))
+
+
+def test_avir_pass_kernels_are_the_default_for_general_ratios():
+    lib = abi.load()
+    r = avir_amd.CImageResizer(16)
+    for (sw, sh, nw, nh, want) in [(1920, 1080, 2500, 1400, abi.PATH_GPASS),
+                                   (1000, 700, 640, 480, abi.PATH_GPASS),
+                                   (640, 480, 1280, 960, abi.PATH_UP2),
+                                   (3840, 2160, 1280, 720, abi.PATH_TILED)]:
+        p = r.plan(sw, sh, nw, nh, 4)
+        assert lib.avirhip_plan_get_path(p) == want, (sw, sh, nw, nh)
+
+
+@pytest.mark.parametrize("sw,sh,nw,nh", [
+    (64, 48, 100, 77), (300, 200, 100, 67), (640, 480, 1024, 768),
+    (120, 100, 45, 77), (9, 7, 31, 5), (300, 200, 33, 29), (50, 40, 50, 40),
+    (1280, 720, 427, 240), (33, 65, 200, 67)])
+def test_lancir_pass_kernels(sw, sh, nw, nh):
+    lib = abi.load()
+    src = rb.lcg_f32((sh, sw, 4), seed=sw + nh)
+    want = (rb.ref_lancir if rb.have_ref() else rb.orc_lancir)(src, nw, nh)
+    l = avir_amd.CLancIR()
+    p = l.plan(sw, sh, nw, nh, 4)
+    abi.check(lib.avirhip_plan_set_path(p, abi.PATH_GPASS), "set_path")
+    _assert_same(l.resize(src, nw, nh), want, "lancir gpass")
+    for kw in [dict(kx=0.7, ky=1.9), dict(kx=-1.5, ky=-0.6, ox=0.4, oy=-0.2),
+               dict(la=2.0), dict(la=4.5, kx=2.2, ky=2.2)]:
+        P = avir_amd.CLancIRParams(0, 0, kw.get("kx", 0), kw.get("ky", 0),
+                                   kw.get("ox", 0), kw.get("oy", 0),
+                                   kw.get("la", 3.0))
+        want = (rb.ref_lancir if rb.have_ref() else rb.orc_lancir)(
+            src, nw, nh, **kw)
+        _assert_same(l.resize(src, nw, nh, aParams=P), want, "lancir %s" % kw)
