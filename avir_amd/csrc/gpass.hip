@@ -33,6 +33,7 @@
 
 #include "plan.h"
 #include <algorithm>
+#include <type_traits>
 #include <string.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -110,41 +111,138 @@ __device__ __forceinline__ void gp_dma( const __amdgpu_buffer_rsrc_t rs,
 
 #define GP_WAIT_VM( n ) asm volatile( "s_waitcnt vmcnt(" #n ")" ::: "memory" )
 
-// One gather output from a ring / buffer of T pixels: tap t reads in[ t ].
-// `ld( t )` returns the input of tap t, `cf( t )` its (uniform) coefficient.
-template< bool LANC, typename T, typename LD, typename CF >
-__device__ __forceinline__ T gp_dot( const int nt, LD ld, CF cf )
+// s_waitcnt takes an immediate: a wave-uniform count picks its instruction.
+// Waiting for MORE than `n` to retire is always safe (loads retire in order).
+__device__ __forceinline__ void gp_wait_vm( const int n )
 {
+	switch( n )
+	{
+		case 0: GP_WAIT_VM( 0 ); break;
+		case 1: GP_WAIT_VM( 1 ); break;
+		case 2: GP_WAIT_VM( 2 ); break;
+		case 3: GP_WAIT_VM( 3 ); break;
+		case 4: GP_WAIT_VM( 4 ); break;
+		case 5: GP_WAIT_VM( 5 ); break;
+		case 6: GP_WAIT_VM( 6 ); break;
+		case 7: GP_WAIT_VM( 7 ); break;
+		case 8: GP_WAIT_VM( 8 ); break;
+		case 9: GP_WAIT_VM( 9 ); break;
+		case 10: GP_WAIT_VM( 10 ); break;
+		case 11: GP_WAIT_VM( 11 ); break;
+		case 12: GP_WAIT_VM( 12 ); break;
+		default: GP_WAIT_VM( 12 ); break;
+	}
+}
+
+// One gather output: tap t reads ld( t ); cf4( b ) returns the coefficients
+// of taps 4b .. 4b + 3 (rows are padded to a multiple of four; padded taps are
+// never multiplied: x * 0 is not a no-op for non-finite x). NTC > 0: the tap
+// count is a compile-time constant and everything unrolls.
+template< bool LANC, typename T, int NTC, typename LD, typename CF >
+__device__ __forceinline__ T gp_dot( const int nt_, LD ld, CF cf4 )
+{
+	const int nt = ( NTC > 0 ? NTC : nt_ );
+	const int nb = nt >> 2;
+
 	if( LANC )
 	{
 		// (t0*p0 + t2*p2 + ...) + (t1*p1 + t3*p3 + ...), bare first products
 		// (lancir.h:2482-2515); nt is even
-		T ea = cf( 0 ) * ld( 0 );
-		T oa = cf( 1 ) * ld( 1 );
-#pragma unroll 4
-		for( int t = 2; t < nt; t += 2 )
+		T ea, oa;
+		int b = 0;
+
+		if( nt >= 4 )
 		{
-			ea = ea + cf( t ) * ld( t );
-			oa = oa + cf( t + 1 ) * ld( t + 1 );
+			const f4 c = cf4( 0 );
+			ea = c.x * ld( 0 );
+			oa = c.y * ld( 1 );
+			ea = ea + c.z * ld( 2 );
+			oa = oa + c.w * ld( 3 );
+			b = 1;
+		}
+		else
+		{
+			const f4 c = cf4( 0 );
+			ea = c.x * ld( 0 );
+			oa = c.y * ld( 1 );
+			return( ea + oa );
+		}
+		if( NTC > 0 )
+		{
+#pragma unroll
+			for( int bb = 1; bb < ( NTC > 0 ? NTC / 4 : 1 ); bb++ )
+			{
+				const f4 c = cf4( bb );
+				ea = ea + c.x * ld( 4 * bb );
+				oa = oa + c.y * ld( 4 * bb + 1 );
+				ea = ea + c.z * ld( 4 * bb + 2 );
+				oa = oa + c.w * ld( 4 * bb + 3 );
+			}
+		}
+		else
+		{
+#pragma unroll 2
+			for( ; b < nb; b++ )
+			{
+				const f4 c = cf4( b );
+				ea = ea + c.x * ld( 4 * b );
+				oa = oa + c.y * ld( 4 * b + 1 );
+				ea = ea + c.z * ld( 4 * b + 2 );
+				oa = oa + c.w * ld( 4 * b + 3 );
+			}
+		}
+
+		if( nt & 2 )
+		{
+			const f4 c = cf4( nb );
+			ea = ea + c.x * ld( 4 * nb );
+			oa = oa + c.y * ld( 4 * nb + 1 );
 		}
 
 		return( ea + oa );
 	}
 
 	T acc = (T) 0.0f;
-	int t = 0;
 
-	for( ; t + 4 <= nt; t += 4 )
+	if( NTC > 0 )
 	{
-		acc = acc + cf( t ) * ld( t );
-		acc = acc + cf( t + 1 ) * ld( t + 1 );
-		acc = acc + cf( t + 2 ) * ld( t + 2 );
-		acc = acc + cf( t + 3 ) * ld( t + 3 );
+#pragma unroll
+		for( int b = 0; b < ( NTC > 0 ? NTC / 4 : 1 ); b++ )
+		{
+			const f4 c = cf4( b );
+			acc = acc + c.x * ld( 4 * b );
+			acc = acc + c.y * ld( 4 * b + 1 );
+			acc = acc + c.z * ld( 4 * b + 2 );
+			acc = acc + c.w * ld( 4 * b + 3 );
+		}
+	}
+	else
+	{
+#pragma unroll 2
+		for( int b = 0; b < nb; b++ )
+		{
+			const f4 c = cf4( b );
+			acc = acc + c.x * ld( 4 * b );
+			acc = acc + c.y * ld( 4 * b + 1 );
+			acc = acc + c.z * ld( 4 * b + 2 );
+			acc = acc + c.w * ld( 4 * b + 3 );
+		}
 	}
 
-	for( ; t < nt; t++ )
+	if( nt & 3 )
 	{
-		acc = acc + cf( t ) * ld( t );
+		const f4 c = cf4( nb );
+		acc = acc + c.x * ld( 4 * nb );
+
+		if(( nt & 3 ) > 1 )
+		{
+			acc = acc + c.y * ld( 4 * nb + 1 );
+		}
+
+		if(( nt & 3 ) > 2 )
+		{
+			acc = acc + c.z * ld( 4 * nb + 2 );
+		}
 	}
 
 	return( acc );
@@ -154,14 +252,40 @@ __device__ __forceinline__ T gp_dot( const int nt, LD ld, CF cf )
 // vertical pass
 // ---------------------------------------------------------------------
 
-template< int MODE, bool LANC >
+// One source row per step: the row's pixels travel global memory -> register
+// queue (GV_PF rows in flight, statically indexed: the step loop is unrolled
+// GV_PF times) -> whatever the mode keeps of them:
+//   PRE   a 7-row FIR window in registers (statically indexed too); each
+//         step yields one row of C, stored in the LDS ring the gathers read. The clamped source view makes FIR( Sext )
+//         the clamped view of C for EVERY index (rows before the first / after
+//         the last are constant), so there are no edge cases, only clamped
+//         row loads; rows of C above the zero-stuffed view's end are zero.
+//   NONE  the row goes into the LDS source ring.
+//   POST  the same, and gather outputs go through a second LDS ring that the
+//         correction FIR reads.
+// After every step the outputs whose last input has arrived are produced (a
+// wave-uniform while loop). LDS holds only what is addressed dynamically:
+// rs rows >= NT + 1 of source (NONE / POST), rc rows of C (>= NT + 1) or of
+// gather outputs (8).
+#define GV_PF 4 // row pairs in flight
+
+// RW > 0 (needs NTC > 0): the gather window lives in REGISTERS. An output is
+// produced in the very step its last input row arrives, so its window is
+// always "the last NTC rows": with the step loop unrolled RW times (RW a power
+// of two >= NTC) the window's ring slots are compile-time constants -- no LDS
+// reads for the taps at all, LDS only holds the landing queue and the tables.
+template< int MODE, bool LANC, int NTC, int RW >
 __global__ void __launch_bounds__( 64 ) k_gv( const GVParams P )
 {
 	extern __shared__ __attribute__(( aligned( 16 ))) char smem[];
 	const GPAxis& A = P.ax;
 	f2* const sring = (f2*) smem;                       // [rs][32 px][2 halves]
 	f2* const mring = sring + (size_t) P.rs * 64;       // [rc][32 px][2]
-	const unsigned sring_lds = (unsigned) (unsigned long) (lds_char*) smem;
+	// behind the rings and the 6 KiB landing queue: this chunk's coefficient
+	// rows (padded to four taps) and positions -- in LDS, not behind scalar
+	// loads: a scalar load in the tap loop costs its whole latency per use
+	// (every wait on lgkmcnt with one outstanding is a full drain)
+	float* const ctab = (float*) ( smem + ( P.rs + P.rc ) * 512 + 6 * 1024 );
 
 	const int lane = threadIdx.x;
 	const int strip = blockIdx.x % P.nstrips;
@@ -176,46 +300,20 @@ __global__ void __launch_bounds__( 64 ) k_gv( const GVParams P )
 	}
 
 	gp_cint* const a_start = (gp_cint*) (unsigned long) A.start;
-	gp_cint* const a_fidx = (gp_cint*) (unsigned long) A.fidx;
-	gp_cfloat* const a_coef = (gp_cfloat*) (unsigned long) A.coef;
 	const int smask = P.rs - 1;
 	const int mmask = P.rc - 1;
 	const int slast = A.in_len - 1;
-	const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
-		(void*) P.src, 0, 0x7fffffff, 0x00020000 );
+	const int nt = ( NTC > 0 ? NTC : A.nt );
+	const int ntp = ( nt + 3 ) & ~3;
 
-	// DMA lane -> (row parity, pixel): lanes 0-31 take row u, 32-63 row u + 1
-	const int dpx = gp_clamp( x0 + ( lane & 31 ), P.width - 1 );
-	const int drow = lane >> 5;
-	const int srow_b = (int) P.src_ss * 4;
-
-	// arithmetic lane -> half pixel
+	// this lane's half pixel; lanes right of the image redo its last pixel
 	const int hx = x0 + ( lane >> 1 );
 	const bool xok = ( hx < P.width );
 	const long dcol = (long) hx * 4 + ( lane & 1 ) * 2;
 
-	// source rows [ua, ub] -> ring (aligned pairs; clamped row indices)
-	auto issue_rows = [&]( int ua, const int ub )
+	auto mread = [&]( const int m ) -> f2
 	{
-		for( int u = ua & ~1; u <= ub; u += 2 )
-		{
-			const int r = gp_clamp( u + drow, slast );
-			gp_dma( rsrc, sring_lds + ( u & smask ) * 512,
-				r * srow_b + dpx * 16 );
-		}
-	};
-
-	// rows above the view's last replicated sample read 0 (zero-stuffed view,
-	// avir.h:3260-3402): overwrite them once their DMA has landed
-	auto zero_rows = [&]( const int ua, const int ub )
-	{
-		if( MODE != GP_PRE && ub > A.view_mmax )
-		{
-			for( int u = max( ua & ~1, A.view_mmax + 1 ); u <= ub + 1; u++ )
-			{
-				sring[ ( u & smask ) * 64 + lane ] = (f2) 0.0f;
-			}
-		}
+		return( mring[ ( m & mmask ) * 64 + lane ]);
 	};
 
 	auto sread = [&]( const int u ) -> f2
@@ -223,190 +321,308 @@ __global__ void __launch_bounds__( 64 ) k_gv( const GVParams P )
 		return( sring[ ( u & smask ) * 64 + lane ]);
 	};
 
-	auto mread = [&]( const int m ) -> f2
-	{
-		return( mring[ ( m & mmask ) * 64 + lane ]);
-	};
-
 	const f2 f0 = (f2) A.f[ 0 ], f1 = (f2) A.f[ 1 ], f2_ = (f2) A.f[ 2 ],
 		f3 = (f2) A.f[ 3 ];
 
-	// source row range a block of gather outputs [ga, gb] needs
-	auto need_lo = [&]( const int ga ) -> int
+	// gather outputs this chunk evaluates: [ga, gb]
+	const int glast = A.g_len - 1;
+	const int ga = ( MODE == GP_POST ? gp_clamp( y0 - A.e - 3, glast ) : y0 );
+	const int gb = ( MODE == GP_POST ? gp_clamp( y1 - 1 - A.e + 3, glast ) :
+		y1 - 1 );
+
+	// source rows fed: u_a .. u_b (PRE: six rows of FIR warm-up first)
+	const int u_a = a_start[ ga ] - ( MODE == GP_PRE ? 6 : 0 );
+	const int u_b = a_start[ gb ] + nt - 1;
+
+	// stage the tables (plain loads: they retire before the first DMA goes out)
+	int* const stab = (int*) ( ctab + ( gb - ga + 1 ) * ntp );
+
+	for( int i = lane; i < ( gb - ga + 1 ) * ntp; i += 64 )
 	{
-		if( MODE == GP_PRE )
-		{
-			// C rows from start[ga] on; C[m] reads S[clamp(m) - 6 .. clamp(m)]
-			return( gp_clamp( a_start[ ga ], A.c_len - 1 ) - 2 * A.e );
-		}
-
-		return( a_start[ ga ]);
-	};
-
-	auto need_hi = [&]( const int gb ) -> int
-	{
-		const int h = a_start[ gb ] + A.nt - 1;
-
-		if( MODE == GP_PRE )
-		{
-			return( gp_clamp( h, A.c_len - 1 ));
-		}
-
-		return( h );
-	};
-
-	// gather outputs a block of final outputs [n0, n1) needs
-	auto g_lo = [&]( const int n0 ) -> int
-	{
-		return( MODE == GP_POST ? gp_clamp( n0 - A.e - 3, A.g_len - 1 ) : n0 );
-	};
-
-	auto g_hi = [&]( const int n1 ) -> int
-	{
-		return( MODE == GP_POST ? gp_clamp( n1 - 1 - A.e + 3, A.g_len - 1 ) :
-			n1 - 1 );
-	};
-
-	int s_next;            // first source row not yet issued
-	int m_next;            // PRE: first C row not yet computed; POST: first G row
-	int n0 = y0;
-
-	// prologue: rows of the first block
-	{
-		const int n1 = min( n0 + P.blk, y1 );
-		const int ga = g_lo( n0 );
-		const int gb = g_hi( n1 );
-		const int ua = need_lo( ga );
-		const int ub = need_hi( gb );
-		issue_rows( ua, ub );
-		s_next = ( ub | 1 ) + 1;
-		m_next = ( MODE == GP_PRE ? a_start[ ga ] : ga );
+		const int gi = i / ntp;
+		const int t = i - gi * ntp;
+		const long row = ( LANC ? A.fidx[ ga + gi ] : ga + gi );
+		ctab[ i ] = ( t < nt ? A.coef[ row * nt + t ] : 0.0f );
 	}
 
-	while( n0 < y1 )
+	for( int i = lane; i <= gb - ga; i += 64 )
 	{
-		const int n1 = min( n0 + P.blk, y1 );
-		const int ga = g_lo( n0 );
-		const int gb = g_hi( n1 );
+		stab[ i ] = A.start[ ga + i ] + nt - 1;
+	}
 
-		// this block's rows have landed ...
-		GP_WAIT_VM( 0 );
-		zero_rows( need_lo( ga ), need_hi( gb ));
+	int g = ga;                 // next gather output
+	int g_need = a_start[ g ] + nt - 1; // its last input row
+	int n = y0;                 // POST: next final output
 
-		// ... and the next block's go out before the arithmetic starts
-		if( n1 < y1 )
+	auto store_row = [&]( const int y, const f2 o )
+	{
+		if( xok )
 		{
-			const int nn1 = min( n1 + P.blk, y1 );
-			const int ub = need_hi( g_hi( nn1 ));
-
-			if( ub >= s_next )
-			{
-				issue_rows( s_next, ub );
-				s_next = ( ub | 1 ) + 1;
-			}
+			*(f2*) ( P.dst + (long) ( y - P.dst_row0 ) * P.dst_ss + dcol ) = o;
 		}
+	};
 
-		if( MODE == GP_PRE )
-		{
-			// C rows up to the last one this block reads
-			const int mh = a_start[ gb ] + A.nt - 1;
+	f2 win[ RW > 0 ? RW : 1 ]; // RW > 0: the last RW rows the gathers read
+#pragma unroll
+	for( int i = 0; i < ( RW > 0 ? RW : 1 ); i++ )
+	{
+		win[ i ] = (f2) 0.0f;
+	}
 
-			for( ; m_next <= mh; m_next++ )
-			{
-				f2 c;
-
-				if( m_next > A.view_mmax )
-				{
-					c = (f2) 0.0f;
-				}
-				else
-				{
-					const int cc = gp_clamp( m_next, A.c_len - 1 ) - A.e;
-					c = f0 * sread( cc );
-					c = c + f1 * ( sread( cc + 1 ) + sread( cc - 1 ));
-					c = c + f2_ * ( sread( cc + 2 ) + sread( cc - 2 ));
-					c = c + f3 * ( sread( cc + 3 ) + sread( cc - 3 ));
-				}
-
-				mring[ ( m_next & mmask ) * 64 + lane ] = c;
-			}
-		}
-
+	// gather output g is done: store it, or (POST) run the correction FIR
+	auto finish = [&]( const f2 o )
+	{
 		if( MODE == GP_POST )
 		{
-			// G rows up to the last one this block's FIR reads
-			for( ; m_next <= gb; m_next++ )
+			mring[ ( g & mmask ) * 64 + lane ] = o;
+
+			// final outputs whose FIR window [c - 3, c + 3] (clamped) is
+			// complete: c + 3 <= g, or g is the last gather output
+			while( n < y1 && ( gp_clamp( n - A.e + 3, glast ) <= g ))
 			{
-				const int s0 = a_start[ m_next ];
-				gp_cfloat* cr = a_coef + (long) ( LANC ? a_fidx[ m_next ] :
-					m_next ) * A.nt;
-
-				const f2 g = gp_dot< LANC, f2 >( A.nt,
-					[&]( const int t ) { return( sread( s0 + t )); },
-					[&]( const int t ) { return( (f2) cr[ t ]); } );
-
-				mring[ ( m_next & mmask ) * 64 + lane ] = g;
+				const int c = n - A.e;
+				f2 r = f0 * mread( gp_clamp( c, glast ));
+				r = r + f1 * ( mread( gp_clamp( c + 1, glast )) +
+					mread( gp_clamp( c - 1, glast )));
+				r = r + f2_ * ( mread( gp_clamp( c + 2, glast )) +
+					mread( gp_clamp( c - 2, glast )));
+				r = r + f3 * ( mread( gp_clamp( c + 3, glast )) +
+					mread( gp_clamp( c - 3, glast )));
+				store_row( n, r );
+				n++;
 			}
 		}
-
-		for( int n = n0; n < n1; n++ )
+		else
 		{
+			store_row( g, o );
+		}
+
+		g++;
+		g_need = ( g <= gb ? __builtin_amdgcn_readfirstlane(
+			stab[ g - ga ]) : 0x7fffffff );
+	};
+
+	// everything whose inputs are complete once row `u` is in its ring.
+	// IC: the step's phase within the unrolled loop (window slot of row u).
+	auto drain = [&]( const int u, auto IC )
+	{
+		constexpr int I = decltype( IC )::value;
+
+		while( g <= gb && g_need <= u )
+		{
+			const int s0 = g_need - nt + 1;
+			const float* const cr = ctab + ( g - ga ) * ntp;
 			f2 o;
 
-			if( MODE == GP_POST )
+			if( RW > 0 )
 			{
-				const int glast = A.g_len - 1;
-				const int c = n - A.e;
-				o = f0 * mread( gp_clamp( c, glast ));
-				o = o + f1 * ( mread( gp_clamp( c + 1, glast )) +
-					mread( gp_clamp( c - 1, glast )));
-				o = o + f2_ * ( mread( gp_clamp( c + 2, glast )) +
-					mread( gp_clamp( c - 2, glast )));
-				o = o + f3 * ( mread( gp_clamp( c + 3, glast )) +
-					mread( gp_clamp( c - 3, glast )));
+				// g_need == u: outputs are drained the step they complete
+				o = gp_dot< LANC, f2, NTC >( nt,
+					[&]( const int t ) { return( win[ ( I - ( NTC - 1 ) + t +
+						4 * ( RW > 0 ? RW : 1 )) & (( RW > 0 ? RW : 1 ) - 1 )]); },
+					[&]( const int b ) { return( *(const f4*) ( cr + 4 * b )); } );
+			}
+			else
+			if( MODE == GP_PRE )
+			{
+				o = gp_dot< LANC, f2, NTC >( nt,
+					[&]( const int t ) { return( mread( s0 + t )); },
+					[&]( const int b ) { return( *(const f4*) ( cr + 4 * b )); } );
 			}
 			else
 			{
-				const int s0 = a_start[ n ];
-				gp_cfloat* cr = a_coef + (long) ( LANC ? a_fidx[ n ] : n ) *
-					A.nt;
-
-				if( MODE == GP_PRE )
-				{
-					o = gp_dot< LANC, f2 >( A.nt,
-						[&]( const int t ) { return( mread( s0 + t )); },
-						[&]( const int t ) { return( (f2) cr[ t ]); } );
-				}
-				else
-				{
-					o = gp_dot< LANC, f2 >( A.nt,
-						[&]( const int t ) { return( sread( s0 + t )); },
-						[&]( const int t ) { return( (f2) cr[ t ]); } );
-				}
+				o = gp_dot< LANC, f2, NTC >( nt,
+					[&]( const int t ) { return( sread( s0 + t )); },
+					[&]( const int b ) { return( *(const f4*) ( cr + 4 * b )); } );
 			}
 
-			if( xok )
-			{
-				*(f2*) ( P.dst + (long) ( n - P.dst_row0 ) * P.dst_ss + dcol ) =
-					o;
-			}
+			finish( o );
+		}
+	};
+
+	// ---- the feed: source rows by LDS-DMA, two rows per instruction (lanes
+	// 0-31 row 2p, lanes 32-63 row 2p + 1), GV_PF pairs in flight. Waiting
+	// for "at most GV_PF vector-memory operations outstanding" right after
+	// issuing pair p + GV_PF guarantees pair p has landed (loads retire in
+	// order; stores in between only make the wait stricter).
+	const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+		(void*) P.src, 0, 0x7fffffff, 0x00020000 );
+	const unsigned lds0 = (unsigned) (unsigned long) (lds_char*) smem;
+	const int dpx = gp_clamp( x0 + ( lane & 31 ), P.width - 1 );
+	const int srow_b = (int) P.src_ss * 4;
+	// PRE: pairs land in a queue of GV_PF + 1 slots behind the C ring;
+	// NONE / POST: straight in the source ring (rs >= nt + 2 * GV_PF + 3)
+	const unsigned qbase = lds0 + (unsigned) ( P.rs + P.rc ) * 512;
+	const int pa = u_a >> 1; // first pair (arithmetic shift: floor)
+	const int pb = u_b >> 1;
+
+	auto issue_pair = [&]( const int p )
+	{
+		if( p <= pb )
+		{
+			const int r = gp_clamp( p * 2 + ( lane >> 5 ), slast );
+			const unsigned slot = ( MODE == GP_PRE || RW > 0 ?
+				qbase + (unsigned) (( p - pa ) % ( GV_PF + 1 )) * 1024 :
+				lds0 + (unsigned) (( p * 2 ) & smask ) * 512 );
+
+			gp_dma( rsrc, slot, r * srow_b + dpx * 16 );
+		}
+		else
+		{
+			// keep the count of operations per step uniform: a load nobody
+			// reads (its queue slot is past the data)
+			gp_dma( rsrc, qbase + (unsigned) ( GV_PF + 1 ) * 1024,
+				dpx * 16 );
+		}
+	};
+
+	for( int k = 0; k < GV_PF; k++ )
+	{
+		issue_pair( pa + k );
+	}
+
+	f2 tw[ 8 ]; // PRE: the FIR window (rows u - 6 .. u in slots ( u - u_a ) & 7)
+#pragma unroll
+	for( int i = 0; i < 8; i++ )
+	{
+		tw[ i ] = (f2) 0.0f;
+	}
+
+	// steps run over whole pairs; rows before u_a / after u_b of the first /
+	// last pair are fed like any other (clamped loads), outputs never need
+	// them
+	const int u0 = pa * 2;
+
+	constexpr int UN = ( RW > 8 ? RW : 8 );
+
+	auto step = [&]( const int u, auto IC )
+	{
+		constexpr int i = decltype( IC )::value;
+
+		if( u > ( pb * 2 + 1 ))
+		{
+			return;
 		}
 
-		n0 = n1;
+		if(( i & 1 ) == 0 )
+		{
+			issue_pair(( u >> 1 ) + GV_PF );
+			GP_WAIT_VM( 4 ); // == GV_PF
+		}
+
+		const f2* const qs = (const f2*) ( smem + ( P.rs + P.rc ) * 512 +
+			((( u >> 1 ) - pa ) % ( GV_PF + 1 )) * 1024 + ( i & 1 ) * 512 );
+
+		if( MODE == GP_PRE )
+		{
+			tw[ i & 7 ] = qs[ lane ];
+			f2 c = f0 * tw[ ( i - 3 ) & 7 ];
+			c = c + f1 * ( tw[ ( i - 2 ) & 7 ] + tw[ ( i - 4 ) & 7 ]);
+			c = c + f2_ * ( tw[ ( i - 1 ) & 7 ] + tw[ ( i - 5 ) & 7 ]);
+			c = c + f3 * ( tw[ i & 7 ] + tw[ ( i - 6 ) & 7 ]);
+
+			if( u > A.view_mmax )
+			{
+				c = (f2) 0.0f;
+			}
+
+			if( RW > 0 )
+			{
+				win[ i & (( RW > 0 ? RW : 1 ) - 1 )] = c;
+			}
+			else
+			{
+				mring[ ( u & mmask ) * 64 + lane ] = c;
+			}
+
+			if( u - u0 >= 6 )
+			{
+				drain( u, IC );
+			}
+		}
+		else
+		{
+			if( RW > 0 )
+			{
+				f2 v = qs[ lane ];
+
+				if( u > A.view_mmax )
+				{
+					v = (f2) 0.0f;
+				}
+
+				win[ i & (( RW > 0 ? RW : 1 ) - 1 )] = v;
+			}
+			else
+			if( u > A.view_mmax )
+			{
+				sring[ ( u & smask ) * 64 + lane ] = (f2) 0.0f;
+			}
+
+			drain( u, IC );
+		}
+	};
+
+	for( int ub = u0; ub <= u_b; ub += UN )
+	{
+		step( ub + 0, std::integral_constant< int, 0 >() );
+		step( ub + 1, std::integral_constant< int, 1 >() );
+		step( ub + 2, std::integral_constant< int, 2 >() );
+		step( ub + 3, std::integral_constant< int, 3 >() );
+		step( ub + 4, std::integral_constant< int, 4 >() );
+		step( ub + 5, std::integral_constant< int, 5 >() );
+		step( ub + 6, std::integral_constant< int, 6 >() );
+		step( ub + 7, std::integral_constant< int, 7 >() );
+
+		if( UN > 8 )
+		{
+			step( ub + 8, std::integral_constant< int, 8 >() );
+			step( ub + 9, std::integral_constant< int, 9 >() );
+			step( ub + 10, std::integral_constant< int, 10 >() );
+			step( ub + 11, std::integral_constant< int, 11 >() );
+			step( ub + 12, std::integral_constant< int, 12 >() );
+			step( ub + 13, std::integral_constant< int, 13 >() );
+			step( ub + 14, std::integral_constant< int, 14 >() );
+			step( ub + 15, std::integral_constant< int, 15 >() );
+		}
+
+		if( UN > 16 )
+		{
+			step( ub + 16, std::integral_constant< int, 16 >() );
+			step( ub + 17, std::integral_constant< int, 17 >() );
+			step( ub + 18, std::integral_constant< int, 18 >() );
+			step( ub + 19, std::integral_constant< int, 19 >() );
+			step( ub + 20, std::integral_constant< int, 20 >() );
+			step( ub + 21, std::integral_constant< int, 21 >() );
+			step( ub + 22, std::integral_constant< int, 22 >() );
+			step( ub + 23, std::integral_constant< int, 23 >() );
+			step( ub + 24, std::integral_constant< int, 24 >() );
+			step( ub + 25, std::integral_constant< int, 25 >() );
+			step( ub + 26, std::integral_constant< int, 26 >() );
+			step( ub + 27, std::integral_constant< int, 27 >() );
+			step( ub + 28, std::integral_constant< int, 28 >() );
+			step( ub + 29, std::integral_constant< int, 29 >() );
+			step( ub + 30, std::integral_constant< int, 30 >() );
+			step( ub + 31, std::integral_constant< int, 31 >() );
+		}
 	}
+
+	GP_WAIT_VM( 0 );
 }
 
 // ---------------------------------------------------------------------
 // horizontal pass
 // ---------------------------------------------------------------------
 
+#define GH_NB 4 // source row buffers: rows r .. r + 3 are in LDS or in flight
+
 template< int MODE, bool LANC, int NTC >
 __global__ void __launch_bounds__( 64 ) k_gh( const GHParams P )
 {
 	extern __shared__ __attribute__(( aligned( 16 ))) char smem[];
 	const GPAxis& A = P.ax;
-	f4* const sbuf = (f4*) smem;                    // [2][sbuf px]
-	f4* const mbuf = sbuf + 2 * (size_t) P.sbuf;    // [mbuf px]
+	f4* const sbuf = (f4*) smem;                    // [GH_NB][sbuf px]
+	f4* const mbuf = sbuf + GH_NB * (size_t) P.sbuf; // [mbuf px]
 	float* const cfl = (float*) ( mbuf + P.mbuf );  // NTC == 0: [nt][64 lanes]
 	const unsigned sbuf_lds = (unsigned) (unsigned long) (lds_char*) smem;
 
@@ -476,33 +692,24 @@ __global__ void __launch_bounds__( 64 ) k_gh( const GHParams P )
 		}
 	}
 
-	issue_row( r0, 0 );
+	for( int k = 0; k < GH_NB - 1 && r0 + k < r1; k++ )
+	{
+		issue_row( r0 + k, k );
+	}
 
 	for( int r = r0; r < r1; r++ )
 	{
-		const int buf = ( r - r0 ) & 1;
+		const int buf = ( r - r0 ) & ( GH_NB - 1 );
 		const f4* const s = sbuf + buf * P.sbuf;
 
-		// next row's segment goes out, then wait for this row's: at most the
-		// P.nseg pieces just issued may still be in flight (loads return in
-		// order; the previous row's store may or may not have retired)
-		if( r + 1 < r1 )
+		// row r + 3 goes out (into the buffer row r - 1 has left), then wait
+		// for row r: only the pieces of the rows after it may be in flight
+		if( r + GH_NB - 1 < r1 )
 		{
-			issue_row( r + 1, buf ^ 1 );
+			issue_row( r + GH_NB - 1, ( buf + GH_NB - 1 ) & ( GH_NB - 1 ));
+		}
 
-			switch( P.nseg )
-			{
-				case 1: GP_WAIT_VM( 1 ); break;
-				case 2: GP_WAIT_VM( 2 ); break;
-				case 3: GP_WAIT_VM( 3 ); break;
-				case 4: GP_WAIT_VM( 4 ); break;
-				default: GP_WAIT_VM( 0 ); break;
-			}
-		}
-		else
-		{
-			GP_WAIT_VM( 0 );
-		}
+		gp_wait_vm( min( GH_NB - 1, r1 - 1 - r ) * P.nseg );
 
 		if( MODE != GP_PRE && slo + scnt - 1 > A.view_mmax )
 		{
@@ -547,10 +754,30 @@ __global__ void __launch_bounds__( 64 ) k_gh( const GHParams P )
 		{
 			const f4* const in = ( MODE == GP_PRE ? mbuf : s ) + gs;
 
-			o = gp_dot< LANC, f4 >( nt,
+			o = gp_dot< LANC, f4, NTC >( nt,
 				[&]( const int t ) { return( in[ t ]); },
-				[&]( const int t ) { return( NTC > 0 ? cf[ NTC > 0 ? t : 0 ] :
-					cfl[ t * 64 + lane ]); } );
+				[&]( const int b ) -> f4
+				{
+					f4 c;
+
+					if( NTC > 0 )
+					{
+						c.x = cf[ ( 4 * b ) % ( NTC > 0 ? NTC : 1 )];
+						c.y = cf[ ( 4 * b + 1 ) % ( NTC > 0 ? NTC : 1 )];
+						c.z = cf[ ( 4 * b + 2 ) % ( NTC > 0 ? NTC : 1 )];
+						c.w = cf[ ( 4 * b + 3 ) % ( NTC > 0 ? NTC : 1 )];
+					}
+					else
+					{
+						// (rows beyond nt hold whatever: never multiplied)
+						c.x = cfl[ ( 4 * b ) * 64 + lane ];
+						c.y = cfl[ ( 4 * b + 1 ) * 64 + lane ];
+						c.z = cfl[ ( 4 * b + 2 ) * 64 + lane ];
+						c.w = cfl[ ( 4 * b + 3 ) * 64 + lane ];
+					}
+
+					return( c );
+				} );
 		}
 
 		if( MODE == GP_POST )
@@ -643,12 +870,12 @@ static bool match_avir_axis( const LAxis& ax, GPAxisHost& H )
 	}
 
 	if( fir != nullptr && ( fir -> rf != 1 || fir -> lat != 3 ||
-		fir -> view != VIEW_CLAMP || fir -> e != 3 ))
+		fir -> view != VIEW_CLAMP || fir -> e < 0 || fir -> e > 3 ))
 	{
 		return( false );
 	}
 
-	if( gat -> view == VIEW_RAW || gat -> maxtaps < 2 || gat -> maxtaps > 40 )
+	if( gat -> view == VIEW_RAW || gat -> maxtaps < 2 || gat -> maxtaps > 64 )
 	{
 		return( false );
 	}
@@ -673,12 +900,15 @@ static bool match_avir_axis( const LAxis& ax, GPAxisHost& H )
 	A.view_mmax = ( gat -> view == VIEW_ZS ? gat -> zs_mmax : 0x7fffffff );
 	A.g_len = gat -> out_len;
 	A.out_len = ax.dst_len;
-	A.e = 3;
+	A.e = ( fir != nullptr ? fir -> e : 0 );
 	A.c_len = 0;
 
 	if( mode == GP_PRE )
 	{
-		if( fir -> in_len != ax.src_len || gat -> in_len != fir -> out_len ||
+		// (the window algebra below is written for e == lat == 3: C[m] reads
+		// S[clamp(m) - 6 .. clamp(m)])
+		if( fir -> e != 3 || fir -> in_len != ax.src_len ||
+			gat -> in_len != fir -> out_len ||
 			fir -> out_len != ax.src_len + 2 * fir -> e )
 		{
 			return( false );
@@ -720,7 +950,7 @@ static void match_lancir_axis( const LancirAxisDev& L, GPAxisHost& H )
 {
 	GPAxis& A = H.a;
 	memset( &A, 0, sizeof( A ));
-	H.ok = ( L.kernel_len >= 2 && L.kernel_len <= 40 &&
+	H.ok = ( L.kernel_len >= 2 && L.kernel_len <= 64 &&
 		( L.kernel_len & 1 ) == 0 );
 
 	A.mode = GP_NONE; A.lanc = 1; A.nt = L.kernel_len;
@@ -821,7 +1051,7 @@ int gpass_prepare( avirhip_plan* p )
 
 			// the FIR and POST stages run one buffer entry per lane and pass
 			const bool fits = ( maxs <= 256 && ( A.mode == GP_NONE ||
-				maxm <= ( A.mode == GP_POST ? 64 : 128 )));
+				maxm <= 64 ));
 
 			if( fits )
 			{
@@ -848,70 +1078,48 @@ int gpass_prepare( avirhip_plan* p )
 		D -> d_hseg = (int*) q;
 	}
 
-	// ---- vertical pass geometry: block height and ring sizes from the
-	// largest spans any block has
+	// ---- vertical pass geometry: LDS rings hold what the gathers address
+	// dynamically, one window plus the row being written
 	{
 		const GPAxis& A = D -> v.a;
-		const std::vector< int >& st = D -> v.start;
-		int blk = 8;
+		int rs = 2, rc = 2;
 
-		for( ; blk >= 1; blk >>= 1 )
+		// tap counts the register-window kernels exist for (launch_gv): no
+		// window in LDS at all
+		static const int regwin[] = { 6, 8, 10, 12, 14, 16, 18, 19, 20, 21,
+			22, 24 };
+
+		bool rw = false;
+
+		for( size_t i = 0; i < sizeof( regwin ) / sizeof( regwin[ 0 ]); i++ )
 		{
-			int span_s = 0, span_m = 0;
-
-			for( int n0 = 0; n0 < A.out_len; n0++ )
-			{
-				// any block start (chunks begin at arbitrary rows in bands)
-				const int n1 = std::min( A.out_len, n0 + blk );
-				int ga = n0, gb = n1 - 1;
-
-				if( A.mode == GP_POST )
-				{
-					ga = std::max( 0, std::min( n0 - A.e - 3, A.g_len - 1 ));
-					gb = std::max( 0, std::min( n1 - 1 - A.e + 3, A.g_len - 1 ));
-				}
-
-				// two consecutive blocks live in the source ring at once
-				const int n2 = std::min( A.out_len, n1 + blk );
-				int gb2 = n2 - 1;
-
-				if( A.mode == GP_POST )
-				{
-					gb2 = std::max( 0, std::min( n2 - 1 - A.e + 3, A.g_len - 1 ));
-				}
-
-				int ua = st[ ga ], ub = st[ gb2 ] + A.nt - 1;
-
-				if( A.mode == GP_PRE )
-				{
-					ua = std::max( 0, std::min( ua, A.c_len - 1 )) - 2 * A.e;
-					ub = std::max( 0, std::min( ub, A.c_len - 1 ));
-					span_m = std::max( span_m, st[ gb ] + A.nt - st[ ga ]);
-				}
-				else
-				if( A.mode == GP_POST )
-				{
-					span_m = std::max( span_m, gb - ga + 1 + 7 );
-				}
-
-				span_s = std::max( span_s, ub - ua + 1 + 4 );
-			}
-
-			const int rs = next_pow2( span_s );
-			const int rc = ( A.mode == GP_NONE ? 2 : next_pow2( span_m + 1 ));
-
-			if(( rs + rc ) * 512 <= 48 * 1024 || blk == 1 )
-			{
-				if(( rs + rc ) * 512 > 64 * 1024 )
-				{
-					delete D;
-					return( AVIRHIP_OK );
-				}
-
-				D -> v_blk = blk; D -> v_rs = rs; D -> v_rc = rc;
-				break;
-			}
+			rw |= ( A.nt == regwin[ i ]);
 		}
+
+		if( rw )
+		{
+			rc = ( A.mode == GP_POST ? 8 : 2 );
+		}
+		else
+		if( A.mode == GP_PRE )
+		{
+			rc = next_pow2( A.nt + 1 );
+		}
+		else
+		{
+			// the window, the row pair being consumed and 4 pairs in flight
+			rs = next_pow2( A.nt + 2 * 4 + 3 );
+			rc = ( A.mode == GP_POST ? 8 : 2 );
+		}
+
+		// (+ the PRE landing queue: 5 pair slots and one dump slot)
+		if(( rs + rc ) * 512 + 6 * 1024 > 64 * 1024 )
+		{
+			delete D;
+			return( AVIRHIP_OK );
+		}
+
+		D -> v_blk = 1; D -> v_rs = rs; D -> v_rc = rc;
 	}
 
 	// row offsets travel as 32-bit byte offsets
@@ -956,8 +1164,20 @@ template< int MODE, bool LANC >
 static void launch_gv( const GVParams& P, int items, size_t lds,
 	hipStream_t st )
 {
-	hipLaunchKernelGGL(( k_gv< MODE, LANC > ), dim3( items ), dim3( 64 ), lds,
-		st, P );
+	// register-window variants for the common tap counts (ring = next power
+	// of two), the LDS-window kernel for everything else
+#define GV_CASE( NT, RW ) case NT: hipLaunchKernelGGL(( k_gv< MODE, LANC, NT, \
+	RW > ), dim3( items ), dim3( 64 ), lds, st, P ); break;
+	switch( P.ax.nt )
+	{
+		GV_CASE( 6, 8 ) GV_CASE( 8, 8 ) GV_CASE( 10, 16 ) GV_CASE( 12, 16 )
+		GV_CASE( 14, 16 ) GV_CASE( 16, 16 ) GV_CASE( 18, 32 )
+		GV_CASE( 19, 32 ) GV_CASE( 20, 32 ) GV_CASE( 21, 32 )
+		GV_CASE( 22, 32 ) GV_CASE( 24, 32 )
+		default: hipLaunchKernelGGL(( k_gv< MODE, LANC, 0, 0 > ),
+			dim3( items ), dim3( 64 ), lds, st, P ); break;
+	}
+#undef GV_CASE
 }
 
 template< int MODE, bool LANC >
@@ -987,16 +1207,27 @@ static int run_v( const GPData* D, const float* src, long src_ss, int width,
 	P.nstrips = ( width + 31 ) / 32;
 	P.blk = D -> v_blk; P.rs = D -> v_rs; P.rc = D -> v_rc;
 
-	// chunk height: enough work items to fill the CUs a few times over, few
-	// enough that a chunk's warm-up rows (its first window) stay a small part
+	// chunk height: a chunk's first window (NT rows, + 6 of FIR warm-up) is
+	// fed before its first output; aim for ~6000 waves (256 CUs x up to 16
+	// resident, a few rounds) but never below ~4 windows of rows per chunk
 	const int rows = row_hi - row_lo;
-	int nch = std::max( 1, std::min( rows / ( 4 * P.blk ),
-		( 4096 + P.nstrips - 1 ) / P.nstrips ));
+	const int minrows = std::max( 16, (int) ( (long) ( P.ax.nt + 6 ) *
+		std::max( 1, P.ax.out_len ) / std::max( 1, P.ax.in_len )));
 
-	P.chunk = (( rows + nch - 1 ) / nch + P.blk - 1 ) / P.blk * P.blk;
+	int nch = std::max( 1, std::min( rows / minrows,
+		( 6144 + P.nstrips - 1 ) / P.nstrips ));
+
+	P.chunk = ( rows + nch - 1 ) / nch;
+
+	// the chunk's coefficient rows and positions live in LDS: <= 6 KiB
+	const int ntp = ( P.ax.nt + 3 ) & ~3;
+	const int gextra = ( P.ax.mode == GP_POST ? 7 : 0 );
+	const int maxg = std::max( gextra + 1, 6144 / ( ntp * 4 + 4 ));
+	P.chunk = std::max( 1, std::min( P.chunk, maxg - gextra ));
 	nch = ( rows + P.chunk - 1 ) / P.chunk;
 	const int items = P.nstrips * nch;
-	const size_t lds = (size_t) ( P.rs + P.rc ) * 512;
+	const size_t lds = (size_t) ( P.rs + P.rc ) * 512 + 6 * 1024 +
+		(size_t) ( P.chunk + gextra ) * ( ntp * 4 + 4 ) + 64;
 	const GPAxis& A = P.ax;
 
 	if( A.lanc )
@@ -1042,8 +1273,8 @@ static int run_h( const GPData* D, const float* src, long src_ss, int src_w,
 	P.chunk = ( rows + nch - 1 ) / nch;
 	nch = ( rows + P.chunk - 1 ) / P.chunk;
 	const int items = P.nstrips * nch;
-	const size_t lds = (size_t) ( 2 * P.sbuf + P.mbuf ) * 16 +
-		(size_t) P.ax.nt * 64 * 4;
+	const size_t lds = (size_t) ( GH_NB * P.sbuf + P.mbuf ) * 16 +
+		(size_t) (( P.ax.nt + 3 ) & ~3 ) * 64 * 4;
 	const GPAxis& A = P.ax;
 
 	if( A.lanc )

@@ -1040,8 +1040,8 @@ def test_lancir_pass_kernels(sw, sh, nw, nh):
     for kw in [dict(kx=0.7, ky=1.9), dict(kx=-1.5, ky=-0.6, ox=0.4, oy=-0.2),
                dict(la=2.0), dict(la=4.5, kx=2.2, ky=2.2)]:
         P = avir_amd.CLancIRParams(0, 0, kw.get("kx", 0), kw.get("ky", 0),
-                                   kw.get("ox", 0), kw.get("oy", 0),
-                                   kw.get("la", 3.0))
+                                   kw.get("ox", 0), kw.get("oy", 0))
+        P.la = kw.get("la", 3.0)
         want = (rb.ref_lancir if rb.have_ref() else rb.orc_lancir)(
             src, nw, nh, **kw)
         _assert_same(l.resize(src, nw, nh, aParams=P), want, "lancir %s" % kw)
