@@ -1116,10 +1116,10 @@ int finalize_avir_plan( avirhip_plan* p )
 	{
 		p -> fused_ok |= 8;
 
-		// the pass kernels take every general ratio; exact 2x keeps its
-		// marching kernel, and {2, 3}-fold downsizing on both axes the
-		// integer-ratio passes of dn.hip
-		if( p -> auto_path != 4 && !fused_dn_both( p ))
+		// exact 2x keeps its marching kernel; otherwise the pass kernels
+		// where they measured faster than the tiles (gpass_preferred)
+		if( p -> auto_path != 4 && !fused_dn_both( p ) &&
+			gpass_preferred( p ))
 		{
 			p -> auto_path = 5;
 		}

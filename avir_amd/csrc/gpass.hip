@@ -33,6 +33,7 @@
 
 #include "plan.h"
 #include <algorithm>
+#include <math.h>
 #include <type_traits>
 #include <string.h>
 #include <stdio.h>
@@ -1160,6 +1161,71 @@ bool gpass_ok( const avirhip_plan* p )
 	return( p -> gpass != nullptr );
 }
 
+// Whether the pass kernels are the fastest path for this plan (measured on
+// MI355X, profiles/r02_gpass): LANCIR always; AVIR when both axes upsize (FIR7
+// then 12-tap gather) from a float RGBA source -- integer sources keep the
+// tiled kernels, whose loader converts them in place of a pack pass, and the
+// long-tap downsizing chains are still faster there too.
+bool gpass_preferred( const avirhip_plan* p )
+{
+	const GPData* D = (const GPData*) p -> gpass;
+
+	if( D == nullptr )
+	{
+		return( false );
+	}
+
+	if( p -> is_lancir )
+	{
+		return( true );
+	}
+
+	return( D -> h.a.mode == GP_PRE && D -> v.a.mode == GP_PRE &&
+		p -> in_type == AVIRHIP_F32 && p -> io_ch == 4 && !p -> gamma );
+}
+
+// Rows per work item. All waves of a launch should be resident at once, or
+// fill whole rounds: one straggler round doubles the launch (measured: 4661
+// waves on 4608 slots ran as long as 9216). `warm` = rows of work a chunk
+// spends before its first output; `wpc` = waves a CU holds.
+static int balanced_chunk( int rows, int nstrips, int min_chunk, int max_chunk,
+	int warm, int wpc )
+{
+	const double cap = 256.0 * wpc;
+	double best = -1.0;
+	int best_chunk = std::max( 1, std::min( rows, max_chunk ));
+	min_chunk = std::max( 1, std::min( min_chunk, best_chunk ));
+
+	for( int nch = 1; nch <= rows; nch++ )
+	{
+		const int chunk = ( rows + nch - 1 ) / nch;
+
+		if( chunk > max_chunk )
+		{
+			continue;
+		}
+
+		if( chunk < min_chunk )
+		{
+			break;
+		}
+
+		const int n = ( rows + chunk - 1 ) / chunk;
+		const double items = (double) n * nstrips;
+		const double rounds = ceil( items / cap );
+		const double eff = items / ( rounds * cap ) * chunk /
+			( chunk + (double) warm );
+
+		if( eff > best )
+		{
+			best = eff;
+			best_chunk = chunk;
+		}
+	}
+
+	return( best_chunk );
+}
+
 template< int MODE, bool LANC >
 static void launch_gv( const GVParams& P, int items, size_t lds,
 	hipStream_t st )
@@ -1208,23 +1274,22 @@ static int run_v( const GPData* D, const float* src, long src_ss, int width,
 	P.blk = D -> v_blk; P.rs = D -> v_rs; P.rc = D -> v_rc;
 
 	// chunk height: a chunk's first window (NT rows, + 6 of FIR warm-up) is
-	// fed before its first output; aim for ~6000 waves (256 CUs x up to 16
-	// resident, a few rounds) but never below ~4 windows of rows per chunk
+	// fed before its first output; its coefficient rows and positions live
+	// in LDS (<= 6 KiB)
 	const int rows = row_hi - row_lo;
-	const int minrows = std::max( 16, (int) ( (long) ( P.ax.nt + 6 ) *
-		std::max( 1, P.ax.out_len ) / std::max( 1, P.ax.in_len )));
-
-	int nch = std::max( 1, std::min( rows / minrows,
-		( 6144 + P.nstrips - 1 ) / P.nstrips ));
-
-	P.chunk = ( rows + nch - 1 ) / nch;
-
-	// the chunk's coefficient rows and positions live in LDS: <= 6 KiB
 	const int ntp = ( P.ax.nt + 3 ) & ~3;
 	const int gextra = ( P.ax.mode == GP_POST ? 7 : 0 );
 	const int maxg = std::max( gextra + 1, 6144 / ( ntp * 4 + 4 ));
-	P.chunk = std::max( 1, std::min( P.chunk, maxg - gextra ));
-	nch = ( rows + P.chunk - 1 ) / P.chunk;
+	// warm-up in units of output rows (a fed row costs about a third of one)
+	const int warm = std::max( 1, (int) ( (long) ( P.ax.nt + 6 ) *
+		std::max( 1, P.ax.out_len ) / std::max( 1, P.ax.in_len ) / 3 ));
+
+	const size_t lds_guess = (size_t) ( P.rs + P.rc ) * 512 + 6 * 1024 + 3072;
+	const int wpc = std::max( 1, std::min( 16, (int) ( 160 * 1024 /
+		( lds_guess + 512 ))));
+
+	P.chunk = balanced_chunk( rows, P.nstrips, 8, maxg - gextra, warm, wpc );
+	const int nch = ( rows + P.chunk - 1 ) / P.chunk;
 	const int items = P.nstrips * nch;
 	const size_t lds = (size_t) ( P.rs + P.rc ) * 512 + 6 * 1024 +
 		(size_t) ( P.chunk + gextra ) * ( ntp * 4 + 4 ) + 64;
@@ -1267,11 +1332,16 @@ static int run_h( const GPData* D, const float* src, long src_ss, int src_w,
 	P.sbuf = D -> h_sbuf; P.mbuf = D -> h_mbuf;
 
 	const int rows = row_hi - row_lo;
-	int nch = std::max( 1, std::min( rows / 8,
-		( 8192 + P.nstrips - 1 ) / P.nstrips ));
+	const size_t lds_h = (size_t) ( GH_NB * P.sbuf + P.mbuf ) * 16 +
+		(size_t) (( P.ax.nt + 3 ) & ~3 ) * 64 * 4;
 
-	P.chunk = ( rows + nch - 1 ) / nch;
-	nch = ( rows + P.chunk - 1 ) / P.chunk;
+	const int wpc = std::max( 1, std::min( 16, (int) ( 160 * 1024 /
+		( lds_h + 512 ))));
+
+	// (a chunk's fixed cost: its coefficient row load and three rows of DMA
+	// lead, about two rows of work)
+	P.chunk = balanced_chunk( rows, P.nstrips, 8, rows, 2, wpc );
+	const int nch = ( rows + P.chunk - 1 ) / P.chunk;
 	const int items = P.nstrips * nch;
 	const size_t lds = (size_t) ( GH_NB * P.sbuf + P.mbuf ) * 16 +
 		(size_t) (( P.ax.nt + 3 ) & ~3 ) * 64 * 4;

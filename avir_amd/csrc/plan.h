@@ -200,6 +200,7 @@ int dn_run_v( void* d, const float* flt, long flt_ss, int width, float* dst,
 int gpass_prepare( avirhip_plan* p );
 void gpass_release( avirhip_plan* p );
 bool gpass_ok( const avirhip_plan* p );
+bool gpass_preferred( const avirhip_plan* p );
 int gpass_run( avirhip_plan* p, const float* src, long src_stride, float* dst,
 	int row0, int row1, hipStream_t st );
 bool fused_dn_both( const avirhip_plan* p );

@@ -1018,7 +1018,8 @@ def test_avir_pass_kernels_are_the_default_for_general_ratios():
     lib = abi.load()
     r = avir_amd.CImageResizer(16)
     for (sw, sh, nw, nh, want) in [(1920, 1080, 2500, 1400, abi.PATH_GPASS),
-                                   (1000, 700, 640, 480, abi.PATH_GPASS),
+                                   (800, 600, 4000, 3000, abi.PATH_GPASS),
+                                   (1000, 700, 640, 480, abi.PATH_TILED),
                                    (640, 480, 1280, 960, abi.PATH_UP2),
                                    (3840, 2160, 1280, 720, abi.PATH_TILED)]:
         p = r.plan(sw, sh, nw, nh, 4)

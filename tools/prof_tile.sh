@@ -6,8 +6,8 @@ cd /tmp; export TMPDIR=/tmp
 for W in ${@:-nonint readme}; do
 OUT=$GRAFT_REPO_ROOT/gpurun_out/prof_tile_$W
 rm -rf $OUT; mkdir -p $OUT
-B="timeout 120 python $GRAFT_REPO_ROOT/bench.py --no-cpu --workload $W --steps 10 --warmup 2 --settle-ms 0"
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o t -- timeout 120 python $GRAFT_REPO_ROOT/bench.py --no-cpu --workload $W --steps 200 --settle-ms 100 > $OUT/bench.json 2>/dev/null
+B="timeout 120 python $GRAFT_REPO_ROOT/bench.py --no-cpu --workload $W --steps 10 --warmup 2 --settle-ms 0 ${BPATH:+--path $BPATH}"
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o t -- timeout 120 python $GRAFT_REPO_ROOT/bench.py --no-cpu --workload $W --steps 200 --settle-ms 100 ${BPATH:+--path $BPATH} > $OUT/bench.json 2>/dev/null
 find $OUT/trace -name "*kernel_trace.csv" | xargs rm -f
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --output-format csv -d $OUT/p1 -o t -- $B > /dev/null 2>&1
 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_WAVES SQ_WAIT_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE SQ_INSTS_VMEM_RD --output-format csv -d $OUT/p2 -o t -- $B > /dev/null 2>&1
