@@ -459,7 +459,7 @@ def main():
 
     if rank == 0 and world == 1:
         # a sustained figure: the default timed region is a few ms
-        n = max(args.steps, int(1.0 / max(t / args.steps, 1e-6)))
+        n = max(args.steps, int(1.25 / max(t / args.steps, 1e-6)))
         ts, _ = timed(full_frame, n)
         out["sustained"] = {"steps": n, "seconds": round(ts, 3),
                             "ms_per_step": round(ts / n * 1e3, 4),

@@ -27,7 +27,7 @@ def test_bench_single_gpu_line():
     d = _last_json(r.stdout)
     assert d["n_gpus"] == 1 and d["steps"] == 5 and d["parity"]["ok"]
     assert d["roofline"]["bound"] == "hbm" and 0 < d["roofline"]["frac"] < 1
-    assert d["sustained"]["seconds"] >= 0.9
+    assert d["sustained"]["seconds"] >= 1.0
     assert d["config"]["exec_path"].startswith("exact-2x")
 
 
