@@ -30,6 +30,8 @@
 #include <cstdio>
 #include <vector>
 #include <thread>
+#include <mutex>
+#include <condition_variable>
 #include <algorithm>
 #include <map>
 #include <emmintrin.h>
@@ -52,31 +54,99 @@
 
 namespace {
 
-/* std::thread implementation of the reference's abstract thread pool. */
+/* Implementation of the reference's abstract thread pool (avir.h:2119-2225)
+ * on PERSISTENT worker threads: they are created once per pool and parked on a
+ * condition variable between the passes of resizeImage() (H pass, V pass,
+ * output pass each call startAllWorkloads() once), so a pass costs a wake-up,
+ * not a thread creation per workload. */
 class CRefThreadPool : public avir::CImageResizerThreadPool
 {
 public:
-	explicit CRefThreadPool( int n ) : Count( n ) { }
-	virtual int getSuggestedWorkloadCount() const { return( Count ); }
-	virtual void addWorkload( CWorkload* const w ) { Workloads.push_back( w ); }
-	virtual void startAllWorkloads()
+	explicit CRefThreadPool( int n )
+		: Count( n ), Gen( 0 ), Pending( 0 ), Quit( false )
 	{
-		for( size_t i = 0; i < Workloads.size(); i++ )
+		for( int i = 0; i + 1 < n; i++ )
 		{
-			CWorkload* w = Workloads[ i ];
-			Threads.emplace_back( [w]() { w -> process(); } );
+			Threads.emplace_back( [this, i]() { worker( i ); } );
 		}
 	}
+
+	~CRefThreadPool()
+	{
+		{
+			std::unique_lock< std::mutex > l( M );
+			Quit = true;
+		}
+
+		Wake.notify_all();
+		for( auto& t : Threads ) t.join();
+	}
+
+	virtual int getSuggestedWorkloadCount() const { return( Count ); }
+	virtual void addWorkload( CWorkload* const w ) { Workloads.push_back( w ); }
+
+	virtual void startAllWorkloads()
+	{
+		std::unique_lock< std::mutex > l( M );
+		Pending = (int) Workloads.size();
+		Gen++;
+		Wake.notify_all();
+	}
+
 	virtual void waitAllWorkloadsToFinish()
 	{
-		for( auto& t : Threads ) t.join();
-		Threads.clear();
+		std::unique_lock< std::mutex > l( M );
+		Done.wait( l, [this]() { return( Pending == 0 ); } );
 	}
+
 	virtual void removeAllWorkloads() { Workloads.clear(); }
+
 private:
+	void worker( const int idx )
+	{
+		unsigned long seen = 0;
+
+		while( true )
+		{
+			CWorkload* w = nullptr;
+			{
+				std::unique_lock< std::mutex > l( M );
+				Wake.wait( l, [&]() { return( Quit || Gen != seen ); } );
+
+				if( Quit )
+				{
+					return;
+				}
+
+				seen = Gen;
+
+				if( idx < (int) Workloads.size() )
+				{
+					w = Workloads[ idx ];
+				}
+			}
+
+			if( w != nullptr )
+			{
+				w -> process();
+				std::unique_lock< std::mutex > l( M );
+
+				if( --Pending == 0 )
+				{
+					Done.notify_all();
+				}
+			}
+		}
+	}
+
 	int Count;
 	std::vector< CWorkload* > Workloads;
 	std::vector< std::thread > Threads;
+	std::mutex M;
+	std::condition_variable Wake, Done;
+	unsigned long Gen;
+	int Pending;
+	bool Quit;
 };
 
 void fillParams( avir::CImageResizerParams& P, const double* p )
@@ -109,8 +179,23 @@ void doResizeT( const void* src, int sw, int sh, int sstride, void* dst,
 	V.ox = ox; V.oy = oy; V.BuildMode = build_mode;
 	V.UseSRGBGamma = ( g_use_gamma != 0 );
 	V.AlphaIndex = g_alpha_index;
-	CRefThreadPool pool( threads );
-	if( threads > 1 ) V.ThreadPool = &pool;
+	// one pool per thread count, kept between calls (timing harness)
+	static std::mutex poolm;
+	static std::map< int, CRefThreadPool* > pools;
+	std::unique_lock< std::mutex > plock( poolm );
+
+	if( threads > 1 )
+	{
+		CRefThreadPool*& pp = pools[ threads ];
+
+		if( pp == nullptr )
+		{
+			pp = new CRefThreadPool( threads );
+		}
+
+		V.ThreadPool = pp;
+	}
+
 	r.resizeImage( (const Tin*) src, sw, sh, sstride, (Tout*) dst, nw, nh,
 		ch, k, &V );
 }
