@@ -121,20 +121,31 @@ class BandPipeline(object):
         self._wait(slot)
         if self.rank == root:
             full = self.full[slot]
-            # every receive is posted before the root's own kernels start
+            # Every receive is posted before the root's own kernels start.
+            # One grouped batch per sub-band index: inside a group RCCL drives
+            # all peers' links at once (xGMI is point-to-point: 7 links into
+            # the root), across groups sub-band i + 1 follows sub-band i --
+            # the order the peers send in.
+            peer_subs = {}
             for r in range(self.world):
-                if r == root:
-                    continue
-                a0, a1 = band_rows(self.new_h, self.world, r)
-                for (a, b) in sub_bands(a0, a1, self.nsub):
-                    view = full[a:b]
+                if r != root:
+                    a0, a1 = band_rows(self.new_h, self.world, r)
+                    peer_subs[r] = sub_bands(a0, a1, self.nsub)
+            for i in range(max([len(v) for v in peer_subs.values()] or [0])):
+                ops = []
+                for r, subs in peer_subs.items():
+                    if i >= len(subs):
+                        continue
+                    view = full[subs[i][0]:subs[i][1]]
                     if _p2p_needs_host(dist, view):
                         tmp = view.cpu()
                         self.pending[slot].append(dist.irecv(tmp, r))
                         self.after[slot].append(
                             lambda v=view, t=tmp: v.copy_(t))
                     else:
-                        self.pending[slot].append(dist.irecv(view, r))
+                        ops.append(dist.P2POp(dist.irecv, view, r))
+                if ops:
+                    self.pending[slot].extend(dist.batch_isend_irecv(ops))
             # the root's band goes straight into the stitched frame
             for (a, b) in self.subs:
                 self.resize_rows(full[a:b], a, b)
