@@ -1108,57 +1108,86 @@ public:
 		return( true );
 	}
 
-	// updateFilterStepBuffers + fillRPosBuf, avir.h:5782-5937.
+	// ---- step geometry, in the executor's own terms -----------------------
+	// The kernels read every step's input through an index view (plan.h), so
+	// what a step needs to know is the RANGE of input indices its outputs
+	// touch: [lo, hi] relative to an input array [0, n). The part of the range
+	// below 0 is the step's prefix, the part above n - 1 its suffix -- the
+	// quantities the reference calls InPrefix / InSuffix (and materialises as
+	// replicated pixels, avir.h:5827-5937; here they only parameterise the
+	// views and are exported for plan-parity checks). The coordinate pair
+	// (k, o) that places the resize positions walks the same list: an
+	// upsampler scales it, a decimating filter divides it and shifts it by
+	// its edge pixels.
+	struct Span
+	{
+		int lo, hi;
+		int below() const { return( lo < 0 ? -lo : 0 ); }
+		int above( const int n ) const { return( hi > n - 1 ? hi - ( n - 1 ) : 0 ); }
+	};
+
+	// input indices read by outputs [0, outs) of a symmetric FIR of `cap`
+	// taps and latency `lat` that decimates by `rf` and starts `edge`
+	// outputs before the array
+	static Span firSpan( const int rf, const int lat, const int cap,
+		const int edge, const int outs )
+	{
+		Span r;
+		r.lo = -edge * rf - lat;
+		r.hi = rf * ( outs - 1 - edge ) + ( cap - lat - 1 );
+		return( r );
+	}
+
+	// input indices read by a bank filter of length fl around positions
+	// o + k*j, j in [0, outs)
+	static Span bankSpan( const double o, const double k, const int fl,
+		const int outs )
+	{
+		Span r;
+		r.lo = (int) floor( o ) - ( fl / 2 - 1 );
+		r.hi = (int) floor( o + ( outs - 1 ) * k ) + fl / 2;
+		return( r );
+	}
+
 	static void updateBuffers( PSteps& steps, AxisVars& V, int srcLen,
 		const int newLen )
 	{
-		int upstep = -1;
 		const int cnt = (int) steps.size();
+		int zs = -1; // the upsampling step, if any
 
 		for( int i = 0; i < cnt; i++ )
 		{
 			PStep& fs = *steps[ i ];
-			fs.inLen = srcLen;
+			const int n = srcLen;
+			fs.inLen = n;
 
 			if( fs.up )
 			{
-				upstep = i;
+				// n inputs land on slots 0, rf, 2rf ...; the filter (taps
+				// scattered from each slot) spills lat slots before and the
+				// rest of its length after, and the DC tails must fit too
+				zs = i;
 				V.k *= fs.rf;
 				V.o *= fs.rf;
-				fs.inPrefix = 0;
-				fs.inSuffix = 0;
-				fs.outLen = fs.inLen * fs.rf;
+				fs.inPrefix = fs.inSuffix = 0;
+				fs.outLen = n * fs.rf;
 				fs.outPrefix = fs.lat;
-				fs.outSuffix = fs.fltCap - fs.lat - fs.rf;
+				const int tail = std::max( fs.fltCap - fs.lat - fs.rf,
+					fs.sdcCap - fs.lat );
 
-				int l0 = fs.outPrefix + fs.outLen + fs.outSuffix;
-				const int l = fs.inLen * fs.rf + fs.sdcCap;
-
-				if( l > l0 )
-				{
-					fs.outSuffix += l - l0;
-				}
-
-				l0 = fs.outLen + fs.outSuffix;
-
-				if( fs.pdcCap > l0 )
-				{
-					fs.outSuffix += fs.pdcCap - l0;
-				}
+				fs.outSuffix = std::max( tail, fs.pdcCap - fs.outLen );
 			}
 			else
 			if( fs.rf == 0 )
 			{
-				const int fl2 = fs.bank -> fltLen / 2;
-				const int fl21 = fl2 - 1;
-				const int lpix = (int) floor( V.o ) - fl21;
-				fs.inPrefix = ( lpix < 0 ? -lpix : 0 );
-				const int rpix = (int) floor( V.o + ( newLen - 1 ) * V.k ) +
-					fl2 + 1;
-
-				fs.inSuffix = ( rpix > fs.inLen ? rpix - fs.inLen : 0 );
+				const int fl = fs.bank -> fltLen;
+				const Span need = bankSpan( V.o, V.k, fl, newLen );
+				fs.inPrefix = need.below();
+				fs.inSuffix = ( need.hi + 1 > n ? need.hi + 1 - n : 0 );
 				fs.outLen = newLen;
 
+				// the position table: double arithmetic in the reference's
+				// order (fillRPosBuf, avir.h:5782-5808) -- numerical contract
 				const int fracCount = fs.bank -> fracCount;
 				fs.rpos.resize( newLen );
 
@@ -1178,12 +1207,12 @@ public:
 				V.k /= fs.rf;
 				V.o /= fs.rf;
 				V.o += fs.edge;
-				fs.inPrefix = fs.lat;
-				fs.inSuffix = fs.fltCap - fs.lat - 1;
-				fs.outLen = ( fs.inLen + fs.rf - 1 ) / fs.rf + fs.edge;
-				fs.inSuffix += ( fs.outLen - 1 ) * fs.rf + 1 - fs.inLen;
-				fs.inPrefix += fs.edge * fs.rf;
-				fs.outLen += fs.edge;
+				fs.outLen = ( n + fs.rf - 1 ) / fs.rf + 2 * fs.edge;
+				const Span need = firSpan( fs.rf, fs.lat, fs.fltCap, fs.edge,
+					fs.outLen );
+
+				fs.inPrefix = need.below();
+				fs.inSuffix = need.hi - ( n - 1 );
 			}
 
 			srcLen = fs.outLen;
@@ -1191,32 +1220,33 @@ public:
 
 		V.isResize2 = false;
 
-		if( upstep != -1 )
+		if( zs >= 0 )
 		{
-			// extendUpsample, avir.h:5753-5766.
-			PStep& fs = *steps[ upstep ];
-			PStep& nx = *steps[ upstep + 1 ];
-			fs.inPrefix = ( nx.inPrefix + fs.rf - 1 ) / fs.rf;
-			fs.outPrefix += fs.inPrefix * fs.rf;
-			nx.inPrefix = 0;
-			fs.inSuffix = ( nx.inSuffix + fs.rf - 1 ) / fs.rf;
-			fs.outSuffix += fs.inSuffix * fs.rf;
-			nx.inSuffix = 0;
+			// the step after an upsampler reads the upsampler's OUTPUT buffer
+			// directly: its overhang becomes extra replicated input samples
+			// of the upsampler (whole samples: rounded up to the factor)
+			PStep& up = *steps[ zs ];
+			PStep& nx = *steps[ zs + 1 ];
+			const int pre = ( nx.inPrefix + up.rf - 1 ) / up.rf;
+			const int suf = ( nx.inSuffix + up.rf - 1 ) / up.rf;
+			up.inPrefix = pre; up.outPrefix += pre * up.rf;
+			up.inSuffix = suf; up.outSuffix += suf * up.rf;
+			nx.inPrefix = nx.inSuffix = 0;
 
-			if( fs.rf == 2 && V.resizeStep == upstep + 1 &&
-				!fs.orig.taps.empty() )
-			{
-				V.isResize2 = true;
-			}
+			V.isResize2 = ( up.rf == 2 && V.resizeStep == zs + 1 &&
+				!up.orig.taps.empty() );
 		}
 	}
 
-	// The RPosBuf half of updateBufLenAndRPosPtrs, avir.h:6063-6126.
+	// First tap, tap count and phase offset of every output of the resize
+	// step. After a zero-stuffing 2x upsampler only the even slots hold
+	// samples, so a window that would start on an odd slot starts one slot
+	// later, one tap into the phase (avir.h:6077-6083).
 	static void bindPhases( PSteps& steps, const AxisVars& V )
 	{
 		PStep& fs = *steps[ V.resizeStep ];
 		const int fl = fs.bank -> fltLen;
-		const int fl21 = fl / 2 - 1;
+		const int back = fl / 2 - 1;
 
 		for( int j = 0; j < fs.outLen; j++ )
 		{
@@ -1227,20 +1257,11 @@ public:
 				fs.bank -> phase( rp.fti ); // build on demand
 			}
 
-			if( V.isResize2 )
-			{
-				const int p = rp.srcPosInt - fl21;
-				const int fo = p & 1;
-				rp.srcOffs = p + fo;
-				rp.ftpOff = fo;
-				rp.fl = fl - fo;
-			}
-			else
-			{
-				rp.srcOffs = rp.srcPosInt - fl21;
-				rp.ftpOff = 0;
-				rp.fl = fl;
-			}
+			const int first = rp.srcPosInt - back;
+			const int skip = ( V.isResize2 ? first & 1 : 0 );
+			rp.srcOffs = first + skip;
+			rp.ftpOff = skip;
+			rp.fl = fl - skip;
 		}
 	}
 
