@@ -764,8 +764,10 @@ extern "C" int avirhip_resolve_mem( const void* ptr, int mem )
 
 namespace avirhip {
 
+static int clone_plan( const avirhip_plan* s, int device, avirhip_plan** out );
+
 static int exec_any( avirhip_plan* p, const void* src, int src_mem, void* dst,
-	int dst_mem, int row0, int row1, void* stream )
+	int dst_mem, int row0, int row1, void* stream, bool have_lock = false )
 {
 	src_mem = avirhip_resolve_mem( src, src_mem );
 	dst_mem = avirhip_resolve_mem( dst, dst_mem );
@@ -835,12 +837,59 @@ static int exec_any( avirhip_plan* p, const void* src, int src_mem, void* dst,
 		(long) p -> src_stride * 4 < ( 1L << 22 ) &&
 		(long) p -> new_w * 16 < ( 1L << 22 ));
 
+	// Scratch users take the plan's lock. When another thread holds it (the
+	// reference allows concurrent resizeImage() calls on one object,
+	// README.md:83-85), the call runs on a spare replica of the plan instead
+	// -- same tables, its own scratch -- so that the two calls overlap on
+	// their streams rather than queue behind one buffer set. Up to three
+	// spares; beyond that callers wait.
 	std::unique_lock< std::mutex > guard( p -> exec_mtx, std::defer_lock );
+
+	if( !scratch_free && !have_lock && !guard.try_lock())
+	{
+		avirhip_plan* spare = nullptr;
+		{
+			std::lock_guard< std::mutex > sl( p -> shard_mtx );
+
+			for( size_t i = 0; i < p -> spares.size() && spare == nullptr; i++ )
+			{
+				if( p -> spares[ i ] -> exec_mtx.try_lock())
+				{
+					spare = p -> spares[ i ];
+				}
+			}
+
+			if( spare == nullptr && p -> spares.size() < 3 && !p -> is_spare )
+			{
+				if( clone_plan( p, p -> device, &spare ) == AVIRHIP_OK )
+				{
+					spare -> is_spare = 1;
+					spare -> path = p -> path;
+					spare -> exec_mtx.lock();
+					p -> spares.push_back( spare );
+				}
+				else
+				{
+					spare = nullptr;
+				}
+			}
+		}
+
+		if( spare != nullptr )
+		{
+			// (exec_any on the spare: its mutex is held by this thread)
+			const int rc = exec_any( spare, src, src_mem, dst, dst_mem,
+				row0, row1, stream, true );
+
+			spare -> exec_mtx.unlock();
+			return( rc );
+		}
+
+		guard.lock();
+	}
 
 	if( !scratch_free )
 	{
-		guard.lock();
-
 		if( p -> last_done == nullptr )
 		{
 			AVIRHIP_HIPCHECK( hipEventCreateWithFlags( &p -> last_done,
@@ -959,6 +1008,7 @@ static avirhip_plan* new_plan()
 	p -> tr_mul = 1.0; p -> pk_out = 0.0;
 	p -> gamma = 0; p -> alpha_index = -1; p -> d_srgb_tbl = nullptr;
 	p -> dither = AVIRHIP_DITHER_DEF; p -> errd_line = nullptr;
+	p -> is_spare = 0;
 	p -> ch = 0; p -> io_ch = 0;
 	p -> l_out_mul = 1.0f; p -> l_clamp = 0.0f; p -> l_unity = 1;
 	(void) hipGetDevice( &p -> device );
@@ -1544,6 +1594,13 @@ void avirhip_plan_destroy( avirhip_plan* p )
 	}
 
 	p -> replicas.clear();
+
+	for( size_t i = 0; i < p -> spares.size(); i++ )
+	{
+		avirhip_plan_destroy( p -> spares[ i ]);
+	}
+
+	p -> spares.clear();
 
 	if( p -> last_done != nullptr )
 	{

@@ -127,6 +127,10 @@ struct avirhip_plan
 	// avirhip_resize_sharded: replicas of this plan on other devices, and the
 	// per-replica band / source buffers
 	std::vector< avirhip_plan* > replicas;
+	// same-device copies used when a call finds this plan's scratch busy
+	// (concurrent resizeImage() calls on one object); `is_spare` marks them
+	std::vector< avirhip_plan* > spares;
+	int is_spare;
 	void* shard_band; size_t shard_band_bytes;
 	void* shard_src; size_t shard_src_bytes;
 	// A plan owns scratch buffers (packed source, float result, FltBuf, op

@@ -658,9 +658,10 @@ def test_in_place_device_resize():
 
 def test_concurrent_calls_on_one_object():
     """The reference allows concurrent resizeImage() calls on one object
-    (README.md:83-85). Calls that share a cached plan share its scratch
-    buffers and are serialised inside the library: threads on different
-    streams must all get the right answer."""
+    (README.md:83-85). A call that finds the cached plan's scratch busy runs
+    on a spare replica of the plan (up to three, then callers queue): threads
+    on different streams must all get the right answer -- AVIR tiles, host
+    buffers, and LANCIR plans (whose first calls used to race on scratch)."""
     import threading
     import torch
     src8 = rb.lcg_u8((203, 301, 3), seed=12)
@@ -668,6 +669,10 @@ def test_concurrent_calls_on_one_object():
     srcf = rb.lcg_f32((200, 300, 4), seed=13)
     wantf = _checker_avir(srcf, 130, 87, resbits=8)
     r = avir_amd.CImageResizer(8)
+    lan = avir_amd.CLancIR()
+    srcl = rb.lcg_f32((60, 80, 4), seed=14)
+    wantl2 = (rb.ref_lancir if rb.have_ref() else rb.orc_lancir)(srcl, 160, 120)
+    wantl3 = (rb.ref_lancir if rb.have_ref() else rb.orc_lancir)(srcl, 100, 77)
     errs = []
 
     def worker(i):
@@ -676,7 +681,14 @@ def test_concurrent_calls_on_one_object():
             st = torch.cuda.Stream()
             with torch.cuda.stream(st):
                 for _ in range(10):
-                    if i % 2 == 0:
+                    if i % 3 == 2:
+                        d = torch.from_numpy(srcl).to("cuda:0")
+                        o = lan.resize(d, 160, 120)
+                        o3 = lan.resize(d, 100, 77)
+                        st.synchronize()
+                        _assert_same(o.cpu().numpy(), wantl2, "thread %d lancir 2x" % i)
+                        _assert_same(o3.cpu().numpy(), wantl3, "thread %d lancir" % i)
+                    elif i % 2 == 0:
                         d = torch.from_numpy(src8).to("cuda:0")
                         o = r.resize(d, 100, 67)
                         st.synchronize()
@@ -687,7 +699,7 @@ def test_concurrent_calls_on_one_object():
         except Exception as e:  # noqa: BLE001
             errs.append(e)
 
-    ts = [threading.Thread(target=worker, args=(i,)) for i in range(6)]
+    ts = [threading.Thread(target=worker, args=(i,)) for i in range(9)]
     [t.start() for t in ts]
     [t.join() for t in ts]
     assert not errs, errs[0]
