@@ -33,6 +33,28 @@ def _is_torch(x):
     return type(x).__module__.startswith("torch")
 
 
+class _on_device_of(object):
+    """Makes the device of the first CUDA tensor among `bufs` current for the
+    duration of a call: plans, scratch and the cache key belong to the device
+    that is current when the library is entered."""
+
+    def __init__(self, *bufs):
+        self.ctx = None
+        for b in bufs:
+            if _is_torch(b) and b.is_cuda:
+                import torch
+                self.ctx = torch.cuda.device(b.device)
+                break
+
+    def __enter__(self):
+        if self.ctx is not None:
+            self.ctx.__enter__()
+
+    def __exit__(self, *a):
+        if self.ctx is not None:
+            self.ctx.__exit__(*a)
+
+
 def _numel(x):
     return int(x.numel()) if _is_torch(x) else int(x.size)
 
@@ -123,11 +145,12 @@ class CImageResizer(object):
             _need(NewBuf, NewWidth * NewHeight * ElCountIO, "NewBuf")
         elif NewWidth > 0 and NewHeight > 0:
             _need(NewBuf, NewWidth * NewHeight, "NewBuf")
-        abi.check(self._lib.avirhip_resizer_resize(
-            self._h, sp, sm, SrcWidth, SrcHeight, SrcScanlineSize, dp, dm,
-            NewWidth, NewHeight, ElCountIO, float(k),
-            C.byref(aVars) if aVars is not None else None, st, dt,
-            s1 or s2), "avirhip_resizer_resize")
+        with _on_device_of(SrcBuf, NewBuf):
+            abi.check(self._lib.avirhip_resizer_resize(
+                self._h, sp, sm, SrcWidth, SrcHeight, SrcScanlineSize, dp, dm,
+                NewWidth, NewHeight, ElCountIO, float(k),
+                C.byref(aVars) if aVars is not None else None, st, dt,
+                s1 or s2), "avirhip_resizer_resize")
 
     def plan(self, SrcWidth, SrcHeight, NewWidth, NewHeight, ElCountIO,
              k=0.0, aVars=None, in_type=F32, out_type=F32, SrcScanlineSize=0):
@@ -196,10 +219,12 @@ class CLancIR(object):
             ns = ns if ns >= 1 else NewWidth * ElCount
             _need(SrcBuf, (SrcHeight - 1) * ss + SrcWidth * ElCount, "SrcBuf")
             _need(NewBuf, (NewHeight - 1) * ns + NewWidth * ElCount, "NewBuf")
-        rc = self._lib.avirhip_lancir_resize(
-            self._h, sp, sm, SrcWidth, SrcHeight, dp, dm, NewWidth, NewHeight,
-            ElCount, C.byref(aParams) if aParams is not None else None, st,
-            dt, s1 or s2)
+        with _on_device_of(SrcBuf, NewBuf):
+            rc = self._lib.avirhip_lancir_resize(
+                self._h, sp, sm, SrcWidth, SrcHeight, dp, dm, NewWidth,
+                NewHeight, ElCount,
+                C.byref(aParams) if aParams is not None else None, st, dt,
+                s1 or s2)
         return abi.check(rc, "avirhip_lancir_resize")
 
     def plan(self, SrcWidth, SrcHeight, NewWidth, NewHeight, ElCount,
