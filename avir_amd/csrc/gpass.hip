@@ -754,9 +754,26 @@ __global__ void __launch_bounds__( 64 ) k_gh( const GHParams P )
 		if( gok )
 		{
 			const f4* const in = ( MODE == GP_PRE ? mbuf : s ) + gs;
+			// a compile-time tap count: the whole window is read first (all
+			// its ds_read_b128 in flight at once), then the arithmetic runs
+			// -- left alone the compiler keeps two reads in flight and pays
+			// the LDS latency six times per pixel
+			f4 w[ NTC > 0 ? NTC : 1 ];
+
+			if( NTC > 0 )
+			{
+#pragma unroll
+				for( int t = 0; t < ( NTC > 0 ? NTC : 1 ); t++ )
+				{
+					w[ t ] = in[ t ];
+				}
+
+				__builtin_amdgcn_sched_barrier( 0 );
+			}
 
 			o = gp_dot< LANC, f4, NTC >( nt,
-				[&]( const int t ) { return( in[ t ]); },
+				[&]( const int t ) { return( NTC > 0 ?
+					w[ NTC > 0 ? t % ( NTC > 0 ? NTC : 1 ) : 0 ] : in[ t ]); },
 				[&]( const int b ) -> f4
 				{
 					f4 c;
@@ -1010,20 +1027,26 @@ int gpass_prepare( avirhip_plan* p )
 	{
 		const GPAxis& A = D -> h.a;
 		const std::vector< int >& st = D -> h.start;
-		int ow = ( A.mode == GP_POST ? 58 : 64 );
+		// Strip width: every candidate that fits is priced by the pixels a
+		// wave moves and the lanes it keeps busy per output -- LDS-DMA pieces
+		// are 64 pixels whatever the segment needs (a 67-pixel segment costs
+		// two; the H pass of 1920 -> 2500 moved 88 MB for a 33 MB source with
+		// 64-output strips), and a strip narrower than the wave idles lanes.
+		int ow = 0;
 		std::vector< int > seg;
 		int nstrips = 0, maxs = 0, maxm = 0;
+		double best_cost = 0.0;
 
-		for( ; ow >= 8; ow -= ( ow > 16 ? 6 : 2 ))
+		for( int cw = ( A.mode == GP_POST ? 58 : 64 ); cw >= 8; cw-- )
 		{
-			nstrips = ( A.out_len + ow - 1 ) / ow;
-			seg.assign( (size_t) nstrips * 4, 0 );
-			maxs = 0; maxm = 0;
+			const int cn = ( A.out_len + cw - 1 ) / cw;
+			std::vector< int > cseg( (size_t) cn * 4, 0 );
+			int cs = 0, cm = 0;
 
-			for( int s = 0; s < nstrips; s++ )
+			for( int s = 0; s < cn; s++ )
 			{
-				const int ja = s * ow;
-				const int jb = std::min( A.out_len, ja + ow ) - 1;
+				const int ja = s * cw;
+				const int jb = std::min( A.out_len, ja + cw ) - 1;
 				int ga = ja, gb = jb;
 
 				if( A.mode == GP_POST )
@@ -1044,23 +1067,29 @@ int gpass_prepare( avirhip_plan* p )
 					sb = std::max( 0, std::min( ib, A.c_len - 1 ));
 				}
 
-				seg[ s * 4 ] = sa; seg[ s * 4 + 1 ] = sb - sa + 1;
-				seg[ s * 4 + 2 ] = ma; seg[ s * 4 + 3 ] = mb - ma + 1;
-				maxs = std::max( maxs, sb - sa + 1 );
-				maxm = std::max( maxm, mb - ma + 1 );
+				cseg[ s * 4 ] = sa; cseg[ s * 4 + 1 ] = sb - sa + 1;
+				cseg[ s * 4 + 2 ] = ma; cseg[ s * 4 + 3 ] = mb - ma + 1;
+				cs = std::max( cs, sb - sa + 1 );
+				cm = std::max( cm, mb - ma + 1 );
 			}
 
 			// the FIR and POST stages run one buffer entry per lane and pass
-			const bool fits = ( maxs <= 256 && ( A.mode == GP_NONE ||
-				maxm <= 64 ));
-
-			if( fits )
+			if( cs > 256 || ( A.mode != GP_NONE && cm > 64 ))
 			{
-				break;
+				continue;
+			}
+
+			const double cost = ((( cs + 63 ) / 64 ) * 64 + 64 ) / (double) cw;
+
+			if( ow == 0 || cost < best_cost )
+			{
+				best_cost = cost;
+				ow = cw; nstrips = cn; maxs = cs; maxm = cm;
+				seg.swap( cseg );
 			}
 		}
 
-		if( ow < 8 )
+		if( ow == 0 )
 		{
 			delete D;
 			return( AVIRHIP_OK );
@@ -1281,14 +1310,24 @@ static int run_v( const GPData* D, const float* src, long src_ss, int width,
 	const int gextra = ( P.ax.mode == GP_POST ? 7 : 0 );
 	const int maxg = std::max( gextra + 1, 6144 / ( ntp * 4 + 4 ));
 	// warm-up in units of output rows (a fed row costs about a third of one)
+	const int warm_div = ( getenv( "AVIRHIP_GV_WARMDIV" ) != nullptr ?
+		std::max( 1, atoi( getenv( "AVIRHIP_GV_WARMDIV" ))) : 3 );
+
 	const int warm = std::max( 1, (int) ( (long) ( P.ax.nt + 6 ) *
-		std::max( 1, P.ax.out_len ) / std::max( 1, P.ax.in_len ) / 3 ));
+		std::max( 1, P.ax.out_len ) / std::max( 1, P.ax.in_len ) / warm_div ));
 
 	const size_t lds_guess = (size_t) ( P.rs + P.rc ) * 512 + 6 * 1024 + 3072;
 	const int wpc = std::max( 1, std::min( 16, (int) ( 160 * 1024 /
 		( lds_guess + 512 ))));
 
 	P.chunk = balanced_chunk( rows, P.nstrips, 8, maxg - gextra, warm, wpc );
+
+	if( getenv( "AVIRHIP_GV_CHUNK" ) != nullptr ) // tuning aid
+	{
+		P.chunk = std::max( 1, std::min( atoi( getenv( "AVIRHIP_GV_CHUNK" )),
+			maxg - gextra ));
+	}
+
 	const int nch = ( rows + P.chunk - 1 ) / P.chunk;
 	const int items = P.nstrips * nch;
 	const size_t lds = (size_t) ( P.rs + P.rc ) * 512 + 6 * 1024 +
@@ -1332,8 +1371,10 @@ static int run_h( const GPData* D, const float* src, long src_ss, int src_w,
 	P.sbuf = D -> h_sbuf; P.mbuf = D -> h_mbuf;
 
 	const int rows = row_hi - row_lo;
+	// (tap counts 6 and 12 keep the coefficient row in registers: no LDS table)
+	const bool regcoef = ( P.ax.nt == 6 || P.ax.nt == 12 );
 	const size_t lds_h = (size_t) ( GH_NB * P.sbuf + P.mbuf ) * 16 +
-		(size_t) (( P.ax.nt + 3 ) & ~3 ) * 64 * 4;
+		( regcoef ? 0 : (size_t) (( P.ax.nt + 3 ) & ~3 ) * 64 * 4 );
 
 	const int wpc = std::max( 1, std::min( 16, (int) ( 160 * 1024 /
 		( lds_h + 512 ))));
@@ -1343,8 +1384,7 @@ static int run_h( const GPData* D, const float* src, long src_ss, int src_w,
 	P.chunk = balanced_chunk( rows, P.nstrips, 8, rows, 2, wpc );
 	const int nch = ( rows + P.chunk - 1 ) / P.chunk;
 	const int items = P.nstrips * nch;
-	const size_t lds = (size_t) ( GH_NB * P.sbuf + P.mbuf ) * 16 +
-		(size_t) (( P.ax.nt + 3 ) & ~3 ) * 64 * 4;
+	const size_t lds = lds_h;
 	const GPAxis& A = P.ax;
 
 	if( A.lanc )
