@@ -353,6 +353,9 @@ __global__ void __launch_bounds__( 64 ) k_gv( const GVParams P )
 
 	int g = ga;                 // next gather output
 	int g_need = a_start[ g ] + nt - 1; // its last input row
+	// (the one after it, fetched an output early: the LDS read + readfirstlane
+	// latency stays off the drain loop's critical path)
+	int g_need1 = ( g + 1 <= gb ? a_start[ g + 1 ] + nt - 1 : 0x7fffffff );
 	int n = y0;                 // POST: next final output
 
 	auto store_row = [&]( const int y, const f2 o )
@@ -399,8 +402,9 @@ __global__ void __launch_bounds__( 64 ) k_gv( const GVParams P )
 		}
 
 		g++;
-		g_need = ( g <= gb ? __builtin_amdgcn_readfirstlane(
-			stab[ g - ga ]) : 0x7fffffff );
+		g_need = g_need1;
+		g_need1 = ( g + 1 <= gb ? __builtin_amdgcn_readfirstlane(
+			stab[ g + 1 - ga ]) : 0x7fffffff );
 	};
 
 	// everything whose inputs are complete once row `u` is in its ring.
@@ -457,14 +461,19 @@ __global__ void __launch_bounds__( 64 ) k_gv( const GVParams P )
 	const int pa = u_a >> 1; // first pair (arithmetic shift: floor)
 	const int pb = u_b >> 1;
 
+	int qi = 0; // landing-queue slot of the next pair issued ...
+	int qr = 0; // ... and of the pair being read (both count modulo GV_PF + 1)
+
 	auto issue_pair = [&]( const int p )
 	{
 		if( p <= pb )
 		{
 			const int r = gp_clamp( p * 2 + ( lane >> 5 ), slast );
 			const unsigned slot = ( MODE == GP_PRE || RW > 0 ?
-				qbase + (unsigned) (( p - pa ) % ( GV_PF + 1 )) * 1024 :
+				qbase + (unsigned) qi * 1024 :
 				lds0 + (unsigned) (( p * 2 ) & smask ) * 512 );
+
+			qi = ( qi == GV_PF ? 0 : qi + 1 );
 
 			gp_dma( rsrc, slot, r * srow_b + dpx * 16 );
 		}
@@ -512,7 +521,12 @@ __global__ void __launch_bounds__( 64 ) k_gv( const GVParams P )
 		}
 
 		const f2* const qs = (const f2*) ( smem + ( P.rs + P.rc ) * 512 +
-			((( u >> 1 ) - pa ) % ( GV_PF + 1 )) * 1024 + ( i & 1 ) * 512 );
+			qr * 1024 + ( i & 1 ) * 512 );
+
+		if( i & 1 )
+		{
+			qr = ( qr == GV_PF ? 0 : qr + 1 ); // after the pair's second row
+		}
 
 		if( MODE == GP_PRE )
 		{
