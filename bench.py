@@ -240,6 +240,20 @@ def cpu_baseline(src_np, threads):
             "builds": rows}
 
 
+VALU_NONFMA_PEAK_TFLOPS = 68.0  # profiles/r01_microbench_valu_lds_copy.txt
+
+
+def read_valu_instr():
+    """VALU wave-instructions per launch of the headline kernel from the
+    committed PMC pass (profiles/pmc_traffic.json), or None."""
+    p = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    try:
+        with open(p) as f:
+            return json.load(f).get("valu_wave_instructions_per_launch")
+    except (OSError, ValueError):
+        return None
+
+
 def read_traffic():
     """HBM bytes per launch from the committed PMC pass (profiles/), or None.
     Collected separately with rocprofv3 --pmc as MI355X_MICROARCH.md
@@ -460,6 +474,18 @@ def main():
             "algorithmic_bytes": ALGO_BYTES,
             "kernel_ms": round(ev_ms, 4),
             "kernels_per_step": {1: 5, 2: 2, 3: 1, 4: 1, 5: 2}.get(path)}
+        vi = read_valu_instr()
+        if vi and path == 4:
+            # the unit that does the work: parity forbids FMA, every tap is
+            # a packed multiply + a packed add (2 flops x 64 lanes each)
+            tf = vi * 128.0 / (ev_ms * 1e-3) / 1e12
+            out["roofline"]["valu"] = {
+                "achieved": round(tf, 1), "peak": VALU_NONFMA_PEAK_TFLOPS,
+                "unit": "TFLOP/s (non-FMA fp32)",
+                "frac": round(tf / VALU_NONFMA_PEAK_TFLOPS, 4),
+                "wave_instructions_per_launch": vi,
+                "note": "instruction count from the committed PMC pass; peak "
+                        "= measured packed mul+add rate of the chip"}
 
     if world > 1:
         # secondary measurements: must never take the headline line down
