@@ -1130,14 +1130,21 @@ int gpass_prepare( avirhip_plan* p )
 
 		// tap counts the register-window kernels exist for (launch_gv): no
 		// window in LDS at all
-		static const int regwin[] = { 6, 8, 10, 12, 14, 16, 18, 19, 20, 21,
-			22, 24 };
+		bool rw;
 
-		bool rw = false;
-
-		for( size_t i = 0; i < sizeof( regwin ) / sizeof( regwin[ 0 ]); i++ )
+		if( A.lanc )
 		{
-			rw |= ( A.nt == regwin[ i ]);
+			rw = ( A.nt >= 6 && A.nt <= 24 && ( A.nt & 1 ) == 0 );
+		}
+		else
+		if( A.mode == GP_PRE )
+		{
+			rw = ( A.nt == 12 );
+		}
+		else
+		{
+			rw = ( A.mode == GP_POST && (( A.nt >= 18 && A.nt <= 22 ) ||
+				A.nt == 24 ));
 		}
 
 		if( rw )
@@ -1269,25 +1276,62 @@ static int balanced_chunk( int rows, int nstrips, int min_chunk, int max_chunk,
 	return( best_chunk );
 }
 
-template< int MODE, bool LANC >
+// Register-window variants exist for the tap counts that occur: 12 for AVIR
+// upsizing (FIR7 then gather), 18-24 for AVIR 1 < k < 2 downsizing (gather
+// then FIR7), the even counts 6-24 for LANCIR; the LDS-window kernel takes
+// everything else.
+#define GV_LAUNCH( MODE, LANC, NT, RW ) hipLaunchKernelGGL(( k_gv< MODE, LANC, \
+	NT, RW > ), dim3( items ), dim3( 64 ), lds, st, P )
+
 static void launch_gv( const GVParams& P, int items, size_t lds,
 	hipStream_t st )
 {
-	// register-window variants for the common tap counts (ring = next power
-	// of two), the LDS-window kernel for everything else
-#define GV_CASE( NT, RW ) case NT: hipLaunchKernelGGL(( k_gv< MODE, LANC, NT, \
-	RW > ), dim3( items ), dim3( 64 ), lds, st, P ); break;
-	switch( P.ax.nt )
+	const int nt = P.ax.nt;
+
+	if( P.ax.lanc )
 	{
-		GV_CASE( 6, 8 ) GV_CASE( 8, 8 ) GV_CASE( 10, 16 ) GV_CASE( 12, 16 )
-		GV_CASE( 14, 16 ) GV_CASE( 16, 16 ) GV_CASE( 18, 32 )
-		GV_CASE( 19, 32 ) GV_CASE( 20, 32 ) GV_CASE( 21, 32 )
-		GV_CASE( 22, 32 ) GV_CASE( 24, 32 )
-		default: hipLaunchKernelGGL(( k_gv< MODE, LANC, 0, 0 > ),
-			dim3( items ), dim3( 64 ), lds, st, P ); break;
+		switch( nt )
+		{
+			case 6: GV_LAUNCH( GP_NONE, true, 6, 8 ); break;
+			case 8: GV_LAUNCH( GP_NONE, true, 8, 8 ); break;
+			case 10: GV_LAUNCH( GP_NONE, true, 10, 16 ); break;
+			case 12: GV_LAUNCH( GP_NONE, true, 12, 16 ); break;
+			case 14: GV_LAUNCH( GP_NONE, true, 14, 16 ); break;
+			case 16: GV_LAUNCH( GP_NONE, true, 16, 16 ); break;
+			case 18: GV_LAUNCH( GP_NONE, true, 18, 32 ); break;
+			case 20: GV_LAUNCH( GP_NONE, true, 20, 32 ); break;
+			case 22: GV_LAUNCH( GP_NONE, true, 22, 32 ); break;
+			case 24: GV_LAUNCH( GP_NONE, true, 24, 32 ); break;
+			default: GV_LAUNCH( GP_NONE, true, 0, 0 ); break;
+		}
 	}
-#undef GV_CASE
+	else
+	if( P.ax.mode == GP_PRE )
+	{
+		if( nt == 12 ) GV_LAUNCH( GP_PRE, false, 12, 16 );
+		else GV_LAUNCH( GP_PRE, false, 0, 0 );
+	}
+	else
+	if( P.ax.mode == GP_POST )
+	{
+		switch( nt )
+		{
+			case 18: GV_LAUNCH( GP_POST, false, 18, 32 ); break;
+			case 19: GV_LAUNCH( GP_POST, false, 19, 32 ); break;
+			case 20: GV_LAUNCH( GP_POST, false, 20, 32 ); break;
+			case 21: GV_LAUNCH( GP_POST, false, 21, 32 ); break;
+			case 22: GV_LAUNCH( GP_POST, false, 22, 32 ); break;
+			case 24: GV_LAUNCH( GP_POST, false, 24, 32 ); break;
+			default: GV_LAUNCH( GP_POST, false, 0, 0 ); break;
+		}
+	}
+	else
+	{
+		GV_LAUNCH( GP_NONE, false, 0, 0 );
+	}
 }
+
+#undef GV_LAUNCH
 
 template< int MODE, bool LANC >
 static void launch_gh( const GHParams& P, int items, size_t lds,
@@ -1346,26 +1390,8 @@ static int run_v( const GPData* D, const float* src, long src_ss, int width,
 	const int items = P.nstrips * nch;
 	const size_t lds = (size_t) ( P.rs + P.rc ) * 512 + 6 * 1024 +
 		(size_t) ( P.chunk + gextra ) * ( ntp * 4 + 4 ) + 64;
-	const GPAxis& A = P.ax;
 
-	if( A.lanc )
-	{
-		launch_gv< GP_NONE, true >( P, items, lds, st );
-	}
-	else
-	if( A.mode == GP_PRE )
-	{
-		launch_gv< GP_PRE, false >( P, items, lds, st );
-	}
-	else
-	if( A.mode == GP_POST )
-	{
-		launch_gv< GP_POST, false >( P, items, lds, st );
-	}
-	else
-	{
-		launch_gv< GP_NONE, false >( P, items, lds, st );
-	}
+	launch_gv( P, items, lds, st );
 
 	AVIRHIP_HIPCHECK( hipGetLastError() );
 	return( AVIRHIP_OK );
