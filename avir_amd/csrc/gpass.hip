@@ -75,6 +75,7 @@ struct GVParams
 	float* dst; long dst_ss; int dst_row0;
 	GPAxis ax;
 	int row_lo, row_hi;  // output rows to produce
+	int dbg;             // timing ablations (GP_DBG builds only)
 	int nstrips, chunk;  // 32-px strips, output rows per work item
 	int blk;             // output rows per block
 	int rs, rc;          // ring sizes (rows, powers of two): source, C / G
@@ -268,30 +269,45 @@ __device__ __forceinline__ T gp_dot( const int nt_, LD ld, CF cf4 )
 // wave-uniform while loop). LDS holds only what is addressed dynamically:
 // rs rows >= NT + 1 of source (NONE / POST), rc rows of C (>= NT + 1) or of
 // gather outputs (8).
-#define GV_PF 4 // row pairs in flight
+#define GV_PF 5 // DMA groups in flight (one of them is read a step ahead)
+#define GV_QB (( GV_PF + 2 ) * 1024 ) // landing queue: GV_PF + 1 slots, a dump
 
 // RW > 0 (needs NTC > 0): the gather window lives in REGISTERS. An output is
 // produced in the very step its last input row arrives, so its window is
 // always "the last NTC rows": with the step loop unrolled RW times (RW a power
 // of two >= NTC) the window's ring slots are compile-time constants -- no LDS
 // reads for the taps at all, LDS only holds the landing queue and the tables.
-template< int MODE, bool LANC, int NTC, int RW >
+// WP: lane width. 1 = half pixel (8 B): a wave row is 32 pixels, one DMA
+// instruction lands two rows. 2 = whole pixel (16 B): 64 pixels per wave row,
+// one row per DMA instruction -- twice the independent arithmetic per
+// instruction stream: the kernel is bound by the serial latency of a wave
+// (queue read -> FIR chain -> 12-deep accumulation chain), not by issue slots,
+// so the wide form is the default wherever the image is wide enough.
+template< int WP > struct GVLane;
+template<> struct GVLane< 1 > { typedef f2 T; };
+template<> struct GVLane< 2 > { typedef f4 T; };
+
+template< int MODE, bool LANC, int NTC, int RW, int WP >
 __global__ void __launch_bounds__( 64 ) k_gv( const GVParams P )
 {
+	typedef typename GVLane< WP > :: T VT;
+	constexpr int ROWB = WP * 512;   // LDS bytes of one wave row
+	constexpr int RPG = 2 / WP;      // rows per DMA group (instruction)
+	constexpr int PXW = 32 * WP;     // pixels per wave row
 	extern __shared__ __attribute__(( aligned( 16 ))) char smem[];
 	const GPAxis& A = P.ax;
-	f2* const sring = (f2*) smem;                       // [rs][32 px][2 halves]
-	f2* const mring = sring + (size_t) P.rs * 64;       // [rc][32 px][2]
+	VT* const sring = (VT*) smem;                       // [rs][64 lanes]
+	VT* const mring = sring + (size_t) P.rs * 64;       // [rc][64 lanes]
 	// behind the rings and the 6 KiB landing queue: this chunk's coefficient
 	// rows (padded to four taps) and positions -- in LDS, not behind scalar
 	// loads: a scalar load in the tap loop costs its whole latency per use
 	// (every wait on lgkmcnt with one outstanding is a full drain)
-	float* const ctab = (float*) ( smem + ( P.rs + P.rc ) * 512 + 6 * 1024 );
+	float* const ctab = (float*) ( smem + ( P.rs + P.rc ) * ROWB + GV_QB );
 
 	const int lane = threadIdx.x;
 	const int strip = blockIdx.x % P.nstrips;
 	const int chunk = blockIdx.x / P.nstrips;
-	const int x0 = strip * 32;
+	const int x0 = strip * PXW;
 	const int y0 = P.row_lo + chunk * P.chunk;
 	const int y1 = min( y0 + P.chunk, P.row_hi );
 
@@ -307,23 +323,23 @@ __global__ void __launch_bounds__( 64 ) k_gv( const GVParams P )
 	const int nt = ( NTC > 0 ? NTC : A.nt );
 	const int ntp = ( nt + 3 ) & ~3;
 
-	// this lane's half pixel; lanes right of the image redo its last pixel
-	const int hx = x0 + ( lane >> 1 );
+	// this lane's (half) pixel
+	const int hx = x0 + ( WP == 2 ? lane : lane >> 1 );
 	const bool xok = ( hx < P.width );
-	const long dcol = (long) hx * 4 + ( lane & 1 ) * 2;
+	const long dcol = (long) hx * 4 + ( WP == 2 ? 0 : ( lane & 1 ) * 2 );
 
-	auto mread = [&]( const int m ) -> f2
+	auto mread = [&]( const int m ) -> VT
 	{
 		return( mring[ ( m & mmask ) * 64 + lane ]);
 	};
 
-	auto sread = [&]( const int u ) -> f2
+	auto sread = [&]( const int u ) -> VT
 	{
 		return( sring[ ( u & smask ) * 64 + lane ]);
 	};
 
-	const f2 f0 = (f2) A.f[ 0 ], f1 = (f2) A.f[ 1 ], f2_ = (f2) A.f[ 2 ],
-		f3 = (f2) A.f[ 3 ];
+	const VT f0 = (VT) A.f[ 0 ], f1 = (VT) A.f[ 1 ], f2_ = (VT) A.f[ 2 ],
+		f3 = (VT) A.f[ 3 ];
 
 	// gather outputs this chunk evaluates: [ga, gb]
 	const int glast = A.g_len - 1;
@@ -335,46 +351,107 @@ __global__ void __launch_bounds__( 64 ) k_gv( const GVParams P )
 	const int u_a = a_start[ ga ] - ( MODE == GP_PRE ? 6 : 0 );
 	const int u_b = a_start[ gb ] + nt - 1;
 
-	// stage the tables (plain loads: they retire before the first DMA goes out)
+	// stage the tables (plain loads: they retire before the first DMA goes
+	// out). All of a lane's loads are issued before any is written to LDS --
+	// a load-store loop pays the memory latency once per 64 elements, which
+	// measured as a third of this kernel's time.
 	int* const stab = (int*) ( ctab + ( gb - ga + 1 ) * ntp );
-
-	for( int i = lane; i < ( gb - ga + 1 ) * ntp; i += 64 )
 	{
-		const int gi = i / ntp;
-		const int t = i - gi * ntp;
-		const long row = ( LANC ? A.fidx[ ga + gi ] : ga + gi );
-		ctab[ i ] = ( t < nt ? A.coef[ row * nt + t ] : 0.0f );
-	}
+		const int total = ( gb - ga + 1 ) * ntp;
+		constexpr int GV_TE = 24; // 6 KiB of table / 4 bytes / 64 lanes
+		float tmp[ GV_TE ];
+#pragma unroll
+		for( int k = 0; k < GV_TE; k++ )
+		{
+			const int i = lane + 64 * k;
+			tmp[ k ] = 0.0f;
 
-	for( int i = lane; i <= gb - ga; i += 64 )
-	{
-		stab[ i ] = A.start[ ga + i ] + nt - 1;
+#ifdef GP_DBG
+			if( P.dbg & 16 ) continue;
+#endif
+			if( i < total )
+			{
+				const int gi = i / ntp;
+				const int t = i - gi * ntp;
+				const long row = ( LANC ? A.fidx[ ga + gi ] : ga + gi );
+
+				if( t < nt )
+				{
+					tmp[ k ] = A.coef[ row * nt + t ];
+				}
+			}
+		}
+#pragma unroll
+		for( int k = 0; k < GV_TE; k++ )
+		{
+			const int i = lane + 64 * k;
+
+			if( i < total )
+			{
+				ctab[ i ] = tmp[ k ];
+			}
+		}
+
+		for( int i = lane; i <= gb - ga; i += 64 )
+		{
+			stab[ i ] = A.start[ ga + i ] + nt - 1;
+		}
 	}
 
 	int g = ga;                 // next gather output
 	int g_need = a_start[ g ] + nt - 1; // its last input row
-	// (the one after it, fetched an output early: the LDS read + readfirstlane
-	// latency stays off the drain loop's critical path)
-	int g_need1 = ( g + 1 <= gb ? a_start[ g + 1 ] + nt - 1 : 0x7fffffff );
 	int n = y0;                 // POST: next final output
 
-	auto store_row = [&]( const int y, const f2 o )
+	// output rows leave strictly in order, from y0 on: a running pointer
+	float* dp = P.dst + (long) ( y0 - P.dst_row0 ) * P.dst_ss + dcol;
+
+	auto store_row = [&]( const VT o )
 	{
+#ifdef GP_DBG
+		if(( P.dbg & 1 ) && o.x != 1234.5f ) return;
+#endif
 		if( xok )
 		{
-			*(f2*) ( P.dst + (long) ( y - P.dst_row0 ) * P.dst_ss + dcol ) = o;
+			*(VT*) dp = o;
+		}
+
+		dp += P.dst_ss;
+	};
+
+	// the next output's coefficient row and the position after it are read
+	// from LDS an output ahead, so that their latency hides behind the
+	// arithmetic in between (a wave runs alone on most of its issue slots:
+	// exposed LDS round trips were a third of the step time)
+	constexpr int CNB = ( NTC > 0 && NTC <= 16 ? ( NTC + 3 ) / 4 : 0 );
+	f4 cpre[ CNB > 0 ? CNB : 1 ];
+	int need1_v; // g_need1, still in its vector register
+
+	auto prefetch_tabs = [&]()
+	{
+		// (rows past gb are read -- clamped -- and never used)
+		const int gi = min( g + 1, gb ) - ga;
+		need1_v = ( g + 1 <= gb ? stab[ gi ] : 0x7fffffff );
+
+		if( CNB > 0 )
+		{
+			const float* const cr = ctab + ( min( g, gb ) - ga ) * ntp;
+#pragma unroll
+			for( int b = 0; b < CNB; b++ )
+			{
+				cpre[ b ] = *(const f4*) ( cr + 4 * b );
+			}
 		}
 	};
 
-	f2 win[ RW > 0 ? RW : 1 ]; // RW > 0: the last RW rows the gathers read
+	VT win[ RW > 0 ? RW : 1 ]; // RW > 0: the last RW rows the gathers read
 #pragma unroll
 	for( int i = 0; i < ( RW > 0 ? RW : 1 ); i++ )
 	{
-		win[ i ] = (f2) 0.0f;
+		win[ i ] = (VT) 0.0f;
 	}
 
 	// gather output g is done: store it, or (POST) run the correction FIR
-	auto finish = [&]( const f2 o )
+	auto finish = [&]( const VT o )
 	{
 		if( MODE == GP_POST )
 		{
@@ -385,26 +462,25 @@ __global__ void __launch_bounds__( 64 ) k_gv( const GVParams P )
 			while( n < y1 && ( gp_clamp( n - A.e + 3, glast ) <= g ))
 			{
 				const int c = n - A.e;
-				f2 r = f0 * mread( gp_clamp( c, glast ));
+				VT r = f0 * mread( gp_clamp( c, glast ));
 				r = r + f1 * ( mread( gp_clamp( c + 1, glast )) +
 					mread( gp_clamp( c - 1, glast )));
 				r = r + f2_ * ( mread( gp_clamp( c + 2, glast )) +
 					mread( gp_clamp( c - 2, glast )));
 				r = r + f3 * ( mread( gp_clamp( c + 3, glast )) +
 					mread( gp_clamp( c - 3, glast )));
-				store_row( n, r );
+				store_row( r );
 				n++;
 			}
 		}
 		else
 		{
-			store_row( g, o );
+			store_row( o );
 		}
 
 		g++;
-		g_need = g_need1;
-		g_need1 = ( g + 1 <= gb ? __builtin_amdgcn_readfirstlane(
-			stab[ g + 1 - ga ]) : 0x7fffffff );
+		g_need = __builtin_amdgcn_readfirstlane( need1_v );
+		prefetch_tabs();
 	};
 
 	// everything whose inputs are complete once row `u` is in its ring.
@@ -417,73 +493,81 @@ __global__ void __launch_bounds__( 64 ) k_gv( const GVParams P )
 		{
 			const int s0 = g_need - nt + 1;
 			const float* const cr = ctab + ( g - ga ) * ntp;
-			f2 o;
+			VT o;
 
+#ifdef GP_DBG
+			if( P.dbg & 2 )
+			{
+				o = win[ 0 ];
+			}
+			else
+#endif
 			if( RW > 0 )
 			{
 				// g_need == u: outputs are drained the step they complete
-				o = gp_dot< LANC, f2, NTC >( nt,
+				o = gp_dot< LANC, VT, NTC >( nt,
 					[&]( const int t ) { return( win[ ( I - ( NTC - 1 ) + t +
 						4 * ( RW > 0 ? RW : 1 )) & (( RW > 0 ? RW : 1 ) - 1 )]); },
-					[&]( const int b ) { return( *(const f4*) ( cr + 4 * b )); } );
+					[&]( const int b ) { return( CNB > 0 ? cpre[ CNB > 0 ? b : 0 ] :
+						*(const f4*) ( cr + 4 * b )); } );
 			}
 			else
 			if( MODE == GP_PRE )
 			{
-				o = gp_dot< LANC, f2, NTC >( nt,
+				o = gp_dot< LANC, VT, NTC >( nt,
 					[&]( const int t ) { return( mread( s0 + t )); },
-					[&]( const int b ) { return( *(const f4*) ( cr + 4 * b )); } );
+					[&]( const int b ) { return( CNB > 0 ? cpre[ CNB > 0 ? b : 0 ] :
+						*(const f4*) ( cr + 4 * b )); } );
 			}
 			else
 			{
-				o = gp_dot< LANC, f2, NTC >( nt,
+				o = gp_dot< LANC, VT, NTC >( nt,
 					[&]( const int t ) { return( sread( s0 + t )); },
-					[&]( const int b ) { return( *(const f4*) ( cr + 4 * b )); } );
+					[&]( const int b ) { return( CNB > 0 ? cpre[ CNB > 0 ? b : 0 ] :
+						*(const f4*) ( cr + 4 * b )); } );
 			}
 
 			finish( o );
 		}
 	};
 
-	// ---- the feed: source rows by LDS-DMA, two rows per instruction (lanes
-	// 0-31 row 2p, lanes 32-63 row 2p + 1), GV_PF pairs in flight. Waiting
-	// for "at most GV_PF vector-memory operations outstanding" right after
-	// issuing pair p + GV_PF guarantees pair p has landed (loads retire in
-	// order; stores in between only make the wait stricter).
+	prefetch_tabs();
+
+	// ---- the feed: source rows by LDS-DMA, one group per instruction (WP 1:
+	// a row pair, lanes 0-31 row 2p, lanes 32-63 row 2p + 1; WP 2: one row),
+	// GV_PF groups in flight. Waiting for "at most GV_PF - 1 vector-memory
+	// operations outstanding" right after issuing group p + GV_PF guarantees
+	// group p + 1 has landed (loads retire in order; stores in between only
+	// make the wait stricter): rows are read from the queue a step ahead.
 	const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
 		(void*) P.src, 0, 0x7fffffff, 0x00020000 );
 	const unsigned lds0 = (unsigned) (unsigned long) (lds_char*) smem;
-	const int dpx = gp_clamp( x0 + ( lane & 31 ), P.width - 1 );
+	const int dpx = gp_clamp( x0 + ( lane & ( PXW - 1 )), P.width - 1 );
 	const int srow_b = (int) P.src_ss * 4;
 	// PRE: pairs land in a queue of GV_PF + 1 slots behind the C ring;
 	// NONE / POST: straight in the source ring (rs >= nt + 2 * GV_PF + 3)
-	const unsigned qbase = lds0 + (unsigned) ( P.rs + P.rc ) * 512;
-	const int pa = u_a >> 1; // first pair (arithmetic shift: floor)
-	const int pb = u_b >> 1;
+	const unsigned qbase = lds0 + (unsigned) ( P.rs + P.rc ) * ROWB;
+	const int pa = ( RPG == 2 ? u_a >> 1 : u_a ); // first group (floor)
+	const int pb = ( RPG == 2 ? u_b >> 1 : u_b );
 
 	int qi = 0; // landing-queue slot of the next pair issued ...
 	int qr = 0; // ... and of the pair being read (both count modulo GV_PF + 1)
 
 	auto issue_pair = [&]( const int p )
 	{
-		if( p <= pb )
-		{
-			const int r = gp_clamp( p * 2 + ( lane >> 5 ), slast );
-			const unsigned slot = ( MODE == GP_PRE || RW > 0 ?
-				qbase + (unsigned) qi * 1024 :
-				lds0 + (unsigned) (( p * 2 ) & smask ) * 512 );
+		// past the last group: the count of operations per step stays
+		// uniform -- a load nobody reads, into the dump slot (no branch)
+		const bool live = ( p <= pb );
+		const int r = gp_clamp( min( p, pb ) * RPG +
+			( RPG == 2 ? lane >> 5 : 0 ), slast );
 
-			qi = ( qi == GV_PF ? 0 : qi + 1 );
+		const unsigned slot = ( !live ? qbase + (unsigned) ( GV_PF + 1 ) * 1024 :
+			( MODE == GP_PRE || RW > 0 ? qbase + (unsigned) qi * 1024 :
+			lds0 + (unsigned) (( p * RPG ) & smask ) * ROWB ));
 
-			gp_dma( rsrc, slot, r * srow_b + dpx * 16 );
-		}
-		else
-		{
-			// keep the count of operations per step uniform: a load nobody
-			// reads (its queue slot is past the data)
-			gp_dma( rsrc, qbase + (unsigned) ( GV_PF + 1 ) * 1024,
-				dpx * 16 );
-		}
+		qi = ( !live ? qi : ( qi == GV_PF ? 0 : qi + 1 ));
+
+		gp_dma( rsrc, slot, r * srow_b + dpx * 16 );
 	};
 
 	for( int k = 0; k < GV_PF; k++ )
@@ -491,17 +575,27 @@ __global__ void __launch_bounds__( 64 ) k_gv( const GVParams P )
 		issue_pair( pa + k );
 	}
 
-	f2 tw[ 8 ]; // PRE: the FIR window (rows u - 6 .. u in slots ( u - u_a ) & 7)
+	VT qnext = (VT) 0.0f; // the next step's row of the queue
+
+	GP_WAIT_VM( 4 ); // the first group has landed
+
+	if( MODE == GP_PRE || RW > 0 )
+	{
+		qnext = *(const VT*) ( smem + ( P.rs + P.rc ) * ROWB +
+			lane * sizeof( VT ));
+	}
+
+	VT tw[ 8 ]; // PRE: the FIR window (rows u - 6 .. u in slots ( u - u_a ) & 7)
 #pragma unroll
 	for( int i = 0; i < 8; i++ )
 	{
-		tw[ i ] = (f2) 0.0f;
+		tw[ i ] = (VT) 0.0f;
 	}
 
 	// steps run over whole pairs; rows before u_a / after u_b of the first /
 	// last pair are fed like any other (clamped loads), outputs never need
 	// them
-	const int u0 = pa * 2;
+	const int u0 = pa * RPG;
 
 	constexpr int UN = ( RW > 8 ? RW : 8 );
 
@@ -509,36 +603,50 @@ __global__ void __launch_bounds__( 64 ) k_gv( const GVParams P )
 	{
 		constexpr int i = decltype( IC )::value;
 
-		if( u > ( pb * 2 + 1 ))
+		if( u > ( pb * RPG + RPG - 1 ))
 		{
 			return;
 		}
 
-		if(( i & 1 ) == 0 )
+		if( RPG == 1 || ( i & 1 ) == 0 )
 		{
-			issue_pair(( u >> 1 ) + GV_PF );
-			GP_WAIT_VM( 4 ); // == GV_PF
+#ifdef GP_DBG
+			if( !( P.dbg & 8 ))
+#endif
+			issue_pair(( RPG == 2 ? u >> 1 : u ) + GV_PF );
 		}
 
-		const f2* const qs = (const f2*) ( smem + ( P.rs + P.rc ) * 512 +
-			qr * 1024 + ( i & 1 ) * 512 );
-
-		if( i & 1 )
+		if( RPG == 1 || ( i & 1 ))
 		{
-			qr = ( qr == GV_PF ? 0 : qr + 1 ); // after the pair's second row
+			// row u + 1 opens a group: it is the oldest one in flight
+#ifdef GP_DBG
+			if( !( P.dbg & 4 ))
+#endif
+			GP_WAIT_VM( 4 ); // == GV_PF - 1
+
+			qr = ( qr == GV_PF ? 0 : qr + 1 );
+		}
+
+		// this step's row was read from the queue during the last one
+		const VT qcur = qnext;
+
+		if( MODE == GP_PRE || RW > 0 )
+		{
+			qnext = *(const VT*) ( smem + ( P.rs + P.rc ) * ROWB + qr * 1024 +
+				( RPG == 2 ? (( i + 1 ) & 1 ) * 512 : 0 ) + lane * sizeof( VT ));
 		}
 
 		if( MODE == GP_PRE )
 		{
-			tw[ i & 7 ] = qs[ lane ];
-			f2 c = f0 * tw[ ( i - 3 ) & 7 ];
+			tw[ i & 7 ] = qcur;
+			VT c = f0 * tw[ ( i - 3 ) & 7 ];
 			c = c + f1 * ( tw[ ( i - 2 ) & 7 ] + tw[ ( i - 4 ) & 7 ]);
 			c = c + f2_ * ( tw[ ( i - 1 ) & 7 ] + tw[ ( i - 5 ) & 7 ]);
 			c = c + f3 * ( tw[ i & 7 ] + tw[ ( i - 6 ) & 7 ]);
 
 			if( u > A.view_mmax )
 			{
-				c = (f2) 0.0f;
+				c = (VT) 0.0f;
 			}
 
 			if( RW > 0 )
@@ -559,11 +667,11 @@ __global__ void __launch_bounds__( 64 ) k_gv( const GVParams P )
 		{
 			if( RW > 0 )
 			{
-				f2 v = qs[ lane ];
+				VT v = qcur;
 
 				if( u > A.view_mmax )
 				{
-					v = (f2) 0.0f;
+					v = (VT) 0.0f;
 				}
 
 				win[ i & (( RW > 0 ? RW : 1 ) - 1 )] = v;
@@ -571,13 +679,16 @@ __global__ void __launch_bounds__( 64 ) k_gv( const GVParams P )
 			else
 			if( u > A.view_mmax )
 			{
-				sring[ ( u & smask ) * 64 + lane ] = (f2) 0.0f;
+				sring[ ( u & smask ) * 64 + lane ] = (VT) 0.0f;
 			}
 
 			drain( u, IC );
 		}
 	};
 
+#ifdef GP_DBG
+	if( P.dbg & 32 ) return;
+#endif
 	for( int ub = u0; ub <= u_b; ub += UN )
 	{
 		step( ub + 0, std::integral_constant< int, 0 >() );
@@ -1158,13 +1269,13 @@ int gpass_prepare( avirhip_plan* p )
 		}
 		else
 		{
-			// the window, the row pair being consumed and 4 pairs in flight
-			rs = next_pow2( A.nt + 2 * 4 + 3 );
+			// the window, the row pair being consumed and GV_PF pairs in flight
+			rs = next_pow2( A.nt + 2 * GV_PF + 3 );
 			rc = ( A.mode == GP_POST ? 8 : 2 );
 		}
 
 		// (+ the PRE landing queue: 5 pair slots and one dump slot)
-		if(( rs + rc ) * 512 + 6 * 1024 > 64 * 1024 )
+		if(( rs + rc ) * 512 + GV_QB + 6 * 1024 > 64 * 1024 )
 		{
 			delete D;
 			return( AVIRHIP_OK );
@@ -1234,12 +1345,16 @@ bool gpass_preferred( const avirhip_plan* p )
 		p -> in_type == AVIRHIP_F32 && p -> io_ch == 4 && !p -> gamma );
 }
 
-// Rows per work item. All waves of a launch should be resident at once, or
-// fill whole rounds: one straggler round doubles the launch (measured: 4661
-// waves on 4608 slots ran as long as 9216). `warm` = rows of work a chunk
-// spends before its first output; `wpc` = waves a CU holds.
+// Rows per work item. The vertical pass kernel is bound by vector-ALU issue,
+// not by memory (measured: removing the DMA, its waits or the stores changes a
+// launch by < 10 %): a launch takes as long as its busiest SIMD, that is
+// ceil( waves / 1024 SIMDs ) waves of ( chunk + warm ) rows each, where `warm`
+// = the rows of work a chunk spends before its first output. A single wave
+// per SIMD has nobody to hide its latencies behind (x 1.26, measured), and
+// more waves than the chip holds (`wpc` per CU) run in residency rounds.
+// Fits the k_gv sweep profiles/r02_gpass/chunk_sweep.txt within 10 %.
 static int balanced_chunk( int rows, int nstrips, int min_chunk, int max_chunk,
-	int warm, int wpc )
+	int warm, int wpc, bool valu_bound )
 {
 	const double cap = 256.0 * wpc;
 	double best = -1.0;
@@ -1262,13 +1377,17 @@ static int balanced_chunk( int rows, int nstrips, int min_chunk, int max_chunk,
 
 		const int n = ( rows + chunk - 1 ) / chunk;
 		const double items = (double) n * nstrips;
-		const double rounds = ceil( items / cap );
-		const double eff = items / ( rounds * cap ) * chunk /
-			( chunk + (double) warm );
+		const double res = ceil( items / cap ); // residency rounds
+		const double per = ceil( items / res / 1024.0 ); // waves per SIMD
+		// (k_gh is not ALU-bound: there whole rounds of resident waves is
+		// the model that fits -- 4661 waves on 4608 slots ran as long as 9216)
+		const double cost = ( valu_bound ?
+			res * per * ( chunk + (double) warm ) * ( per < 2.0 ? 1.26 : 1.0 ) :
+			res * cap / items * ( chunk + (double) warm ) / chunk );
 
-		if( eff > best )
+		if( best < 0.0 || cost < best )
 		{
-			best = eff;
+			best = cost;
 			best_chunk = chunk;
 		}
 	}
@@ -1280,10 +1399,13 @@ static int balanced_chunk( int rows, int nstrips, int min_chunk, int max_chunk,
 // upsizing (FIR7 then gather), 18-24 for AVIR 1 < k < 2 downsizing (gather
 // then FIR7), the even counts 6-24 for LANCIR; the LDS-window kernel takes
 // everything else.
-#define GV_LAUNCH( MODE, LANC, NT, RW ) hipLaunchKernelGGL(( k_gv< MODE, LANC, \
-	NT, RW > ), dim3( items ), dim3( 64 ), lds, st, P )
+#define GV_LAUNCH( MODE, LANC, NT, RW ) do { if( wp == 2 ) \
+	hipLaunchKernelGGL(( k_gv< MODE, LANC, NT, RW, 2 > ), dim3( items ), \
+	dim3( 64 ), lds, st, P ); else \
+	hipLaunchKernelGGL(( k_gv< MODE, LANC, NT, RW, 1 > ), dim3( items ), \
+	dim3( 64 ), lds, st, P ); } while( 0 )
 
-static void launch_gv( const GVParams& P, int items, size_t lds,
+static void launch_gv( const GVParams& P, int wp, int items, size_t lds,
 	hipStream_t st )
 {
 	const int nt = P.ax.nt;
@@ -1357,8 +1479,22 @@ static int run_v( const GPData* D, const float* src, long src_ss, int width,
 	P.dst = dst; P.dst_ss = dst_ss; P.dst_row0 = dst_row0;
 	P.ax = D -> v.a;
 	P.row_lo = row_lo; P.row_hi = row_hi;
-	P.nstrips = ( width + 31 ) / 32;
+	P.dbg = ( getenv( "AVIRHIP_GP_DBG" ) != nullptr ? atoi( getenv( "AVIRHIP_GP_DBG" )) : 0 );
 	P.blk = D -> v_blk; P.rs = D -> v_rs; P.rc = D -> v_rc;
+
+	// whole-pixel lanes (64-pixel strips) wherever the image is wide enough
+	// to fill them and the rings stay within 64 KiB
+	int wp = ( width > 48 && ( P.rs + P.rc ) * 1024 + GV_QB + 6 * 1024 <= 64 * 1024 ?
+		2 : 1 );
+
+	if( getenv( "AVIRHIP_GV_WP" ) != nullptr ) // tuning aid
+	{
+		wp = ( atoi( getenv( "AVIRHIP_GV_WP" )) == 2 &&
+			( P.rs + P.rc ) * 1024 + GV_QB + 6 * 1024 <= 64 * 1024 ? 2 : 1 );
+	}
+
+	const int rowb = wp * 512;
+	P.nstrips = ( width + 32 * wp - 1 ) / ( 32 * wp );
 
 	// chunk height: a chunk's first window (NT rows, + 6 of FIR warm-up) is
 	// fed before its first output; its coefficient rows and positions live
@@ -1374,11 +1510,12 @@ static int run_v( const GPData* D, const float* src, long src_ss, int width,
 	const int warm = std::max( 1, (int) ( (long) ( P.ax.nt + 6 ) *
 		std::max( 1, P.ax.out_len ) / std::max( 1, P.ax.in_len ) / warm_div ));
 
-	const size_t lds_guess = (size_t) ( P.rs + P.rc ) * 512 + 6 * 1024 + 3072;
+	const size_t lds_guess = (size_t) ( P.rs + P.rc ) * rowb + GV_QB + 3072;
 	const int wpc = std::max( 1, std::min( 16, (int) ( 160 * 1024 /
 		( lds_guess + 512 ))));
 
-	P.chunk = balanced_chunk( rows, P.nstrips, 8, maxg - gextra, warm, wpc );
+	P.chunk = balanced_chunk( rows, P.nstrips, 8, maxg - gextra, warm, wpc,
+		true );
 
 	if( getenv( "AVIRHIP_GV_CHUNK" ) != nullptr ) // tuning aid
 	{
@@ -1388,10 +1525,18 @@ static int run_v( const GPData* D, const float* src, long src_ss, int width,
 
 	const int nch = ( rows + P.chunk - 1 ) / P.chunk;
 	const int items = P.nstrips * nch;
-	const size_t lds = (size_t) ( P.rs + P.rc ) * 512 + 6 * 1024 +
+	const size_t lds = (size_t) ( P.rs + P.rc ) * rowb + GV_QB +
 		(size_t) ( P.chunk + gextra ) * ( ntp * 4 + 4 ) + 64;
 
-	launch_gv( P, items, lds, st );
+#ifdef GP_DBG
+	{
+		static int once = 0;
+		if( !once++ ) fprintf( stderr, "k_gv: wp %d strips %d chunk %d items %d "
+			"lds %zu nt %d mode %d\n", wp, P.nstrips, P.chunk, items, lds,
+			P.ax.nt, P.ax.mode );
+	}
+#endif
+	launch_gv( P, wp, items, lds, st );
 
 	AVIRHIP_HIPCHECK( hipGetLastError() );
 	return( AVIRHIP_OK );
@@ -1421,7 +1566,7 @@ static int run_h( const GPData* D, const float* src, long src_ss, int src_w,
 
 	// (a chunk's fixed cost: its coefficient row load and three rows of DMA
 	// lead, about two rows of work)
-	P.chunk = balanced_chunk( rows, P.nstrips, 8, rows, 2, wpc );
+	P.chunk = balanced_chunk( rows, P.nstrips, 8, rows, 2, wpc, false );
 	const int nch = ( rows + P.chunk - 1 ) / P.chunk;
 	const int items = P.nstrips * nch;
 	const size_t lds = lds_h;
