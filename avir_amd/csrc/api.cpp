@@ -647,7 +647,12 @@ static int exec_device( avirhip_plan* p, const void* src, void* dst,
 	const bool need_pack = ( p -> gamma || p -> in_type != AVIRHIP_F32 ||
 		p -> ch != p -> io_ch );
 
-	if( need_pack && !raw )
+	// the streaming pass kernel reads integer / narrower sources as they are
+	const bool graw = ( need_pack && !p -> gamma && path == 5 &&
+		( p -> in_type == AVIRHIP_U8 || p -> in_type == AVIRHIP_U16 ||
+		p -> in_type == AVIRHIP_F32 ) && p -> ch == 4 && gpass_takes_raw( p ));
+
+	if( need_pack && !raw && !graw )
 	{
 		if(( rc = do_pack()) != 0 ) return( rc );
 	}
@@ -672,8 +677,16 @@ static int exec_device( avirhip_plan* p, const void* src, void* dst,
 	{
 		if( path == 5 )
 		{
-			if( need_pack && ( rc = do_pack()) != 0 ) return( rc );
-			rc = gpass_run( p, fsrc, sstride, fdst, row0, row1, st );
+			if( graw )
+			{
+				rc = gpass_run( p, nullptr, 0, fdst, row0, row1, st, src,
+					p -> in_type, p -> io_ch, p -> src_stride );
+			}
+			else
+			{
+				if( need_pack && ( rc = do_pack()) != 0 ) return( rc );
+				rc = gpass_run( p, fsrc, sstride, fdst, row0, row1, st );
+			}
 		}
 		else
 		if( path == 4 )

@@ -31,7 +31,7 @@
 // is f0*c + sum f_i*(right_i + left_i); LANCIR accumulates even and odd taps
 // separately from bare first products and adds the two sums at the end.
 
-#include "plan.h"
+#include "gpass_dev.h"
 #include <algorithm>
 #include <math.h>
 #include <type_traits>
@@ -40,34 +40,6 @@
 #include <stdlib.h>
 
 namespace avirhip {
-
-typedef float f4 __attribute__(( ext_vector_type( 4 )));
-typedef float f2 __attribute__(( ext_vector_type( 2 )));
-typedef __attribute__(( address_space( 3 ))) char lds_char;
-// Wave-uniform table reads (positions, coefficient rows) go through the
-// constant address space: they become scalar loads (lgkmcnt), so they never
-// wait on the vector-memory counter the LDS-DMA prefetch keeps busy.
-typedef const __attribute__(( address_space( 4 ))) float gp_cfloat;
-typedef const __attribute__(( address_space( 4 ))) int gp_cint;
-
-enum { GP_NONE = 0, GP_PRE = 1, GP_POST = 2 };
-
-struct GPAxis
-{
-	int mode;          // GP_*
-	int lanc;          // LANCIR summation order
-	int nt;            // taps of every gather output
-	int in_len;        // source length along the axis (clamp range)
-	int c_len;         // PRE: length of the FIR's output array
-	int view_mmax;     // gather input index above which the view reads 0
-	int g_len;         // outputs of the gather
-	int out_len;       // outputs of the axis
-	int e;             // FIR edge pixel count (3)
-	float f[ 4 ];      // FIR taps f0..f3
-	const int* start;  // [g_len] first gather input index (unclamped)
-	const float* coef; // AVIR: [g_len][nt]; LANCIR: [phases][nt]
-	const int* fidx;   // LANCIR: [g_len] phase of each output
-};
 
 struct GVParams
 {
@@ -92,49 +64,6 @@ struct GHParams
 	int nseg;            // DMA instructions per row (uniform)
 	int sbuf, mbuf;      // LDS pixels per source row buffer / mid buffer
 };
-
-__device__ __forceinline__ int gp_clamp( int i, int hi )
-{
-	return( i < 0 ? 0 : ( i > hi ? hi : i ));
-}
-
-// LDS-DMA of 64 x 16 bytes: lane l's 16 bytes land at lds + l * 16. Inline
-// assembly on purpose: the compiler must not know that these loads write LDS,
-// or it would drain them (vmcnt 0) before every LDS read that follows --
-// completion is awaited explicitly, one block / row later.
-__device__ __forceinline__ void gp_dma( const __amdgpu_buffer_rsrc_t rs,
-	const unsigned lds, const int voff )
-{
-	asm volatile( "s_mov_b32 m0, %0\n\t"
-		"buffer_load_dwordx4 %1, %2, 0 offen lds"
-		:: "s"( __builtin_amdgcn_readfirstlane( lds )), "v"( voff ), "s"( rs )
-		: "memory" );
-}
-
-#define GP_WAIT_VM( n ) asm volatile( "s_waitcnt vmcnt(" #n ")" ::: "memory" )
-
-// s_waitcnt takes an immediate: a wave-uniform count picks its instruction.
-// Waiting for MORE than `n` to retire is always safe (loads retire in order).
-__device__ __forceinline__ void gp_wait_vm( const int n )
-{
-	switch( n )
-	{
-		case 0: GP_WAIT_VM( 0 ); break;
-		case 1: GP_WAIT_VM( 1 ); break;
-		case 2: GP_WAIT_VM( 2 ); break;
-		case 3: GP_WAIT_VM( 3 ); break;
-		case 4: GP_WAIT_VM( 4 ); break;
-		case 5: GP_WAIT_VM( 5 ); break;
-		case 6: GP_WAIT_VM( 6 ); break;
-		case 7: GP_WAIT_VM( 7 ); break;
-		case 8: GP_WAIT_VM( 8 ); break;
-		case 9: GP_WAIT_VM( 9 ); break;
-		case 10: GP_WAIT_VM( 10 ); break;
-		case 11: GP_WAIT_VM( 11 ); break;
-		case 12: GP_WAIT_VM( 12 ); break;
-		default: GP_WAIT_VM( 12 ); break;
-	}
-}
 
 // One gather output: tap t reads ld( t ); cf4( b ) returns the coefficients
 // of taps 4b .. 4b + 3 (rows are padded to a multiple of four; padded taps are
@@ -957,17 +886,21 @@ __global__ void __launch_bounds__( 64 ) k_gh( const GHParams P )
 // host side
 // ---------------------------------------------------------------------
 
-struct GPAxisHost
-{
-	bool ok;
-	GPAxis a;       // device pointers filled in
-	double kmax;    // largest source advance per output (ring sizing)
-	std::vector< int > start; // host copy of the positions
-};
+// sacc.hip: the streaming-accumulation kernel of downsizing axes
+struct SAData;
+int sacc_prepare_axis( const GPAxisHost& H, std::vector< void* >& allocs,
+	SAData** out );
+void sacc_release_axis( SAData* D );
+int sacc_run_axis( const SAData* D, int mode, const void* src, int src_type,
+	int src_ch, long s_lane, long s_step, float* dst, long d_lane, long d_step,
+	int lane_lo, int lane_hi, int out_lo, int out_hi, hipStream_t st );
 
 struct GPData
 {
 	GPAxisHost h, v;     // AVIR: H pass first; LANCIR: V pass first
+	SAData* sa_h;        // downsizing axes: by-sample tables (sacc.hip), or
+	SAData* sa_v;        // nullptr where the gather kernels run the axis
+	bool h_geom, v_geom; // the gather kernels' launch geometry exists
 	int* d_hseg;
 	int h_nstrips, h_ow, h_nseg, h_sbuf, h_mbuf;
 	int v_blk, v_rs, v_rc;
@@ -1085,6 +1018,8 @@ static bool match_avir_axis( const LAxis& ax, GPAxisHost& H )
 	A.coef = gat -> d_coef;
 	A.fidx = nullptr;
 	H.start = gat -> h_start;
+	H.h_coef = gat -> h_coef.data();
+	H.h_fidx = nullptr;
 	H.ok = true;
 	return( true );
 }
@@ -1101,6 +1036,8 @@ static void match_lancir_axis( const LancirAxisDev& L, GPAxisHost& H )
 	A.g_len = L.dst_len; A.out_len = L.dst_len; A.e = 0;
 	A.start = L.d_start; A.coef = L.d_flt; A.fidx = L.d_fidx;
 	H.start = L.h_start;
+	H.h_coef = L.h_flt.data();
+	H.h_fidx = L.h_fidx.data();
 
 	for( size_t j = 1; j < H.start.size(); j++ )
 	{
@@ -1121,6 +1058,8 @@ int gpass_prepare( avirhip_plan* p )
 
 	GPData* D = new GPData();
 	D -> mid = nullptr; D -> mid_bytes = 0; D -> d_hseg = nullptr;
+	D -> sa_h = nullptr; D -> sa_v = nullptr;
+	D -> h_geom = false; D -> v_geom = false;
 
 	if( p -> is_lancir )
 	{
@@ -1145,6 +1084,18 @@ int gpass_prepare( avirhip_plan* p )
 	{
 		delete D;
 		return( AVIRHIP_OK );
+	}
+
+	{
+		int rc = sacc_prepare_axis( D -> h, D -> allocs, &D -> sa_h );
+		if( rc == 0 ) rc = sacc_prepare_axis( D -> v, D -> allocs, &D -> sa_v );
+
+		if( rc != 0 )
+		{
+			p -> gpass = D;
+			gpass_release( p );
+			return( rc );
+		}
 	}
 
 	// ---- horizontal pass geometry: strips of `ow` outputs whose gather
@@ -1214,23 +1165,28 @@ int gpass_prepare( avirhip_plan* p )
 			}
 		}
 
-		if( ow == 0 )
+		if( ow == 0 && D -> sa_h == nullptr )
 		{
-			delete D;
+			p -> gpass = D;
+			gpass_release( p );
 			return( AVIRHIP_OK );
 		}
 
+		D -> h_geom = ( ow != 0 );
 		D -> h_ow = ow;
 		D -> h_nstrips = nstrips;
 		D -> h_nseg = ( maxs + 63 ) / 64;
 		D -> h_sbuf = D -> h_nseg * 64;
 		D -> h_mbuf = std::max( 64, (( maxm + 63 ) / 64 ) * 64 );
 		void* q = nullptr;
+		if( ow != 0 )
+		{
 		AVIRHIP_HIPCHECK( hipMalloc( &q, seg.size() * sizeof( int )));
 		D -> allocs.push_back( q );
 		AVIRHIP_HIPCHECK( hipMemcpy( q, seg.data(), seg.size() * sizeof( int ),
 			hipMemcpyHostToDevice ));
 		D -> d_hseg = (int*) q;
+		}
 	}
 
 	// ---- vertical pass geometry: LDS rings hold what the gathers address
@@ -1275,9 +1231,12 @@ int gpass_prepare( avirhip_plan* p )
 		}
 
 		// (+ the PRE landing queue: 5 pair slots and one dump slot)
-		if(( rs + rc ) * 512 + GV_QB + 6 * 1024 > 64 * 1024 )
+		D -> v_geom = (( rs + rc ) * 512 + GV_QB + 6 * 1024 <= 64 * 1024 );
+
+		if( !D -> v_geom && D -> sa_v == nullptr )
 		{
-			delete D;
+			p -> gpass = D;
+			gpass_release( p );
 			return( AVIRHIP_OK );
 		}
 
@@ -1289,9 +1248,11 @@ int gpass_prepare( avirhip_plan* p )
 	const long mid_h = ( p -> is_lancir ? p -> new_h : p -> src_h );
 
 	if( (long) p -> src_h * p -> src_stride * 4 >= ( 1L << 31 ) ||
+		(long) p -> src_h * p -> src_w * 16 >= ( 1L << 31 ) ||
 		mid_h * mid_w * 16 >= ( 1L << 31 ))
 	{
-		delete D;
+		p -> gpass = D;
+		gpass_release( p );
 		return( AVIRHIP_OK );
 	}
 
@@ -1311,6 +1272,8 @@ void gpass_release( avirhip_plan* p )
 			(void) hipFree( D -> allocs[ i ]);
 		}
 
+		sacc_release_axis( D -> sa_h );
+		sacc_release_axis( D -> sa_v );
 		delete D;
 	}
 
@@ -1337,6 +1300,13 @@ bool gpass_preferred( const avirhip_plan* p )
 	}
 
 	if( p -> is_lancir )
+	{
+		return( true );
+	}
+
+	// both axes downsize by 2 or more: the streaming-accumulation kernel
+	// (any source type: its first pass converts)
+	if( D -> sa_h != nullptr && D -> sa_v != nullptr )
 	{
 		return( true );
 	}
@@ -1624,13 +1594,23 @@ static void v_source_rows( const GPData* D, int row0, int row1, int& a, int& b )
 // Runs both passes for output rows [row0, row1) of a float RGBA plan. Returns
 // 1 when the call cannot take this path (alignment), so that the caller falls
 // back.
+// Whether the first pass reads the caller's image as it is (integer types,
+// 1-4 channels): AVIR plans whose horizontal axis streams (sacc.hip).
+bool gpass_takes_raw( const avirhip_plan* p )
+{
+	const GPData* D = (const GPData*) p -> gpass;
+	return( D != nullptr && !p -> is_lancir && D -> sa_h != nullptr );
+}
+
 int gpass_run( avirhip_plan* p, const float* src, long src_stride, float* dst,
-	int row0, int row1, hipStream_t st )
+	int row0, int row1, hipStream_t st, const void* raw, int raw_type,
+	int raw_ch, long raw_stride )
 {
 	GPData* D = (GPData*) p -> gpass;
 
-	if( D == nullptr || ( (uintptr_t) src & 15 ) || ( (uintptr_t) dst & 15 ) ||
-		( src_stride & 3 ) || ( p -> new_stride & 3 ))
+	if( D == nullptr || ( (uintptr_t) dst & 15 ) || ( p -> new_stride & 3 ) ||
+		( raw == nullptr && (( (uintptr_t) src & 15 ) || ( src_stride & 3 ))) ||
+		( raw != nullptr && !gpass_takes_raw( p )))
 	{
 		return( 1 );
 	}
@@ -1654,6 +1634,11 @@ int gpass_run( avirhip_plan* p, const float* src, long src_stride, float* dst,
 
 	if( p -> is_lancir )
 	{
+		if( !D -> h_geom || !D -> v_geom )
+		{
+			return( 1 );
+		}
+
 		// vertical first (lancir.h:601-646): mid = [new_h][src_w], only the
 		// rows of the band
 		const long mid_ss = (long) p -> src_w * 4;
@@ -1671,11 +1656,61 @@ int gpass_run( avirhip_plan* p, const float* src, long src_stride, float* dst,
 	int a, b;
 	v_source_rows( D, row0, row1, a, b );
 
-	if(( rc = run_h( D, src, src_stride, p -> src_w, D -> mid, mid_ss, 0,
-		p -> new_w, a, b + 1, st )) != 0 ) return( rc );
+	rc = 1;
 
-	return( run_v( D, D -> mid, mid_ss, p -> new_w, dst, dst_ss, row0, row0,
-		row1, st ));
+	if( D -> sa_h != nullptr )
+	{
+		if( raw != nullptr )
+		{
+			const long es = ( raw_type == AVIRHIP_U8 ? 1 :
+				( raw_type == AVIRHIP_U16 ? 2 : 4 ));
+
+			rc = sacc_run_axis( D -> sa_h, D -> h.a.mode, raw, raw_type, raw_ch,
+				raw_stride * es, raw_ch * es, D -> mid, mid_ss, 4, a, b + 1, 0,
+				p -> new_w, st );
+		}
+		else
+		{
+			rc = sacc_run_axis( D -> sa_h, D -> h.a.mode, src, AVIRHIP_F32, 4,
+				src_stride * 4, 16, D -> mid, mid_ss, 4, a, b + 1, 0,
+				p -> new_w, st );
+		}
+	}
+
+	if( rc == 1 )
+	{
+		if( !D -> h_geom || raw != nullptr )
+		{
+			return( 1 );
+		}
+
+		rc = run_h( D, src, src_stride, p -> src_w, D -> mid, mid_ss, 0,
+			p -> new_w, a, b + 1, st );
+	}
+
+	if( rc != 0 ) return( rc );
+
+	rc = 1;
+
+	if( D -> sa_v != nullptr )
+	{
+		rc = sacc_run_axis( D -> sa_v, D -> v.a.mode, D -> mid, AVIRHIP_F32, 4,
+			16, mid_ss * 4, dst - (long) row0 * dst_ss, 4, dst_ss, 0,
+			p -> new_w, row0, row1, st );
+	}
+
+	if( rc == 1 )
+	{
+		if( !D -> v_geom )
+		{
+			return( 1 );
+		}
+
+		rc = run_v( D, D -> mid, mid_ss, p -> new_w, dst, dst_ss, row0, row0,
+			row1, st );
+	}
+
+	return( rc );
 }
 
 } // namespace avirhip

@@ -1,0 +1,95 @@
+// gpass_dev.h -- what the pass kernels of gpass.hip and sacc.hip share: the
+// lowered axis as the device sees it, the LDS-DMA and wait-count primitives.
+#ifndef AVIRHIP_GPASS_DEV_H
+#define AVIRHIP_GPASS_DEV_H
+
+#include "plan.h"
+#include <vector>
+
+namespace avirhip {
+
+typedef float f4 __attribute__(( ext_vector_type( 4 )));
+typedef float f2 __attribute__(( ext_vector_type( 2 )));
+typedef __attribute__(( address_space( 3 ))) char lds_char;
+// Wave-uniform table reads (positions, coefficient rows) go through the
+// constant address space: they become scalar loads (lgkmcnt), so they never
+// wait on the vector-memory counter the LDS-DMA prefetch keeps busy.
+typedef const __attribute__(( address_space( 4 ))) float gp_cfloat;
+typedef const __attribute__(( address_space( 4 ))) int gp_cint;
+
+enum { GP_NONE = 0, GP_PRE = 1, GP_POST = 2 };
+
+struct GPAxis
+{
+	int mode;          // GP_*
+	int lanc;          // LANCIR summation order
+	int nt;            // taps of every gather output
+	int in_len;        // source length along the axis (clamp range)
+	int c_len;         // PRE: length of the FIR's output array
+	int view_mmax;     // gather input index above which the view reads 0
+	int g_len;         // outputs of the gather
+	int out_len;       // outputs of the axis
+	int e;             // FIR edge pixel count (3)
+	float f[ 4 ];      // FIR taps f0..f3
+	const int* start;  // [g_len] first gather input index (unclamped)
+	const float* coef; // AVIR: [g_len][nt]; LANCIR: [phases][nt]
+	const int* fidx;   // LANCIR: [g_len] phase of each output
+};
+
+__device__ __forceinline__ int gp_clamp( int i, int hi )
+{
+	return( i < 0 ? 0 : ( i > hi ? hi : i ));
+}
+
+// LDS-DMA of 64 x 16 bytes: lane l's 16 bytes land at lds + l * 16. Inline
+// assembly on purpose: the compiler must not know that these loads write LDS,
+// or it would drain them (vmcnt 0) before every LDS read that follows --
+// completion is awaited explicitly, one block / row later.
+__device__ __forceinline__ void gp_dma( const __amdgpu_buffer_rsrc_t rs,
+	const unsigned lds, const int voff )
+{
+	asm volatile( "s_mov_b32 m0, %0\n\t"
+		"buffer_load_dwordx4 %1, %2, 0 offen lds"
+		:: "s"( __builtin_amdgcn_readfirstlane( lds )), "v"( voff ), "s"( rs )
+		: "memory" );
+}
+
+#define GP_WAIT_VM( n ) asm volatile( "s_waitcnt vmcnt(" #n ")" ::: "memory" )
+
+// s_waitcnt takes an immediate: a wave-uniform count picks its instruction.
+// Waiting for MORE than `n` to retire is always safe (loads retire in order).
+__device__ __forceinline__ void gp_wait_vm( const int n )
+{
+	switch( n )
+	{
+		case 0: GP_WAIT_VM( 0 ); break;
+		case 1: GP_WAIT_VM( 1 ); break;
+		case 2: GP_WAIT_VM( 2 ); break;
+		case 3: GP_WAIT_VM( 3 ); break;
+		case 4: GP_WAIT_VM( 4 ); break;
+		case 5: GP_WAIT_VM( 5 ); break;
+		case 6: GP_WAIT_VM( 6 ); break;
+		case 7: GP_WAIT_VM( 7 ); break;
+		case 8: GP_WAIT_VM( 8 ); break;
+		case 9: GP_WAIT_VM( 9 ); break;
+		case 10: GP_WAIT_VM( 10 ); break;
+		case 11: GP_WAIT_VM( 11 ); break;
+		case 12: GP_WAIT_VM( 12 ); break;
+		default: GP_WAIT_VM( 12 ); break;
+	}
+}
+
+// Host side of a recognised axis.
+struct GPAxisHost
+{
+	bool ok;
+	GPAxis a;       // device pointers filled in
+	double kmax;    // largest source advance per output (ring sizing)
+	std::vector< int > start; // host copy of the positions
+	const float* h_coef; // host copy of the coefficient rows (a.coef's layout)
+	const int* h_fidx;   // LANCIR: host copy of a.fidx
+};
+
+} // namespace avirhip
+
+#endif
