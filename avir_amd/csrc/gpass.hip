@@ -891,9 +891,10 @@ struct SAData;
 int sacc_prepare_axis( const GPAxisHost& H, std::vector< void* >& allocs,
 	SAData** out );
 void sacc_release_axis( SAData* D );
-int sacc_run_axis( const SAData* D, int mode, const void* src, int src_type,
-	int src_ch, long s_lane, long s_step, float* dst, long d_lane, long d_step,
-	int lane_lo, int lane_hi, int out_lo, int out_hi, hipStream_t st );
+int sacc_run_axis( const SAData* D, bool rows, const void* src, int src_type,
+	int src_ch, int live_ch, long s_lane, long s_step, float* dst, long d_lane,
+	long d_step, int lane_lo, int lane_hi, int out_lo, int out_hi,
+	hipStream_t st );
 
 struct GPData
 {
@@ -1306,7 +1307,12 @@ bool gpass_preferred( const avirhip_plan* p )
 
 	// both axes downsize by 2 or more: the streaming-accumulation kernel
 	// (any source type: its first pass converts)
-	if( D -> sa_h != nullptr && D -> sa_v != nullptr )
+	// (measured, profiles/r02_sacc: it wins where its first pass replaces the
+	// pack pass or a long-tap tile loader -- integer or narrower sources; for
+	// float RGBA the gather / whole-ratio kernels stay ahead)
+	if( D -> sa_h != nullptr && D -> sa_v != nullptr && !p -> gamma &&
+		( p -> in_type == AVIRHIP_U8 || p -> in_type == AVIRHIP_U16 ||
+		( p -> in_type == AVIRHIP_F32 && p -> io_ch != 4 )))
 	{
 		return( true );
 	}
@@ -1665,13 +1671,13 @@ int gpass_run( avirhip_plan* p, const float* src, long src_stride, float* dst,
 			const long es = ( raw_type == AVIRHIP_U8 ? 1 :
 				( raw_type == AVIRHIP_U16 ? 2 : 4 ));
 
-			rc = sacc_run_axis( D -> sa_h, D -> h.a.mode, raw, raw_type, raw_ch,
+			rc = sacc_run_axis( D -> sa_h, true, raw, raw_type, raw_ch, raw_ch,
 				raw_stride * es, raw_ch * es, D -> mid, mid_ss, 4, a, b + 1, 0,
 				p -> new_w, st );
 		}
 		else
 		{
-			rc = sacc_run_axis( D -> sa_h, D -> h.a.mode, src, AVIRHIP_F32, 4,
+			rc = sacc_run_axis( D -> sa_h, true, src, AVIRHIP_F32, 4, p -> io_ch,
 				src_stride * 4, 16, D -> mid, mid_ss, 4, a, b + 1, 0,
 				p -> new_w, st );
 		}
@@ -1694,9 +1700,9 @@ int gpass_run( avirhip_plan* p, const float* src, long src_stride, float* dst,
 
 	if( D -> sa_v != nullptr )
 	{
-		rc = sacc_run_axis( D -> sa_v, D -> v.a.mode, D -> mid, AVIRHIP_F32, 4,
-			16, mid_ss * 4, dst - (long) row0 * dst_ss, 4, dst_ss, 0,
-			p -> new_w, row0, row1, st );
+		rc = sacc_run_axis( D -> sa_v, false, D -> mid, AVIRHIP_F32, 4,
+			p -> io_ch, 16, mid_ss * 4, dst - (long) row0 * dst_ss, 4, dst_ss,
+			0, p -> new_w, row0, row1, st );
 	}
 
 	if( rc == 1 )

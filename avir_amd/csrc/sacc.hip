@@ -40,9 +40,8 @@
 
 namespace avirhip {
 
-#define SA_NS 16 // accumulator slots: the most outputs alive at one sample
-#define SA_PF 5  // DMA samples in flight
-#define SA_Q 8   // FIFO slots (+ 1 dump slot)
+#define SA_NS 16 // accumulator slots (at most 15 outputs alive at a sample)
+#define SA_TQ 4  // coefficient-table FIFO: groups of 4 table rows (256 B)
 
 struct SAAxis
 {
@@ -50,8 +49,9 @@ struct SAAxis
 	float f[ 4 ];
 	int u_min;          // view index of table row 0
 	const int* start;   // [g_len] first input of each output (unclamped)
-	const int* meta;    // [rows][2] first, last output alive at the sample
-	const float* tab;   // [rows][16] their coefficients for the sample
+	const int* first;   // [rows] first output alive at the sample
+	const float* tab;   // [rows][16]: coefficients of the outputs alive at the
+	                    // sample, first alive output first; [15] = their count
 };
 
 struct SAParams
@@ -72,21 +72,123 @@ template<> struct SAElem< 2 > { typedef uint16_t T; };
 template<> struct SAElem< 3 > { typedef float T; };
 template<> struct SAElem< 0 > { typedef float T; };
 
-// SRC: 0 float RGBA by LDS-DMA; 1 uint8, 2 uint16, 3 float of CH channels.
-template< int SRC, int CH, bool POST >
+// A pixel's NC live channels. Packed float operations take as long as two
+// scalar ones on this hardware (profiles/r01_microbench_valu_lds_copy.txt), so
+// a channel that is not there costs real time: RGB runs on one packed pair and
+// one scalar (3/4 of the RGBA arithmetic), padded channels are never computed
+// -- they are written as the +0.0f the reference's zero padding would yield.
+template< int NC >
+struct SAV
+{
+	f2 a;    // channels 0, 1
+	f2 b;    // channels 2, 3 (NC == 3: only b.x is computed)
+
+	__device__ __forceinline__ static SAV zero()
+	{
+		SAV r; r.a = (f2) 0.0f; r.b = (f2) 0.0f; return( r );
+	}
+
+	__device__ __forceinline__ static SAV from( const f4 v )
+	{
+		SAV r; r.a = v.xy; r.b = v.zw; return( r );
+	}
+
+	__device__ __forceinline__ f4 to4() const
+	{
+		f4 r; r.xy = a;
+		r.z = ( NC >= 3 ? b.x : 0.0f );
+		r.w = ( NC >= 4 ? b.y : 0.0f );
+
+		if( NC < 2 )
+		{
+			r.y = 0.0f;
+		}
+
+		return( r );
+	}
+
+	// this + c * x (mul, then add: no contraction)
+	__device__ __forceinline__ SAV madd( const float c, const SAV& x ) const
+	{
+		SAV r = *this;
+
+		if( NC >= 2 )
+		{
+			r.a = a + c * x.a;
+		}
+		else
+		{
+			r.a.x = a.x + c * x.a.x;
+		}
+
+		if( NC >= 4 )
+		{
+			r.b = b + c * x.b;
+		}
+		else
+		if( NC == 3 )
+		{
+			r.b.x = b.x + c * x.b.x;
+		}
+
+		return( r );
+	}
+
+	// this + x
+	__device__ __forceinline__ SAV madd1( const SAV& x ) const
+	{
+		SAV r = *this;
+
+		if( NC >= 2 ) r.a = a + x.a; else r.a.x = a.x + x.a.x;
+		if( NC >= 4 ) r.b = b + x.b; else if( NC == 3 ) r.b.x = b.x + x.b.x;
+		return( r );
+	}
+
+	// c * this
+	__device__ __forceinline__ SAV scale( const float c ) const
+	{
+		SAV r = *this;
+
+		if( NC >= 2 ) r.a = c * a; else r.a.x = c * a.x;
+		if( NC >= 4 ) r.b = c * b; else if( NC == 3 ) r.b.x = c * b.x;
+		return( r );
+	}
+};
+
+// LDS-DMA of 64 x 4 bytes (a group of four coefficient-table rows)
+__device__ __forceinline__ void sa_dma4( const __amdgpu_buffer_rsrc_t rs,
+	const unsigned lds, const int voff )
+{
+	asm volatile( "s_mov_b32 m0, %0\n\t"
+		"buffer_load_dword %1, %2, 0 offen lds"
+		:: "s"( __builtin_amdgcn_readfirstlane( lds )), "v"( voff ), "s"( rs )
+		: "memory" );
+}
+
+// SRC: 0 float RGBA by LDS-DMA; 1 uint8, 2 uint16, 3 float of CH channels
+// (lane = image row only). HOR (SRC 0): lanes are image rows -- a DMA
+// instruction then fetches 16 rows x 4 consecutive samples (64 contiguous
+// bytes per row) instead of 64 rows x 1 sample: four times fewer cache lines
+// per instruction.
+template< int SRC, int CH, bool POST, bool HOR, int NC >
 __global__ void __launch_bounds__( 64 ) k_sacc( const SAParams P )
 {
+	typedef SAV< NC > PV;
 	extern __shared__ __attribute__(( aligned( 16 ))) char smem[];
 	const SAAxis& A = P.ax;
-	f4* const fifo = (f4*) smem;                  // [SA_Q + 1][64 lanes]
-	f4* const mring = fifo + ( SA_Q + 1 ) * 64;   // POST: [8][64 lanes]
+	// SRC 0: three groups of four samples (4 KiB each); typed: 8 samples
+	constexpr int DQ_BYTES = ( SRC == 0 ? 3 * 4096 : 8 * 1024 );
+	f4* const fifo = (f4*) smem;
+	float* const tfifo = (float*) ( smem + DQ_BYTES ); // [SA_TQ][4][16] + pad
 
 	const int lane = threadIdx.x;
 	const int strip = blockIdx.x % P.nstrips;
 	const int chunk = blockIdx.x / P.nstrips;
-	const int li = P.lane_lo + strip * 64 + lane;
+	const int l0 = P.lane_lo + strip * 64;
+	const int li = l0 + lane;
 	const bool lok = ( li < P.lane_hi );
-	const int lc = min( li, P.lane_hi - 1 );      // lanes past the end reload
+	const int llast = P.lane_hi - 1;
+	const int lc = min( li, llast );               // lanes past the end reload
 	const int n0 = P.out_lo + chunk * P.chunk;
 	const int n1 = min( n0 + P.chunk, P.out_hi );
 
@@ -96,39 +198,110 @@ __global__ void __launch_bounds__( 64 ) k_sacc( const SAParams P )
 	}
 
 	gp_cint* const a_start = (gp_cint*) (unsigned long) A.start;
-	gp_cint* const a_meta = (gp_cint*) (unsigned long) A.meta;
-	gp_cfloat* const a_tab = (gp_cfloat*) (unsigned long) A.tab;
 	const int nt = A.nt;
 	const int glast = A.g_len - 1;
 	const int slast = A.in_len - 1;
 
-	// accumulated outputs this chunk needs: [ga, gb]
+	// accumulated outputs this chunk needs: [ga, gb]; POST: the correction
+	// FIR reads +-3 around every output, beyond the ends the edge value --
+	// gbv counts those virtual repeats too
 	const int ga = ( POST ? gp_clamp( n0 - A.e - 3, glast ) : n0 );
 	const int gb = ( POST ? gp_clamp( n1 - 1 - A.e + 3, glast ) : n1 - 1 );
+	const int gbv = ( POST ? n1 - 1 - A.e + 3 : gb );
 	const int u_a = a_start[ ga ];
 	const int u_b = a_start[ gb ] + nt - 1;
 
-	// ---- the feed
-	constexpr int G = ( SRC == 1 ? 4 : ( SRC == 2 ? 2 : 1 )); // samples / group
-	typedef typename SAElem< SRC > :: T Tin;
-	// the FIFO slot of sample u is ( u - ub0 ) & 7; groups are aligned in
-	// absolute sample coordinates
-	const int ub0 = ( SRC == 0 ? u_a : ( u_a >= 0 ? u_a / G : -(( -u_a + G - 1 ) / G )) * G );
 	const unsigned lds0 = (unsigned) (unsigned long) (lds_char*) smem;
+
+	// ---- the coefficient-table feed: groups of four rows by LDS-DMA, three
+	// groups ahead of the one being read
+	const __amdgpu_buffer_rsrc_t trs = __builtin_amdgcn_make_buffer_rsrc(
+		(void*) A.tab, 0, 0x7fffffff, 0x00020000 );
+
+	auto t_issue = [&]( const int q ) // group q = table rows 4q .. 4q + 3
+	{
+		sa_dma4( trs, lds0 + DQ_BYTES + (unsigned) ( q & ( SA_TQ - 1 )) * 256,
+			q * 256 + lane * 4 );
+	};
+
+	// this lane's element of sample u's row, `lo` entries in
+	auto t_read = [&]( const int u, const int lo ) -> float
+	{
+		const int r = u - A.u_min;
+		return( tfifo[ (( r >> 2 ) & ( SA_TQ - 1 )) * 64 + ( r & 3 ) * 16 + lo +
+			( lane & 15 )]);
+	};
+
+	// ---- the sample feed
+	constexpr int G = ( SRC == 1 ? 4 : ( SRC == 2 ? 2 : ( SRC == 0 ? 4 : 1 )));
+	typedef typename SAElem< SRC > :: T Tin;
+	// groups are aligned in absolute sample coordinates
+	const int ub0 = ( u_a >= 0 ? u_a / G : -(( -u_a + G - 1 ) / G )) * G;
+	const int q_a = ub0 / G;
 
 	const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
 		(void*) P.src, 0, 0x7fffffff, 0x00020000 );
-	const int lofs = lc * (int) P.s_lane;
 	const int sstep = (int) P.s_step;
+	const int slane = (int) P.s_lane;
 
-	auto issue = [&]( const int u ) // SRC == 0
+	// SRC 0: group q = samples 4q .. 4q + 3, four DMA instructions, in FIFO
+	// third ( q - q_a ) % 3
+	int hrow[ 4 ]; // HOR: byte offsets of the four rows this lane fetches
+#pragma unroll
+	for( int k = 0; k < 4; k++ )
 	{
-		const bool live = ( u <= u_b );
-		const int x = gp_clamp( min( u, u_b ), slast );
-		const unsigned slot = ( live ? (unsigned) (( u - ub0 ) & ( SA_Q - 1 )) :
-			(unsigned) SA_Q );
+		hrow[ k ] = min( l0 + k * 16 + ( lane >> 2 ), llast ) * slane;
+	}
 
-		gp_dma( rsrc, lds0 + slot * 1024, lofs + x * sstep );
+	int ith = 0; // FIFO third of the next group issued (groups go out in order)
+	int rth = 0; // FIFO third of the group holding the sample read next
+
+	auto d_issue = [&]( const int q )
+	{
+		const unsigned base = lds0 + (unsigned) ith * 4096;
+		ith = ( ith == 2 ? 0 : ith + 1 );
+
+		// (groups past the last sample are fetched like any other -- clamped
+		// addresses, nobody reads them: the count of operations per group
+		// stays uniform and there is one copy of this code)
+		if( HOR )
+		{
+			const int x = gp_clamp( q * 4 + ( lane & 3 ), slast ) * sstep;
+#pragma unroll
+			for( int k = 0; k < 4; k++ )
+			{
+				gp_dma( rsrc, base + k * 1024, hrow[ k ] + x );
+			}
+		}
+		else
+		{
+#pragma unroll
+			for( int k = 0; k < 4; k++ )
+			{
+				gp_dma( rsrc, base + k * 1024, lc * slane +
+					gp_clamp( q * 4 + k, slast ) * sstep );
+			}
+		}
+	};
+
+	auto d_read = [&]( const int u ) -> f4 // SRC 0; samples in order
+	{
+		const int r = u - ub0;
+
+		if( u != u_a && ( r & 3 ) == 0 )
+		{
+			rth = ( rth == 2 ? 0 : rth + 1 );
+		}
+
+		const int th = rth;
+
+		if( HOR )
+		{
+			return( fifo[ th * 256 + ( lane >> 4 ) * 64 + ( lane & 15 ) * 4 +
+				( r & 3 )]);
+		}
+
+		return( fifo[ th * 256 + ( r & 3 ) * 64 + lane ]);
 	};
 
 	const unsigned char* const lrow = (const unsigned char*) P.src +
@@ -162,7 +335,7 @@ __global__ void __launch_bounds__( 64 ) k_sacc( const SAParams P )
 
 	auto g_store = [&]( const int q ) // typed: convert, write the FIFO slots
 	{
-		const int sl0 = ( q * G - ub0 ) & ( SA_Q - 1 );
+		const int sl0 = ( q * G - ub0 ) & 7;
 
 		if( g_interior( q ))
 		{
@@ -216,16 +389,40 @@ __global__ void __launch_bounds__( 64 ) k_sacc( const SAParams P )
 		}
 	};
 
-	const int q_a = ( ub0 >= 0 ? ub0 / G : -(( -ub0 ) / G )); // ub0 is aligned
+	auto x_read = [&]( const int u ) -> f4
+	{
+		if( SRC == 0 )
+		{
+			return( d_read( u ));
+		}
+
+		return( fifo[ (( u - ub0 ) & 7 ) * 64 + lane ]);
+	};
+
+	// ---- prologue: the first output's samples may be alive for outputs before
+	// ga too (their row entries come first): `first` of the chunk's first 64
+	// samples, one per lane
+	const int tq_a = ( u_a - A.u_min ) >> 2;
+	t_issue( tq_a );
+	t_issue( tq_a + 1 );
+	t_issue( tq_a + 2 );
+
+	if((( u_a - A.u_min ) & 3 ) != 0 )
+	{
+		t_issue( tq_a + 3 ); // (as if group tq_a had just been entered)
+	}
+
+	const int fv = A.first[ u_a - A.u_min + lane ]; // (table padded by 64 rows)
 
 	if( SRC == 0 )
 	{
-		for( int k = 0; k < SA_PF; k++ )
-		{
-			issue( u_a + k );
-		}
+		d_issue( q_a );
+		d_issue( q_a + 1 );
 
-		GP_WAIT_VM( 4 ); // == SA_PF - 1: the first sample has landed
+		if( u_a != ub0 )
+		{
+			d_issue( q_a + 2 );
+		}
 	}
 	else
 	{
@@ -238,106 +435,83 @@ __global__ void __launch_bounds__( 64 ) k_sacc( const SAParams P )
 		g_load( q_a + 2 );
 	}
 
-	f4 qnext = fifo[ (( u_a - ub0 ) & ( SA_Q - 1 )) * 64 + lane ];
+	// everything issued so far has to land before the first reads (the
+	// compiler's own wait for `fv` does not count the LDS-DMA operations)
+	GP_WAIT_VM( 0 );
 
-	// ---- the accumulators
-	f4 acc[ SA_NS ];
+	auto lo_of = [&]( const int u ) -> int
+	{
+		const int i = u - u_a;
+		return( i < 64 ? max( 0, ga - __builtin_amdgcn_readlane( fv, i )) : 0 );
+	};
+
+	PV xnext = PV::from( x_read( u_a ));
+	int lon = lo_of( u_a );
+	float cnext = t_read( u_a, lon );
+
+	// ---- the accumulators and (POST) the correction FIR's window
+	PV acc[ SA_NS ];
 #pragma unroll
 	for( int i = 0; i < SA_NS; i++ )
 	{
-		acc[ i ] = (f4) 0.0f;
+		acc[ i ] = PV::zero();
 	}
 
-	// ---- scalar pipeline: sample u's coefficient row and last alive output
-	// are loaded during sample u - 1, its first alive output during u - 2
-	auto meta_at = [&]( const int u, const int k ) -> int
-	{
-		return( a_meta[ ( u - A.u_min ) * 2 + k ]);
-	};
-
-	float cc[ 16 ];
-	int lastc, f1;
-	{
-		const int lo = max( 0, ga - meta_at( u_a, 0 ));
-		gp_cfloat* const tr = a_tab + ( u_a - A.u_min ) * 16 + lo;
+	PV w[ 8 ];
 #pragma unroll
-		for( int i = 0; i < 16; i++ )
-		{
-			cc[ i ] = tr[ i ];
-		}
-
-		lastc = meta_at( u_a, 1 );
-		f1 = meta_at( u_a + 1, 0 );
+	for( int i = 0; i < 8; i++ )
+	{
+		w[ i ] = PV::zero();
 	}
 
 	int g = ga;                    // the output being completed
 	int sg = u_a;                  // its first input
 	int sgn = a_start[ min( g + 1, gb )];
 	int u = u_a;                   // the next sample
-	int n = n0;                    // POST: the next final output
 
-	const f4 f0 = (f4) A.f[ 0 ], f1c = (f4) A.f[ 1 ], f2c = (f4) A.f[ 2 ],
-		f3c = (f4) A.f[ 3 ];
+	const float f0 = A.f[ 0 ], f1c = A.f[ 1 ], f2c = A.f[ 2 ], f3c = A.f[ 3 ];
 
 	float* dp = P.dst + (long) li * P.d_lane + (long) n0 * P.d_step;
 
-	auto store_out = [&]( const f4 o )
+	auto store_out = [&]( const PV& o )
 	{
 		if( lok )
 		{
-			*(f4*) dp = o;
+			*(f4*) dp = o.to4();
 		}
 
 		dp += P.d_step;
 	};
 
-	auto mread = [&]( const int m ) -> f4
-	{
-		return( mring[ ( m & 7 ) * 64 + lane ]);
-	};
-
-	auto emit = [&]( const f4 o )
-	{
-		if( POST )
-		{
-			mring[ ( g & 7 ) * 64 + lane ] = o;
-
-			// final outputs whose FIR window [c - 3, c + 3] (clamped) is
-			// complete: c + 3 <= g, or g is the last accumulated output
-			while( n < n1 && gp_clamp( n - A.e + 3, glast ) <= g )
-			{
-				const int c = n - A.e;
-				f4 r = f0 * mread( gp_clamp( c, glast ));
-				r = r + f1c * ( mread( gp_clamp( c + 1, glast )) +
-					mread( gp_clamp( c - 1, glast )));
-				r = r + f2c * ( mread( gp_clamp( c + 2, glast )) +
-					mread( gp_clamp( c - 2, glast )));
-				r = r + f3c * ( mread( gp_clamp( c + 3, glast )) +
-					mread( gp_clamp( c - 3, glast )));
-				store_out( r );
-				n++;
-			}
-		}
-		else
-		{
-			store_out( o );
-		}
-	};
-
 	// One output: the samples up to its last input, then the accumulator
-	// leaves. SC: its slot (compile-time). Returns true after the last one.
-	auto body = [&]( auto SC ) -> bool
+	// leaves. SC: its slot (compile-time); FC: the chunk's first output (its
+	// samples' table rows may start before ga). Returns true after the last.
+	auto body = [&]( auto SC, auto FC ) -> bool
 	{
 		constexpr int S = decltype( SC )::value;
-		const int end = sg + nt - 1;
+		constexpr bool FIRST = decltype( FC )::value;
+		const int end = ( g <= gb ? sg + nt - 1 : u - 1 );
 
+#pragma clang loop unroll( disable )
 		while( u <= end )
 		{
-			// -- the feed: sample u + 1 becomes readable
+			// -- the feeds
+			if((( u - A.u_min ) & 3 ) == 0 )
+			{
+				t_issue((( u - A.u_min ) >> 2 ) + 3 );
+			}
+
 			if( SRC == 0 )
 			{
-				issue( u + SA_PF );
-				GP_WAIT_VM( 4 ); // == SA_PF - 1
+				if((( u - ub0 ) & 3 ) == 0 )
+				{
+					// entering a group: the one after the next goes out; the
+					// next one (read from the last sample of this one on) was
+					// issued a group ago -- only the four (five, with a table
+					// group) youngest operations may still be in flight
+					d_issue( q_a + (( u - ub0 ) >> 2 ) + 2 );
+					GP_WAIT_VM( 4 );
+				}
 			}
 			else
 			if((( u - ub0 ) & ( G - 1 )) == 0 && u != u_a )
@@ -347,24 +521,18 @@ __global__ void __launch_bounds__( 64 ) k_sacc( const SAParams P )
 				g_load( q + 2 );
 			}
 
-			const f4 x = qnext;
-			qnext = fifo[ (( u + 1 - ub0 ) & ( SA_Q - 1 )) * 64 + lane ];
+			const PV x = xnext;
+			const float cv = cnext;
+			const int lo = lon;
+			xnext = PV::from( x_read( u + 1 ));
+			lon = ( FIRST ? lo_of( u + 1 ) : 0 );
+			cnext = t_read( u + 1, lon );
 
-			// -- the scalar pipeline: sample u + 1's row
-			float cn[ 16 ];
-			const int lo1 = max( 0, ga - f1 );
-			gp_cfloat* const tr = a_tab + ( u + 1 - A.u_min ) * 16 + lo1;
-#pragma unroll
-			for( int i = 0; i < 16; i++ )
-			{
-				cn[ i ] = tr[ i ];
-			}
+			// -- sample u into the outputs alive: g .. g + nl - 1
+			const int cnt = __builtin_amdgcn_readlane( __float_as_int( cv ),
+				15 - lo );
 
-			const int lastn = meta_at( u + 1, 1 );
-			const int f2 = meta_at( u + 2, 0 );
-
-			// -- sample u into the outputs alive: g .. min( last, gb )
-			const int nl = min( lastc, gb ) - g + 1;
+			const int nl = min( cnt - lo, gb - g + 1 );
 
 			// One wave-uniform branch per alive output, nested: the first
 			// output that is not alive leaves the chain. (A switch with
@@ -373,58 +541,91 @@ __global__ void __launch_bounds__( 64 ) k_sacc( const SAParams P )
 			// into all 16 products and four selects each -- the empty asm
 			// statement keeps every block a real branch.)
 #define SA_T( i, inner ) if( i < nl ) { asm volatile( "" ::: "memory" ); \
-	acc[ ( S + i ) & ( SA_NS - 1 )] = acc[ ( S + i ) & ( SA_NS - 1 )] + \
-	cc[ i ] * x; inner }
+	acc[ ( S + i ) & ( SA_NS - 1 )] = acc[ ( S + i ) & ( SA_NS - 1 )].madd( \
+	__int_as_float( __builtin_amdgcn_readlane( __float_as_int( cv ), i )), x ); \
+	inner }
 
 			SA_T( 0, SA_T( 1, SA_T( 2, SA_T( 3, SA_T( 4, SA_T( 5, SA_T( 6,
 			SA_T( 7, SA_T( 8, SA_T( 9, SA_T( 10, SA_T( 11, SA_T( 12,
-			SA_T( 13, SA_T( 14, SA_T( 15, ; ))))))))))))))))
+			SA_T( 13, SA_T( 14, ; )))))))))))))))
 
 #undef SA_T
 
-#pragma unroll
-			for( int i = 0; i < 16; i++ )
-			{
-				cc[ i ] = cn[ i ];
-			}
-
-			lastc = lastn;
-			f1 = f2;
 			u++;
 		}
 
-		emit( acc[ S ]);
-		acc[ S ] = (f4) 0.0f;
+		if( POST )
+		{
+			// the window of the last eight accumulated outputs; past the last
+			// one the edge value repeats, before the first one it does too
+			// (not a ?: on the two array elements: that selects an ADDRESS and
+			// keeps both arrays in scratch memory)
+			PV val = acc[ S ];
+
+			if( g > gb )
+			{
+				val = w[ ( S + 7 ) & 7 ];
+			}
+			w[ S & 7 ] = val;
+
+			if( FIRST && n0 - A.e - 3 < 0 )
+			{
+#pragma unroll
+				for( int i = 0; i < 8; i++ )
+				{
+					w[ i ] = val;
+				}
+			}
+
+			// output n = g + e - 3: f0*G[c] + sum f_i*( G[c+i] + G[c-i] ), c = g - 3
+			if( g >= n0 - A.e + 3 )
+			{
+				PV r = w[ ( S + 5 ) & 7 ].scale( f0 );
+				r = r.madd( f1c, w[ ( S + 6 ) & 7 ].madd1( w[ ( S + 4 ) & 7 ]));
+				r = r.madd( f2c, w[ ( S + 7 ) & 7 ].madd1( w[ ( S + 3 ) & 7 ]));
+				r = r.madd( f3c, w[ S & 7 ].madd1( w[ ( S + 2 ) & 7 ]));
+				store_out( r );
+			}
+		}
+		else
+		{
+			store_out( acc[ S ]);
+		}
+
+		acc[ S ] = PV::zero();
 		g++;
 		sg = sgn;
 		sgn = a_start[ min( g + 1, gb )];
-		return( g > gb );
+		return( g > gbv );
 	};
 
-	for( ; ; )
+	typedef std::integral_constant< bool, true > TC;
+	typedef std::integral_constant< bool, false > FC;
+
+	if( !body( std::integral_constant< int, 0 >(), TC() ))
 	{
-		if( body( std::integral_constant< int, 0 >() )) break;
-		if( body( std::integral_constant< int, 1 >() )) break;
-		if( body( std::integral_constant< int, 2 >() )) break;
-		if( body( std::integral_constant< int, 3 >() )) break;
-		if( body( std::integral_constant< int, 4 >() )) break;
-		if( body( std::integral_constant< int, 5 >() )) break;
-		if( body( std::integral_constant< int, 6 >() )) break;
-		if( body( std::integral_constant< int, 7 >() )) break;
-		if( body( std::integral_constant< int, 8 >() )) break;
-		if( body( std::integral_constant< int, 9 >() )) break;
-		if( body( std::integral_constant< int, 10 >() )) break;
-		if( body( std::integral_constant< int, 11 >() )) break;
-		if( body( std::integral_constant< int, 12 >() )) break;
-		if( body( std::integral_constant< int, 13 >() )) break;
-		if( body( std::integral_constant< int, 14 >() )) break;
-		if( body( std::integral_constant< int, 15 >() )) break;
+		for( ; ; )
+		{
+			if( body( std::integral_constant< int, 1 >(), FC() )) break;
+			if( body( std::integral_constant< int, 2 >(), FC() )) break;
+			if( body( std::integral_constant< int, 3 >(), FC() )) break;
+			if( body( std::integral_constant< int, 4 >(), FC() )) break;
+			if( body( std::integral_constant< int, 5 >(), FC() )) break;
+			if( body( std::integral_constant< int, 6 >(), FC() )) break;
+			if( body( std::integral_constant< int, 7 >(), FC() )) break;
+			if( body( std::integral_constant< int, 8 >(), FC() )) break;
+			if( body( std::integral_constant< int, 9 >(), FC() )) break;
+			if( body( std::integral_constant< int, 10 >(), FC() )) break;
+			if( body( std::integral_constant< int, 11 >(), FC() )) break;
+			if( body( std::integral_constant< int, 12 >(), FC() )) break;
+			if( body( std::integral_constant< int, 13 >(), FC() )) break;
+			if( body( std::integral_constant< int, 14 >(), FC() )) break;
+			if( body( std::integral_constant< int, 15 >(), FC() )) break;
+			if( body( std::integral_constant< int, 0 >(), FC() )) break;
+		}
 	}
 
-	if( SRC == 0 )
-	{
-		GP_WAIT_VM( 0 ); // no LDS-DMA may outlive the workgroup's LDS
-	}
+	GP_WAIT_VM( 0 ); // no LDS-DMA may outlive the workgroup's LDS
 }
 
 // ---------------------------------------------------------------------
@@ -457,7 +658,7 @@ int sacc_prepare_axis( const GPAxisHost& H, std::vector< void* >& allocs,
 	*out = nullptr;
 	const GPAxis& A = H.a;
 
-	if( !H.ok || A.mode == GP_PRE || A.lanc || A.view_mmax != 0x7fffffff ||
+	if( !H.ok || A.mode != GP_POST || A.lanc || A.view_mmax != 0x7fffffff ||
 		A.g_len < 1 || getenv( "AVIRHIP_NO_SACC" ) != nullptr )
 	{
 		return( AVIRHIP_OK );
@@ -468,8 +669,8 @@ int sacc_prepare_axis( const GPAxisHost& H, std::vector< void* >& allocs,
 	const int u_min = st[ 0 ];
 	const int u_max = st[ A.g_len - 1 ] + nt - 1;
 	const int rows = u_max - u_min + 1;
-	const int pad = 4;
-	std::vector< int > meta( (size_t) ( rows + pad ) * 2, 0 );
+	const int pad = 96; // table groups are fetched ahead, `first` 64 at a time
+	std::vector< int > meta( (size_t) ( rows + pad ), 0 );
 	std::vector< float > tab( (size_t) ( rows + pad ) * 16, 0.0f );
 	int first = 0, last = 0;
 
@@ -487,13 +688,14 @@ int sacc_prepare_axis( const GPAxisHost& H, std::vector< void* >& allocs,
 			last++;
 		}
 
-		if( last - first + 1 > SA_NS || last < first )
+		if( last - first + 1 > SA_NS - 1 || last < first )
 		{
 			return( AVIRHIP_OK );
 		}
 
-		meta[ (size_t) r * 2 ] = first;
-		meta[ (size_t) r * 2 + 1 ] = last;
+		meta[ (size_t) r ] = first;
+		const int cnt = last - first + 1;
+		memcpy( &tab[ (size_t) r * 16 + 15 ], &cnt, sizeof( cnt ));
 
 		for( int g = first; g <= last; g++ )
 		{
@@ -506,8 +708,7 @@ int sacc_prepare_axis( const GPAxisHost& H, std::vector< void* >& allocs,
 
 	for( int r = rows; r < rows + pad; r++ )
 	{
-		meta[ (size_t) r * 2 ] = A.g_len - 1;
-		meta[ (size_t) r * 2 + 1 ] = A.g_len - 1;
+		meta[ (size_t) r ] = A.g_len - 1;
 	}
 
 	SAData* D = new SAData();
@@ -521,7 +722,7 @@ int sacc_prepare_axis( const GPAxisHost& H, std::vector< void* >& allocs,
 
 	void* q = nullptr;
 	int rc = sa_upload( allocs, meta.data(), meta.size() * sizeof( int ), &q );
-	D -> a.meta = (const int*) q;
+	D -> a.first = (const int*) q;
 
 	if( rc == 0 )
 	{
@@ -544,42 +745,38 @@ void sacc_release_axis( SAData* D )
 	delete D;
 }
 
-template< int SRC, int CH >
-static void sa_launch2( const SAParams& P, bool post, int items, size_t lds,
+template< int SRC, int CH, bool HOR, int NC >
+static void sa_launch2( const SAParams& P, int items, size_t lds,
 	hipStream_t st )
 {
-	if( post )
-	{
-		hipLaunchKernelGGL(( k_sacc< SRC, CH, true > ), dim3( items ),
-			dim3( 64 ), lds, st, P );
-	}
-	else
-	{
-		hipLaunchKernelGGL(( k_sacc< SRC, CH, false > ), dim3( items ),
-			dim3( 64 ), lds, st, P );
-	}
+	hipLaunchKernelGGL(( k_sacc< SRC, CH, true, HOR, NC > ), dim3( items ),
+		dim3( 64 ), lds, st, P );
 }
 
+// typed sources: the channels of the image are the live ones
 template< int SRC >
-static void sa_launch1( const SAParams& P, int ch, bool post, int items,
-	size_t lds, hipStream_t st )
+static void sa_launch1( const SAParams& P, int ch, int items, size_t lds,
+	hipStream_t st )
 {
 	switch( ch )
 	{
-		case 1: sa_launch2< SRC, 1 >( P, post, items, lds, st ); break;
-		case 2: sa_launch2< SRC, 2 >( P, post, items, lds, st ); break;
-		case 3: sa_launch2< SRC, 3 >( P, post, items, lds, st ); break;
-		default: sa_launch2< SRC, 4 >( P, post, items, lds, st ); break;
+		case 1: sa_launch2< SRC, 1, false, 1 >( P, items, lds, st ); break;
+		case 2: sa_launch2< SRC, 2, false, 2 >( P, items, lds, st ); break;
+		case 3: sa_launch2< SRC, 3, false, 3 >( P, items, lds, st ); break;
+		default: sa_launch2< SRC, 4, false, 4 >( P, items, lds, st ); break;
 	}
 }
 
 // One pass. src_type / src_ch: AVIRHIP_F32 with 4 channels goes by LDS-DMA
 // (16-byte aligned base and strides required: returns 1 otherwise); U8, U16
 // and narrower floats are read as they are. Strides in bytes (source) and
-// floats (destination); `mode` is the axis' GP_POST / GP_NONE.
-int sacc_run_axis( const SAData* D, int mode, const void* src, int src_type,
-	int src_ch, long s_lane, long s_step, float* dst, long d_lane, long d_step,
-	int lane_lo, int lane_hi, int out_lo, int out_hi, hipStream_t st )
+// floats (destination); `rows`: the lanes are image rows (horizontal pass) --
+// integer sources only come so; `live_ch`: channels of the float RGBA source
+// that carry data (the others are zero padding and come out as zeros).
+int sacc_run_axis( const SAData* D, bool rows, const void* src, int src_type,
+	int src_ch, int live_ch, long s_lane, long s_step, float* dst, long d_lane,
+	long d_step, int lane_lo, int lane_hi, int out_lo, int out_hi,
+	hipStream_t st )
 {
 	if( lane_hi <= lane_lo || out_hi <= out_lo )
 	{
@@ -613,14 +810,13 @@ int sacc_run_axis( const SAData* D, int mode, const void* src, int src_type,
 	// samples before its first output completes (they are multiplied into
 	// this chunk's outputs only: no arithmetic is repeated). The kernel is
 	// ALU-bound: whole rounds of the 1024 SIMDs, two or more waves on each.
-	const size_t lds = (size_t) ( SA_Q + 1 ) * 1024 +
-		( mode == GP_POST ? 8 * 1024 : 0 );
+	const size_t lds = (size_t) ( dma ? 3 * 4096 : 8 * 1024 ) + SA_TQ * 256 + 64;
 
 	const double cap = 256.0 * std::max( 1, std::min( 16,
 		(int) ( 160 * 1024 / ( lds + 512 ))));
 
 	const double warm = std::max( 1.0, P.ax.nt / std::max( 1.0, D -> k ) *
-		0.35 ) + ( mode == GP_POST ? 2.0 : 0.0 );
+		0.35 ) + 2.0;
 
 	double best = -1.0;
 	int best_chunk = nout;
@@ -657,26 +853,38 @@ int sacc_run_axis( const SAData* D, int mode, const void* src, int src_type,
 	}
 
 	const int items = P.nstrips * (( nout + P.chunk - 1 ) / P.chunk );
-	const bool post = ( mode == GP_POST );
+	if( !dma && !rows )
+	{
+		return( 1 );
+	}
 
 	if( dma )
 	{
-		sa_launch2< 0, 4 >( P, post, items, lds, st );
+		if( rows )
+		{
+			if( live_ch == 3 ) sa_launch2< 0, 4, true, 3 >( P, items, lds, st );
+			else sa_launch2< 0, 4, true, 4 >( P, items, lds, st );
+		}
+		else
+		{
+			if( live_ch == 3 ) sa_launch2< 0, 4, false, 3 >( P, items, lds, st );
+			else sa_launch2< 0, 4, false, 4 >( P, items, lds, st );
+		}
 	}
 	else
 	if( src_type == AVIRHIP_U8 )
 	{
-		sa_launch1< 1 >( P, src_ch, post, items, lds, st );
+		sa_launch1< 1 >( P, src_ch, items, lds, st );
 	}
 	else
 	if( src_type == AVIRHIP_U16 )
 	{
-		sa_launch1< 2 >( P, src_ch, post, items, lds, st );
+		sa_launch1< 2 >( P, src_ch, items, lds, st );
 	}
 	else
 	if( src_type == AVIRHIP_F32 )
 	{
-		sa_launch1< 3 >( P, src_ch, post, items, lds, st );
+		sa_launch1< 3 >( P, src_ch, items, lds, st );
 	}
 	else
 	{
