@@ -567,6 +567,55 @@ static int exec_device( avirhip_plan* p, const void* src, void* dst,
 	// intermediate is only allocated when they actually run
 	if( !p -> is_lancir && ( rc = ensure_scratch( p )) != 0 ) return( rc );
 
+	if( p -> is_lancir && p -> inner != nullptr && p -> path != 1 )
+	{
+		avirhip_plan* const q = p -> inner;
+		const LancirAxisDev& V = p -> lv;
+		void* m;
+
+		if( p -> packed == nullptr )
+		{
+			if(( rc = dev_alloc( p, (size_t) p -> src_w * p -> src_h * 4 *
+				sizeof( float ), &m )) != 0 ) return( rc );
+			p -> packed = (float*) m;
+		}
+
+		if( p -> lres == nullptr )
+		{
+			if(( rc = dev_alloc( p, (size_t) p -> new_w * p -> new_h * 4 *
+				sizeof( float ), &m )) != 0 ) return( rc );
+			p -> lres = (float*) m;
+		}
+
+		if( row1 <= row0 )
+		{
+			return( AVIRHIP_OK );
+		}
+
+		// the source rows this band's vertical windows read
+		const int sa = std::max( 0, std::min( V.h_start[ row0 ],
+			p -> src_h - 1 ));
+		const int sb = std::max( 0, std::min( V.h_start[ row1 - 1 ] +
+			V.kernel_len - 1, p -> src_h - 1 ));
+		const size_t es = ( p -> in_type == AVIRHIP_U8 ? 1 :
+			( p -> in_type == AVIRHIP_U16 ? 2 : 4 ));
+
+		if(( rc = launch_pack( (const char*) src + (size_t) sa *
+			p -> src_stride * es, p -> in_type, p -> packed + (size_t) sa *
+			p -> src_w * 4, p -> src_w, sb - sa + 1, 4, 4, p -> src_stride,
+			st )) != 0 ) return( rc );
+
+		q -> path = p -> path;
+
+		if(( rc = exec_device( q, p -> packed, p -> lres, row0, row1, st )) != 0 )
+		{
+			return( rc );
+		}
+
+		return( launch_lancir_out( p, p -> lres, (long) p -> new_w * 4, dst,
+			row1 - row0, st ));
+	}
+
 	if( p -> is_lancir )
 	{
 		const int lpath = ( p -> path != 0 ? p -> path : p -> auto_path );
@@ -1024,6 +1073,7 @@ static avirhip_plan* new_plan()
 	p -> is_spare = 0;
 	p -> ch = 0; p -> io_ch = 0;
 	p -> l_out_mul = 1.0f; p -> l_clamp = 0.0f; p -> l_unity = 1;
+	p -> inner = nullptr;
 	(void) hipGetDevice( &p -> device );
 	return( p );
 }
@@ -1227,6 +1277,39 @@ static int finalize_lancir_plan( avirhip_plan* p )
 			p -> auto_path = 5;
 		}
 	}
+
+	// RGBA with integer elements or an output gain: the fast kernels compute
+	// in float RGBA with unity gain -- run them in an inner plan of that
+	// kind, between the pack pass and the output stage (both of which are
+	// what the reference does around its float core, lancir.h:541-710)
+	if( rc == 0 && p -> auto_path == 1 && p -> io_ch == 4 &&
+		!( p -> in_type == AVIRHIP_F32 && p -> out_type == AVIRHIP_F32 &&
+		p -> l_unity ) && getenv( "AVIRHIP_NO_INNER" ) == nullptr )
+	{
+		avirhip_plan* q = new_plan();
+		q -> device = p -> device;
+		q -> is_lancir = 1;
+		q -> src_w = p -> src_w; q -> src_h = p -> src_h;
+		q -> src_stride = p -> src_w * 4;
+		q -> new_w = p -> new_w; q -> new_h = p -> new_h;
+		q -> new_stride = p -> new_w * 4;
+		q -> ch = 4; q -> io_ch = 4;
+		q -> in_type = AVIRHIP_F32; q -> out_type = AVIRHIP_F32;
+		q -> lv = p -> lv; q -> lh = p -> lh; // (device pointers re-uploaded)
+		rc = finalize_lancir_plan( q );
+
+		if( rc == 0 && q -> auto_path != 1 )
+		{
+			p -> inner = q;
+			p -> auto_path = q -> auto_path;
+			p -> fused_ok |= ( q -> fused_ok & ( 4 | 8 ));
+		}
+		else
+		{
+			avirhip_plan_destroy( q );
+		}
+	}
+
 	return( rc );
 }
 
@@ -1620,6 +1703,8 @@ void avirhip_plan_destroy( avirhip_plan* p )
 		(void) hipEventDestroy( p -> last_done );
 	}
 
+	avirhip_plan_destroy( p -> inner );
+	p -> inner = nullptr;
 	fused_release( p );
 	up2_release( p );
 	lanc2_release( p );

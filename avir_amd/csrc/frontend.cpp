@@ -77,7 +77,9 @@ struct PlanCache
 
 			for( auto it = m.begin(); it != m.end(); ++it )
 			{
-				bytes += it -> second.p -> alloc_bytes;
+				bytes += it -> second.p -> alloc_bytes +
+					( it -> second.p -> inner != nullptr ?
+					it -> second.p -> inner -> alloc_bytes : 0 );
 
 				if( &it -> second != keep && it -> second.busy == 0 &&
 					!it -> second.pinned && ( victim == m.end() ||

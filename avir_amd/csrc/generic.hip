@@ -1194,22 +1194,108 @@ int launch_lancir_generic( const avirhip_plan* p, const void* src, void* dst,
 
 	if( !direct )
 	{
-		const int l = p -> new_w * p -> ch;
-		const dim3 go(( l + 255 ) / 256, nrows );
+		return( launch_lancir_out( p, res, rstride, dst, nrows, st ));
+	}
+
+	return( AVIRHIP_OK );
+}
+
+// RGBA rows: a scanline is whole groups of four elements (no tail), one thread
+// converts a pixel -- a 16-byte load, the clamps, four nearest-even roundings
+// and one 4- or 8-byte store.
+template< typename Tout >
+__global__ void __launch_bounds__( 256 ) k_lancir_out_px4( const float* res,
+	Tout* dst, int w, long res_stride, long dst_stride, int nrows, int unity,
+	float out_mul, float clampv )
+{
+	const int x = blockIdx.x * blockDim.x + threadIdx.x;
+	const int ry = blockIdx.y;
+
+	if( x >= w || ry >= nrows )
+	{
+		return;
+	}
+
+	typedef float f4v __attribute__(( ext_vector_type( 4 )));
+	const f4v v4 = *(const f4v*) ( res + (long) ry * res_stride + (long) x * 4 );
+	float v[ 4 ] = { v4.x, v4.y, v4.z, v4.w };
+	unsigned int q[ 4 ];
+#pragma unroll
+	for( int c = 0; c < 4; c++ )
+	{
+		float t = v[ c ];
+
+		if( !unity )
+		{
+			t = t * out_mul;
+		}
+
+		t = ( t < clampv ? t : clampv );
+		t = ( t > 0.0f ? t : 0.0f );
+		q[ c ] = (unsigned int) (int) rintf( t );
+	}
+
+	Tout* const op = dst + (long) ry * dst_stride + (long) x * 4;
+
+	if( sizeof( Tout ) == 1 )
+	{
+		*(unsigned int*) op = q[ 0 ] | ( q[ 1 ] << 8 ) | ( q[ 2 ] << 16 ) |
+			( q[ 3 ] << 24 );
+	}
+	else
+	{
+		typedef unsigned int u2v __attribute__(( ext_vector_type( 2 )));
+		u2v o; o.x = q[ 0 ] | ( q[ 1 ] << 16 ); o.y = q[ 2 ] | ( q[ 3 ] << 16 );
+		*(u2v*) op = o;
+	}
+}
+
+// The output stage alone: `nrows` result rows of new_w * ch floats (row pitch
+// rstride) into the caller's rows.
+int launch_lancir_out( const avirhip_plan* p, const float* res, long rstride,
+	void* dst, int nrows, hipStream_t st )
+{
+	const size_t oes = ( p -> out_type == AVIRHIP_U8 ? 1 : 2 );
+
+	if( p -> ch == 4 && p -> out_type != AVIRHIP_F32 && ( rstride & 3 ) == 0 &&
+		( (uintptr_t) res & 15 ) == 0 && ( (uintptr_t) dst & ( 4 * oes - 1 )) == 0 &&
+		( p -> new_stride & 3 ) == 0 )
+	{
+		const dim3 gp(( p -> new_w + 255 ) / 256, nrows );
+
+		if( p -> out_type == AVIRHIP_U8 )
+		{
+			hipLaunchKernelGGL( k_lancir_out_px4< uint8_t >, gp, dim3( 256 ), 0,
+				st, res, (uint8_t*) dst, p -> new_w, rstride,
+				(long) p -> new_stride, nrows, p -> l_unity, p -> l_out_mul,
+				p -> l_clamp );
+		}
+		else
+		{
+			hipLaunchKernelGGL( k_lancir_out_px4< uint16_t >, gp, dim3( 256 ), 0,
+				st, res, (uint16_t*) dst, p -> new_w, rstride,
+				(long) p -> new_stride, nrows, p -> l_unity, p -> l_out_mul,
+				p -> l_clamp );
+		}
+
+		AVIRHIP_HIPCHECK( hipGetLastError() );
+		return( AVIRHIP_OK );
+	}
+
+	const int l = p -> new_w * p -> ch;
+	const dim3 go(( l + 255 ) / 256, nrows );
 
 #define LO( T, isf ) hipLaunchKernelGGL( k_lancir_out< T >, go, dim3( 256 ), 0, \
-			st, res, (T*) dst, l, rstride, (long) p -> new_stride, nrows, \
-			p -> l_unity, p -> l_out_mul, p -> l_clamp, isf )
+		st, res, (T*) dst, l, rstride, (long) p -> new_stride, nrows, \
+		p -> l_unity, p -> l_out_mul, p -> l_clamp, isf )
 
-		if( p -> out_type == AVIRHIP_U8 ) { LO( uint8_t, 0 ); }
-		else if( p -> out_type == AVIRHIP_U16 ) { LO( uint16_t, 0 ); }
-		else { LO( float, 1 ); }
+	if( p -> out_type == AVIRHIP_U8 ) { LO( uint8_t, 0 ); }
+	else if( p -> out_type == AVIRHIP_U16 ) { LO( uint16_t, 0 ); }
+	else { LO( float, 1 ); }
 
 #undef LO
 
-		AVIRHIP_HIPCHECK( hipGetLastError() );
-	}
-
+	AVIRHIP_HIPCHECK( hipGetLastError() );
 	return( AVIRHIP_OK );
 }
 

@@ -108,6 +108,10 @@ struct avirhip_plan
 	avirhip::LancirAxisDev lv, lh;
 	float l_out_mul, l_clamp;
 	int l_unity;
+	// LANCIR with integer / scaled RGBA I/O: a float RGBA, unity-gain plan of
+	// the same geometry whose fast kernels run between a pack pass and the
+	// output stage (nullptr: this plan runs its own kernels)
+	avirhip_plan* inner;
 
 	int path;       // forced path (0 = auto)
 	int fused_ok;   // tiled kernels: bit 0 = two-pass (path 2), bit 1 = fused (3)
@@ -173,6 +177,8 @@ int launch_epilogue( const float* res, void* dst, int out_type, long n,
 int launch_errd( const float* res, void* dst, int out_type, int w, int h,
 	int ch, int ech, double tr_mul, double pk_out, int gamma, int alpha_index,
 	float* line, hipStream_t st );
+int launch_lancir_out( const avirhip_plan* p, const float* res, long rstride,
+	void* dst, int nrows, hipStream_t st );
 int launch_lancir_generic( const avirhip_plan* p, const void* src, void* dst,
 	float* tmp, int row0, int row1, hipStream_t st );
 

@@ -795,6 +795,34 @@ def test_lancir_exact_2x_kernel(sw, sh):
     _assert_same(l.resize(src, 2 * sw, 2 * sh), want, "lancir generic")
 
 
+def test_lancir_integer_rgba_runs_the_fast_kernels_in_row_bands():
+    """uint8 / uint16 RGBA (and float with an output gain): the float kernels
+    run in an inner plan between the pack pass and the output stage; whole
+    frames and row bands equal the generic kernels' result."""
+    lib = abi.load()
+    checker = rb.ref_lancir if rb.have_ref() else rb.orc_lancir
+    for (sw, sh, nw, nh, tin, tout) in [
+            (96, 70, 192, 140, np.uint8, np.uint8),     # exact 2x kernel
+            (200, 150, 77, 58, np.uint8, np.uint8),     # pass kernels
+            (120, 90, 150, 131, np.uint16, np.uint8),
+            (64, 48, 100, 77, np.uint8, np.float32)]:
+        s = rb.lcg_u8((sh, sw, 4, np.dtype(tin).itemsize), seed=11)
+        s = s.view(tin).reshape(sh, sw, 4)
+        want = checker(s, nw, nh, out_dtype=tout)
+        l = avir_amd.CLancIR()
+        p = l.plan(sw, sh, nw, nh, 4, None, avir_amd._NP2T[np.dtype(tin)],
+                   avir_amd._NP2T[np.dtype(tout)])
+        assert lib.avirhip_plan_get_path(p) in (abi.PATH_UP2, abi.PATH_GPASS)
+        got = l.resize(s, nw, nh, out_dtype=tout)
+        _assert_same(got, want, "lancir inner %r" % ((sw, sh, nw, nh),))
+        out = np.zeros((nh, nw, 4), tout)
+        for a_, b_ in [(0, nh // 3), (nh // 3, nh // 3 + 5), (nh // 3 + 5, nh)]:
+            abi.check(lib.avirhip_resize_band(
+                p, s.ctypes.data, abi.MEM_HOST, out[a_:b_].ctypes.data,
+                abi.MEM_HOST, a_, b_, None), "band")
+        _assert_same(out, want, "lancir inner bands")
+
+
 def test_lancir_params_steps_offsets_la():
     checker = rb.ref_lancir if rb.have_ref() else rb.orc_lancir
     s = rb.lcg_f32((60, 80, 4), seed=9)

@@ -9,6 +9,8 @@ from avir_amd import abi, synth
 dev = torch.device("cuda", 0)
 lib = abi.load()
 for (sw, sh, nw, nh, ch, dt) in [(5184, 3456, 1920, 1280, 3, torch.uint8),
+                                 (5184, 3456, 1920, 1280, 4, torch.uint8),
+                                 (1920, 1080, 3840, 2160, 4, torch.uint8),
                                  (3840, 2160, 7680, 4320, 4, torch.float32),
                                  (1920, 1080, 3840, 2160, 3, torch.uint8),
                                  (3840, 2160, 1280, 720, 4, torch.float32),
