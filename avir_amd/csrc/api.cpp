@@ -602,8 +602,8 @@ static int exec_device( avirhip_plan* p, const void* src, void* dst,
 
 		if(( rc = launch_pack( (const char*) src + (size_t) sa *
 			p -> src_stride * es, p -> in_type, p -> packed + (size_t) sa *
-			p -> src_w * 4, p -> src_w, sb - sa + 1, 4, 4, p -> src_stride,
-			st )) != 0 ) return( rc );
+			p -> src_w * 4, p -> src_w, sb - sa + 1, p -> io_ch, 4,
+			p -> src_stride, st )) != 0 ) return( rc );
 
 		q -> path = p -> path;
 
@@ -612,8 +612,13 @@ static int exec_device( avirhip_plan* p, const void* src, void* dst,
 			return( rc );
 		}
 
-		return( launch_lancir_out( p, p -> lres, (long) p -> new_w * 4, dst,
-			row1 - row0, st ));
+		if( p -> io_ch == 4 )
+		{
+			return( launch_lancir_out( p, p -> lres, (long) p -> new_w * 4, dst,
+				row1 - row0, st ));
+		}
+
+		return( launch_lancir_out_pad( p, p -> lres, dst, row1 - row0, st ));
 	}
 
 	if( p -> is_lancir )
@@ -1073,7 +1078,7 @@ static avirhip_plan* new_plan()
 	p -> is_spare = 0;
 	p -> ch = 0; p -> io_ch = 0;
 	p -> l_out_mul = 1.0f; p -> l_clamp = 0.0f; p -> l_unity = 1;
-	p -> inner = nullptr;
+	p -> inner = nullptr; p -> l_order = 4;
 	(void) hipGetDevice( &p -> device );
 	return( p );
 }
@@ -1282,9 +1287,10 @@ static int finalize_lancir_plan( avirhip_plan* p )
 	// in float RGBA with unity gain -- run them in an inner plan of that
 	// kind, between the pack pass and the output stage (both of which are
 	// what the reference does around its float core, lancir.h:541-710)
-	if( rc == 0 && p -> auto_path == 1 && p -> io_ch == 4 &&
-		!( p -> in_type == AVIRHIP_F32 && p -> out_type == AVIRHIP_F32 &&
-		p -> l_unity ) && getenv( "AVIRHIP_NO_INNER" ) == nullptr )
+	if( rc == 0 && p -> auto_path == 1 && p -> inner == nullptr &&
+		!( p -> io_ch == 4 && p -> in_type == AVIRHIP_F32 &&
+		p -> out_type == AVIRHIP_F32 && p -> l_unity ) &&
+		getenv( "AVIRHIP_NO_INNER" ) == nullptr )
 	{
 		avirhip_plan* q = new_plan();
 		q -> device = p -> device;
@@ -1296,6 +1302,8 @@ static int finalize_lancir_plan( avirhip_plan* p )
 		q -> ch = 4; q -> io_ch = 4;
 		q -> in_type = AVIRHIP_F32; q -> out_type = AVIRHIP_F32;
 		q -> lv = p -> lv; q -> lh = p -> lh; // (device pointers re-uploaded)
+		// 1-3 channels run zero-padded to RGBA, in THEIR summation order
+		q -> l_order = p -> io_ch;
 		rc = finalize_lancir_plan( q );
 
 		if( rc == 0 && q -> auto_path != 1 )
@@ -1331,6 +1339,7 @@ static int clone_plan( const avirhip_plan* s, int device, avirhip_plan** out )
 	q -> dither = s -> dither;
 	q -> l_out_mul = s -> l_out_mul; q -> l_clamp = s -> l_clamp;
 	q -> l_unity = s -> l_unity;
+	q -> l_order = s -> l_order;
 	q -> h = s -> h; q -> v = s -> v;     // host vectors; device pointers are
 	q -> lv = s -> lv; q -> lh = s -> lh; // replaced by the uploads below
 	q -> path = s -> path;

@@ -1250,6 +1250,91 @@ __global__ void __launch_bounds__( 256 ) k_lancir_out_px4( const float* res,
 	}
 }
 
+// 1-3 channel images computed zero-padded to RGBA: the result rows hold four
+// floats per pixel, the scanline new_w * CH elements -- element i = x * CH + c
+// rounds by ITS position (full groups of four nearest-even, the tail + 0.5).
+template< typename Tout, int CH >
+__global__ void __launch_bounds__( 256 ) k_lancir_out_pad( const float* res,
+	Tout* dst, int w, long dst_stride, int nrows, int unity, float out_mul,
+	float clampv, int is_float )
+{
+	const int x = blockIdx.x * blockDim.x + threadIdx.x;
+	const int ry = blockIdx.y;
+
+	if( x >= w || ry >= nrows )
+	{
+		return;
+	}
+
+	typedef float f4v __attribute__(( ext_vector_type( 4 )));
+	const f4v v4 = *(const f4v*) ( res + ( (long) ry * w + x ) * 4 );
+	const float vv[ 4 ] = { v4.x, v4.y, v4.z, v4.w };
+	const int l = w * CH;
+	Tout* const op = dst + (long) ry * dst_stride + (long) x * CH;
+#pragma unroll
+	for( int c = 0; c < CH; c++ )
+	{
+		float v = vv[ c ];
+
+		if( !unity )
+		{
+			v = v * out_mul;
+		}
+
+		if( is_float )
+		{
+			op[ c ] = (Tout) v;
+		}
+		else
+		if( x * CH + c < ( l & ~3 ))
+		{
+			v = ( v < clampv ? v : clampv );
+			v = ( v > 0.0f ? v : 0.0f );
+			op[ c ] = (Tout) (int) rintf( v );
+		}
+		else
+		{
+			op[ c ] = (Tout) (int) (( v > clampv ? clampv :
+				( v < 0.0f ? 0.0f : v )) + 0.5f );
+		}
+	}
+}
+
+template< typename Tout >
+static void launch_out_pad( const avirhip_plan* p, const float* res, void* dst,
+	int nrows, int is_float, hipStream_t st )
+{
+	const dim3 gp(( p -> new_w + 255 ) / 256, nrows );
+
+#define LP( CH ) hipLaunchKernelGGL(( k_lancir_out_pad< Tout, CH > ), gp, \
+		dim3( 256 ), 0, st, res, (Tout*) dst, p -> new_w, \
+		(long) p -> new_stride, nrows, p -> l_unity, p -> l_out_mul, \
+		p -> l_clamp, is_float )
+
+	switch( p -> io_ch )
+	{
+		case 1: LP( 1 ); break;
+		case 2: LP( 2 ); break;
+		default: LP( 3 ); break;
+	}
+
+#undef LP
+}
+
+int launch_lancir_out_pad( const avirhip_plan* p, const float* res, void* dst,
+	int nrows, hipStream_t st )
+{
+	if( p -> out_type == AVIRHIP_U8 )
+		launch_out_pad< uint8_t >( p, res, dst, nrows, 0, st );
+	else if( p -> out_type == AVIRHIP_U16 )
+		launch_out_pad< uint16_t >( p, res, dst, nrows, 0, st );
+	else
+		launch_out_pad< float >( p, res, dst, nrows, 1, st );
+
+	AVIRHIP_HIPCHECK( hipGetLastError() );
+	return( AVIRHIP_OK );
+}
+
 // The output stage alone: `nrows` result rows of new_w * ch floats (row pitch
 // rstride) into the caller's rows.
 int launch_lancir_out( const avirhip_plan* p, const float* res, long rstride,

@@ -69,11 +69,85 @@ struct GHParams
 // of taps 4b .. 4b + 3 (rows are padded to a multiple of four; padded taps are
 // never multiplied: x * 0 is not a no-op for non-finite x). NTC > 0: the tap
 // count is a compile-time constant and everything unrolls.
+//
+// LANCIR's summation order depends on the image's channel count (the lane
+// structure of resize1..4, lancir.h:2102-2544; generic.hip spells it out):
+// `lord` = 4: even and odd taps; 1, 2, 3: four sums over taps 4g + j, folded
+// (s0 + s2) + (s1 + s3) for 1 and 2 channels, (s0 + s1) + (s2 + s3) for 3, with
+// the two tail taps of a length 4n + 2 entering where that code adds them --
+// for RGB differently in channel 0 (`ch0`: this lane's .x is channel 0).
 template< bool LANC, typename T, int NTC, typename LD, typename CF >
-__device__ __forceinline__ T gp_dot( const int nt_, LD ld, CF cf4 )
+__device__ __forceinline__ T gp_dot( const int nt_, LD ld, CF cf4,
+	const int lord = 4, const bool ch0 = true )
 {
 	const int nt = ( NTC > 0 ? NTC : nt_ );
 	const int nb = nt >> 2;
+
+	if( LANC && lord != 4 )
+	{
+		T a0, a1, a2, a3;
+		{
+			const f4 c = cf4( 0 );
+			a0 = c.x * ld( 0 );
+			a1 = c.y * ld( 1 );
+			a2 = c.z * ld( 2 );
+			a3 = c.w * ld( 3 );
+		}
+
+		if( NTC > 0 )
+		{
+#pragma unroll
+			for( int b = 1; b < ( NTC > 0 ? NTC / 4 : 1 ); b++ )
+			{
+				const f4 c = cf4( b );
+				a0 = a0 + c.x * ld( 4 * b );
+				a1 = a1 + c.y * ld( 4 * b + 1 );
+				a2 = a2 + c.z * ld( 4 * b + 2 );
+				a3 = a3 + c.w * ld( 4 * b + 3 );
+			}
+		}
+		else
+		{
+			for( int b = 1; b < nb; b++ )
+			{
+				const f4 c = cf4( b );
+				a0 = a0 + c.x * ld( 4 * b );
+				a1 = a1 + c.y * ld( 4 * b + 1 );
+				a2 = a2 + c.z * ld( 4 * b + 2 );
+				a3 = a3 + c.w * ld( 4 * b + 3 );
+			}
+		}
+
+		if( nt & 2 )
+		{
+			const f4 c = cf4( nb );
+			const T t0 = c.x * ld( 4 * nb );
+			const T t1 = c.y * ld( 4 * nb + 1 );
+
+			if( lord == 3 )
+			{
+				a0 = a0 + t0;
+				T r = (( a0 + a1 ) + ( a2 + a3 )) + t1;     // channels 1, 2
+				const T r0 = ( a0 + ( a1 + t1 )) + ( a2 + a3 ); // channel 0
+
+				if( ch0 )
+				{
+					r.x = r0.x;
+				}
+
+				return( r );
+			}
+
+			return((( a0 + a2 ) + t0 ) + (( a1 + a3 ) + t1 ));
+		}
+
+		if( lord == 3 )
+		{
+			return(( a0 + a1 ) + ( a2 + a3 ));
+		}
+
+		return(( a0 + a2 ) + ( a1 + a3 ));
+	}
 
 	if( LANC )
 	{
@@ -256,6 +330,8 @@ __global__ void __launch_bounds__( 64 ) k_gv( const GVParams P )
 	const int hx = x0 + ( WP == 2 ? lane : lane >> 1 );
 	const bool xok = ( hx < P.width );
 	const long dcol = (long) hx * 4 + ( WP == 2 ? 0 : ( lane & 1 ) * 2 );
+	// (LANCIR, RGB: channel 0 sums its tail taps differently -- gp_dot)
+	const bool ach = ( WP == 2 || ( lane & 1 ) == 0 );
 
 	auto mread = [&]( const int m ) -> VT
 	{
@@ -438,7 +514,7 @@ __global__ void __launch_bounds__( 64 ) k_gv( const GVParams P )
 					[&]( const int t ) { return( win[ ( I - ( NTC - 1 ) + t +
 						4 * ( RW > 0 ? RW : 1 )) & (( RW > 0 ? RW : 1 ) - 1 )]); },
 					[&]( const int b ) { return( CNB > 0 ? cpre[ CNB > 0 ? b : 0 ] :
-						*(const f4*) ( cr + 4 * b )); } );
+						*(const f4*) ( cr + 4 * b )); }, A.lanc, ach );
 			}
 			else
 			if( MODE == GP_PRE )
@@ -446,14 +522,14 @@ __global__ void __launch_bounds__( 64 ) k_gv( const GVParams P )
 				o = gp_dot< LANC, VT, NTC >( nt,
 					[&]( const int t ) { return( mread( s0 + t )); },
 					[&]( const int b ) { return( CNB > 0 ? cpre[ CNB > 0 ? b : 0 ] :
-						*(const f4*) ( cr + 4 * b )); } );
+						*(const f4*) ( cr + 4 * b )); }, A.lanc, ach );
 			}
 			else
 			{
 				o = gp_dot< LANC, VT, NTC >( nt,
 					[&]( const int t ) { return( sread( s0 + t )); },
 					[&]( const int b ) { return( CNB > 0 ? cpre[ CNB > 0 ? b : 0 ] :
-						*(const f4*) ( cr + 4 * b )); } );
+						*(const f4*) ( cr + 4 * b )); }, A.lanc, ach );
 			}
 
 			finish( o );
@@ -849,7 +925,7 @@ __global__ void __launch_bounds__( 64 ) k_gh( const GHParams P )
 					}
 
 					return( c );
-				} );
+				}, A.lanc, true );
 		}
 
 		if( MODE == GP_POST )
@@ -1025,14 +1101,16 @@ static bool match_avir_axis( const LAxis& ax, GPAxisHost& H )
 	return( true );
 }
 
-static void match_lancir_axis( const LancirAxisDev& L, GPAxisHost& H )
+static void match_lancir_axis( const LancirAxisDev& L, int order,
+	GPAxisHost& H )
 {
 	GPAxis& A = H.a;
 	memset( &A, 0, sizeof( A ));
 	H.ok = ( L.kernel_len >= 2 && L.kernel_len <= 64 &&
 		( L.kernel_len & 1 ) == 0 );
 
-	A.mode = GP_NONE; A.lanc = 1; A.nt = L.kernel_len;
+	A.mode = GP_NONE; A.lanc = ( order >= 1 && order <= 3 ? order : 4 );
+	A.nt = L.kernel_len;
 	A.in_len = L.src_len; A.view_mmax = 0x7fffffff;
 	A.g_len = L.dst_len; A.out_len = L.dst_len; A.e = 0;
 	A.start = L.d_start; A.coef = L.d_flt; A.fidx = L.d_fidx;
@@ -1064,8 +1142,16 @@ int gpass_prepare( avirhip_plan* p )
 
 	if( p -> is_lancir )
 	{
-		match_lancir_axis( p -> lv, D -> v );
-		match_lancir_axis( p -> lh, D -> h );
+		// (l_order: the channel count whose summation order applies -- the
+		// padded RGBA inner plan of a 1-3 channel image keeps the image's)
+		match_lancir_axis( p -> lv, p -> l_order, D -> v );
+		match_lancir_axis( p -> lh, p -> l_order, D -> h );
+
+		if( p -> l_order != 4 && ( p -> lv.kernel_len < 4 ||
+			p -> lh.kernel_len < 4 ))
+		{
+			D -> h.ok = false;
+		}
 
 		// the float pipeline only: integer I/O and the OutMul / clamp output
 		// stage stay with the generic kernels

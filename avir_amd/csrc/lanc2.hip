@@ -252,7 +252,8 @@ int lanc2_prepare( avirhip_plan* p )
 {
 	p -> lanc2 = nullptr;
 
-	if( !p -> is_lancir || p -> ch != 4 || p -> in_type != AVIRHIP_F32 ||
+	if( !p -> is_lancir || p -> ch != 4 || p -> l_order != 4 ||
+		p -> in_type != AVIRHIP_F32 ||
 		p -> out_type != AVIRHIP_F32 || !p -> l_unity ||
 		p -> new_stride != p -> new_w * 4 )
 	{

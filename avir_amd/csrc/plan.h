@@ -112,6 +112,7 @@ struct avirhip_plan
 	// the same geometry whose fast kernels run between a pack pass and the
 	// output stage (nullptr: this plan runs its own kernels)
 	avirhip_plan* inner;
+	int l_order; // LANCIR: channel count whose summation order the kernels use
 
 	int path;       // forced path (0 = auto)
 	int fused_ok;   // tiled kernels: bit 0 = two-pass (path 2), bit 1 = fused (3)
@@ -179,6 +180,8 @@ int launch_errd( const float* res, void* dst, int out_type, int w, int h,
 	float* line, hipStream_t st );
 int launch_lancir_out( const avirhip_plan* p, const float* res, long rstride,
 	void* dst, int nrows, hipStream_t st );
+int launch_lancir_out_pad( const avirhip_plan* p, const float* res, void* dst,
+	int nrows, hipStream_t st );
 int launch_lancir_generic( const avirhip_plan* p, const void* src, void* dst,
 	float* tmp, int row0, int row1, hipStream_t st );
 

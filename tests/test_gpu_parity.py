@@ -801,21 +801,32 @@ def test_lancir_integer_rgba_runs_the_fast_kernels_in_row_bands():
     frames and row bands equal the generic kernels' result."""
     lib = abi.load()
     checker = rb.ref_lancir if rb.have_ref() else rb.orc_lancir
-    for (sw, sh, nw, nh, tin, tout) in [
-            (96, 70, 192, 140, np.uint8, np.uint8),     # exact 2x kernel
-            (200, 150, 77, 58, np.uint8, np.uint8),     # pass kernels
-            (120, 90, 150, 131, np.uint16, np.uint8),
-            (64, 48, 100, 77, np.uint8, np.float32)]:
-        s = rb.lcg_u8((sh, sw, 4, np.dtype(tin).itemsize), seed=11)
-        s = s.view(tin).reshape(sh, sw, 4)
+    for (sw, sh, nw, nh, ch, tin, tout) in [
+            (96, 70, 192, 140, 4, np.uint8, np.uint8),     # exact 2x kernel
+            (200, 150, 77, 58, 4, np.uint8, np.uint8),     # pass kernels
+            (120, 90, 150, 131, 4, np.uint16, np.uint8),
+            (64, 48, 100, 77, 4, np.uint8, np.float32),
+            # 1-3 channels: zero-padded to RGBA, their own summation order
+            (96, 70, 192, 140, 3, np.uint8, np.uint8),
+            (200, 150, 77, 58, 3, np.uint8, np.uint8),
+            (201, 150, 89, 131, 3, np.uint16, np.uint16),
+            (130, 97, 211, 160, 3, np.float32, np.float32),
+            (120, 90, 150, 131, 1, np.uint8, np.uint8),
+            (64, 48, 100, 77, 2, np.uint8, np.float32),
+            (300, 200, 100, 67, 2, np.float32, np.uint8)]:
+        if np.dtype(tin).kind == "u":
+            s = rb.lcg_u8((sh, sw, ch, np.dtype(tin).itemsize), seed=11)
+            s = s.view(tin).reshape(sh, sw, ch)
+        else:
+            s = rb.lcg_f32((sh, sw, ch), seed=12) * 1.2 - 0.1
         want = checker(s, nw, nh, out_dtype=tout)
         l = avir_amd.CLancIR()
-        p = l.plan(sw, sh, nw, nh, 4, None, avir_amd._NP2T[np.dtype(tin)],
+        p = l.plan(sw, sh, nw, nh, ch, None, avir_amd._NP2T[np.dtype(tin)],
                    avir_amd._NP2T[np.dtype(tout)])
         assert lib.avirhip_plan_get_path(p) in (abi.PATH_UP2, abi.PATH_GPASS)
         got = l.resize(s, nw, nh, out_dtype=tout)
-        _assert_same(got, want, "lancir inner %r" % ((sw, sh, nw, nh),))
-        out = np.zeros((nh, nw, 4), tout)
+        _assert_same(got, want, "lancir inner %r" % ((sw, sh, nw, nh, ch),))
+        out = np.zeros((nh, nw, ch), tout)
         for a_, b_ in [(0, nh // 3), (nh // 3, nh // 3 + 5), (nh // 3 + 5, nh)]:
             abi.check(lib.avirhip_resize_band(
                 p, s.ctypes.data, abi.MEM_HOST, out[a_:b_].ctypes.data,
