@@ -1065,6 +1065,52 @@ def test_avir_pass_kernels(sw, sh, nw, nh, bits):
     _assert_same(got, want, "gpass %dx%d->%dx%d b%d" % (sw, sh, nw, nh, bits))
 
 
+SACC = [
+    # (sw, sh, nw, nh): k >= 2 on both axes (24 .. 64 taps), mixed with other
+    # kinds of axes, sizes that end strips / groups / chunks at every residue
+    (300, 200, 100, 67), (640, 480, 200, 150), (519, 346, 192, 128),
+    (1000, 700, 211, 333), (257, 260, 64, 129), (90, 300, 41, 61),
+    (301, 203, 75, 50), (64, 64, 32, 32), (200, 100, 40, 50), (37, 33, 9, 8),
+    (640, 480, 1024, 100), (300, 1000, 100, 1500), (1300, 66, 300, 33),
+]
+
+
+@pytest.mark.parametrize("ch,tin", [(3, np.uint8), (4, np.uint8), (1, np.uint8),
+                                    (2, np.uint16), (3, np.uint16),
+                                    (3, np.float32), (4, np.float32)])
+@pytest.mark.parametrize("sw,sh,nw,nh", SACC)
+def test_avir_streaming_accumulation_kernel(sw, sh, nw, nh, ch, tin):
+    """sacc.hip (inside path 5): the downsizing axes' kernel reads integer and
+    narrow sources as they are; bit for bit against the reference, whole frames
+    and row bands."""
+    lib = abi.load()
+    if np.dtype(tin).kind == "u":
+        src = rb.lcg_u8((sh, sw, ch, np.dtype(tin).itemsize), seed=sw + ch)
+        src = src.view(tin).reshape(sh, sw, ch)
+        bits = 8 * np.dtype(tin).itemsize
+    else:
+        src = rb.lcg_f32((sh, sw, ch), seed=sw * 3 + ch)
+        bits = 16
+    want = _checker_avir(src, nw, nh, resbits=bits)
+    try:
+        got = _run_avir(src, nw, nh, resbits=bits, path=abi.PATH_GPASS)
+    except avir_amd.AvirHipError as e:
+        assert "cannot run this plan" in str(e)
+        return
+    _assert_same(got, want, "sacc %r" % ((sw, sh, nw, nh, ch, tin),))
+    r = avir_amd.CImageResizer(bits)
+    p = r.plan(sw, sh, nw, nh, ch, 0.0, None, rb._DT[src.dtype],
+               rb._DT[src.dtype])
+    abi.check(lib.avirhip_plan_set_path(p, abi.PATH_GPASS), "set_path")
+    out = np.zeros((nh, nw, ch), tin)
+    for a_, b_ in [(0, nh // 3), (nh // 3, nh // 3 + 1), (nh // 3 + 1, nh)]:
+        if b_ > a_:
+            abi.check(lib.avirhip_resize_band(
+                p, src.ctypes.data, abi.MEM_HOST, out[a_:b_].ctypes.data,
+                abi.MEM_HOST, a_, b_, None), "band")
+    _assert_same(out, want, "sacc bands")
+
+
 def test_avir_pass_kernels_are_the_default_for_general_ratios():
     lib = abi.load()
     r = avir_amd.CImageResizer(16)
@@ -1074,6 +1120,14 @@ def test_avir_pass_kernels_are_the_default_for_general_ratios():
                                    (640, 480, 1280, 960, abi.PATH_UP2),
                                    (3840, 2160, 1280, 720, abi.PATH_TILED)]:
         p = r.plan(sw, sh, nw, nh, 4)
+        assert lib.avirhip_plan_get_path(p) == want, (sw, sh, nw, nh)
+    # integer sources: the streaming kernel reads them (k >= 2 on both axes);
+    # upsizing takes the pass kernels once the frame is large
+    r8 = avir_amd.CImageResizer(8)
+    for (sw, sh, nw, nh, want) in [(5184, 3456, 1920, 1280, abi.PATH_GPASS),
+                                   (1920, 1080, 2500, 1400, abi.PATH_GPASS),
+                                   (640, 480, 1024, 768, abi.PATH_TILED)]:
+        p = r8.plan(sw, sh, nw, nh, 3, 0.0, None, abi.U8, abi.U8)
         assert lib.avirhip_plan_get_path(p) == want, (sw, sh, nw, nh)
 
 
