@@ -473,14 +473,52 @@ __global__ void __launch_bounds__( 64 ) k_sacc( const SAParams P )
 
 	float* dp = P.dst + (long) li * P.d_lane + (long) n0 * P.d_step;
 
+	// Row lanes: a lane's outputs are consecutive in memory, a store of one
+	// output per lane would write 64 x 16 bytes to 64 different rows -- the
+	// first version did, and the counters showed 290 MB written for the
+	// 106 MB intermediate of the README photo case (partial lines evicted and
+	// re-merged) and 400 MB fetched for a 54 MB source. Four outputs are
+	// collected in LDS and leave as 64 contiguous bytes per row, 16 rows per
+	// store instruction.
+	constexpr bool ROWS = ( HOR || SRC != 0 );
+	f4* const ofifo = (f4*) ( smem + DQ_BYTES + SA_TQ * 256 + 64 ); // [4][64]
+	int n_out = n0;
+	const int orow = l0 + ( lane >> 2 ); // + 16 k: the rows this lane stores
+
 	auto store_out = [&]( const PV& o )
 	{
-		if( lok )
+		if( !ROWS )
 		{
-			*(f4*) dp = o.to4();
+			if( lok )
+			{
+				*(f4*) dp = o.to4();
+			}
+
+			dp += P.d_step;
+			return;
 		}
 
-		dp += P.d_step;
+		ofifo[ ( n_out & 3 ) * 64 + lane ] = o.to4();
+
+		if(( n_out & 3 ) == 3 || n_out == n1 - 1 )
+		{
+			const int nb = n_out & ~3;
+			const int n = nb + ( lane & 3 );
+			const bool nok = ( n >= n0 && n <= n_out );
+#pragma unroll
+			for( int k = 0; k < 4; k++ )
+			{
+				const f4 v = ofifo[ ( lane & 3 ) * 64 + k * 16 + ( lane >> 2 )];
+				const int r = orow + k * 16;
+
+				if( nok && r < P.lane_hi )
+				{
+					*(f4*) ( P.dst + (long) r * P.d_lane + (long) n * 4 ) = v;
+				}
+			}
+		}
+
+		n_out++;
 	};
 
 	// One output: the samples up to its last input, then the accumulator
@@ -797,7 +835,8 @@ int sacc_run_axis( const SAData* D, bool rows, const void* src, int src_type,
 		return( 1 );
 	}
 
-	if( (uintptr_t) dst & 15 || ( d_lane & 3 ) || ( d_step & 3 ))
+	if( (uintptr_t) dst & 15 || ( d_lane & 3 ) || ( d_step & 3 ) ||
+		( rows && d_step != 4 ))
 	{
 		return( 1 );
 	}
@@ -810,7 +849,8 @@ int sacc_run_axis( const SAData* D, bool rows, const void* src, int src_type,
 	// samples before its first output completes (they are multiplied into
 	// this chunk's outputs only: no arithmetic is repeated). The kernel is
 	// ALU-bound: whole rounds of the 1024 SIMDs, two or more waves on each.
-	const size_t lds = (size_t) ( dma ? 3 * 4096 : 8 * 1024 ) + SA_TQ * 256 + 64;
+	const size_t lds = (size_t) ( dma ? 3 * 4096 : 8 * 1024 ) + SA_TQ * 256 + 64 +
+		( rows ? 4096 : 0 );
 
 	const double cap = 256.0 * std::max( 1, std::min( 16,
 		(int) ( 160 * 1024 / ( lds + 512 ))));
