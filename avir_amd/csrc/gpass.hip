@@ -15,16 +15,20 @@
 // (profiles/r02_tile). Here a wavefront owns a strip and never synchronises
 // with another wave:
 //
-//   k_gv  vertical pass. Lane = half pixel (8 B) of a 32-pixel strip: a row
-//         is one contiguous 512-byte segment. Source rows arrive by LDS-DMA
-//         (two rows per instruction) in an LDS ring, one block of output rows
-//         ahead of the arithmetic; FIR7 rows and gather windows are read from
-//         the rings with wave-uniform row addresses; coefficients are
-//         wave-uniform scalar loads.
+//   k_gv  vertical pass. Lane = whole pixel of a 64-pixel strip (half pixel /
+//         32-pixel strips for images narrower than 49 pixels): a row is one
+//         contiguous 1-KiB segment. Source rows arrive by LDS-DMA in a landing
+//         queue, read a step ahead of their use; the FIR7 window and -- for
+//         the tap counts that occur -- the gather window live in registers
+//         (the step loop is unrolled to the window length, ring slots are
+//         compile-time); coefficient rows are staged in LDS per chunk and read
+//         as broadcasts one output ahead.
 //   k_gh  horizontal pass. Lane = whole output pixel (16 B) of a strip of up
 //         to 64 outputs; its coefficient row stays in registers while the wave
-//         walks down its rows; the row's source segment arrives by LDS-DMA one
-//         row ahead.
+//         walks down its rows; the row's source segment arrives by LDS-DMA
+//         three rows ahead.
+//   k_sacc (sacc.hip) takes the downsizing axes (k >= 2) of integer / narrow
+//         sources: streaming accumulation instead of a gather window.
 //
 // Arithmetic contract (bit-exact): mul and add separate (-ffp-contract=off),
 // AVIR sums start from +0.0f and take their taps in ascending order, the FIR

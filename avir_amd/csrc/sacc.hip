@@ -16,19 +16,22 @@
 //     the reference's order, starting from +0.0f: bit-exact;
 //   * the coefficients of the (outputs alive) x (sample) pairs are wave-uniform:
 //     the host lays them out by SAMPLE (16 floats per sample, first alive output
-//     first), the kernel reads a sample's row with scalar loads one sample
-//     ahead -- no LDS, no vector registers for coefficients;
+//     first, their count last); table rows travel through an LDS FIFO by
+//     LDS-DMA, a sample's row is one ds_read_b32 (lane i: entry i), entry i
+//     becomes the scalar operand of the multiply by v_readlane;
 //   * accumulator slots are compile-time: the loop over outputs is unrolled 16
 //     times (output g lives in slot g % 16), the loop over the samples that
 //     complete an output is dynamic.
 //
 // Both passes are the same kernel: only the lane and step strides differ.
-// Samples reach the lanes through a small LDS FIFO (8 slots of 64 x 16 B):
-// float RGBA sources by LDS-DMA (per-lane addresses: a row of a strip, or 64
-// rows of a column), integer / narrower sources (the caller's image, first
-// pass only) by per-lane wide loads of whole 4-, 8-, 12- or 16-byte groups
-// converted in registers -- packScanline's (float) cast and zero padding
-// (avir.h:2777-2840) without a float copy of the source.
+// Samples reach the lanes through a small LDS FIFO: float RGBA sources by
+// LDS-DMA in groups of four samples (column lanes: 4 rows x 64 pixels; row
+// lanes: 16 rows x 4 consecutive samples per instruction), integer / narrower
+// sources (the caller's image, first pass only) by per-lane wide loads of
+// whole 4-, 8-, 12- or 16-byte groups converted in registers -- packScanline's
+// (float) cast and zero padding (avir.h:2777-2840) without a float copy of
+// the source. Row lanes collect four outputs in LDS and store 64 contiguous
+// bytes per row.
 
 #include "gpass_dev.h"
 #include <algorithm>
