@@ -213,6 +213,7 @@ __global__ void __launch_bounds__( 64 ) k_sacc( const SAParams P )
 	const int gbv = ( POST ? n1 - 1 - A.e + 3 : gb );
 	const int u_a = a_start[ ga ];
 	const int u_b = a_start[ gb ] + nt - 1;
+	(void) u_b;
 
 	const unsigned lds0 = (unsigned) (unsigned long) (lds_char*) smem;
 
@@ -322,17 +323,19 @@ __global__ void __launch_bounds__( 64 ) k_sacc( const SAParams P )
 		return( q * G >= 0 && q * G + G - 1 <= slast );
 	};
 
-	auto g_load = [&]( const int q ) // typed: whole group, one wide load
+	// typed: whole group, one wide load -- UNCONDITIONAL (groups on the edge
+	// or past the data read a clamped address and are not used: a load under
+	// a condition made the compiler wait for it on the spot, every group at
+	// full memory latency); the image is at least one group wide (host check)
+	auto g_load = [&]( const int q )
 	{
-		if( g_interior( q ) && q * G <= u_b )
-		{
-			const sa_u32u* const gp = (const sa_u32u*) ( lrow + (long) q * G *
-				CH * sizeof( Tin ));
+		const int gs = max( 0, min( q * G, slast + 1 - G ));
+		const sa_u32u* const gp = (const sa_u32u*) ( lrow + (long) gs * CH *
+			sizeof( Tin ));
 #pragma unroll
-			for( int k = 0; k < CH; k++ )
-			{
-				gw[ k ] = gp[ k ];
-			}
+		for( int k = 0; k < CH; k++ )
+		{
+			gw[ k ] = gp[ k ];
 		}
 	};
 
@@ -409,10 +412,12 @@ __global__ void __launch_bounds__( 64 ) k_sacc( const SAParams P )
 	t_issue( tq_a );
 	t_issue( tq_a + 1 );
 	t_issue( tq_a + 2 );
+	int tq_next = tq_a + 3; // typed sources: the next table group to go out
 
-	if((( u_a - A.u_min ) & 3 ) != 0 )
+	if( SRC != 0 || (( u_a - A.u_min ) & 3 ) != 0 )
 	{
 		t_issue( tq_a + 3 ); // (as if group tq_a had just been entered)
+		tq_next = tq_a + 4;
 	}
 
 	const int fv = A.first[ u_a - A.u_min + lane ]; // (table padded by 64 rows)
@@ -537,13 +542,13 @@ __global__ void __launch_bounds__( 64 ) k_sacc( const SAParams P )
 		while( u <= end )
 		{
 			// -- the feeds
-			if((( u - A.u_min ) & 3 ) == 0 )
-			{
-				t_issue((( u - A.u_min ) >> 2 ) + 3 );
-			}
-
 			if( SRC == 0 )
 			{
+				if((( u - A.u_min ) & 3 ) == 0 )
+				{
+					t_issue((( u - A.u_min ) >> 2 ) + 3 );
+				}
+
 				if((( u - ub0 ) & 3 ) == 0 )
 				{
 					// entering a group: the one after the next goes out; the
@@ -560,6 +565,19 @@ __global__ void __launch_bounds__( 64 ) k_sacc( const SAParams P )
 				const int q = q_a + (( u - ub0 ) / G );
 				g_store( q + 1 );
 				g_load( q + 2 );
+
+				// Table groups go out HERE, after this trigger's loads: the
+				// compiler's wait for those loads at the next trigger counts
+				// operations it does not know of -- an LDS-DMA issued just
+				// before a wait would be waited for at full memory latency
+				// (44 % of the wave-cycles of the first version were waits).
+				// Three groups of lookahead: a group is read two triggers
+				// after it went out at the earliest.
+				while( tq_next <= (( u - A.u_min ) >> 2 ) + 3 )
+				{
+					t_issue( tq_next );
+					tq_next++;
+				}
 			}
 
 			const PV x = xnext;
@@ -896,7 +914,7 @@ int sacc_run_axis( const SAData* D, bool rows, const void* src, int src_type,
 	}
 
 	const int items = P.nstrips * (( nout + P.chunk - 1 ) / P.chunk );
-	if( !dma && !rows )
+	if( !dma && ( !rows || P.ax.in_len < 4 ))
 	{
 		return( 1 );
 	}
