@@ -731,15 +731,39 @@ static int exec_device( avirhip_plan* p, const void* src, void* dst,
 	{
 		if( path == 5 )
 		{
-			if( graw )
+			// integer output without gamma / error diffusion: the last pass
+			// converts and stores into the caller's image itself
+			void* iout = ( !direct && !p -> gamma &&
+				p -> dither == AVIRHIP_DITHER_DEF &&
+				( p -> out_type == AVIRHIP_U8 || p -> out_type == AVIRHIP_U16 ) &&
+				getenv( "AVIRHIP_NO_FUSED_OUT" ) == nullptr ? dst : nullptr );
+
+			if( !graw && need_pack && ( rc = do_pack()) != 0 ) return( rc );
+
+			for( int pass = 0; pass < 2; pass++ )
 			{
-				rc = gpass_run( p, nullptr, 0, fdst, row0, row1, st, src,
-					p -> in_type, p -> io_ch, p -> src_stride );
-			}
-			else
-			{
-				if( need_pack && ( rc = do_pack()) != 0 ) return( rc );
-				rc = gpass_run( p, fsrc, sstride, fdst, row0, row1, st );
+				if( graw )
+				{
+					rc = gpass_run( p, nullptr, 0, fdst, row0, row1, st, src,
+						p -> in_type, p -> io_ch, p -> src_stride, iout );
+				}
+				else
+				{
+					rc = gpass_run( p, fsrc, sstride, fdst, row0, row1, st,
+						nullptr, 0, 0, 0, iout );
+				}
+
+				if( rc == 0 && iout != nullptr )
+				{
+					return( AVIRHIP_OK ); // (no epilogue)
+				}
+
+				if( rc != 1 || iout == nullptr )
+				{
+					break;
+				}
+
+				iout = nullptr; // this plan's last pass cannot: float result
 			}
 		}
 		else

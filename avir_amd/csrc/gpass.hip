@@ -55,6 +55,7 @@ struct GVParams
 	int nstrips, chunk;  // 32-px strips, output rows per work item
 	int blk;             // output rows per block
 	int rs, rc;          // ring sizes (rows, powers of two): source, C / G
+	GPOut out;           // on != 0 (whole-pixel lanes): integer output stage
 };
 
 struct GHParams
@@ -413,12 +414,28 @@ __global__ void __launch_bounds__( 64 ) k_gv( const GVParams P )
 
 	// output rows leave strictly in order, from y0 on: a running pointer
 	float* dp = P.dst + (long) ( y0 - P.dst_row0 ) * P.dst_ss + dcol;
+	long orow = y0 - P.dst_row0; // (integer output stage: row of P.out.base)
 
 	auto store_row = [&]( const VT o )
 	{
 #ifdef GP_DBG
 		if(( P.dbg & 1 ) && o.x != 1234.5f ) return;
 #endif
+		if( WP == 2 && P.out.on != 0 )
+		{
+			if( xok )
+			{
+				f4 o4;
+				o4.x = o.x; o4.y = o.y;
+				o4.z = ( WP == 2 ? o[ WP == 2 ? 2 : 0 ] : 0.0f );
+				o4.w = ( WP == 2 ? o[ WP == 2 ? 3 : 0 ] : 0.0f );
+				gp_store_int( P.out, orow, hx, o4 );
+			}
+
+			orow++;
+			return;
+		}
+
 		if( xok )
 		{
 			*(VT*) dp = o;
@@ -974,7 +991,7 @@ void sacc_release_axis( SAData* D );
 int sacc_run_axis( const SAData* D, bool rows, const void* src, int src_type,
 	int src_ch, int live_ch, long s_lane, long s_step, float* dst, long d_lane,
 	long d_step, int lane_lo, int lane_hi, int out_lo, int out_hi,
-	hipStream_t st );
+	hipStream_t st, const GPOut* out = nullptr );
 
 struct GPData
 {
@@ -1548,9 +1565,16 @@ static void launch_gh( const GHParams& P, int items, size_t lds,
 
 static int run_v( const GPData* D, const float* src, long src_ss, int width,
 	float* dst, long dst_ss, int dst_row0, int row_lo, int row_hi,
-	hipStream_t st )
+	hipStream_t st, const GPOut* out = nullptr )
 {
 	GVParams P;
+	memset( &P.out, 0, sizeof( P.out ));
+
+	if( out != nullptr )
+	{
+		P.out = *out;
+	}
+
 	P.src = src; P.src_ss = src_ss; P.width = width;
 	P.dst = dst; P.dst_ss = dst_ss; P.dst_row0 = dst_row0;
 	P.ax = D -> v.a;
@@ -1567,6 +1591,17 @@ static int run_v( const GPData* D, const float* src, long src_ss, int width,
 	{
 		wp = ( atoi( getenv( "AVIRHIP_GV_WP" )) == 2 &&
 			( P.rs + P.rc ) * 1024 + GV_QB + 6 * 1024 <= 64 * 1024 ? 2 : 1 );
+	}
+
+	if( out != nullptr )
+	{
+		// the integer output stage converts whole pixels
+		if(( P.rs + P.rc ) * 1024 + GV_QB + 6 * 1024 > 64 * 1024 )
+		{
+			return( 1 );
+		}
+
+		wp = 2;
 	}
 
 	const int rowb = wp * 512;
@@ -1708,13 +1743,42 @@ bool gpass_takes_raw( const avirhip_plan* p )
 	return( D != nullptr && !p -> is_lancir && D -> sa_h != nullptr );
 }
 
+// `iout` != nullptr: the caller's integer image (the band's first row) -- the
+// last pass converts and stores there (no float result, no epilogue pass);
+// returns 1 if this plan's last pass cannot (the caller then runs unfused).
 int gpass_run( avirhip_plan* p, const float* src, long src_stride, float* dst,
 	int row0, int row1, hipStream_t st, const void* raw, int raw_type,
-	int raw_ch, long raw_stride )
+	int raw_ch, long raw_stride, void* iout )
 {
+	GPOut O;
+	memset( &O, 0, sizeof( O ));
+
+	if( iout != nullptr )
+	{
+		if( p -> is_lancir || p -> gamma || p -> dither != AVIRHIP_DITHER_DEF ||
+			( p -> out_type != AVIRHIP_U8 && p -> out_type != AVIRHIP_U16 ) ||
+			( p -> out_type == AVIRHIP_U8 && p -> io_ch == 4 &&
+			(( (uintptr_t) iout & 3 ) != 0 )))
+		{
+			return( 1 );
+		}
+
+		O.on = 1; O.type = p -> out_type; O.ch = p -> io_ch;
+		O.use_tr = ( p -> tr_mul != 1.0 );
+		O.tr_mul = (float) p -> tr_mul;
+		O.tr_muli = (float) ( 1.0 / p -> tr_mul );
+		O.pk_out = (float) p -> pk_out;
+		O.base = iout;
+		O.stride = (long) p -> new_w * p -> io_ch;
+		dst = (float*) iout; // (alignment checks below: not written as floats)
+	}
+
+	const GPOut* const out = ( iout != nullptr ? &O : nullptr );
+
 	GPData* D = (GPData*) p -> gpass;
 
-	if( D == nullptr || ( (uintptr_t) dst & 15 ) || ( p -> new_stride & 3 ) ||
+	if( D == nullptr || ( iout == nullptr && ( (uintptr_t) dst & 15 )) ||
+		( p -> is_lancir && ( p -> new_stride & 3 )) ||
 		( raw == nullptr && (( (uintptr_t) src & 15 ) || ( src_stride & 3 ))) ||
 		( raw != nullptr && !gpass_takes_raw( p )))
 	{
@@ -1802,7 +1866,7 @@ int gpass_run( avirhip_plan* p, const float* src, long src_stride, float* dst,
 	{
 		rc = sacc_run_axis( D -> sa_v, false, D -> mid, AVIRHIP_F32, 4,
 			p -> io_ch, 16, mid_ss * 4, dst - (long) row0 * dst_ss, 4, dst_ss,
-			0, p -> new_w, row0, row1, st );
+			0, p -> new_w, row0, row1, st, out );
 	}
 
 	if( rc == 1 )
@@ -1813,7 +1877,7 @@ int gpass_run( avirhip_plan* p, const float* src, long src_stride, float* dst,
 		}
 
 		rc = run_v( D, D -> mid, mid_ss, p -> new_w, dst, dst_ss, row0, row0,
-			row1, st );
+			row1, st, out );
 	}
 
 	return( rc );

@@ -79,6 +79,70 @@ __device__ __forceinline__ void gp_wait_vm( const int n )
 	}
 }
 
+// The integer output stage fused into the last pass' store
+// (CImageResizerDithererDefINL::dither, avir.h:4392-4419 + unpackScanline,
+// avir.h:3155-3215, without gamma): round, optional bit-depth truncation,
+// clamp, C cast -- the arithmetic of k_epilogue_px (generic.hip).
+struct GPOut
+{
+	int on;          // 0: float RGBA rows (no output stage)
+	int type;        // AVIRHIP_U8 / AVIRHIP_U16
+	int ch;          // channels of the caller's pixels (1..4)
+	int use_tr;
+	float tr_mul, tr_muli, pk_out;
+	void* base;      // the caller's rows (row 0 = the band's first row)
+	long stride;     // elements per row
+};
+
+__device__ __forceinline__ float gp_round( const float d )
+{
+	return( d < 0.0f ? -(float) (int) ( 0.5f - d ) : (float) (int) ( d + 0.5f ));
+}
+
+// pixel x of row `row` (both relative to O.base)
+__device__ __forceinline__ void gp_store_int( const GPOut& O, const long row,
+	const int x, const f4 o )
+{
+	const float v[ 4 ] = { o.x, o.y, o.z, o.w };
+	unsigned int q[ 4 ];
+#pragma unroll
+	for( int c = 0; c < 4; c++ )
+	{
+		float t = v[ c ];
+		t = ( O.use_tr ? gp_round( t * O.tr_muli ) * O.tr_mul : gp_round( t ));
+		t = ( t < 0.0f ? 0.0f : ( t > O.pk_out ? O.pk_out : t ));
+		q[ c ] = (unsigned int) t;
+	}
+
+	if( O.type == AVIRHIP_U8 )
+	{
+		unsigned char* const p = (unsigned char*) O.base + row * O.stride +
+			(long) x * O.ch;
+
+		if( O.ch == 4 )
+		{
+			*(unsigned int*) p = q[ 0 ] | ( q[ 1 ] << 8 ) | ( q[ 2 ] << 16 ) |
+				( q[ 3 ] << 24 );
+		}
+		else
+		{
+			p[ 0 ] = (unsigned char) q[ 0 ];
+			if( O.ch > 1 ) p[ 1 ] = (unsigned char) q[ 1 ];
+			if( O.ch > 2 ) p[ 2 ] = (unsigned char) q[ 2 ];
+		}
+	}
+	else
+	{
+		unsigned short* const p = (unsigned short*) O.base + row * O.stride +
+			(long) x * O.ch;
+
+		p[ 0 ] = (unsigned short) q[ 0 ];
+		if( O.ch > 1 ) p[ 1 ] = (unsigned short) q[ 1 ];
+		if( O.ch > 2 ) p[ 2 ] = (unsigned short) q[ 2 ];
+		if( O.ch > 3 ) p[ 3 ] = (unsigned short) q[ 3 ];
+	}
+}
+
 // Host side of a recognised axis.
 struct GPAxisHost
 {

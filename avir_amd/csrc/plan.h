@@ -217,7 +217,8 @@ bool gpass_preferred( const avirhip_plan* p );
 bool gpass_takes_raw( const avirhip_plan* p );
 int gpass_run( avirhip_plan* p, const float* src, long src_stride, float* dst,
 	int row0, int row1, hipStream_t st, const void* raw = nullptr,
-	int raw_type = 0, int raw_ch = 0, long raw_stride = 0 );
+	int raw_type = 0, int raw_ch = 0, long raw_stride = 0,
+	void* iout = nullptr );
 bool fused_dn_both( const avirhip_plan* p );
 
 // up2.hip: specialised exact-2x RGBA kernel (path 4)

@@ -64,6 +64,7 @@ struct SAParams
 	int lane_lo, lane_hi;                 // lanes [lo, hi): rows or pixels
 	int out_lo, out_hi;                   // outputs [lo, hi)
 	int nstrips, chunk;
+	GPOut out;       // on != 0 (column lanes): integer output stage
 	SAAxis ax;
 };
 
@@ -497,6 +498,17 @@ __global__ void __launch_bounds__( 64 ) k_sacc( const SAParams P )
 	{
 		if( !ROWS )
 		{
+			if( P.out.on != 0 )
+			{
+				if( lok )
+				{
+					gp_store_int( P.out, n_out - P.out_lo, li, o.to4() );
+				}
+
+				n_out++;
+				return;
+			}
+
 			if( lok )
 			{
 				*(f4*) dp = o.to4();
@@ -835,7 +847,7 @@ static void sa_launch1( const SAParams& P, int ch, int items, size_t lds,
 int sacc_run_axis( const SAData* D, bool rows, const void* src, int src_type,
 	int src_ch, int live_ch, long s_lane, long s_step, float* dst, long d_lane,
 	long d_step, int lane_lo, int lane_hi, int out_lo, int out_hi,
-	hipStream_t st )
+	hipStream_t st, const GPOut* out )
 {
 	if( lane_hi <= lane_lo || out_hi <= out_lo )
 	{
@@ -848,6 +860,17 @@ int sacc_run_axis( const SAData* D, bool rows, const void* src, int src_type,
 	P.lane_lo = lane_lo; P.lane_hi = lane_hi;
 	P.out_lo = out_lo; P.out_hi = out_hi;
 	P.ax = D -> a;
+	memset( &P.out, 0, sizeof( P.out ));
+
+	if( out != nullptr )
+	{
+		if( rows || lane_lo != 0 )
+		{
+			return( 1 );
+		}
+
+		P.out = *out;
+	}
 
 	const bool dma = ( src_type == AVIRHIP_F32 && src_ch == 4 );
 
@@ -856,7 +879,8 @@ int sacc_run_axis( const SAData* D, bool rows, const void* src, int src_type,
 		return( 1 );
 	}
 
-	if( (uintptr_t) dst & 15 || ( d_lane & 3 ) || ( d_step & 3 ) ||
+	if(( out == nullptr && ( (uintptr_t) dst & 15 )) || ( d_lane & 3 ) ||
+		( d_step & 3 ) ||
 		( rows && d_step != 4 ))
 	{
 		return( 1 );

@@ -1111,6 +1111,47 @@ def test_avir_streaming_accumulation_kernel(sw, sh, nw, nh, ch, tin):
     _assert_same(out, want, "sacc bands")
 
 
+@pytest.mark.parametrize("ch", [1, 3, 4])
+@pytest.mark.parametrize("tin,tout,bits", [
+    (np.uint8, np.uint8, 8), (np.uint16, np.uint16, 16),
+    (np.uint16, np.uint16, 10), (np.float32, np.uint8, 8),
+    (np.uint8, np.uint16, 16)])
+def test_avir_pass_kernels_store_integer_images_themselves(ch, tin, tout, bits):
+    """Path 5 with integer output: the last pass rounds, truncates to the
+    result bit depth, clamps and stores into the caller's image (no float
+    result, no epilogue pass) -- k_gv for upsizing / mixed plans, k_sacc for
+    k >= 2; whole frames and row bands against the reference."""
+    lib = abi.load()
+    for (sw, sh, nw, nh) in [(64, 48, 100, 77), (129, 67, 513, 259),
+                             (300, 200, 100, 67), (90, 300, 200, 120),
+                             (257, 260, 64, 129)]:
+        if np.dtype(tin).kind == "u":
+            src = rb.lcg_u8((sh, sw, ch, np.dtype(tin).itemsize), seed=sw + ch)
+            src = src.view(tin).reshape(sh, sw, ch)
+        else:
+            src = rb.lcg_f32((sh, sw, ch), seed=sw * 5 + ch) * 1.2 - 0.1
+            if np.dtype(tout).kind == "u":
+                src = src * float(np.iinfo(tout).max)
+        want = _checker_avir(src, nw, nh, resbits=bits, out_dtype=tout)
+        try:
+            got = _run_avir(src, nw, nh, resbits=bits, out_dtype=tout,
+                            path=abi.PATH_GPASS)
+        except avir_amd.AvirHipError as e:
+            assert "cannot run this plan" in str(e)
+            continue
+        _assert_same(got, want, "fused out %r" % ((sw, sh, nw, nh, ch),))
+        r = avir_amd.CImageResizer(bits)
+        p = r.plan(sw, sh, nw, nh, ch, 0.0, None, rb._DT[src.dtype],
+                   rb._DT[np.dtype(tout)])
+        abi.check(lib.avirhip_plan_set_path(p, abi.PATH_GPASS), "set_path")
+        out = np.zeros((nh, nw, ch), tout)
+        for a_, b_ in [(0, nh // 2), (nh // 2, nh)]:
+            abi.check(lib.avirhip_resize_band(
+                p, src.ctypes.data, abi.MEM_HOST, out[a_:b_].ctypes.data,
+                abi.MEM_HOST, a_, b_, None), "band")
+        _assert_same(out, want, "fused out bands")
+
+
 def test_avir_pass_kernels_are_the_default_for_general_ratios():
     lib = abi.load()
     r = avir_amd.CImageResizer(16)
