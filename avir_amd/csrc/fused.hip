@@ -159,9 +159,11 @@ __device__ __forceinline__ void run_op( const TOp& op, const f4* in,
 		// they cost a dependent vector load per tap and output)
 		const int tid = ty * 32 + tx;
 
-		if( tid <= op.lat )
+		// (deep decimation steps have hundreds of taps: 204 -> 1 pixels is a
+		// 771-tap filter, lat = 385 -- more than one tap per thread)
+		for( int i = tid; i <= op.lat; i += 256 )
 		{
-			cfl[ tid ] = op.flt[ tid ];
+			cfl[ i ] = op.flt[ i ];
 		}
 
 		__syncthreads();
@@ -636,7 +638,19 @@ static int make_geom( avirhip_plan* p, FusedData* F, bool useh, bool usev,
 		else mA = std::max( mA, reg[ i ]);
 	}
 
-	long mC = 16, mS = 2; // mC >= 12: FIR taps of the longest decimating filter
+	long mC = 16, mS = 2; // mC: FIR taps of the longest (decimating) filter ...
+
+	for( int s = 0; s < nh + nv; s++ )
+	{
+		const LOp& op = ( s < nh ? p -> h.ops[ s ] : p -> v.ops[ s - nh ]);
+
+		if( op.type == OP_FIR )
+		{
+			mC = std::max( mC, (long) op.lat + 1 );
+		}
+	}
+
+	// ... or the coefficient rows of a gather's outputs
 
 	for( int s = 0; s < nh; s++ )
 	{

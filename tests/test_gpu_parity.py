@@ -1192,3 +1192,32 @@ def test_lancir_pass_kernels(sw, sh, nw, nh):
         want = (rb.ref_lancir if rb.have_ref() else rb.orc_lancir)(
             src, nw, nh, **kw)
         _assert_same(l.resize(src, nw, nh, aParams=P), want, "lancir %s" % kw)
+
+
+# ---- regression + differential fuzz ----
+
+@pytest.mark.parametrize("sw,sh,nw,nh", [(204, 60, 1, 30), (500, 60, 2, 30),
+                                         (500, 60, 1, 30), (700, 40, 3, 20)])
+def test_avir_deep_decimation_on_the_tiled_path(sw, sh, nw, nh):
+    """204 -> 1 pixels is one 771-tap decimating filter (lat 385): the tile
+    kernel used to stage one tap per thread (256) and read the rest as
+    garbage -- on the automatic path. Found by tools/fuzz_paths.py."""
+    src = rb.lcg_f32((sh, sw, 4), seed=sw + 7)
+    want = _checker_avir(src, nw, nh, resbits=16)
+    _assert_same(_run_avir(src, nw, nh, resbits=16), want, "auto")
+    _assert_same(_run_avir(src, nw, nh, resbits=16, path=abi.PATH_TILED), want,
+                 "tiled")
+
+
+def test_execution_paths_agree_on_random_plans():
+    """tools/fuzz_paths.py: 600 random geometries x channel counts x element
+    types, AVIR and LANCIR -- the automatic path and every forcible fast path
+    equal the generic kernels bit for bit."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools",
+                                                     "fuzz_paths.py"),
+                        "600", "3"], capture_output=True, text=True,
+                       timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
