@@ -1211,13 +1211,14 @@ def test_avir_deep_decimation_on_the_tiled_path(sw, sh, nw, nh):
 
 def test_execution_paths_agree_on_random_plans():
     """tools/fuzz_paths.py: 600 random geometries x channel counts x element
-    types, AVIR and LANCIR -- the automatic path and every forcible fast path
-    equal the generic kernels bit for bit."""
+    types x parameters (gamma, build modes, steps, offsets), AVIR and LANCIR
+    -- the automatic path, its row bands and every forcible fast path equal
+    the generic kernels bit for bit, and those the reference itself."""
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, os.path.join(root, "tools",
                                                      "fuzz_paths.py"),
-                        "600", "3"], capture_output=True, text=True,
-                       timeout=600)
+                        "600", "3"] + (["ref"] if rb.have_ref() else []),
+                       capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]

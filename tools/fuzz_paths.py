@@ -1,7 +1,10 @@
 #!/usr/bin/env python3
-"""Differential fuzz of the execution paths (no reference needed): random
-geometries, channel counts and element types; the automatic path and every
-forcible fast path must equal the generic kernels (path 1) bit for bit."""
+"""Differential fuzz of the execution paths: random geometries, channel
+counts, element types and parameters; the automatic path, its row bands and
+every forcible fast path must equal the generic kernels (path 1) bit for bit.
+With a third argument "ref" the generic kernels' result is also compared with
+the reference itself (oracle/_ref must be built; the test suite's checker).
+usage: fuzz_paths.py [cases] [seed] [ref]"""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -12,6 +15,9 @@ lib = abi.load()
 rng = np.random.RandomState(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 200
 DT = [np.uint8, np.uint16, np.float32]
+REF = len(sys.argv) > 3 and sys.argv[3] == "ref"
+if REF:
+    from oracle import bind as rb
 bad = 0
 ran = {}
 
@@ -35,34 +41,83 @@ for it in range(N):
     tout = DT[rng.randint(0, 3)]
     src = make(sh, sw, ch, tin, it + 7)
     if tin == np.float32 and tout != np.float32:
-        src = src * float(np.iinfo(tout).max)
+        src = src * 1.2 - 0.1  # float sources are [0, 1]: exercise both clamps
     lanc = rng.rand() < 0.35
     res = {}
-    for path in (1, 0, 5, 2, 4):
+    bits = int(rng.choice([8, 10, 16]))
+    v = avir_amd.CImageResizerVars()
+    lp = None
+    if lanc:
+        if rng.rand() < 0.4:
+            lp = avir_amd.CLancIRParams(0, 0, float(rng.choice([0, 0.7, 1.9, -1.5])),
+                                        float(rng.choice([0, 2.2, -0.6])),
+                                        float(rng.choice([0, 0.4])),
+                                        float(rng.choice([0, -0.2])))
+            lp.la = float(rng.choice([2.0, 3.0, 4.5]))
+    else:
+        if rng.rand() < 0.25:
+            v.UseSRGBGamma = 1
+            v.AlphaIndex = int(rng.choice([-1, 0, 3, 1]))
+        if rng.rand() < 0.2:
+            v.BuildMode = int(rng.randint(0, 4))
+        if rng.rand() < 0.2:
+            v.ox, v.oy = float(rng.uniform(-1, 1)), float(rng.uniform(-1, 1))
+    kstep = float(rng.choice([0.0, 0.0, 0.0, 1.7, 0.6])) if not lanc else 0.0
+    for path in (1, 0, 5, 2, 3, 4):
         try:
             if lanc:
                 r = avir_amd.CLancIR()
-                p = r.plan(sw, sh, nw, nh, ch, None, avir_amd._NP2T[np.dtype(tin)],
+                p = r.plan(sw, sh, nw, nh, ch, lp, avir_amd._NP2T[np.dtype(tin)],
                            avir_amd._NP2T[np.dtype(tout)])
             else:
-                bits = int(rng.choice([8, 10, 16])) if path == 1 else bits
                 r = avir_amd.CImageResizer(bits)
-                p = r.plan(sw, sh, nw, nh, ch, 0.0, None,
+                p = r.plan(sw, sh, nw, nh, ch, kstep, v,
                            avir_amd._NP2T[np.dtype(tin)],
                            avir_amd._NP2T[np.dtype(tout)])
             if lib.avirhip_plan_set_path(p, path) != 0:
                 continue
-            res[path] = r.resize(src, nw, nh, out_dtype=tout)
+            if lanc:
+                res[path] = r.resize(src, nw, nh, out_dtype=tout, aParams=lp)
+            else:
+                res[path] = r.resize(src, nw, nh, k=kstep, out_dtype=tout,
+                                     aVars=v)
             ran[path] = ran.get(path, 0) + 1
+            if path == 0 and nh > 2 and rng.rand() < 0.3:
+                # row bands of the automatic path
+                out = np.zeros((nh, nw, ch), tout)
+                cut = int(rng.randint(1, nh))
+                for a_, b_ in [(0, cut), (cut, nh)]:
+                    abi.check(lib.avirhip_resize_band(
+                        p, src.ctypes.data, abi.MEM_HOST, out[a_:b_].ctypes.data,
+                        abi.MEM_HOST, a_, b_, None), "band")
+                res["bands"] = out
         except avir_amd.AvirHipError as e:
             if path in (0, 1):
                 print("ERROR", it, (sw, sh, nw, nh, ch, tin.__name__,
                                     tout.__name__, lanc), path, e)
                 bad += 1
+    if REF and 1 in res:
+        if lanc:
+            kw = {} if lp is None else dict(kx=lp.kx, ky=lp.ky, ox=lp.ox,
+                                           oy=lp.oy, la=lp.la)
+            want = rb.ref_lancir(src, nw, nh, out_dtype=tout, **kw)
+        else:
+            want = rb.ref_avir(src, nw, nh, k=kstep, out_dtype=tout,
+                               resbits=bits, ox=v.ox, oy=v.oy,
+                               build_mode=v.BuildMode,
+                               gamma=bool(v.UseSRGBGamma), alpha=v.AlphaIndex)
+        if want.tobytes() != res[1].tobytes():
+            print("REF MISMATCH", it, (sw, sh, nw, nh, ch, tin.__name__,
+                                       tout.__name__, lanc, bits,
+                                       v.UseSRGBGamma, v.AlphaIndex,
+                                       v.BuildMode, kstep))
+            bad += 1
     for path, got in res.items():
         if path != 1 and 1 in res and got.tobytes() != res[1].tobytes():
             print("MISMATCH", it, (sw, sh, nw, nh, ch, tin.__name__,
-                                   tout.__name__, "lancir" if lanc else bits),
+                                   tout.__name__, "lancir" if lanc else bits,
+                                   v.UseSRGBGamma, v.AlphaIndex, v.BuildMode,
+                                   kstep),
                   "path", path, "differs in",
                   int((got != res[1]).sum()), "elements")
             bad += 1
