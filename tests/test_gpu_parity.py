@@ -1222,3 +1222,43 @@ def test_execution_paths_agree_on_random_plans():
                         "600", "3"] + (["ref"] if rb.have_ref() else []),
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def test_misaligned_device_buffers():
+    """Device buffers that start 1-3 elements off a 16-byte boundary (views
+    into larger tensors): the LDS-DMA / vector-store paths step aside, results
+    and the bytes around the destination are untouched."""
+    import torch
+    from avir_amd import synth
+    dev = torch.device("cuda", 0)
+    bad = 0
+    for (sw, sh, nw, nh) in [(64, 48, 128, 96), (100, 80, 131, 117), (300, 200, 100, 67), (200, 150, 77, 58), (90, 70, 90, 70)]:
+        for lanc in (False, True):
+            for ch, dt in [(4, np.float32), (3, np.uint8), (4, np.uint8), (1, np.float32)]:
+                if np.dtype(dt).kind == "u":
+                    a = synth.lcg_u8((sh, sw, ch), seed=5)
+                else:
+                    a = synth.lcg_f32((sh, sw, ch), seed=5)
+                es = a.dtype.itemsize
+                r = avir_amd.CLancIR() if lanc else avir_amd.CImageResizer(8 if es == 1 else 16)
+                want = r.resize(a, nw, nh)
+                n_in, n_out = a.size, nh * nw * ch
+                for off_in, off_out in [(0, 0), (1, 0), (0, 1), (3, 2), (2, 3)]:
+                    tin = torch.zeros(n_in + 8, dtype=torch.from_numpy(a).dtype, device=dev)
+                    tout = torch.zeros(n_out + 8, dtype=tin.dtype, device=dev)
+                    src = tin[off_in:off_in + n_in].view(sh, sw, ch)
+                    src.copy_(torch.from_numpy(a))
+                    dst = tout[off_out:off_out + n_out].view(nh, nw, ch)
+                    if lanc:
+                        r.resizeImage(src, sw, sh, dst, nw, nh, ch)
+                    else:
+                        r.resizeImage(src, sw, sh, 0, dst, nw, nh, ch, 0.0)
+                    torch.cuda.synchronize()
+                    got = dst.cpu().numpy()
+                    if got.tobytes() != want.tobytes():
+                        bad += 1
+                        print("MISMATCH", (sw, sh, nw, nh), lanc, ch, dt.__name__, off_in, off_out)
+                    if tout[:off_out].any() or tout[off_out + n_out:].any():
+                        bad += 1
+                        print("OVERWRITE", (sw, sh, nw, nh), lanc, ch, dt.__name__, off_in, off_out)
+    assert bad == 0
