@@ -108,9 +108,21 @@ __device__ __forceinline__ void gp_store_int( const GPOut& O, const long row,
 #pragma unroll
 	for( int c = 0; c < 4; c++ )
 	{
+		// avir::round's branch for negative values is dropped: whatever it
+		// returns for them is <= 0 and the clamp that follows makes it 0 --
+		// as does the truncation of d + 0.5 (<= 0 for every d < 0)
 		float t = v[ c ];
-		t = ( O.use_tr ? gp_round( t * O.tr_muli ) * O.tr_mul : gp_round( t ));
-		t = ( t < 0.0f ? 0.0f : ( t > O.pk_out ? O.pk_out : t ));
+
+		if( O.use_tr )
+		{
+			t = (float) (int) ( t * O.tr_muli + 0.5f ) * O.tr_mul;
+		}
+		else
+		{
+			t = (float) (int) ( t + 0.5f );
+		}
+
+		t = fminf( fmaxf( t, 0.0f ), O.pk_out );
 		q[ c ] = (unsigned int) t;
 	}
 
