@@ -1265,6 +1265,18 @@ int finalize_avir_plan( avirhip_plan* p )
 		{
 			p -> auto_path = 5;
 		}
+
+		// exact 2x with integer pixels on both sides: the pass kernels read
+		// and write the caller's images themselves, the marching kernel
+		// needs a pack pass before and an epilogue pass behind it
+		// (1920x1080 -> 3840x2160 RGB u8: 0.084 against 0.089 ms)
+		if( p -> auto_path == 4 && gpass_preferred( p ) && !p -> gamma &&
+			p -> dither == AVIRHIP_DITHER_DEF &&
+			( p -> in_type == AVIRHIP_U8 || p -> in_type == AVIRHIP_U16 ) &&
+			( p -> out_type == AVIRHIP_U8 || p -> out_type == AVIRHIP_U16 ))
+		{
+			p -> auto_path = 5;
+		}
 	}
 
 	if( rc == 0 && p -> ch != p -> io_ch && p -> auto_path == 1 )

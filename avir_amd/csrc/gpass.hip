@@ -68,6 +68,9 @@ struct GHParams
 	const int* seg;      // [nstrips][4]: source lo, count; mid lo, count
 	int nseg;            // DMA instructions per row (uniform)
 	int sbuf, mbuf;      // LDS pixels per source row buffer / mid buffer
+	const void* raw;     // SRC != 0: the caller's image (integer / narrower
+	long raw_ss;         // pixels), elements per row, channels
+	int raw_ch;
 };
 
 // One gather output: tap t reads ld( t ); cf4( b ) returns the coefficients
@@ -768,7 +771,16 @@ __global__ void __launch_bounds__( 64 ) k_gv( const GVParams P )
 
 #define GH_NB 4 // source row buffers: rows r .. r + 3 are in LDS or in flight
 
-template< int MODE, bool LANC, int NTC >
+// SRC: 0 float RGBA by LDS-DMA; 1 uint8, 2 uint16, 3 float pixels of raw_ch
+// channels, read as they are (packScanline's cast and zero padding,
+// avir.h:2777-2840, in the loader: no float copy of the source): a lane loads
+// its pixel of each 64-pixel piece a row ahead, converts and writes it into
+// the row buffer after the row in hand has been computed.
+template< int SRC > struct GHElem { typedef float T; };
+template<> struct GHElem< 1 > { typedef unsigned char T; };
+template<> struct GHElem< 2 > { typedef unsigned short T; };
+
+template< int MODE, bool LANC, int NTC, int SRC >
 __global__ void __launch_bounds__( 64 ) k_gh( const GHParams P )
 {
 	extern __shared__ __attribute__(( aligned( 16 ))) char smem[];
@@ -844,9 +856,60 @@ __global__ void __launch_bounds__( 64 ) k_gh( const GHParams P )
 		}
 	}
 
-	for( int k = 0; k < GH_NB - 1 && r0 + k < r1; k++ )
+	// typed sources: the row in flight (up to four pieces, four channels)
+	typedef typename GHElem< SRC > :: T Tin;
+	float rw[ SRC != 0 ? 4 : 1 ][ 4 ];
+
+	auto t_load = [&]( const int r )
 	{
-		issue_row( r0 + k, k );
+		const Tin* const row = (const Tin*) P.raw + (long) r * P.raw_ss;
+#pragma unroll
+		for( int k = 0; k < ( SRC != 0 ? 4 : 1 ); k++ )
+		{
+			if( k < P.nseg )
+			{
+				const Tin* const px = row + (long) gp_clamp( slo + k * 64 + lane,
+					slast ) * P.raw_ch;
+#pragma unroll
+				for( int c = 0; c < 4; c++ )
+				{
+					rw[ k ][ c ] = ( c < P.raw_ch ? (float) px[ c ] : 0.0f );
+				}
+			}
+		}
+	};
+
+	auto t_store = [&]( const int buf )
+	{
+#pragma unroll
+		for( int k = 0; k < ( SRC != 0 ? 4 : 1 ); k++ )
+		{
+			if( k < P.nseg )
+			{
+				f4 o;
+				o.x = rw[ k ][ 0 ]; o.y = rw[ k ][ 1 ];
+				o.z = rw[ k ][ 2 ]; o.w = rw[ k ][ 3 ];
+				sbuf[ buf * P.sbuf + k * 64 + lane ] = o;
+			}
+		}
+	};
+
+	if( SRC != 0 )
+	{
+		t_load( r0 );
+		t_store( 0 );
+
+		if( r0 + 1 < r1 )
+		{
+			t_load( r0 + 1 );
+		}
+	}
+	else
+	{
+		for( int k = 0; k < GH_NB - 1 && r0 + k < r1; k++ )
+		{
+			issue_row( r0 + k, k );
+		}
 	}
 
 	for( int r = r0; r < r1; r++ )
@@ -854,14 +917,18 @@ __global__ void __launch_bounds__( 64 ) k_gh( const GHParams P )
 		const int buf = ( r - r0 ) & ( GH_NB - 1 );
 		const f4* const s = sbuf + buf * P.sbuf;
 
-		// row r + 3 goes out (into the buffer row r - 1 has left), then wait
-		// for row r: only the pieces of the rows after it may be in flight
-		if( r + GH_NB - 1 < r1 )
+		if( SRC == 0 )
 		{
-			issue_row( r + GH_NB - 1, ( buf + GH_NB - 1 ) & ( GH_NB - 1 ));
-		}
+			// row r + 3 goes out (into the buffer row r - 1 has left), then
+			// wait for row r: only the pieces of the rows after it may be in
+			// flight
+			if( r + GH_NB - 1 < r1 )
+			{
+				issue_row( r + GH_NB - 1, ( buf + GH_NB - 1 ) & ( GH_NB - 1 ));
+			}
 
-		gp_wait_vm( min( GH_NB - 1, r1 - 1 - r ) * P.nseg );
+			gp_wait_vm( min( GH_NB - 1, r1 - 1 - r ) * P.nseg );
+		}
 
 		if( MODE != GP_PRE && slo + scnt - 1 > A.view_mmax )
 		{
@@ -975,6 +1042,17 @@ __global__ void __launch_bounds__( 64 ) k_gh( const GHParams P )
 		{
 			*(f4*) ( P.dst + (long) ( r - P.dst_row0 ) * P.dst_ss +
 				(long) j * 4 ) = o;
+		}
+
+		if( SRC != 0 && r + 1 < r1 )
+		{
+			// row r + 1 (loaded a row ago) into its buffer, row r + 2 out
+			t_store(( buf + 1 ) & ( GH_NB - 1 ));
+
+			if( r + 2 < r1 )
+			{
+				t_load( r + 2 );
+			}
 		}
 	}
 }
@@ -1548,18 +1626,52 @@ static void launch_gv( const GVParams& P, int wp, int items, size_t lds,
 
 #undef GV_LAUNCH
 
-template< int MODE, bool LANC >
-static void launch_gh( const GHParams& P, int items, size_t lds,
+template< int MODE, bool LANC, int SRC >
+static void launch_gh2( const GHParams& P, int items, size_t lds,
 	hipStream_t st )
 {
-	switch( P.ax.nt )
+	const int nt = P.ax.nt;
+
+	// (register-resident coefficient rows for the tap counts that occur: 6
+	// LANCIR, 12 AVIR upsizing; raw sources only come with AVIR plans)
+	if constexpr( SRC == 0 )
 	{
-		case 6: hipLaunchKernelGGL(( k_gh< MODE, LANC, 6 > ), dim3( items ),
-			dim3( 64 ), lds, st, P ); break;
-		case 12: hipLaunchKernelGGL(( k_gh< MODE, LANC, 12 > ), dim3( items ),
-			dim3( 64 ), lds, st, P ); break;
-		default: hipLaunchKernelGGL(( k_gh< MODE, LANC, 0 > ), dim3( items ),
-			dim3( 64 ), lds, st, P ); break;
+		if( nt == 6 )
+		{
+			hipLaunchKernelGGL(( k_gh< MODE, LANC, 6, 0 > ), dim3( items ),
+				dim3( 64 ), lds, st, P );
+			return;
+		}
+	}
+
+	if constexpr( SRC == 0 || MODE == GP_PRE )
+	{
+		if( nt == 12 )
+		{
+			hipLaunchKernelGGL(( k_gh< MODE, LANC, 12, SRC > ), dim3( items ),
+				dim3( 64 ), lds, st, P );
+			return;
+		}
+	}
+
+	hipLaunchKernelGGL(( k_gh< MODE, LANC, 0, SRC > ), dim3( items ),
+		dim3( 64 ), lds, st, P );
+}
+
+// src_kind: 0 float RGBA (LDS-DMA); 1 uint8, 2 uint16, 3 float pixels read raw
+template< int MODE, bool LANC >
+static void launch_gh( const GHParams& P, int src_kind, int items, size_t lds,
+	hipStream_t st )
+{
+	switch( LANC ? 0 : src_kind )
+	{
+		case 1: launch_gh2< MODE, LANC, ( LANC ? 0 : 1 ) >( P, items, lds, st );
+			break;
+		case 2: launch_gh2< MODE, LANC, ( LANC ? 0 : 2 ) >( P, items, lds, st );
+			break;
+		case 3: launch_gh2< MODE, LANC, ( LANC ? 0 : 3 ) >( P, items, lds, st );
+			break;
+		default: launch_gh2< MODE, LANC, 0 >( P, items, lds, st ); break;
 	}
 }
 
@@ -1655,9 +1767,19 @@ static int run_v( const GPData* D, const float* src, long src_ss, int width,
 
 static int run_h( const GPData* D, const float* src, long src_ss, int src_w,
 	float* dst, long dst_ss, int dst_row0, int dst_w, int row_lo, int row_hi,
-	hipStream_t st )
+	hipStream_t st, const void* raw = nullptr, int raw_type = 0,
+	int raw_ch = 0, long raw_stride = 0 )
 {
 	GHParams P;
+	P.raw = raw; P.raw_ss = raw_stride; P.raw_ch = raw_ch;
+	const int src_kind = ( raw == nullptr ? 0 : ( raw_type == AVIRHIP_U8 ? 1 :
+		( raw_type == AVIRHIP_U16 ? 2 : 3 )));
+
+	if( raw != nullptr && ( D -> h_nseg > 4 || D -> h.a.lanc ))
+	{
+		return( 1 );
+	}
+
 	P.src = src; P.src_ss = src_ss; P.src_w = src_w;
 	P.dst = dst; P.dst_ss = dst_ss; P.dst_row0 = dst_row0; P.dst_w = dst_w;
 	P.ax = D -> h.a;
@@ -1685,21 +1807,21 @@ static int run_h( const GPData* D, const float* src, long src_ss, int src_w,
 
 	if( A.lanc )
 	{
-		launch_gh< GP_NONE, true >( P, items, lds, st );
+		launch_gh< GP_NONE, true >( P, 0, items, lds, st );
 	}
 	else
 	if( A.mode == GP_PRE )
 	{
-		launch_gh< GP_PRE, false >( P, items, lds, st );
+		launch_gh< GP_PRE, false >( P, src_kind, items, lds, st );
 	}
 	else
 	if( A.mode == GP_POST )
 	{
-		launch_gh< GP_POST, false >( P, items, lds, st );
+		launch_gh< GP_POST, false >( P, src_kind, items, lds, st );
 	}
 	else
 	{
-		launch_gh< GP_NONE, false >( P, items, lds, st );
+		launch_gh< GP_NONE, false >( P, src_kind, items, lds, st );
 	}
 
 	AVIRHIP_HIPCHECK( hipGetLastError() );
@@ -1740,7 +1862,8 @@ static void v_source_rows( const GPData* D, int row0, int row1, int& a, int& b )
 bool gpass_takes_raw( const avirhip_plan* p )
 {
 	const GPData* D = (const GPData*) p -> gpass;
-	return( D != nullptr && !p -> is_lancir && D -> sa_h != nullptr );
+	return( D != nullptr && !p -> is_lancir && ( D -> sa_h != nullptr ||
+		( D -> h_geom && D -> h_nseg <= 4 )));
 }
 
 // `iout` != nullptr: the caller's integer image (the band's first row) -- the
@@ -1849,13 +1972,13 @@ int gpass_run( avirhip_plan* p, const float* src, long src_stride, float* dst,
 
 	if( rc == 1 )
 	{
-		if( !D -> h_geom || raw != nullptr )
+		if( !D -> h_geom )
 		{
 			return( 1 );
 		}
 
 		rc = run_h( D, src, src_stride, p -> src_w, D -> mid, mid_ss, 0,
-			p -> new_w, a, b + 1, st );
+			p -> new_w, a, b + 1, st, raw, raw_type, raw_ch, raw_stride );
 	}
 
 	if( rc != 0 ) return( rc );
