@@ -606,8 +606,16 @@ static int exec_device( avirhip_plan* p, const void* src, void* dst,
 			p -> src_stride, st )) != 0 ) return( rc );
 
 		q -> path = p -> path;
+		q -> lfuse.on = ( getenv( "AVIRHIP_NO_FUSED_OUT" ) == nullptr );
+		q -> lfuse.done = 0;
+		q -> lfuse.type = p -> out_type; q -> lfuse.ch = p -> io_ch;
+		q -> lfuse.unity = p -> l_unity; q -> lfuse.out_mul = p -> l_out_mul;
+		q -> lfuse.clampv = p -> l_clamp;
+		q -> lfuse.dst = dst; q -> lfuse.stride = p -> new_stride;
+		rc = exec_device( q, p -> packed, p -> lres, row0, row1, st );
+		q -> lfuse.on = 0;
 
-		if(( rc = exec_device( q, p -> packed, p -> lres, row0, row1, st )) != 0 )
+		if( rc != 0 || q -> lfuse.done )
 		{
 			return( rc );
 		}
@@ -1103,6 +1111,7 @@ static avirhip_plan* new_plan()
 	p -> ch = 0; p -> io_ch = 0;
 	p -> l_out_mul = 1.0f; p -> l_clamp = 0.0f; p -> l_unity = 1;
 	p -> inner = nullptr; p -> l_order = 4;
+	memset( &p -> lfuse, 0, sizeof( p -> lfuse ));
 	(void) hipGetDevice( &p -> device );
 	return( p );
 }

@@ -71,6 +71,7 @@ struct GHParams
 	const void* raw;     // SRC != 0: the caller's image (integer / narrower
 	long raw_ss;         // pixels), elements per row, channels
 	int raw_ch;
+	GPLOut lout;         // on != 0: LANCIR's output stage in the store
 };
 
 // One gather output: tap t reads ld( t ); cf4( b ) returns the coefficients
@@ -1038,6 +1039,14 @@ __global__ void __launch_bounds__( 64 ) k_gh( const GHParams P )
 			}
 		}
 
+		if( LANC && P.lout.on != 0 )
+		{
+			if( jok )
+			{
+				gp_store_lancir( P.lout, r - P.dst_row0, j, o );
+			}
+		}
+		else
 		if( jok )
 		{
 			*(f4*) ( P.dst + (long) ( r - P.dst_row0 ) * P.dst_ss +
@@ -1768,9 +1777,16 @@ static int run_v( const GPData* D, const float* src, long src_ss, int width,
 static int run_h( const GPData* D, const float* src, long src_ss, int src_w,
 	float* dst, long dst_ss, int dst_row0, int dst_w, int row_lo, int row_hi,
 	hipStream_t st, const void* raw = nullptr, int raw_type = 0,
-	int raw_ch = 0, long raw_stride = 0 )
+	int raw_ch = 0, long raw_stride = 0, const GPLOut* lout = nullptr )
 {
 	GHParams P;
+	memset( &P.lout, 0, sizeof( P.lout ));
+
+	if( lout != nullptr )
+	{
+		P.lout = *lout;
+	}
+
 	P.raw = raw; P.raw_ss = raw_stride; P.raw_ch = raw_ch;
 	const int src_kind = ( raw == nullptr ? 0 : ( raw_type == AVIRHIP_U8 ? 1 :
 		( raw_type == AVIRHIP_U16 ? 2 : 3 )));
@@ -1938,6 +1954,22 @@ int gpass_run( avirhip_plan* p, const float* src, long src_stride, float* dst,
 
 		if(( rc = run_v( D, src, src_stride, p -> src_w, D -> mid, mid_ss, 0,
 			row0, row1, st )) != 0 ) return( rc );
+
+		if( p -> lfuse.on )
+		{
+			// (an inner plan: the outer plan's output stage goes into the
+			// store of this pass, its result rows are never written)
+			GPLOut L;
+			memset( &L, 0, sizeof( L ));
+			L.on = 1; L.type = p -> lfuse.type; L.ch = p -> lfuse.ch;
+			L.unity = p -> lfuse.unity; L.out_mul = p -> lfuse.out_mul;
+			L.clampv = p -> lfuse.clampv;
+			L.l4 = ( p -> new_w * p -> lfuse.ch ) & ~3;
+			L.base = p -> lfuse.dst; L.stride = p -> lfuse.stride;
+			p -> lfuse.done = 1;
+			return( run_h( D, D -> mid, mid_ss, p -> src_w, dst, dst_ss, row0,
+				p -> new_w, row0, row1, st, nullptr, 0, 0, 0, &L ));
+		}
 
 		return( run_h( D, D -> mid, mid_ss, p -> src_w, dst, dst_ss, row0,
 			p -> new_w, row0, row1, st ));

@@ -155,6 +155,73 @@ __device__ __forceinline__ void gp_store_int( const GPOut& O, const long row,
 	}
 }
 
+// LANCIR's output stage (outputScanline, lancir.h:1772-2056, as k_lancir_out /
+// k_lancir_out_pad of generic.hip spell it out) fused into the horizontal
+// pass' store: gain, then for integer elements the clamps and -- by the
+// ELEMENT's position in its scanline of l = width * ch elements -- nearest-even
+// rounding (whole groups of four) or + 0.5 truncation (the 1-3 element tail).
+struct GPLOut
+{
+	int on;
+	int type;        // AVIRHIP_U8 / AVIRHIP_U16 / AVIRHIP_F32
+	int ch;          // channels of the caller's pixels (1..4)
+	int unity;
+	float out_mul, clampv;
+	int l4;          // ( width * ch ) & ~3
+	void* base;      // the caller's rows (row 0 = the band's first row)
+	long stride;     // elements per row
+};
+
+__device__ __forceinline__ void gp_store_lancir( const GPLOut& O,
+	const long row, const int x, const f4 o )
+{
+	const float vv[ 4 ] = { o.x, o.y, o.z, o.w };
+	const long e0 = row * O.stride + (long) x * O.ch;
+#pragma unroll
+	for( int c = 0; c < 4; c++ )
+	{
+		if( c < O.ch )
+		{
+			float v = vv[ c ];
+
+			if( !O.unity )
+			{
+				v = v * O.out_mul;
+			}
+
+			if( O.type == AVIRHIP_F32 )
+			{
+				((float*) O.base )[ e0 + c ] = v;
+			}
+			else
+			{
+				unsigned int q;
+
+				if( x * O.ch + c < O.l4 )
+				{
+					v = ( v < O.clampv ? v : O.clampv );
+					v = ( v > 0.0f ? v : 0.0f );
+					q = (unsigned int) (int) rintf( v );
+				}
+				else
+				{
+					q = (unsigned int) (int) (( v > O.clampv ? O.clampv :
+						( v < 0.0f ? 0.0f : v )) + 0.5f );
+				}
+
+				if( O.type == AVIRHIP_U8 )
+				{
+					((unsigned char*) O.base )[ e0 + c ] = (unsigned char) q;
+				}
+				else
+				{
+					((unsigned short*) O.base )[ e0 + c ] = (unsigned short) q;
+				}
+			}
+		}
+	}
+}
+
 // Host side of a recognised axis.
 struct GPAxisHost
 {

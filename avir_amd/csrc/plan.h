@@ -113,6 +113,10 @@ struct avirhip_plan
 	// output stage (nullptr: this plan runs its own kernels)
 	avirhip_plan* inner;
 	int l_order; // LANCIR: channel count whose summation order the kernels use
+	// (set on an INNER plan by its owner around a call: the owner's output
+	// stage, fused into the last pass when that is a pass kernel)
+	struct { int on, done, type, ch, unity; float out_mul, clampv; void* dst;
+		long stride; } lfuse;
 
 	int path;       // forced path (0 = auto)
 	int fused_ok;   // tiled kernels: bit 0 = two-pass (path 2), bit 1 = fused (3)
