@@ -600,12 +600,21 @@ static int exec_device( avirhip_plan* p, const void* src, void* dst,
 		const size_t es = ( p -> in_type == AVIRHIP_U8 ? 1 :
 			( p -> in_type == AVIRHIP_U16 ? 2 : 4 ));
 
-		if(( rc = launch_pack( (const char*) src + (size_t) sa *
-			p -> src_stride * es, p -> in_type, p -> packed + (size_t) sa *
-			p -> src_w * 4, p -> src_w, sb - sa + 1, p -> io_ch, 4,
-			p -> src_stride, st )) != 0 ) return( rc );
-
 		q -> path = p -> path;
+
+		// the inner plan's first pass reads this image itself where it can;
+		// otherwise the pack pass makes its float RGBA copy
+		q -> lraw.on = ( getenv( "AVIRHIP_NO_FUSED_OUT" ) == nullptr &&
+			gpass_lancir_takes_raw( q ));
+
+		q -> lraw.ptr = src; q -> lraw.type = p -> in_type;
+		q -> lraw.ch = p -> io_ch; q -> lraw.stride = p -> src_stride;
+
+		if( !q -> lraw.on && ( rc = launch_pack( (const char*) src +
+			(size_t) sa * p -> src_stride * es, p -> in_type, p -> packed +
+			(size_t) sa * p -> src_w * 4, p -> src_w, sb - sa + 1, p -> io_ch,
+			4, p -> src_stride, st )) != 0 ) return( rc );
+
 		q -> lfuse.on = ( getenv( "AVIRHIP_NO_FUSED_OUT" ) == nullptr );
 		q -> lfuse.done = 0;
 		q -> lfuse.type = p -> out_type; q -> lfuse.ch = p -> io_ch;
@@ -614,6 +623,7 @@ static int exec_device( avirhip_plan* p, const void* src, void* dst,
 		q -> lfuse.dst = dst; q -> lfuse.stride = p -> new_stride;
 		rc = exec_device( q, p -> packed, p -> lres, row0, row1, st );
 		q -> lfuse.on = 0;
+		q -> lraw.on = 0;
 
 		if( rc != 0 || q -> lfuse.done )
 		{
@@ -1112,6 +1122,7 @@ static avirhip_plan* new_plan()
 	p -> l_out_mul = 1.0f; p -> l_clamp = 0.0f; p -> l_unity = 1;
 	p -> inner = nullptr; p -> l_order = 4;
 	memset( &p -> lfuse, 0, sizeof( p -> lfuse ));
+	memset( &p -> lraw, 0, sizeof( p -> lraw ));
 	(void) hipGetDevice( &p -> device );
 	return( p );
 }

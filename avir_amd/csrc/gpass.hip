@@ -56,6 +56,10 @@ struct GVParams
 	int blk;             // output rows per block
 	int rs, rc;          // ring sizes (rows, powers of two): source, C / G
 	GPOut out;           // on != 0 (whole-pixel lanes): integer output stage
+	const void* raw;     // != nullptr (whole-pixel lanes): the caller's image
+	long raw_ss;         // (integer / narrower pixels), elements per row,
+	int raw_ch, raw_kind; // channels, 1 uint8 / 2 uint16 / 3 float
+	long raw_elems;      // elements of that image (the loader's bound)
 };
 
 struct GHParams
@@ -71,6 +75,7 @@ struct GHParams
 	const void* raw;     // SRC != 0: the caller's image (integer / narrower
 	long raw_ss;         // pixels), elements per row, channels
 	int raw_ch;
+	long raw_elems;      // elements of that image (the loader's bound)
 	GPLOut lout;         // on != 0: LANCIR's output stage in the store
 };
 
@@ -260,6 +265,77 @@ __device__ __forceinline__ T gp_dot( const int nt_, LD ld, CF cf4,
 	}
 
 	return( acc );
+}
+
+// One raw pixel (1 uint8, 2 uint16, 3 float elements; `ch` of them) as float
+// RGBA with zero padding: ONE load of four elements at the pixel's (possibly
+// unaligned) address -- what it reads past the pixel is dropped; only where
+// those four elements would cross the end of the image (its last pixel) are
+// the channels loaded one by one. Per-element loads everywhere cost three or
+// four vector-memory instructions per pixel and as much time as the pack pass
+// they replace. (Buffer loads force dword alignment: global loads it is.)
+__device__ __forceinline__ f4 gp_load_raw( const void* const base,
+	const int kind, const int ch, const long eoff, const long total )
+{
+	float v[ 4 ] = { 0.0f, 0.0f, 0.0f, 0.0f };
+	const bool fast = ( eoff + 4 <= total );
+	// integer elements, branch-free: the load starts at most at total - 4 and
+	// the value is shifted down by the elements it started early (non-zero
+	// for the image's last pixel only; the image holds >= 4 elements)
+	const long ea = min( eoff, total - 4 );
+	const int sh = (int) ( eoff - ea );
+
+	if( kind == 1 )
+	{
+		typedef unsigned int u32u __attribute__(( aligned( 1 )));
+		const unsigned int w = *(const u32u*) ( (const unsigned char*) base +
+			ea ) >> ( 8 * sh );
+#pragma unroll
+		for( int c = 0; c < 4; c++ )
+		{
+			v[ c ] = ( c < ch ? (float) (( w >> ( 8 * c )) & 0xffu ) : 0.0f );
+		}
+	}
+	else
+	if( kind == 2 )
+	{
+		typedef unsigned long long u64u __attribute__(( aligned( 2 )));
+		const unsigned long long w = *(const u64u*) (
+			(const unsigned short*) base + ea ) >> ( 16 * sh );
+#pragma unroll
+		for( int c = 0; c < 4; c++ )
+		{
+			v[ c ] = ( c < ch ? (float) (unsigned int) (( w >> ( 16 * c )) &
+				0xffffull ) : 0.0f );
+		}
+	}
+	else
+	{
+		const float* const p = (const float*) base + eoff;
+
+		if( fast )
+		{
+			typedef float f4u __attribute__(( ext_vector_type( 4 ),
+				aligned( 4 )));
+			const f4u w = *(const f4u*) p;
+			const float ww[ 4 ] = { w.x, w.y, w.z, w.w };
+#pragma unroll
+			for( int c = 0; c < 4; c++ )
+			{
+				v[ c ] = ( c < ch ? ww[ c ] : 0.0f );
+			}
+		}
+		else
+		{
+			for( int c = 0; c < ch; c++ )
+			{
+				v[ c ] = p[ c ];
+			}
+		}
+	}
+
+	f4 o; o.x = v[ 0 ]; o.y = v[ 1 ]; o.z = v[ 2 ]; o.w = v[ 3 ];
+	return( o );
 }
 
 // ---------------------------------------------------------------------
@@ -600,9 +676,41 @@ __global__ void __launch_bounds__( 64 ) k_gv( const GVParams P )
 		gp_dma( rsrc, slot, r * srow_b + dpx * 16 );
 	};
 
-	for( int k = 0; k < GV_PF; k++ )
+	// Raw sources (integer / narrower pixels, whole-pixel lanes): a lane loads
+	// its pixel of row u + 2 during step u, converts and writes it into the
+	// queue slot (or ring row) of row u + 1 at the start of the next step --
+	// the (float) cast and zero padding of the pack pass, in the loader.
+	const bool typed = ( WP == 2 && P.raw != nullptr );
+
+	f4 trv = (f4) 0.0f;
+
+	auto t_load = [&]( const int u )
 	{
-		issue_pair( pa + k );
+		trv = gp_load_raw( P.raw, P.raw_kind, P.raw_ch, (long) gp_clamp( u,
+			slast ) * P.raw_ss + (long) dpx * P.raw_ch, P.raw_elems );
+	};
+
+	auto t_store = [&]( const int u ) // row u: queue slot qr, or its ring row
+	{
+		const f4 o = trv;
+		const int off = ( MODE == GP_PRE || RW > 0 ?
+			( P.rs + P.rc ) * ROWB + qr * 1024 : ( u & smask ) * ROWB );
+
+		((f4*) ( smem + off ))[ lane ] = o;
+	};
+
+	if( typed )
+	{
+		t_load( pa );
+		t_store( pa );
+		t_load( pa + 1 );
+	}
+	else
+	{
+		for( int k = 0; k < GV_PF; k++ )
+		{
+			issue_pair( pa + k );
+		}
 	}
 
 	VT qnext = (VT) 0.0f; // the next step's row of the queue
@@ -638,23 +746,32 @@ __global__ void __launch_bounds__( 64 ) k_gv( const GVParams P )
 			return;
 		}
 
-		if( RPG == 1 || ( i & 1 ) == 0 )
+		if( typed )
 		{
-#ifdef GP_DBG
-			if( !( P.dbg & 8 ))
-#endif
-			issue_pair(( RPG == 2 ? u >> 1 : u ) + GV_PF );
-		}
-
-		if( RPG == 1 || ( i & 1 ))
-		{
-			// row u + 1 opens a group: it is the oldest one in flight
-#ifdef GP_DBG
-			if( !( P.dbg & 4 ))
-#endif
-			GP_WAIT_VM( 4 ); // == GV_PF - 1
-
 			qr = ( qr == GV_PF ? 0 : qr + 1 );
+			t_store( u + 1 );
+			t_load( u + 2 );
+		}
+		else
+		{
+			if( RPG == 1 || ( i & 1 ) == 0 )
+			{
+#ifdef GP_DBG
+				if( !( P.dbg & 8 ))
+#endif
+				issue_pair(( RPG == 2 ? u >> 1 : u ) + GV_PF );
+			}
+
+			if( RPG == 1 || ( i & 1 ))
+			{
+				// row u + 1 opens a group: it is the oldest one in flight
+#ifdef GP_DBG
+				if( !( P.dbg & 4 ))
+#endif
+				GP_WAIT_VM( 4 ); // == GV_PF - 1
+
+				qr = ( qr == GV_PF ? 0 : qr + 1 );
+			}
 		}
 
 		// this step's row was read from the queue during the last one
@@ -858,24 +975,18 @@ __global__ void __launch_bounds__( 64 ) k_gh( const GHParams P )
 	}
 
 	// typed sources: the row in flight (up to four pieces, four channels)
-	typedef typename GHElem< SRC > :: T Tin;
-	float rw[ SRC != 0 ? 4 : 1 ][ 4 ];
+	f4 rw[ SRC != 0 ? 4 : 1 ];
 
 	auto t_load = [&]( const int r )
 	{
-		const Tin* const row = (const Tin*) P.raw + (long) r * P.raw_ss;
 #pragma unroll
 		for( int k = 0; k < ( SRC != 0 ? 4 : 1 ); k++ )
 		{
 			if( k < P.nseg )
 			{
-				const Tin* const px = row + (long) gp_clamp( slo + k * 64 + lane,
-					slast ) * P.raw_ch;
-#pragma unroll
-				for( int c = 0; c < 4; c++ )
-				{
-					rw[ k ][ c ] = ( c < P.raw_ch ? (float) px[ c ] : 0.0f );
-				}
+				rw[ k ] = gp_load_raw( P.raw, SRC, P.raw_ch, (long) r * P.raw_ss +
+					(long) gp_clamp( slo + k * 64 + lane, slast ) * P.raw_ch,
+					P.raw_elems );
 			}
 		}
 	};
@@ -887,10 +998,7 @@ __global__ void __launch_bounds__( 64 ) k_gh( const GHParams P )
 		{
 			if( k < P.nseg )
 			{
-				f4 o;
-				o.x = rw[ k ][ 0 ]; o.y = rw[ k ][ 1 ];
-				o.z = rw[ k ][ 2 ]; o.w = rw[ k ][ 3 ];
-				sbuf[ buf * P.sbuf + k * 64 + lane ] = o;
+				sbuf[ buf * P.sbuf + k * 64 + lane ] = rw[ k ];
 			}
 		}
 	};
@@ -1686,10 +1794,21 @@ static void launch_gh( const GHParams& P, int src_kind, int items, size_t lds,
 
 static int run_v( const GPData* D, const float* src, long src_ss, int width,
 	float* dst, long dst_ss, int dst_row0, int row_lo, int row_hi,
-	hipStream_t st, const GPOut* out = nullptr )
+	hipStream_t st, const GPOut* out = nullptr, const void* raw = nullptr,
+	int raw_type = 0, int raw_ch = 0, long raw_stride = 0 )
 {
 	GVParams P;
 	memset( &P.out, 0, sizeof( P.out ));
+	P.raw = raw; P.raw_ss = raw_stride; P.raw_ch = raw_ch;
+	P.raw_kind = ( raw_type == AVIRHIP_U8 ? 1 : ( raw_type == AVIRHIP_U16 ? 2 : 3 ));
+	// (rows are raw_stride elements apart; the last one ends with its pixels)
+	P.raw_elems = (long) ( D -> v.a.in_len - 1 ) * raw_stride +
+		(long) width * raw_ch;
+
+	if( raw != nullptr && P.raw_elems < 4 )
+	{
+		return( 1 );
+	}
 
 	if( out != nullptr )
 	{
@@ -1714,9 +1833,10 @@ static int run_v( const GPData* D, const float* src, long src_ss, int width,
 			( P.rs + P.rc ) * 1024 + GV_QB + 6 * 1024 <= 64 * 1024 ? 2 : 1 );
 	}
 
-	if( out != nullptr )
+	if( out != nullptr || raw != nullptr )
 	{
-		// the integer output stage converts whole pixels
+		// the integer output stage and the raw-source loader handle whole
+		// pixels
 		if(( P.rs + P.rc ) * 1024 + GV_QB + 6 * 1024 > 64 * 1024 )
 		{
 			return( 1 );
@@ -1792,6 +1912,13 @@ static int run_h( const GPData* D, const float* src, long src_ss, int src_w,
 		( raw_type == AVIRHIP_U16 ? 2 : 3 )));
 
 	if( raw != nullptr && ( D -> h_nseg > 4 || D -> h.a.lanc ))
+	{
+		return( 1 );
+	}
+
+	P.raw_elems = (long) ( row_hi - 1 ) * raw_stride + (long) src_w * raw_ch;
+
+	if( raw != nullptr && P.raw_elems < 4 )
 	{
 		return( 1 );
 	}
@@ -1873,6 +2000,18 @@ static void v_source_rows( const GPData* D, int row0, int row1, int& a, int& b )
 // Runs both passes for output rows [row0, row1) of a float RGBA plan. Returns
 // 1 when the call cannot take this path (alignment), so that the caller falls
 // back.
+// LANCIR (an inner plan): whether its vertical pass -- the first one -- can
+// read the owner's integer / narrower image itself (whole-pixel lanes).
+bool gpass_lancir_takes_raw( const avirhip_plan* p )
+{
+	const GPData* D = (const GPData*) p -> gpass;
+	const int lpath = ( p -> path != 0 ? p -> path : p -> auto_path );
+
+	return( D != nullptr && p -> is_lancir && lpath == 5 && D -> v_geom &&
+		D -> h_geom && p -> src_w > 48 &&
+		( D -> v_rs + D -> v_rc ) * 1024 + GV_QB + 6 * 1024 <= 64 * 1024 );
+}
+
 // Whether the first pass reads the caller's image as it is (integer types,
 // 1-4 channels): AVIR plans whose horizontal axis streams (sacc.hip).
 bool gpass_takes_raw( const avirhip_plan* p )
@@ -1952,6 +2091,16 @@ int gpass_run( avirhip_plan* p, const float* src, long src_stride, float* dst,
 		// rows of the band
 		const long mid_ss = (long) p -> src_w * 4;
 
+		if( p -> lraw.on )
+		{
+			// (an inner plan: the owner's image, read as it is)
+			rc = run_v( D, src, src_stride, p -> src_w, D -> mid, mid_ss, 0,
+				row0, row1, st, nullptr, p -> lraw.ptr, p -> lraw.type,
+				p -> lraw.ch, p -> lraw.stride );
+
+			if( rc != 0 ) return( rc );
+		}
+		else
 		if(( rc = run_v( D, src, src_stride, p -> src_w, D -> mid, mid_ss, 0,
 			row0, row1, st )) != 0 ) return( rc );
 

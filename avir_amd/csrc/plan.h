@@ -117,6 +117,7 @@ struct avirhip_plan
 	// stage, fused into the last pass when that is a pass kernel)
 	struct { int on, done, type, ch, unity; float out_mul, clampv; void* dst;
 		long stride; } lfuse;
+	struct { int on, type, ch; const void* ptr; long stride; } lraw;
 
 	int path;       // forced path (0 = auto)
 	int fused_ok;   // tiled kernels: bit 0 = two-pass (path 2), bit 1 = fused (3)
@@ -219,6 +220,7 @@ void gpass_release( avirhip_plan* p );
 bool gpass_ok( const avirhip_plan* p );
 bool gpass_preferred( const avirhip_plan* p );
 bool gpass_takes_raw( const avirhip_plan* p );
+bool gpass_lancir_takes_raw( const avirhip_plan* p );
 int gpass_run( avirhip_plan* p, const float* src, long src_stride, float* dst,
 	int row0, int row1, hipStream_t st, const void* raw = nullptr,
 	int raw_type = 0, int raw_ch = 0, long raw_stride = 0,
