@@ -1163,11 +1163,11 @@ def test_avir_pass_kernels_are_the_default_for_general_ratios():
         p = r.plan(sw, sh, nw, nh, 4)
         assert lib.avirhip_plan_get_path(p) == want, (sw, sh, nw, nh)
     # integer sources: the streaming kernel reads them (k >= 2 on both axes);
-    # upsizing takes the pass kernels once the frame is large
+    # upsizing takes the pass kernels (both ends fused: no pack, no epilogue)
     r8 = avir_amd.CImageResizer(8)
     for (sw, sh, nw, nh, want) in [(5184, 3456, 1920, 1280, abi.PATH_GPASS),
                                    (1920, 1080, 2500, 1400, abi.PATH_GPASS),
-                                   (640, 480, 1024, 768, abi.PATH_TILED)]:
+                                   (640, 480, 1024, 768, abi.PATH_GPASS)]:
         p = r8.plan(sw, sh, nw, nh, 3, 0.0, None, abi.U8, abi.U8)
         assert lib.avirhip_plan_get_path(p) == want, (sw, sh, nw, nh)
 
