@@ -752,8 +752,9 @@ static int exec_device( avirhip_plan* p, const void* src, void* dst,
 			// integer output without gamma / error diffusion: the last pass
 			// converts and stores into the caller's image itself
 			void* iout = ( !direct && !p -> gamma &&
-				p -> dither == AVIRHIP_DITHER_DEF &&
-				( p -> out_type == AVIRHIP_U8 || p -> out_type == AVIRHIP_U16 ) &&
+				(( p -> dither == AVIRHIP_DITHER_DEF &&
+				( p -> out_type == AVIRHIP_U8 || p -> out_type == AVIRHIP_U16 )) ||
+				p -> out_type == AVIRHIP_F32 ) &&
 				getenv( "AVIRHIP_NO_FUSED_OUT" ) == nullptr ? dst : nullptr );
 
 			if( !graw && need_pack && ( rc = do_pack()) != 0 ) return( rc );

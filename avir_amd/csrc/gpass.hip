@@ -1642,8 +1642,9 @@ bool gpass_preferred( const avirhip_plan* p )
 		p -> in_type == AVIRHIP_U16 || p -> in_type == AVIRHIP_F32 ) &&
 		D -> h_geom && D -> h_nseg <= 4 );
 
-	const bool fused_out = ( !p -> gamma && p -> dither == AVIRHIP_DITHER_DEF &&
-		( p -> out_type == AVIRHIP_U8 || p -> out_type == AVIRHIP_U16 ));
+	const bool fused_out = ( !p -> gamma && (( p -> dither == AVIRHIP_DITHER_DEF &&
+		( p -> out_type == AVIRHIP_U8 || p -> out_type == AVIRHIP_U16 )) ||
+		p -> out_type == AVIRHIP_F32 ));
 
 	return(( raw_in && fused_out ) ||
 		(long) p -> new_w * p -> new_h >= 2000000L );
@@ -2049,8 +2050,11 @@ int gpass_run( avirhip_plan* p, const float* src, long src_stride, float* dst,
 
 	if( iout != nullptr )
 	{
-		if( p -> is_lancir || p -> gamma || p -> dither != AVIRHIP_DITHER_DEF ||
-			( p -> out_type != AVIRHIP_U8 && p -> out_type != AVIRHIP_U16 ) ||
+		if( p -> is_lancir || p -> gamma ||
+			( p -> out_type != AVIRHIP_F32 &&
+			p -> dither != AVIRHIP_DITHER_DEF ) ||
+			( p -> out_type != AVIRHIP_U8 && p -> out_type != AVIRHIP_U16 &&
+			!( p -> out_type == AVIRHIP_F32 && p -> io_ch < 4 )) ||
 			( p -> out_type == AVIRHIP_U8 && p -> io_ch == 4 &&
 			(( (uintptr_t) iout & 3 ) != 0 )))
 		{

@@ -86,7 +86,7 @@ __device__ __forceinline__ void gp_wait_vm( const int n )
 struct GPOut
 {
 	int on;          // 0: float RGBA rows (no output stage)
-	int type;        // AVIRHIP_U8 / AVIRHIP_U16
+	int type;        // AVIRHIP_U8 / AVIRHIP_U16; AVIRHIP_F32 with 1-3 channels
 	int ch;          // channels of the caller's pixels (1..4)
 	int use_tr;
 	float tr_mul, tr_muli, pk_out;
@@ -104,6 +104,17 @@ __device__ __forceinline__ void gp_store_int( const GPOut& O, const long row,
 	const int x, const f4 o )
 {
 	const float v[ 4 ] = { o.x, o.y, o.z, o.w };
+
+	if( O.type == AVIRHIP_F32 )
+	{
+		// float pixels of 1-3 channels: the padding is dropped, nothing else
+		float* const p = (float*) O.base + row * O.stride + (long) x * O.ch;
+		p[ 0 ] = v[ 0 ];
+		if( O.ch > 1 ) p[ 1 ] = v[ 1 ];
+		if( O.ch > 2 ) p[ 2 ] = v[ 2 ];
+		return;
+	}
+
 	unsigned int q[ 4 ];
 #pragma unroll
 	for( int c = 0; c < 4; c++ )
