@@ -1513,8 +1513,7 @@ int gpass_prepare( avirhip_plan* p )
 		}
 		else
 		{
-			rw = ( A.mode == GP_POST && (( A.nt >= 18 && A.nt <= 22 ) ||
-				A.nt == 24 ));
+			rw = ( A.mode == GP_POST && A.nt >= 13 && A.nt <= 25 );
 		}
 
 		if( rw )
@@ -1624,6 +1623,15 @@ bool gpass_preferred( const avirhip_plan* p )
 	// two more launches not to matter -- 1920x1080 -> 2500x1400 RGB u8: 0.068
 	// against 0.094 ms on the tiles (whose loader converts in place), but
 	// 640x480 -> 1024x768: 0.036 against 0.032
+	// both axes downsize by 1 < k < 2 (zero-stuffed 13 .. 25-tap gathers, then
+	// the correction FIR): ahead of the tiles on large frames (3840x2160 ->
+	// 2560x1440 RGBA float 0.137 against 0.179 ms), even with them at 1080p
+	if( D -> h.a.mode == GP_POST && D -> v.a.mode == GP_POST &&
+		D -> sa_h == nullptr && D -> sa_v == nullptr )
+	{
+		return( (long) p -> new_w * p -> new_h >= 2000000L );
+	}
+
 	if( D -> h.a.mode != GP_PRE || D -> v.a.mode != GP_PRE )
 	{
 		return( false );
@@ -1743,12 +1751,21 @@ static void launch_gv( const GVParams& P, int wp, int items, size_t lds,
 	{
 		switch( nt )
 		{
+			// (13 .. 25 taps: the 1 < k < 2 plans, avir.h bank lengths 26 .. 50
+			// over the zero-stuffed view)
+			case 13: GV_LAUNCH( GP_POST, false, 13, 16 ); break;
+			case 14: GV_LAUNCH( GP_POST, false, 14, 16 ); break;
+			case 15: GV_LAUNCH( GP_POST, false, 15, 16 ); break;
+			case 16: GV_LAUNCH( GP_POST, false, 16, 16 ); break;
+			case 17: GV_LAUNCH( GP_POST, false, 17, 32 ); break;
 			case 18: GV_LAUNCH( GP_POST, false, 18, 32 ); break;
 			case 19: GV_LAUNCH( GP_POST, false, 19, 32 ); break;
 			case 20: GV_LAUNCH( GP_POST, false, 20, 32 ); break;
 			case 21: GV_LAUNCH( GP_POST, false, 21, 32 ); break;
 			case 22: GV_LAUNCH( GP_POST, false, 22, 32 ); break;
+			case 23: GV_LAUNCH( GP_POST, false, 23, 32 ); break;
 			case 24: GV_LAUNCH( GP_POST, false, 24, 32 ); break;
+			case 25: GV_LAUNCH( GP_POST, false, 25, 32 ); break;
 			default: GV_LAUNCH( GP_POST, false, 0, 0 ); break;
 		}
 	}
