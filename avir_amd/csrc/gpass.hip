@@ -45,844 +45,6 @@
 
 namespace avirhip {
 
-struct GVParams
-{
-	const float* src; long src_ss; int width; // px per row, floats per row
-	float* dst; long dst_ss; int dst_row0;
-	GPAxis ax;
-	int row_lo, row_hi;  // output rows to produce
-	int dbg;             // timing ablations (GP_DBG builds only)
-	int nstrips, chunk;  // 32-px strips, output rows per work item
-	int blk;             // output rows per block
-	int rs, rc;          // ring sizes (rows, powers of two): source, C / G
-	GPOut out;           // on != 0 (whole-pixel lanes): integer output stage
-	const void* raw;     // != nullptr (whole-pixel lanes): the caller's image
-	long raw_ss;         // (integer / narrower pixels), elements per row,
-	int raw_ch, raw_kind; // channels, 1 uint8 / 2 uint16 / 3 float
-	long raw_elems;      // elements of that image (the loader's bound)
-};
-
-struct GHParams
-{
-	const float* src; long src_ss; int src_w;
-	float* dst; long dst_ss; int dst_row0; int dst_w;
-	GPAxis ax;
-	int row_lo, row_hi;  // rows (of both images) to process
-	int nstrips, ow, chunk; // outputs per strip, rows per work item
-	const int* seg;      // [nstrips][4]: source lo, count; mid lo, count
-	int nseg;            // DMA instructions per row (uniform)
-	int sbuf, mbuf;      // LDS pixels per source row buffer / mid buffer
-	const void* raw;     // SRC != 0: the caller's image (integer / narrower
-	long raw_ss;         // pixels), elements per row, channels
-	int raw_ch;
-	long raw_elems;      // elements of that image (the loader's bound)
-	GPLOut lout;         // on != 0: LANCIR's output stage in the store
-};
-
-// One gather output: tap t reads ld( t ); cf4( b ) returns the coefficients
-// of taps 4b .. 4b + 3 (rows are padded to a multiple of four; padded taps are
-// never multiplied: x * 0 is not a no-op for non-finite x). NTC > 0: the tap
-// count is a compile-time constant and everything unrolls.
-//
-// LANCIR's summation order depends on the image's channel count (the lane
-// structure of resize1..4, lancir.h:2102-2544; generic.hip spells it out):
-// `lord` = 4: even and odd taps; 1, 2, 3: four sums over taps 4g + j, folded
-// (s0 + s2) + (s1 + s3) for 1 and 2 channels, (s0 + s1) + (s2 + s3) for 3, with
-// the two tail taps of a length 4n + 2 entering where that code adds them --
-// for RGB differently in channel 0 (`ch0`: this lane's .x is channel 0).
-template< bool LANC, typename T, int NTC, typename LD, typename CF >
-__device__ __forceinline__ T gp_dot( const int nt_, LD ld, CF cf4,
-	const int lord = 4, const bool ch0 = true )
-{
-	const int nt = ( NTC > 0 ? NTC : nt_ );
-	const int nb = nt >> 2;
-
-	if( LANC && lord != 4 )
-	{
-		T a0, a1, a2, a3;
-		{
-			const f4 c = cf4( 0 );
-			a0 = c.x * ld( 0 );
-			a1 = c.y * ld( 1 );
-			a2 = c.z * ld( 2 );
-			a3 = c.w * ld( 3 );
-		}
-
-		if( NTC > 0 )
-		{
-#pragma unroll
-			for( int b = 1; b < ( NTC > 0 ? NTC / 4 : 1 ); b++ )
-			{
-				const f4 c = cf4( b );
-				a0 = a0 + c.x * ld( 4 * b );
-				a1 = a1 + c.y * ld( 4 * b + 1 );
-				a2 = a2 + c.z * ld( 4 * b + 2 );
-				a3 = a3 + c.w * ld( 4 * b + 3 );
-			}
-		}
-		else
-		{
-			for( int b = 1; b < nb; b++ )
-			{
-				const f4 c = cf4( b );
-				a0 = a0 + c.x * ld( 4 * b );
-				a1 = a1 + c.y * ld( 4 * b + 1 );
-				a2 = a2 + c.z * ld( 4 * b + 2 );
-				a3 = a3 + c.w * ld( 4 * b + 3 );
-			}
-		}
-
-		if( nt & 2 )
-		{
-			const f4 c = cf4( nb );
-			const T t0 = c.x * ld( 4 * nb );
-			const T t1 = c.y * ld( 4 * nb + 1 );
-
-			if( lord == 3 )
-			{
-				a0 = a0 + t0;
-				T r = (( a0 + a1 ) + ( a2 + a3 )) + t1;     // channels 1, 2
-				const T r0 = ( a0 + ( a1 + t1 )) + ( a2 + a3 ); // channel 0
-
-				if( ch0 )
-				{
-					r.x = r0.x;
-				}
-
-				return( r );
-			}
-
-			return((( a0 + a2 ) + t0 ) + (( a1 + a3 ) + t1 ));
-		}
-
-		if( lord == 3 )
-		{
-			return(( a0 + a1 ) + ( a2 + a3 ));
-		}
-
-		return(( a0 + a2 ) + ( a1 + a3 ));
-	}
-
-	if( LANC )
-	{
-		// (t0*p0 + t2*p2 + ...) + (t1*p1 + t3*p3 + ...), bare first products
-		// (lancir.h:2482-2515); nt is even
-		T ea, oa;
-		int b = 0;
-
-		if( nt >= 4 )
-		{
-			const f4 c = cf4( 0 );
-			ea = c.x * ld( 0 );
-			oa = c.y * ld( 1 );
-			ea = ea + c.z * ld( 2 );
-			oa = oa + c.w * ld( 3 );
-			b = 1;
-		}
-		else
-		{
-			const f4 c = cf4( 0 );
-			ea = c.x * ld( 0 );
-			oa = c.y * ld( 1 );
-			return( ea + oa );
-		}
-		if( NTC > 0 )
-		{
-#pragma unroll
-			for( int bb = 1; bb < ( NTC > 0 ? NTC / 4 : 1 ); bb++ )
-			{
-				const f4 c = cf4( bb );
-				ea = ea + c.x * ld( 4 * bb );
-				oa = oa + c.y * ld( 4 * bb + 1 );
-				ea = ea + c.z * ld( 4 * bb + 2 );
-				oa = oa + c.w * ld( 4 * bb + 3 );
-			}
-		}
-		else
-		{
-#pragma unroll 2
-			for( ; b < nb; b++ )
-			{
-				const f4 c = cf4( b );
-				ea = ea + c.x * ld( 4 * b );
-				oa = oa + c.y * ld( 4 * b + 1 );
-				ea = ea + c.z * ld( 4 * b + 2 );
-				oa = oa + c.w * ld( 4 * b + 3 );
-			}
-		}
-
-		if( nt & 2 )
-		{
-			const f4 c = cf4( nb );
-			ea = ea + c.x * ld( 4 * nb );
-			oa = oa + c.y * ld( 4 * nb + 1 );
-		}
-
-		return( ea + oa );
-	}
-
-	T acc = (T) 0.0f;
-
-	if( NTC > 0 )
-	{
-#pragma unroll
-		for( int b = 0; b < ( NTC > 0 ? NTC / 4 : 1 ); b++ )
-		{
-			const f4 c = cf4( b );
-			acc = acc + c.x * ld( 4 * b );
-			acc = acc + c.y * ld( 4 * b + 1 );
-			acc = acc + c.z * ld( 4 * b + 2 );
-			acc = acc + c.w * ld( 4 * b + 3 );
-		}
-	}
-	else
-	{
-#pragma unroll 2
-		for( int b = 0; b < nb; b++ )
-		{
-			const f4 c = cf4( b );
-			acc = acc + c.x * ld( 4 * b );
-			acc = acc + c.y * ld( 4 * b + 1 );
-			acc = acc + c.z * ld( 4 * b + 2 );
-			acc = acc + c.w * ld( 4 * b + 3 );
-		}
-	}
-
-	if( nt & 3 )
-	{
-		const f4 c = cf4( nb );
-		acc = acc + c.x * ld( 4 * nb );
-
-		if(( nt & 3 ) > 1 )
-		{
-			acc = acc + c.y * ld( 4 * nb + 1 );
-		}
-
-		if(( nt & 3 ) > 2 )
-		{
-			acc = acc + c.z * ld( 4 * nb + 2 );
-		}
-	}
-
-	return( acc );
-}
-
-// One raw pixel (1 uint8, 2 uint16, 3 float elements; `ch` of them) as float
-// RGBA with zero padding: ONE load of four elements at the pixel's (possibly
-// unaligned) address -- what it reads past the pixel is dropped; only where
-// those four elements would cross the end of the image (its last pixel) are
-// the channels loaded one by one. Per-element loads everywhere cost three or
-// four vector-memory instructions per pixel and as much time as the pack pass
-// they replace. (Buffer loads force dword alignment: global loads it is.)
-__device__ __forceinline__ f4 gp_load_raw( const void* const base,
-	const int kind, const int ch, const long eoff, const long total )
-{
-	float v[ 4 ] = { 0.0f, 0.0f, 0.0f, 0.0f };
-	const bool fast = ( eoff + 4 <= total );
-	// integer elements, branch-free: the load starts at most at total - 4 and
-	// the value is shifted down by the elements it started early (non-zero
-	// for the image's last pixel only; the image holds >= 4 elements)
-	const long ea = min( eoff, total - 4 );
-	const int sh = (int) ( eoff - ea );
-
-	if( kind == 1 )
-	{
-		typedef unsigned int u32u __attribute__(( aligned( 1 )));
-		const unsigned int w = *(const u32u*) ( (const unsigned char*) base +
-			ea ) >> ( 8 * sh );
-#pragma unroll
-		for( int c = 0; c < 4; c++ )
-		{
-			v[ c ] = ( c < ch ? (float) (( w >> ( 8 * c )) & 0xffu ) : 0.0f );
-		}
-	}
-	else
-	if( kind == 2 )
-	{
-		typedef unsigned long long u64u __attribute__(( aligned( 2 )));
-		const unsigned long long w = *(const u64u*) (
-			(const unsigned short*) base + ea ) >> ( 16 * sh );
-#pragma unroll
-		for( int c = 0; c < 4; c++ )
-		{
-			v[ c ] = ( c < ch ? (float) (unsigned int) (( w >> ( 16 * c )) &
-				0xffffull ) : 0.0f );
-		}
-	}
-	else
-	{
-		const float* const p = (const float*) base + eoff;
-
-		if( fast )
-		{
-			typedef float f4u __attribute__(( ext_vector_type( 4 ),
-				aligned( 4 )));
-			const f4u w = *(const f4u*) p;
-			const float ww[ 4 ] = { w.x, w.y, w.z, w.w };
-#pragma unroll
-			for( int c = 0; c < 4; c++ )
-			{
-				v[ c ] = ( c < ch ? ww[ c ] : 0.0f );
-			}
-		}
-		else
-		{
-			for( int c = 0; c < ch; c++ )
-			{
-				v[ c ] = p[ c ];
-			}
-		}
-	}
-
-	f4 o; o.x = v[ 0 ]; o.y = v[ 1 ]; o.z = v[ 2 ]; o.w = v[ 3 ];
-	return( o );
-}
-
-// ---------------------------------------------------------------------
-// vertical pass
-// ---------------------------------------------------------------------
-
-// One source row per step: the row's pixels travel global memory -> register
-// queue (GV_PF rows in flight, statically indexed: the step loop is unrolled
-// GV_PF times) -> whatever the mode keeps of them:
-//   PRE   a 7-row FIR window in registers (statically indexed too); each
-//         step yields one row of C, stored in the LDS ring the gathers read. The clamped source view makes FIR( Sext )
-//         the clamped view of C for EVERY index (rows before the first / after
-//         the last are constant), so there are no edge cases, only clamped
-//         row loads; rows of C above the zero-stuffed view's end are zero.
-//   NONE  the row goes into the LDS source ring.
-//   POST  the same, and gather outputs go through a second LDS ring that the
-//         correction FIR reads.
-// After every step the outputs whose last input has arrived are produced (a
-// wave-uniform while loop). LDS holds only what is addressed dynamically:
-// rs rows >= NT + 1 of source (NONE / POST), rc rows of C (>= NT + 1) or of
-// gather outputs (8).
-#define GV_PF 5 // DMA groups in flight (one of them is read a step ahead)
-#define GV_QB (( GV_PF + 2 ) * 1024 ) // landing queue: GV_PF + 1 slots, a dump
-
-// RW > 0 (needs NTC > 0): the gather window lives in REGISTERS. An output is
-// produced in the very step its last input row arrives, so its window is
-// always "the last NTC rows": with the step loop unrolled RW times (RW a power
-// of two >= NTC) the window's ring slots are compile-time constants -- no LDS
-// reads for the taps at all, LDS only holds the landing queue and the tables.
-// WP: lane width. 1 = half pixel (8 B): a wave row is 32 pixels, one DMA
-// instruction lands two rows. 2 = whole pixel (16 B): 64 pixels per wave row,
-// one row per DMA instruction -- twice the independent arithmetic per
-// instruction stream: the kernel is bound by the serial latency of a wave
-// (queue read -> FIR chain -> 12-deep accumulation chain), not by issue slots,
-// so the wide form is the default wherever the image is wide enough.
-template< int WP > struct GVLane;
-template<> struct GVLane< 1 > { typedef f2 T; };
-template<> struct GVLane< 2 > { typedef f4 T; };
-
-template< int MODE, bool LANC, int NTC, int RW, int WP >
-__global__ void __launch_bounds__( 64 ) k_gv( const GVParams P )
-{
-	typedef typename GVLane< WP > :: T VT;
-	constexpr int ROWB = WP * 512;   // LDS bytes of one wave row
-	constexpr int RPG = 2 / WP;      // rows per DMA group (instruction)
-	constexpr int PXW = 32 * WP;     // pixels per wave row
-	extern __shared__ __attribute__(( aligned( 16 ))) char smem[];
-	const GPAxis& A = P.ax;
-	VT* const sring = (VT*) smem;                       // [rs][64 lanes]
-	VT* const mring = sring + (size_t) P.rs * 64;       // [rc][64 lanes]
-	// behind the rings and the 6 KiB landing queue: this chunk's coefficient
-	// rows (padded to four taps) and positions -- in LDS, not behind scalar
-	// loads: a scalar load in the tap loop costs its whole latency per use
-	// (every wait on lgkmcnt with one outstanding is a full drain)
-	float* const ctab = (float*) ( smem + ( P.rs + P.rc ) * ROWB + GV_QB );
-
-	const int lane = threadIdx.x;
-	const int strip = blockIdx.x % P.nstrips;
-	const int chunk = blockIdx.x / P.nstrips;
-	const int x0 = strip * PXW;
-	const int y0 = P.row_lo + chunk * P.chunk;
-	const int y1 = min( y0 + P.chunk, P.row_hi );
-
-	if( y0 >= y1 )
-	{
-		return;
-	}
-
-	gp_cint* const a_start = (gp_cint*) (unsigned long) A.start;
-	const int smask = P.rs - 1;
-	const int mmask = P.rc - 1;
-	const int slast = A.in_len - 1;
-	const int nt = ( NTC > 0 ? NTC : A.nt );
-	const int ntp = ( nt + 3 ) & ~3;
-
-	// this lane's (half) pixel
-	const int hx = x0 + ( WP == 2 ? lane : lane >> 1 );
-	const bool xok = ( hx < P.width );
-	const long dcol = (long) hx * 4 + ( WP == 2 ? 0 : ( lane & 1 ) * 2 );
-	// (LANCIR, RGB: channel 0 sums its tail taps differently -- gp_dot)
-	const bool ach = ( WP == 2 || ( lane & 1 ) == 0 );
-
-	auto mread = [&]( const int m ) -> VT
-	{
-		return( mring[ ( m & mmask ) * 64 + lane ]);
-	};
-
-	auto sread = [&]( const int u ) -> VT
-	{
-		return( sring[ ( u & smask ) * 64 + lane ]);
-	};
-
-	const VT f0 = (VT) A.f[ 0 ], f1 = (VT) A.f[ 1 ], f2_ = (VT) A.f[ 2 ],
-		f3 = (VT) A.f[ 3 ];
-
-	// gather outputs this chunk evaluates: [ga, gb]
-	const int glast = A.g_len - 1;
-	const int ga = ( MODE == GP_POST ? gp_clamp( y0 - A.e - 3, glast ) : y0 );
-	const int gb = ( MODE == GP_POST ? gp_clamp( y1 - 1 - A.e + 3, glast ) :
-		y1 - 1 );
-
-	// source rows fed: u_a .. u_b (PRE: six rows of FIR warm-up first)
-	const int u_a = a_start[ ga ] - ( MODE == GP_PRE ? 6 : 0 );
-	const int u_b = a_start[ gb ] + nt - 1;
-
-	// stage the tables (plain loads: they retire before the first DMA goes
-	// out). All of a lane's loads are issued before any is written to LDS --
-	// a load-store loop pays the memory latency once per 64 elements, which
-	// measured as a third of this kernel's time.
-	int* const stab = (int*) ( ctab + ( gb - ga + 1 ) * ntp );
-	{
-		const int total = ( gb - ga + 1 ) * ntp;
-		constexpr int GV_TE = 24; // 6 KiB of table / 4 bytes / 64 lanes
-		float tmp[ GV_TE ];
-#pragma unroll
-		for( int k = 0; k < GV_TE; k++ )
-		{
-			const int i = lane + 64 * k;
-			tmp[ k ] = 0.0f;
-
-#ifdef GP_DBG
-			if( P.dbg & 16 ) continue;
-#endif
-			if( i < total )
-			{
-				const int gi = i / ntp;
-				const int t = i - gi * ntp;
-				const long row = ( LANC ? A.fidx[ ga + gi ] : ga + gi );
-
-				if( t < nt )
-				{
-					tmp[ k ] = A.coef[ row * nt + t ];
-				}
-			}
-		}
-#pragma unroll
-		for( int k = 0; k < GV_TE; k++ )
-		{
-			const int i = lane + 64 * k;
-
-			if( i < total )
-			{
-				ctab[ i ] = tmp[ k ];
-			}
-		}
-
-		for( int i = lane; i <= gb - ga; i += 64 )
-		{
-			stab[ i ] = A.start[ ga + i ] + nt - 1;
-		}
-	}
-
-	int g = ga;                 // next gather output
-	int g_need = a_start[ g ] + nt - 1; // its last input row
-	int n = y0;                 // POST: next final output
-
-	// output rows leave strictly in order, from y0 on: a running pointer
-	float* dp = P.dst + (long) ( y0 - P.dst_row0 ) * P.dst_ss + dcol;
-	long orow = y0 - P.dst_row0; // (integer output stage: row of P.out.base)
-
-	auto store_row = [&]( const VT o )
-	{
-#ifdef GP_DBG
-		if(( P.dbg & 1 ) && o.x != 1234.5f ) return;
-#endif
-		if( WP == 2 && P.out.on != 0 )
-		{
-			if( xok )
-			{
-				f4 o4;
-				o4.x = o.x; o4.y = o.y;
-				o4.z = ( WP == 2 ? o[ WP == 2 ? 2 : 0 ] : 0.0f );
-				o4.w = ( WP == 2 ? o[ WP == 2 ? 3 : 0 ] : 0.0f );
-				gp_store_int( P.out, orow, hx, o4 );
-			}
-
-			orow++;
-			return;
-		}
-
-		if( xok )
-		{
-			*(VT*) dp = o;
-		}
-
-		dp += P.dst_ss;
-	};
-
-	// the next output's coefficient row and the position after it are read
-	// from LDS an output ahead, so that their latency hides behind the
-	// arithmetic in between (a wave runs alone on most of its issue slots:
-	// exposed LDS round trips were a third of the step time)
-	constexpr int CNB = ( NTC > 0 && NTC <= 16 ? ( NTC + 3 ) / 4 : 0 );
-	f4 cpre[ CNB > 0 ? CNB : 1 ];
-	int need1_v; // g_need1, still in its vector register
-
-	auto prefetch_tabs = [&]()
-	{
-		// (rows past gb are read -- clamped -- and never used)
-		const int gi = min( g + 1, gb ) - ga;
-		need1_v = ( g + 1 <= gb ? stab[ gi ] : 0x7fffffff );
-
-		if( CNB > 0 )
-		{
-			const float* const cr = ctab + ( min( g, gb ) - ga ) * ntp;
-#pragma unroll
-			for( int b = 0; b < CNB; b++ )
-			{
-				cpre[ b ] = *(const f4*) ( cr + 4 * b );
-			}
-		}
-	};
-
-	VT win[ RW > 0 ? RW : 1 ]; // RW > 0: the last RW rows the gathers read
-#pragma unroll
-	for( int i = 0; i < ( RW > 0 ? RW : 1 ); i++ )
-	{
-		win[ i ] = (VT) 0.0f;
-	}
-
-	// gather output g is done: store it, or (POST) run the correction FIR
-	auto finish = [&]( const VT o )
-	{
-		if( MODE == GP_POST )
-		{
-			mring[ ( g & mmask ) * 64 + lane ] = o;
-
-			// final outputs whose FIR window [c - 3, c + 3] (clamped) is
-			// complete: c + 3 <= g, or g is the last gather output
-			while( n < y1 && ( gp_clamp( n - A.e + 3, glast ) <= g ))
-			{
-				const int c = n - A.e;
-				VT r = f0 * mread( gp_clamp( c, glast ));
-				r = r + f1 * ( mread( gp_clamp( c + 1, glast )) +
-					mread( gp_clamp( c - 1, glast )));
-				r = r + f2_ * ( mread( gp_clamp( c + 2, glast )) +
-					mread( gp_clamp( c - 2, glast )));
-				r = r + f3 * ( mread( gp_clamp( c + 3, glast )) +
-					mread( gp_clamp( c - 3, glast )));
-				store_row( r );
-				n++;
-			}
-		}
-		else
-		{
-			store_row( o );
-		}
-
-		g++;
-		g_need = __builtin_amdgcn_readfirstlane( need1_v );
-		prefetch_tabs();
-	};
-
-	// everything whose inputs are complete once row `u` is in its ring.
-	// IC: the step's phase within the unrolled loop (window slot of row u).
-	auto drain = [&]( const int u, auto IC )
-	{
-		constexpr int I = decltype( IC )::value;
-
-		while( g <= gb && g_need <= u )
-		{
-			const int s0 = g_need - nt + 1;
-			const float* const cr = ctab + ( g - ga ) * ntp;
-			VT o;
-
-#ifdef GP_DBG
-			if( P.dbg & 2 )
-			{
-				o = win[ 0 ];
-			}
-			else
-#endif
-			if( RW > 0 )
-			{
-				// g_need == u: outputs are drained the step they complete
-				o = gp_dot< LANC, VT, NTC >( nt,
-					[&]( const int t ) { return( win[ ( I - ( NTC - 1 ) + t +
-						4 * ( RW > 0 ? RW : 1 )) & (( RW > 0 ? RW : 1 ) - 1 )]); },
-					[&]( const int b ) { return( CNB > 0 ? cpre[ CNB > 0 ? b : 0 ] :
-						*(const f4*) ( cr + 4 * b )); }, A.lanc, ach );
-			}
-			else
-			if( MODE == GP_PRE )
-			{
-				o = gp_dot< LANC, VT, NTC >( nt,
-					[&]( const int t ) { return( mread( s0 + t )); },
-					[&]( const int b ) { return( CNB > 0 ? cpre[ CNB > 0 ? b : 0 ] :
-						*(const f4*) ( cr + 4 * b )); }, A.lanc, ach );
-			}
-			else
-			{
-				o = gp_dot< LANC, VT, NTC >( nt,
-					[&]( const int t ) { return( sread( s0 + t )); },
-					[&]( const int b ) { return( CNB > 0 ? cpre[ CNB > 0 ? b : 0 ] :
-						*(const f4*) ( cr + 4 * b )); }, A.lanc, ach );
-			}
-
-			finish( o );
-		}
-	};
-
-	prefetch_tabs();
-
-	// ---- the feed: source rows by LDS-DMA, one group per instruction (WP 1:
-	// a row pair, lanes 0-31 row 2p, lanes 32-63 row 2p + 1; WP 2: one row),
-	// GV_PF groups in flight. Waiting for "at most GV_PF - 1 vector-memory
-	// operations outstanding" right after issuing group p + GV_PF guarantees
-	// group p + 1 has landed (loads retire in order; stores in between only
-	// make the wait stricter): rows are read from the queue a step ahead.
-	const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
-		(void*) P.src, 0, 0x7fffffff, 0x00020000 );
-	const unsigned lds0 = (unsigned) (unsigned long) (lds_char*) smem;
-	const int dpx = gp_clamp( x0 + ( lane & ( PXW - 1 )), P.width - 1 );
-	const int srow_b = (int) P.src_ss * 4;
-	// PRE: pairs land in a queue of GV_PF + 1 slots behind the C ring;
-	// NONE / POST: straight in the source ring (rs >= nt + 2 * GV_PF + 3)
-	const unsigned qbase = lds0 + (unsigned) ( P.rs + P.rc ) * ROWB;
-	const int pa = ( RPG == 2 ? u_a >> 1 : u_a ); // first group (floor)
-	const int pb = ( RPG == 2 ? u_b >> 1 : u_b );
-
-	int qi = 0; // landing-queue slot of the next pair issued ...
-	int qr = 0; // ... and of the pair being read (both count modulo GV_PF + 1)
-
-	auto issue_pair = [&]( const int p )
-	{
-		// past the last group: the count of operations per step stays
-		// uniform -- a load nobody reads, into the dump slot (no branch)
-		const bool live = ( p <= pb );
-		const int r = gp_clamp( min( p, pb ) * RPG +
-			( RPG == 2 ? lane >> 5 : 0 ), slast );
-
-		const unsigned slot = ( !live ? qbase + (unsigned) ( GV_PF + 1 ) * 1024 :
-			( MODE == GP_PRE || RW > 0 ? qbase + (unsigned) qi * 1024 :
-			lds0 + (unsigned) (( p * RPG ) & smask ) * ROWB ));
-
-		qi = ( !live ? qi : ( qi == GV_PF ? 0 : qi + 1 ));
-
-		gp_dma( rsrc, slot, r * srow_b + dpx * 16 );
-	};
-
-	// Raw sources (integer / narrower pixels, whole-pixel lanes): a lane loads
-	// its pixel of row u + 2 during step u, converts and writes it into the
-	// queue slot (or ring row) of row u + 1 at the start of the next step --
-	// the (float) cast and zero padding of the pack pass, in the loader.
-	const bool typed = ( WP == 2 && P.raw != nullptr );
-
-	f4 trv = (f4) 0.0f;
-
-	auto t_load = [&]( const int u )
-	{
-		trv = gp_load_raw( P.raw, P.raw_kind, P.raw_ch, (long) gp_clamp( u,
-			slast ) * P.raw_ss + (long) dpx * P.raw_ch, P.raw_elems );
-	};
-
-	auto t_store = [&]( const int u ) // row u: queue slot qr, or its ring row
-	{
-		const f4 o = trv;
-		const int off = ( MODE == GP_PRE || RW > 0 ?
-			( P.rs + P.rc ) * ROWB + qr * 1024 : ( u & smask ) * ROWB );
-
-		((f4*) ( smem + off ))[ lane ] = o;
-	};
-
-	if( typed )
-	{
-		t_load( pa );
-		t_store( pa );
-		t_load( pa + 1 );
-	}
-	else
-	{
-		for( int k = 0; k < GV_PF; k++ )
-		{
-			issue_pair( pa + k );
-		}
-	}
-
-	VT qnext = (VT) 0.0f; // the next step's row of the queue
-
-	GP_WAIT_VM( 4 ); // the first group has landed
-
-	if( MODE == GP_PRE || RW > 0 )
-	{
-		qnext = *(const VT*) ( smem + ( P.rs + P.rc ) * ROWB +
-			lane * sizeof( VT ));
-	}
-
-	VT tw[ 8 ]; // PRE: the FIR window (rows u - 6 .. u in slots ( u - u_a ) & 7)
-#pragma unroll
-	for( int i = 0; i < 8; i++ )
-	{
-		tw[ i ] = (VT) 0.0f;
-	}
-
-	// steps run over whole pairs; rows before u_a / after u_b of the first /
-	// last pair are fed like any other (clamped loads), outputs never need
-	// them
-	const int u0 = pa * RPG;
-
-	constexpr int UN = ( RW > 8 ? RW : 8 );
-
-	auto step = [&]( const int u, auto IC )
-	{
-		constexpr int i = decltype( IC )::value;
-
-		if( u > ( pb * RPG + RPG - 1 ))
-		{
-			return;
-		}
-
-		if( typed )
-		{
-			qr = ( qr == GV_PF ? 0 : qr + 1 );
-			t_store( u + 1 );
-			t_load( u + 2 );
-		}
-		else
-		{
-			if( RPG == 1 || ( i & 1 ) == 0 )
-			{
-#ifdef GP_DBG
-				if( !( P.dbg & 8 ))
-#endif
-				issue_pair(( RPG == 2 ? u >> 1 : u ) + GV_PF );
-			}
-
-			if( RPG == 1 || ( i & 1 ))
-			{
-				// row u + 1 opens a group: it is the oldest one in flight
-#ifdef GP_DBG
-				if( !( P.dbg & 4 ))
-#endif
-				GP_WAIT_VM( 4 ); // == GV_PF - 1
-
-				qr = ( qr == GV_PF ? 0 : qr + 1 );
-			}
-		}
-
-		// this step's row was read from the queue during the last one
-		const VT qcur = qnext;
-
-		if( MODE == GP_PRE || RW > 0 )
-		{
-			qnext = *(const VT*) ( smem + ( P.rs + P.rc ) * ROWB + qr * 1024 +
-				( RPG == 2 ? (( i + 1 ) & 1 ) * 512 : 0 ) + lane * sizeof( VT ));
-		}
-
-		if( MODE == GP_PRE )
-		{
-			tw[ i & 7 ] = qcur;
-			VT c = f0 * tw[ ( i - 3 ) & 7 ];
-			c = c + f1 * ( tw[ ( i - 2 ) & 7 ] + tw[ ( i - 4 ) & 7 ]);
-			c = c + f2_ * ( tw[ ( i - 1 ) & 7 ] + tw[ ( i - 5 ) & 7 ]);
-			c = c + f3 * ( tw[ i & 7 ] + tw[ ( i - 6 ) & 7 ]);
-
-			if( u > A.view_mmax )
-			{
-				c = (VT) 0.0f;
-			}
-
-			if( RW > 0 )
-			{
-				win[ i & (( RW > 0 ? RW : 1 ) - 1 )] = c;
-			}
-			else
-			{
-				mring[ ( u & mmask ) * 64 + lane ] = c;
-			}
-
-			if( u - u0 >= 6 )
-			{
-				drain( u, IC );
-			}
-		}
-		else
-		{
-			if( RW > 0 )
-			{
-				VT v = qcur;
-
-				if( u > A.view_mmax )
-				{
-					v = (VT) 0.0f;
-				}
-
-				win[ i & (( RW > 0 ? RW : 1 ) - 1 )] = v;
-			}
-			else
-			if( u > A.view_mmax )
-			{
-				sring[ ( u & smask ) * 64 + lane ] = (VT) 0.0f;
-			}
-
-			drain( u, IC );
-		}
-	};
-
-#ifdef GP_DBG
-	if( P.dbg & 32 ) return;
-#endif
-	for( int ub = u0; ub <= u_b; ub += UN )
-	{
-		step( ub + 0, std::integral_constant< int, 0 >() );
-		step( ub + 1, std::integral_constant< int, 1 >() );
-		step( ub + 2, std::integral_constant< int, 2 >() );
-		step( ub + 3, std::integral_constant< int, 3 >() );
-		step( ub + 4, std::integral_constant< int, 4 >() );
-		step( ub + 5, std::integral_constant< int, 5 >() );
-		step( ub + 6, std::integral_constant< int, 6 >() );
-		step( ub + 7, std::integral_constant< int, 7 >() );
-
-		if( UN > 8 )
-		{
-			step( ub + 8, std::integral_constant< int, 8 >() );
-			step( ub + 9, std::integral_constant< int, 9 >() );
-			step( ub + 10, std::integral_constant< int, 10 >() );
-			step( ub + 11, std::integral_constant< int, 11 >() );
-			step( ub + 12, std::integral_constant< int, 12 >() );
-			step( ub + 13, std::integral_constant< int, 13 >() );
-			step( ub + 14, std::integral_constant< int, 14 >() );
-			step( ub + 15, std::integral_constant< int, 15 >() );
-		}
-
-		if( UN > 16 )
-		{
-			step( ub + 16, std::integral_constant< int, 16 >() );
-			step( ub + 17, std::integral_constant< int, 17 >() );
-			step( ub + 18, std::integral_constant< int, 18 >() );
-			step( ub + 19, std::integral_constant< int, 19 >() );
-			step( ub + 20, std::integral_constant< int, 20 >() );
-			step( ub + 21, std::integral_constant< int, 21 >() );
-			step( ub + 22, std::integral_constant< int, 22 >() );
-			step( ub + 23, std::integral_constant< int, 23 >() );
-			step( ub + 24, std::integral_constant< int, 24 >() );
-			step( ub + 25, std::integral_constant< int, 25 >() );
-			step( ub + 26, std::integral_constant< int, 26 >() );
-			step( ub + 27, std::integral_constant< int, 27 >() );
-			step( ub + 28, std::integral_constant< int, 28 >() );
-			step( ub + 29, std::integral_constant< int, 29 >() );
-			step( ub + 30, std::integral_constant< int, 30 >() );
-			step( ub + 31, std::integral_constant< int, 31 >() );
-		}
-	}
-
-	GP_WAIT_VM( 0 );
-}
-
 // ---------------------------------------------------------------------
 // horizontal pass
 // ---------------------------------------------------------------------
@@ -1658,125 +820,6 @@ bool gpass_preferred( const avirhip_plan* p )
 		(long) p -> new_w * p -> new_h >= 2000000L );
 }
 
-// Rows per work item. The vertical pass kernel is bound by vector-ALU issue,
-// not by memory (measured: removing the DMA, its waits or the stores changes a
-// launch by < 10 %): a launch takes as long as its busiest SIMD, that is
-// ceil( waves / 1024 SIMDs ) waves of ( chunk + warm ) rows each, where `warm`
-// = the rows of work a chunk spends before its first output. A single wave
-// per SIMD has nobody to hide its latencies behind (x 1.26, measured), and
-// more waves than the chip holds (`wpc` per CU) run in residency rounds.
-// Fits the k_gv sweep profiles/r02_gpass/chunk_sweep.txt within 10 %.
-static int balanced_chunk( int rows, int nstrips, int min_chunk, int max_chunk,
-	int warm, int wpc, bool valu_bound )
-{
-	const double cap = 256.0 * wpc;
-	double best = -1.0;
-	int best_chunk = std::max( 1, std::min( rows, max_chunk ));
-	min_chunk = std::max( 1, std::min( min_chunk, best_chunk ));
-
-	for( int nch = 1; nch <= rows; nch++ )
-	{
-		const int chunk = ( rows + nch - 1 ) / nch;
-
-		if( chunk > max_chunk )
-		{
-			continue;
-		}
-
-		if( chunk < min_chunk )
-		{
-			break;
-		}
-
-		const int n = ( rows + chunk - 1 ) / chunk;
-		const double items = (double) n * nstrips;
-		const double res = ceil( items / cap ); // residency rounds
-		const double per = ceil( items / res / 1024.0 ); // waves per SIMD
-		// (k_gh is not ALU-bound: there whole rounds of resident waves is
-		// the model that fits -- 4661 waves on 4608 slots ran as long as 9216)
-		const double cost = ( valu_bound ?
-			res * per * ( chunk + (double) warm ) * ( per < 2.0 ? 1.26 : 1.0 ) :
-			res * cap / items * ( chunk + (double) warm ) / chunk );
-
-		if( best < 0.0 || cost < best )
-		{
-			best = cost;
-			best_chunk = chunk;
-		}
-	}
-
-	return( best_chunk );
-}
-
-// Register-window variants exist for the tap counts that occur: 12 for AVIR
-// upsizing (FIR7 then gather), 18-24 for AVIR 1 < k < 2 downsizing (gather
-// then FIR7), the even counts 6-24 for LANCIR; the LDS-window kernel takes
-// everything else.
-#define GV_LAUNCH( MODE, LANC, NT, RW ) do { if( wp == 2 ) \
-	hipLaunchKernelGGL(( k_gv< MODE, LANC, NT, RW, 2 > ), dim3( items ), \
-	dim3( 64 ), lds, st, P ); else \
-	hipLaunchKernelGGL(( k_gv< MODE, LANC, NT, RW, 1 > ), dim3( items ), \
-	dim3( 64 ), lds, st, P ); } while( 0 )
-
-static void launch_gv( const GVParams& P, int wp, int items, size_t lds,
-	hipStream_t st )
-{
-	const int nt = P.ax.nt;
-
-	if( P.ax.lanc )
-	{
-		switch( nt )
-		{
-			case 6: GV_LAUNCH( GP_NONE, true, 6, 8 ); break;
-			case 8: GV_LAUNCH( GP_NONE, true, 8, 8 ); break;
-			case 10: GV_LAUNCH( GP_NONE, true, 10, 16 ); break;
-			case 12: GV_LAUNCH( GP_NONE, true, 12, 16 ); break;
-			case 14: GV_LAUNCH( GP_NONE, true, 14, 16 ); break;
-			case 16: GV_LAUNCH( GP_NONE, true, 16, 16 ); break;
-			case 18: GV_LAUNCH( GP_NONE, true, 18, 32 ); break;
-			case 20: GV_LAUNCH( GP_NONE, true, 20, 32 ); break;
-			case 22: GV_LAUNCH( GP_NONE, true, 22, 32 ); break;
-			case 24: GV_LAUNCH( GP_NONE, true, 24, 32 ); break;
-			default: GV_LAUNCH( GP_NONE, true, 0, 0 ); break;
-		}
-	}
-	else
-	if( P.ax.mode == GP_PRE )
-	{
-		if( nt == 12 ) GV_LAUNCH( GP_PRE, false, 12, 16 );
-		else GV_LAUNCH( GP_PRE, false, 0, 0 );
-	}
-	else
-	if( P.ax.mode == GP_POST )
-	{
-		switch( nt )
-		{
-			// (13 .. 25 taps: the 1 < k < 2 plans, avir.h bank lengths 26 .. 50
-			// over the zero-stuffed view)
-			case 13: GV_LAUNCH( GP_POST, false, 13, 16 ); break;
-			case 14: GV_LAUNCH( GP_POST, false, 14, 16 ); break;
-			case 15: GV_LAUNCH( GP_POST, false, 15, 16 ); break;
-			case 16: GV_LAUNCH( GP_POST, false, 16, 16 ); break;
-			case 17: GV_LAUNCH( GP_POST, false, 17, 32 ); break;
-			case 18: GV_LAUNCH( GP_POST, false, 18, 32 ); break;
-			case 19: GV_LAUNCH( GP_POST, false, 19, 32 ); break;
-			case 20: GV_LAUNCH( GP_POST, false, 20, 32 ); break;
-			case 21: GV_LAUNCH( GP_POST, false, 21, 32 ); break;
-			case 22: GV_LAUNCH( GP_POST, false, 22, 32 ); break;
-			case 23: GV_LAUNCH( GP_POST, false, 23, 32 ); break;
-			case 24: GV_LAUNCH( GP_POST, false, 24, 32 ); break;
-			case 25: GV_LAUNCH( GP_POST, false, 25, 32 ); break;
-			default: GV_LAUNCH( GP_POST, false, 0, 0 ); break;
-		}
-	}
-	else
-	{
-		GV_LAUNCH( GP_NONE, false, 0, 0 );
-	}
-}
-
-#undef GV_LAUNCH
-
 template< int MODE, bool LANC, int SRC >
 static void launch_gh2( const GHParams& P, int items, size_t lds,
 	hipStream_t st )
@@ -1824,108 +867,6 @@ static void launch_gh( const GHParams& P, int src_kind, int items, size_t lds,
 			break;
 		default: launch_gh2< MODE, LANC, 0 >( P, items, lds, st ); break;
 	}
-}
-
-static int run_v( const GPData* D, const float* src, long src_ss, int width,
-	float* dst, long dst_ss, int dst_row0, int row_lo, int row_hi,
-	hipStream_t st, const GPOut* out = nullptr, const void* raw = nullptr,
-	int raw_type = 0, int raw_ch = 0, long raw_stride = 0 )
-{
-	GVParams P;
-	memset( &P.out, 0, sizeof( P.out ));
-	P.raw = raw; P.raw_ss = raw_stride; P.raw_ch = raw_ch;
-	P.raw_kind = ( raw_type == AVIRHIP_U8 ? 1 : ( raw_type == AVIRHIP_U16 ? 2 : 3 ));
-	// (rows are raw_stride elements apart; the last one ends with its pixels)
-	P.raw_elems = (long) ( D -> v.a.in_len - 1 ) * raw_stride +
-		(long) width * raw_ch;
-
-	if( raw != nullptr && P.raw_elems < 4 )
-	{
-		return( 1 );
-	}
-
-	if( out != nullptr )
-	{
-		P.out = *out;
-	}
-
-	P.src = src; P.src_ss = src_ss; P.width = width;
-	P.dst = dst; P.dst_ss = dst_ss; P.dst_row0 = dst_row0;
-	P.ax = D -> v.a;
-	P.row_lo = row_lo; P.row_hi = row_hi;
-	P.dbg = ( getenv( "AVIRHIP_GP_DBG" ) != nullptr ? atoi( getenv( "AVIRHIP_GP_DBG" )) : 0 );
-	P.blk = D -> v_blk; P.rs = D -> v_rs; P.rc = D -> v_rc;
-
-	// whole-pixel lanes (64-pixel strips) wherever the image is wide enough
-	// to fill them and the rings stay within 64 KiB
-	int wp = ( width > 48 && ( P.rs + P.rc ) * 1024 + GV_QB + 6 * 1024 <= 64 * 1024 ?
-		2 : 1 );
-
-	if( getenv( "AVIRHIP_GV_WP" ) != nullptr ) // tuning aid
-	{
-		wp = ( atoi( getenv( "AVIRHIP_GV_WP" )) == 2 &&
-			( P.rs + P.rc ) * 1024 + GV_QB + 6 * 1024 <= 64 * 1024 ? 2 : 1 );
-	}
-
-	if( out != nullptr || raw != nullptr )
-	{
-		// the integer output stage and the raw-source loader handle whole
-		// pixels
-		if(( P.rs + P.rc ) * 1024 + GV_QB + 6 * 1024 > 64 * 1024 )
-		{
-			return( 1 );
-		}
-
-		wp = 2;
-	}
-
-	const int rowb = wp * 512;
-	P.nstrips = ( width + 32 * wp - 1 ) / ( 32 * wp );
-
-	// chunk height: a chunk's first window (NT rows, + 6 of FIR warm-up) is
-	// fed before its first output; its coefficient rows and positions live
-	// in LDS (<= 6 KiB)
-	const int rows = row_hi - row_lo;
-	const int ntp = ( P.ax.nt + 3 ) & ~3;
-	const int gextra = ( P.ax.mode == GP_POST ? 7 : 0 );
-	const int maxg = std::max( gextra + 1, 6144 / ( ntp * 4 + 4 ));
-	// warm-up in units of output rows (a fed row costs about a third of one)
-	const int warm_div = ( getenv( "AVIRHIP_GV_WARMDIV" ) != nullptr ?
-		std::max( 1, atoi( getenv( "AVIRHIP_GV_WARMDIV" ))) : 3 );
-
-	const int warm = std::max( 1, (int) ( (long) ( P.ax.nt + 6 ) *
-		std::max( 1, P.ax.out_len ) / std::max( 1, P.ax.in_len ) / warm_div ));
-
-	const size_t lds_guess = (size_t) ( P.rs + P.rc ) * rowb + GV_QB + 3072;
-	const int wpc = std::max( 1, std::min( 16, (int) ( 160 * 1024 /
-		( lds_guess + 512 ))));
-
-	P.chunk = balanced_chunk( rows, P.nstrips, 8, maxg - gextra, warm, wpc,
-		true );
-
-	if( getenv( "AVIRHIP_GV_CHUNK" ) != nullptr ) // tuning aid
-	{
-		P.chunk = std::max( 1, std::min( atoi( getenv( "AVIRHIP_GV_CHUNK" )),
-			maxg - gextra ));
-	}
-
-	const int nch = ( rows + P.chunk - 1 ) / P.chunk;
-	const int items = P.nstrips * nch;
-	const size_t lds = (size_t) ( P.rs + P.rc ) * rowb + GV_QB +
-		(size_t) ( P.chunk + gextra ) * ( ntp * 4 + 4 ) + 64;
-
-#ifdef GP_DBG
-	{
-		static int once = 0;
-		if( !once++ ) fprintf( stderr, "k_gv: wp %d strips %d chunk %d items %d "
-			"lds %zu nt %d mode %d\n", wp, P.nstrips, P.chunk, items, lds,
-			P.ax.nt, P.ax.mode );
-	}
-#endif
-	launch_gv( P, wp, items, lds, st );
-
-	AVIRHIP_HIPCHECK( hipGetLastError() );
-	return( AVIRHIP_OK );
 }
 
 static int run_h( const GPData* D, const float* src, long src_ss, int src_w,
@@ -2131,14 +1072,14 @@ int gpass_run( avirhip_plan* p, const float* src, long src_stride, float* dst,
 		if( p -> lraw.on )
 		{
 			// (an inner plan: the owner's image, read as it is)
-			rc = run_v( D, src, src_stride, p -> src_w, D -> mid, mid_ss, 0,
+			rc = gpass_run_v( D -> v.a, D -> v_blk, D -> v_rs, D -> v_rc, src, src_stride, p -> src_w, D -> mid, mid_ss, 0,
 				row0, row1, st, nullptr, p -> lraw.ptr, p -> lraw.type,
 				p -> lraw.ch, p -> lraw.stride );
 
 			if( rc != 0 ) return( rc );
 		}
 		else
-		if(( rc = run_v( D, src, src_stride, p -> src_w, D -> mid, mid_ss, 0,
+		if(( rc = gpass_run_v( D -> v.a, D -> v_blk, D -> v_rs, D -> v_rc, src, src_stride, p -> src_w, D -> mid, mid_ss, 0,
 			row0, row1, st )) != 0 ) return( rc );
 
 		if( p -> lfuse.on )
@@ -2217,7 +1158,7 @@ int gpass_run( avirhip_plan* p, const float* src, long src_stride, float* dst,
 			return( 1 );
 		}
 
-		rc = run_v( D, D -> mid, mid_ss, p -> new_w, dst, dst_ss, row0, row0,
+		rc = gpass_run_v( D -> v.a, D -> v_blk, D -> v_rs, D -> v_rc, D -> mid, mid_ss, p -> new_w, dst, dst_ss, row0, row0,
 			row1, st, out );
 	}
 

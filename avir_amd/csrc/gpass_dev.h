@@ -5,6 +5,12 @@
 
 #include "plan.h"
 #include <vector>
+#include <algorithm>
+#include <math.h>
+#include <type_traits>
+#include <string.h>
+#include <stdio.h>
+#include <stdlib.h>
 
 namespace avirhip {
 
@@ -243,6 +249,363 @@ struct GPAxisHost
 	const float* h_coef; // host copy of the coefficient rows (a.coef's layout)
 	const int* h_fidx;   // LANCIR: host copy of a.fidx
 };
+
+// ---- shared by gpass.hip (horizontal pass, host side) and gpassv.hip
+// (vertical pass): launch parameters, the gather's dot product, the raw-pixel
+// loader, the work-item sizing
+
+struct GVParams
+{
+	const float* src; long src_ss; int width; // px per row, floats per row
+	float* dst; long dst_ss; int dst_row0;
+	GPAxis ax;
+	int row_lo, row_hi;  // output rows to produce
+	int dbg;             // timing ablations (GP_DBG builds only)
+	int nstrips, chunk;  // 32-px strips, output rows per work item
+	int blk;             // output rows per block
+	int rs, rc;          // ring sizes (rows, powers of two): source, C / G
+	GPOut out;           // on != 0 (whole-pixel lanes): integer output stage
+	const void* raw;     // != nullptr (whole-pixel lanes): the caller's image
+	long raw_ss;         // (integer / narrower pixels), elements per row,
+	int raw_ch, raw_kind; // channels, 1 uint8 / 2 uint16 / 3 float
+	long raw_elems;      // elements of that image (the loader's bound)
+};
+
+struct GHParams
+{
+	const float* src; long src_ss; int src_w;
+	float* dst; long dst_ss; int dst_row0; int dst_w;
+	GPAxis ax;
+	int row_lo, row_hi;  // rows (of both images) to process
+	int nstrips, ow, chunk; // outputs per strip, rows per work item
+	const int* seg;      // [nstrips][4]: source lo, count; mid lo, count
+	int nseg;            // DMA instructions per row (uniform)
+	int sbuf, mbuf;      // LDS pixels per source row buffer / mid buffer
+	const void* raw;     // SRC != 0: the caller's image (integer / narrower
+	long raw_ss;         // pixels), elements per row, channels
+	int raw_ch;
+	long raw_elems;      // elements of that image (the loader's bound)
+	GPLOut lout;         // on != 0: LANCIR's output stage in the store
+};
+
+// One gather output: tap t reads ld( t ); cf4( b ) returns the coefficients
+// of taps 4b .. 4b + 3 (rows are padded to a multiple of four; padded taps are
+// never multiplied: x * 0 is not a no-op for non-finite x). NTC > 0: the tap
+// count is a compile-time constant and everything unrolls.
+//
+// LANCIR's summation order depends on the image's channel count (the lane
+// structure of resize1..4, lancir.h:2102-2544; generic.hip spells it out):
+// `lord` = 4: even and odd taps; 1, 2, 3: four sums over taps 4g + j, folded
+// (s0 + s2) + (s1 + s3) for 1 and 2 channels, (s0 + s1) + (s2 + s3) for 3, with
+// the two tail taps of a length 4n + 2 entering where that code adds them --
+// for RGB differently in channel 0 (`ch0`: this lane's .x is channel 0).
+template< bool LANC, typename T, int NTC, typename LD, typename CF >
+__device__ __forceinline__ T gp_dot( const int nt_, LD ld, CF cf4,
+	const int lord = 4, const bool ch0 = true )
+{
+	const int nt = ( NTC > 0 ? NTC : nt_ );
+	const int nb = nt >> 2;
+
+	if( LANC && lord != 4 )
+	{
+		T a0, a1, a2, a3;
+		{
+			const f4 c = cf4( 0 );
+			a0 = c.x * ld( 0 );
+			a1 = c.y * ld( 1 );
+			a2 = c.z * ld( 2 );
+			a3 = c.w * ld( 3 );
+		}
+
+		if( NTC > 0 )
+		{
+#pragma unroll
+			for( int b = 1; b < ( NTC > 0 ? NTC / 4 : 1 ); b++ )
+			{
+				const f4 c = cf4( b );
+				a0 = a0 + c.x * ld( 4 * b );
+				a1 = a1 + c.y * ld( 4 * b + 1 );
+				a2 = a2 + c.z * ld( 4 * b + 2 );
+				a3 = a3 + c.w * ld( 4 * b + 3 );
+			}
+		}
+		else
+		{
+			for( int b = 1; b < nb; b++ )
+			{
+				const f4 c = cf4( b );
+				a0 = a0 + c.x * ld( 4 * b );
+				a1 = a1 + c.y * ld( 4 * b + 1 );
+				a2 = a2 + c.z * ld( 4 * b + 2 );
+				a3 = a3 + c.w * ld( 4 * b + 3 );
+			}
+		}
+
+		if( nt & 2 )
+		{
+			const f4 c = cf4( nb );
+			const T t0 = c.x * ld( 4 * nb );
+			const T t1 = c.y * ld( 4 * nb + 1 );
+
+			if( lord == 3 )
+			{
+				a0 = a0 + t0;
+				T r = (( a0 + a1 ) + ( a2 + a3 )) + t1;     // channels 1, 2
+				const T r0 = ( a0 + ( a1 + t1 )) + ( a2 + a3 ); // channel 0
+
+				if( ch0 )
+				{
+					r.x = r0.x;
+				}
+
+				return( r );
+			}
+
+			return((( a0 + a2 ) + t0 ) + (( a1 + a3 ) + t1 ));
+		}
+
+		if( lord == 3 )
+		{
+			return(( a0 + a1 ) + ( a2 + a3 ));
+		}
+
+		return(( a0 + a2 ) + ( a1 + a3 ));
+	}
+
+	if( LANC )
+	{
+		// (t0*p0 + t2*p2 + ...) + (t1*p1 + t3*p3 + ...), bare first products
+		// (lancir.h:2482-2515); nt is even
+		T ea, oa;
+		int b = 0;
+
+		if( nt >= 4 )
+		{
+			const f4 c = cf4( 0 );
+			ea = c.x * ld( 0 );
+			oa = c.y * ld( 1 );
+			ea = ea + c.z * ld( 2 );
+			oa = oa + c.w * ld( 3 );
+			b = 1;
+		}
+		else
+		{
+			const f4 c = cf4( 0 );
+			ea = c.x * ld( 0 );
+			oa = c.y * ld( 1 );
+			return( ea + oa );
+		}
+		if( NTC > 0 )
+		{
+#pragma unroll
+			for( int bb = 1; bb < ( NTC > 0 ? NTC / 4 : 1 ); bb++ )
+			{
+				const f4 c = cf4( bb );
+				ea = ea + c.x * ld( 4 * bb );
+				oa = oa + c.y * ld( 4 * bb + 1 );
+				ea = ea + c.z * ld( 4 * bb + 2 );
+				oa = oa + c.w * ld( 4 * bb + 3 );
+			}
+		}
+		else
+		{
+#pragma unroll 2
+			for( ; b < nb; b++ )
+			{
+				const f4 c = cf4( b );
+				ea = ea + c.x * ld( 4 * b );
+				oa = oa + c.y * ld( 4 * b + 1 );
+				ea = ea + c.z * ld( 4 * b + 2 );
+				oa = oa + c.w * ld( 4 * b + 3 );
+			}
+		}
+
+		if( nt & 2 )
+		{
+			const f4 c = cf4( nb );
+			ea = ea + c.x * ld( 4 * nb );
+			oa = oa + c.y * ld( 4 * nb + 1 );
+		}
+
+		return( ea + oa );
+	}
+
+	T acc = (T) 0.0f;
+
+	if( NTC > 0 )
+	{
+#pragma unroll
+		for( int b = 0; b < ( NTC > 0 ? NTC / 4 : 1 ); b++ )
+		{
+			const f4 c = cf4( b );
+			acc = acc + c.x * ld( 4 * b );
+			acc = acc + c.y * ld( 4 * b + 1 );
+			acc = acc + c.z * ld( 4 * b + 2 );
+			acc = acc + c.w * ld( 4 * b + 3 );
+		}
+	}
+	else
+	{
+#pragma unroll 2
+		for( int b = 0; b < nb; b++ )
+		{
+			const f4 c = cf4( b );
+			acc = acc + c.x * ld( 4 * b );
+			acc = acc + c.y * ld( 4 * b + 1 );
+			acc = acc + c.z * ld( 4 * b + 2 );
+			acc = acc + c.w * ld( 4 * b + 3 );
+		}
+	}
+
+	if( nt & 3 )
+	{
+		const f4 c = cf4( nb );
+		acc = acc + c.x * ld( 4 * nb );
+
+		if(( nt & 3 ) > 1 )
+		{
+			acc = acc + c.y * ld( 4 * nb + 1 );
+		}
+
+		if(( nt & 3 ) > 2 )
+		{
+			acc = acc + c.z * ld( 4 * nb + 2 );
+		}
+	}
+
+	return( acc );
+}
+
+// One raw pixel (1 uint8, 2 uint16, 3 float elements; `ch` of them) as float
+// RGBA with zero padding: ONE load of four elements at the pixel's (possibly
+// unaligned) address -- what it reads past the pixel is dropped; only where
+// those four elements would cross the end of the image (its last pixel) are
+// the channels loaded one by one. Per-element loads everywhere cost three or
+// four vector-memory instructions per pixel and as much time as the pack pass
+// they replace. (Buffer loads force dword alignment: global loads it is.)
+__device__ __forceinline__ f4 gp_load_raw( const void* const base,
+	const int kind, const int ch, const long eoff, const long total )
+{
+	float v[ 4 ] = { 0.0f, 0.0f, 0.0f, 0.0f };
+	const bool fast = ( eoff + 4 <= total );
+	// integer elements, branch-free: the load starts at most at total - 4 and
+	// the value is shifted down by the elements it started early (non-zero
+	// for the image's last pixel only; the image holds >= 4 elements)
+	const long ea = min( eoff, total - 4 );
+	const int sh = (int) ( eoff - ea );
+
+	if( kind == 1 )
+	{
+		typedef unsigned int u32u __attribute__(( aligned( 1 )));
+		const unsigned int w = *(const u32u*) ( (const unsigned char*) base +
+			ea ) >> ( 8 * sh );
+#pragma unroll
+		for( int c = 0; c < 4; c++ )
+		{
+			v[ c ] = ( c < ch ? (float) (( w >> ( 8 * c )) & 0xffu ) : 0.0f );
+		}
+	}
+	else
+	if( kind == 2 )
+	{
+		typedef unsigned long long u64u __attribute__(( aligned( 2 )));
+		const unsigned long long w = *(const u64u*) (
+			(const unsigned short*) base + ea ) >> ( 16 * sh );
+#pragma unroll
+		for( int c = 0; c < 4; c++ )
+		{
+			v[ c ] = ( c < ch ? (float) (unsigned int) (( w >> ( 16 * c )) &
+				0xffffull ) : 0.0f );
+		}
+	}
+	else
+	{
+		const float* const p = (const float*) base + eoff;
+
+		if( fast )
+		{
+			typedef float f4u __attribute__(( ext_vector_type( 4 ),
+				aligned( 4 )));
+			const f4u w = *(const f4u*) p;
+			const float ww[ 4 ] = { w.x, w.y, w.z, w.w };
+#pragma unroll
+			for( int c = 0; c < 4; c++ )
+			{
+				v[ c ] = ( c < ch ? ww[ c ] : 0.0f );
+			}
+		}
+		else
+		{
+			for( int c = 0; c < ch; c++ )
+			{
+				v[ c ] = p[ c ];
+			}
+		}
+	}
+
+	f4 o; o.x = v[ 0 ]; o.y = v[ 1 ]; o.z = v[ 2 ]; o.w = v[ 3 ];
+	return( o );
+}
+
+#define GV_PF 5 // k_gv: DMA groups in flight (one of them is read a step ahead)
+#define GV_QB (( GV_PF + 2 ) * 1024 ) // landing queue: GV_PF + 1 slots, a dump
+
+// Rows per work item. The vertical pass kernel is bound by vector-ALU issue,
+// not by memory (measured: removing the DMA, its waits or the stores changes a
+// launch by < 10 %): a launch takes as long as its busiest SIMD, that is
+// ceil( waves / 1024 SIMDs ) waves of ( chunk + warm ) rows each, where `warm`
+// = the rows of work a chunk spends before its first output. A single wave
+// per SIMD has nobody to hide its latencies behind (x 1.26, measured), and
+// more waves than the chip holds (`wpc` per CU) run in residency rounds.
+// Fits the k_gv sweep profiles/r02_gpass/chunk_sweep.txt within 10 %.
+static inline int balanced_chunk( int rows, int nstrips, int min_chunk, int max_chunk,
+	int warm, int wpc, bool valu_bound )
+{
+	const double cap = 256.0 * wpc;
+	double best = -1.0;
+	int best_chunk = std::max( 1, std::min( rows, max_chunk ));
+	min_chunk = std::max( 1, std::min( min_chunk, best_chunk ));
+
+	for( int nch = 1; nch <= rows; nch++ )
+	{
+		const int chunk = ( rows + nch - 1 ) / nch;
+
+		if( chunk > max_chunk )
+		{
+			continue;
+		}
+
+		if( chunk < min_chunk )
+		{
+			break;
+		}
+
+		const int n = ( rows + chunk - 1 ) / chunk;
+		const double items = (double) n * nstrips;
+		const double res = ceil( items / cap ); // residency rounds
+		const double per = ceil( items / res / 1024.0 ); // waves per SIMD
+		// (k_gh is not ALU-bound: there whole rounds of resident waves is
+		// the model that fits -- 4661 waves on 4608 slots ran as long as 9216)
+		const double cost = ( valu_bound ?
+			res * per * ( chunk + (double) warm ) * ( per < 2.0 ? 1.26 : 1.0 ) :
+			res * cap / items * ( chunk + (double) warm ) / chunk );
+
+		if( best < 0.0 || cost < best )
+		{
+			best = cost;
+			best_chunk = chunk;
+		}
+	}
+
+	return( best_chunk );
+}
+
+// gpassv.hip
+int gpass_run_v( const GPAxis& A, int v_blk, int v_rs, int v_rc,
+	const float* src, long src_ss, int width, float* dst, long dst_ss,
+	int dst_row0, int row_lo, int row_hi, hipStream_t st,
+	const GPOut* out = nullptr, const void* raw = nullptr, int raw_type = 0,
+	int raw_ch = 0, long raw_stride = 0 );
 
 } // namespace avirhip
 
