@@ -115,10 +115,20 @@ __global__ void __launch_bounds__( 64 ) k_gh( const GHParams P )
 	const int gs = A.start[ g ] - ( MODE == GP_PRE ? mlo : slo );
 	// a compile-time tap count keeps the row in registers; any other count
 	// parks it in LDS, tap-major (lane-consecutive: conflict-free reads)
-	float cf[ NTC > 0 ? NTC : 1 ];
+	// (NTC == -1: any count up to 28, in registers too)
+	float cf[ NTC > 0 ? NTC : ( NTC < 0 ? 28 : 1 )];
 	{
 		const float* cr = A.coef + (long) ( LANC ? A.fidx[ g ] : g ) * nt;
 
+		if( NTC < 0 )
+		{
+#pragma unroll
+			for( int t = 0; t < ( NTC < 0 ? 28 : 1 ); t++ )
+			{
+				cf[ t ] = ( t < nt ? cr[ t ] : 0.0f );
+			}
+		}
+		else
 		if( NTC > 0 )
 		{
 #pragma unroll
@@ -267,6 +277,14 @@ __global__ void __launch_bounds__( 64 ) k_gh( const GHParams P )
 				{
 					f4 c;
 
+					if( NTC < 0 )
+					{
+						c.x = cf[ NTC < 0 ? ( 4 * b ) % 28 : 0 ];
+						c.y = cf[ NTC < 0 ? ( 4 * b + 1 ) % 28 : 0 ];
+						c.z = cf[ NTC < 0 ? ( 4 * b + 2 ) % 28 : 0 ];
+						c.w = cf[ NTC < 0 ? ( 4 * b + 3 ) % 28 : 0 ];
+					}
+					else
 					if( NTC > 0 )
 					{
 						c.x = cf[ ( 4 * b ) % ( NTC > 0 ? NTC : 1 )];
@@ -848,6 +866,18 @@ static void launch_gh2( const GHParams& P, int items, size_t lds,
 		}
 	}
 
+	// (gather-then-FIR7 axes, 1 < k < 2: 13 .. 25 taps -- one variant with the
+	// coefficient row in registers for any count up to 28)
+	if constexpr( MODE == GP_POST && !LANC )
+	{
+		if( nt <= 28 )
+		{
+			hipLaunchKernelGGL(( k_gh< MODE, LANC, -1, SRC > ), dim3( items ),
+				dim3( 64 ), lds, st, P );
+			return;
+		}
+	}
+
 	hipLaunchKernelGGL(( k_gh< MODE, LANC, 0, SRC > ), dim3( items ),
 		dim3( 64 ), lds, st, P );
 }
@@ -908,7 +938,8 @@ static int run_h( const GPData* D, const float* src, long src_ss, int src_w,
 
 	const int rows = row_hi - row_lo;
 	// (tap counts 6 and 12 keep the coefficient row in registers: no LDS table)
-	const bool regcoef = ( P.ax.nt == 6 || P.ax.nt == 12 );
+	const bool regcoef = ( P.ax.nt == 6 || P.ax.nt == 12 ||
+		( P.ax.mode == GP_POST && !P.ax.lanc && P.ax.nt <= 28 ));
 	const size_t lds_h = (size_t) ( GH_NB * P.sbuf + P.mbuf ) * 16 +
 		( regcoef ? 0 : (size_t) (( P.ax.nt + 3 ) & ~3 ) * 64 * 4 );
 

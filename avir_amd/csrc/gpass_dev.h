@@ -432,6 +432,43 @@ __device__ __forceinline__ T gp_dot( const int nt_, LD ld, CF cf4,
 
 	T acc = (T) 0.0f;
 
+	if( NTC < 0 )
+	{
+		// any count up to 28: the caller keeps the coefficient row in
+		// registers (cf4( b ), b compile-time); whole blocks of four taps and
+		// the last partial block behind wave-uniform branches
+#pragma unroll
+		for( int b = 0; b < 7; b++ )
+		{
+			if( 4 * b + 4 <= nt )
+			{
+				const f4 c = cf4( b );
+				acc = acc + c.x * ld( 4 * b );
+				acc = acc + c.y * ld( 4 * b + 1 );
+				acc = acc + c.z * ld( 4 * b + 2 );
+				acc = acc + c.w * ld( 4 * b + 3 );
+			}
+			else
+			if( 4 * b < nt )
+			{
+				const f4 c = cf4( b );
+				acc = acc + c.x * ld( 4 * b );
+
+				if(( nt & 3 ) > 1 )
+				{
+					acc = acc + c.y * ld( 4 * b + 1 );
+				}
+
+				if(( nt & 3 ) > 2 )
+				{
+					acc = acc + c.z * ld( 4 * b + 2 );
+				}
+			}
+		}
+
+		return( acc );
+	}
+
 	if( NTC > 0 )
 	{
 #pragma unroll
