@@ -89,6 +89,32 @@ int gpass_run_v( const GPAxis& A_, int v_blk, int v_rs, int v_rc,
 		wp = 2;
 	}
 
+	if( wp == 1 )
+	{
+		// half-pixel lanes (images narrower than 49 pixels, or windows too
+		// long for whole-pixel rings) only exist as the LDS-window kernel:
+		// its rings hold the window, whatever the plan sized them for
+		int rs = 2, rc = 2;
+
+		if( P.ax.mode == GP_PRE )
+		{
+			rc = 2;
+			while( rc < P.ax.nt + 1 ) rc <<= 1;
+		}
+		else
+		{
+			while( rs < P.ax.nt + 2 * GV_PF + 3 ) rs <<= 1;
+			rc = ( P.ax.mode == GP_POST ? 8 : 2 );
+		}
+
+		if(( rs + rc ) * 512 + GV_QB + 6 * 1024 > 64 * 1024 )
+		{
+			return( 1 );
+		}
+
+		P.rs = rs; P.rc = rc;
+	}
+
 	const int rowb = wp * 512;
 	P.nstrips = ( width + 32 * wp - 1 ) / ( 32 * wp );
 

@@ -43,9 +43,14 @@ template< int WP > struct GVLane;
 template<> struct GVLane< 1 > { typedef f2 T; };
 template<> struct GVLane< 2 > { typedef f4 T; };
 
-template< int MODE, bool LANC, int NTC, int RW, int WP >
+// LVAR (LANCIR variants only -- compiled in, they cost the float RGBA kernels
+// 35 .. 50 registers): bit 0 = the four-lane summation orders of 1-3 channel
+// images (gp_dot), bit 1 = the raw-source loader.
+template< int MODE, bool LANC, int NTC, int RW, int WP, int LVAR >
 __global__ void __launch_bounds__( 64 ) k_gv( const GVParams P )
 {
+	// (a value the compiler can see is never 4 / always 4)
+	const int lord = (( LVAR & 1 ) ? ( P.ax.lanc & 3 ) : 4 );
 	typedef typename GVLane< WP > :: T VT;
 	constexpr int ROWB = WP * 512;   // LDS bytes of one wave row
 	constexpr int RPG = 2 / WP;      // rows per DMA group (instruction)
@@ -283,7 +288,7 @@ __global__ void __launch_bounds__( 64 ) k_gv( const GVParams P )
 					[&]( const int t ) { return( win[ ( I - ( NTC - 1 ) + t +
 						4 * ( RW > 0 ? RW : 1 )) & (( RW > 0 ? RW : 1 ) - 1 )]); },
 					[&]( const int b ) { return( CNB > 0 ? cpre[ CNB > 0 ? b : 0 ] :
-						*(const f4*) ( cr + 4 * b )); }, A.lanc, ach );
+						*(const f4*) ( cr + 4 * b )); }, lord, ach );
 			}
 			else
 			if( MODE == GP_PRE )
@@ -291,14 +296,14 @@ __global__ void __launch_bounds__( 64 ) k_gv( const GVParams P )
 				o = gp_dot< LANC, VT, NTC >( nt,
 					[&]( const int t ) { return( mread( s0 + t )); },
 					[&]( const int b ) { return( CNB > 0 ? cpre[ CNB > 0 ? b : 0 ] :
-						*(const f4*) ( cr + 4 * b )); }, A.lanc, ach );
+						*(const f4*) ( cr + 4 * b )); }, lord, ach );
 			}
 			else
 			{
 				o = gp_dot< LANC, VT, NTC >( nt,
 					[&]( const int t ) { return( sread( s0 + t )); },
 					[&]( const int b ) { return( CNB > 0 ? cpre[ CNB > 0 ? b : 0 ] :
-						*(const f4*) ( cr + 4 * b )); }, A.lanc, ach );
+						*(const f4*) ( cr + 4 * b )); }, lord, ach );
 			}
 
 			finish( o );
@@ -348,7 +353,7 @@ __global__ void __launch_bounds__( 64 ) k_gv( const GVParams P )
 	// its pixel of row u + 2 during step u, converts and writes it into the
 	// queue slot (or ring row) of row u + 1 at the start of the next step --
 	// the (float) cast and zero padding of the pack pass, in the loader.
-	const bool typed = ( WP == 2 && P.raw != nullptr );
+	const bool typed = ( WP == 2 && ( LVAR & 2 ) != 0 && P.raw != nullptr );
 
 	f4 trv = (f4) 0.0f;
 
@@ -551,14 +556,34 @@ __global__ void __launch_bounds__( 64 ) k_gv( const GVParams P )
 	GP_WAIT_VM( 0 );
 }
 
+// (half-pixel lanes: the LDS-window kernel only, see gpass_run_v)
 #define GV_LAUNCH( MODE, LANC, NT, RW ) do { if( wp == 2 ) \
-	hipLaunchKernelGGL(( k_gv< MODE, LANC, NT, RW, 2 > ), dim3( items ), \
+	hipLaunchKernelGGL(( k_gv< MODE, LANC, NT, RW, 2, 0 > ), dim3( items ), \
 	dim3( 64 ), lds, st, P ); else \
-	hipLaunchKernelGGL(( k_gv< MODE, LANC, NT, RW, 1 > ), dim3( items ), \
+	hipLaunchKernelGGL(( k_gv< MODE, LANC, 0, 0, 1, 0 > ), dim3( items ), \
 	dim3( 64 ), lds, st, P ); } while( 0 )
+
+// LANCIR: + the summation order of the image's channel count, + raw sources
+#define GV_LAUNCH_L1( NT, RW, WPV, LV ) hipLaunchKernelGGL(( k_gv< GP_NONE, \
+	true, NT, RW, WPV, LV > ), dim3( items ), dim3( 64 ), lds, st, P )
+
+// (float sources: gpassv_lanc.hip; raw sources -- whole-pixel lanes only --:
+// gpassv_lancraw.hip)
+#define GV_LAUNCH_L( NT, RW ) do { \
+	const bool l3_ = ( P.ax.lanc != 4 ); \
+	if( wp != 2 ) { if( l3_ ) GV_LAUNCH_L1( 0, 0, 1, 1 ); \
+		else GV_LAUNCH_L1( 0, 0, 1, 0 ); } \
+	else { if( l3_ ) GV_LAUNCH_L1( NT, RW, 2, 1 ); \
+		else GV_LAUNCH_L1( NT, RW, 2, 0 ); } } while( 0 )
+
+#define GV_LAUNCH_LR( NT, RW ) do { \
+	if( P.ax.lanc != 4 ) GV_LAUNCH_L1( NT, RW, 2, 3 ); \
+	else GV_LAUNCH_L1( NT, RW, 2, 2 ); } while( 0 )
 
 // the launchers of the variant groups (one translation unit each)
 void launch_gv_lanc( const GVParams& P, int wp, int items, size_t lds,
+	hipStream_t st );
+void launch_gv_lanc_raw( const GVParams& P, int items, size_t lds,
 	hipStream_t st );
 void launch_gv_post( const GVParams& P, int wp, int items, size_t lds,
 	hipStream_t st );
