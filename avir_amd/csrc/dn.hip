@@ -56,6 +56,8 @@ struct DnHParams
 	                               // caller's image, converted by the loader
 	float* dst; long dst_ss;       // FltBuf, floats per row
 	int row_lo, row_hi;            // source rows to process
+	long src_elems;                // integer images: elements up to the end of
+	                               // row row_hi - 1 (the loader's bound)
 };
 
 struct DnVParams
@@ -150,21 +152,33 @@ __device__ __forceinline__ void dn_accumulate( const float ( &c )[ NT ],
 
 // one row segment of an integer image -> float RGBA pixels in LDS (the cast
 // and the channel padding of packScanline, avir.h:2777-2840); all loads of
-// the segment are issued before the first conversion
+// the segment are issued before the first conversion. A pixel is ONE
+// unaligned load of four elements, shifted down where it had to start early
+// (the image's last pixel) -- three or four element loads per pixel made the
+// integer form of this pass 20 us slower than the float one.
 template< typename Tin, int NQ >
-__device__ __forceinline__ void dn_load_raw( const Tin* row, const int ch,
-	const int in0, const int in_len, const int nin, const int lane, f4* dst )
+__device__ __forceinline__ void dn_load_raw( const Tin* base, const long row_e,
+	const long total_e, const int ch, const int in0, const int in_len,
+	const int nin, const int lane, f4* dst )
 {
-	Tin v[ NQ ][ 4 ];
+	unsigned long long v[ NQ ];
 #pragma unroll
 	for( int q = 0; q < NQ; q++ )
 	{
-		const Tin* s = row + (long) dn_clampi( in0 + q * 64 + lane,
+		const long e = row_e + (long) dn_clampi( in0 + q * 64 + lane,
 			in_len - 1 ) * ch;
-#pragma unroll
-		for( int c = 0; c < 4; c++ )
+		const long ea = ( e < total_e - 4 ? e : total_e - 4 );
+		const int sh = (int) ( e - ea );
+
+		if( sizeof( Tin ) == 1 )
 		{
-			v[ q ][ c ] = ( c < ch ? s[ c ] : (Tin) 0 );
+			typedef unsigned int u32u __attribute__(( aligned( 1 )));
+			v[ q ] = *(const u32u*) ( base + ea ) >> ( 8 * sh );
+		}
+		else
+		{
+			typedef unsigned long long u64u __attribute__(( aligned( 2 )));
+			v[ q ] = *(const u64u*) ( base + ea ) >> ( 16 * sh );
 		}
 	}
 #pragma unroll
@@ -172,9 +186,18 @@ __device__ __forceinline__ void dn_load_raw( const Tin* row, const int ch,
 	{
 		if( q * 64 + lane < nin )
 		{
-			f4 o;
-			o.x = (float) v[ q ][ 0 ]; o.y = (float) v[ q ][ 1 ];
-			o.z = (float) v[ q ][ 2 ]; o.w = (float) v[ q ][ 3 ];
+			float w[ 4 ];
+#pragma unroll
+			for( int c = 0; c < 4; c++ )
+			{
+				const unsigned int u = (unsigned int) ( sizeof( Tin ) == 1 ?
+					( v[ q ] >> ( 8 * c )) & 0xffull :
+					( v[ q ] >> ( 16 * c )) & 0xffffull );
+
+				w[ c ] = ( c < ch ? (float) u : 0.0f );
+			}
+
+			f4 o; o.x = w[ 0 ]; o.y = w[ 1 ]; o.z = w[ 2 ]; o.w = w[ 3 ];
 			dst[ q * 64 + lane ] = o;
 		}
 	}
@@ -240,13 +263,15 @@ __global__ void __launch_bounds__( 256 ) k_dnh( const DnHParams P )
 	else
 	if( P.src_type == AVIRHIP_U8 )
 	{
-		dn_load_raw< uint8_t, NDMA >( (const uint8_t*) P.src + (long) y *
-			P.src_ss, P.src_ch, in0, P.A.in_len, NIN, lane, sS[ wave ]);
+		dn_load_raw< uint8_t, NDMA >( (const uint8_t*) P.src, (long) y *
+			P.src_ss, P.src_elems, P.src_ch, in0, P.A.in_len, NIN, lane,
+			sS[ wave ]);
 	}
 	else
 	{
-		dn_load_raw< uint16_t, NDMA >( (const uint16_t*) P.src + (long) y *
-			P.src_ss, P.src_ch, in0, P.A.in_len, NIN, lane, sS[ wave ]);
+		dn_load_raw< uint16_t, NDMA >( (const uint16_t*) P.src, (long) y *
+			P.src_ss, P.src_elems, P.src_ch, in0, P.A.in_len, NIN, lane,
+			sS[ wave ]);
 	}
 
 	asm volatile( "s_waitcnt vmcnt(0)" ::: "memory" );
@@ -595,6 +620,13 @@ int dn_run_h( void* d, const void* src, int src_type, int src_ch, long src_ss,
 	P.src = src; P.src_ss = src_ss; P.dst = flt; P.dst_ss = flt_ss;
 	P.src_type = src_type; P.src_ch = src_ch;
 	P.row_lo = a; P.row_hi = b;
+	P.src_elems = (long) ( b - 1 ) * src_ss + (long) D -> h.in_len * src_ch;
+
+	if( src_type != AVIRHIP_F32 && P.src_elems < 4 )
+	{
+		return( 1 );
+	}
+
 	const int R = 3;
 	const int seg = 64 * R - 6;
 	const dim3 grid(( D -> h.out_len + seg - 1 ) / seg, ( b - a + 3 ) / 4 );
