@@ -287,24 +287,38 @@ __device__ __forceinline__ void load_raw_tile( const TileParams& P, f4* bufA,
 	const int cols, const int wave, const int lane )
 {
 	const int ch = P.src_ch;
+	// A pixel is ONE unaligned load of four elements, shifted down where it
+	// had to start early (the image's last pixel): elements [0, total)
+	const long total = (long) ( P.src_h - 1 ) * P.src_ss + (long) P.src_w * ch;
 
 	for( int y = wave; y < rows; y += 4 )
 	{
 		const int gy = clampi( row_lo + y, P.src_h - 1 );
-		const Tin* row = (const Tin*) P.src + (long) gy * P.src_ss;
+		const long row_e = (long) gy * P.src_ss;
 
 		for( int x0 = 0; x0 < cols; x0 += 256 )
 		{
-			float v[ 4 ][ 4 ];
+			unsigned long long v[ 4 ];
 #pragma unroll
 			for( int u = 0; u < 4; u++ )
 			{
 				const int x = x0 + u * 64 + lane;
-				const Tin* s = row + (long) clampi( col_lo + x, P.src_w - 1 ) * ch;
-#pragma unroll
-				for( int c = 0; c < 4; c++ )
+				const long e = row_e + (long) clampi( col_lo + x, P.src_w - 1 ) *
+					ch;
+				const long ea = ( e < total - 4 ? e : total - 4 );
+				const int sh = (int) ( e - ea );
+
+				if( sizeof( Tin ) == 1 )
 				{
-					v[ u ][ c ] = ( c < ch && x < cols ? (float) s[ c ] : 0.0f );
+					typedef unsigned int u32u __attribute__(( aligned( 1 )));
+					v[ u ] = *(const u32u*) ( (const Tin*) P.src + ea ) >>
+						( 8 * sh );
+				}
+				else
+				{
+					typedef unsigned long long u64u __attribute__(( aligned( 2 )));
+					v[ u ] = *(const u64u*) ( (const Tin*) P.src + ea ) >>
+						( 16 * sh );
 				}
 			}
 #pragma unroll
@@ -314,9 +328,19 @@ __device__ __forceinline__ void load_raw_tile( const TileParams& P, f4* bufA,
 
 				if( x < cols )
 				{
+					float w[ 4 ];
+#pragma unroll
+					for( int c = 0; c < 4; c++ )
+					{
+						const unsigned int q = (unsigned int) ( sizeof( Tin ) == 1 ?
+							( v[ u ] >> ( 8 * c )) & 0xffull :
+							( v[ u ] >> ( 16 * c )) & 0xffffull );
+
+						w[ c ] = ( c < ch ? (float) q : 0.0f );
+					}
+
 					f4 o;
-					o.x = v[ u ][ 0 ]; o.y = v[ u ][ 1 ];
-					o.z = v[ u ][ 2 ]; o.w = v[ u ][ 3 ];
+					o.x = w[ 0 ]; o.y = w[ 1 ]; o.z = w[ 2 ]; o.w = w[ 3 ];
 					bufA[ y * cp + x ] = o;
 				}
 			}
@@ -999,6 +1023,13 @@ int fused_run( avirhip_plan* p, int mode, const void* src, int src_type,
 	if(( src_type != AVIRHIP_U8 && src_type != AVIRHIP_U16 ) ||
 		!fused_takes_raw( p, mode ) ||
 		( src_type == AVIRHIP_U16 && ( (uintptr_t) src & 1 )))
+	{
+		return( 1 );
+	}
+
+	// (the integer loaders read four elements per pixel)
+	if( src_type != AVIRHIP_F32 && (long) ( p -> src_h - 1 ) * src_stride +
+		(long) p -> src_w * src_ch < 4 )
 	{
 		return( 1 );
 	}
