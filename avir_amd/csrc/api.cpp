@@ -791,15 +791,33 @@ static int exec_device( avirhip_plan* p, const void* src, void* dst,
 			rc = up2_run( p, fsrc, sstride, fdst, row0, row1, st );
 		}
 		else
-		if( raw )
 		{
-			rc = fused_run( p, path, src, p -> in_type, p -> io_ch,
-				p -> src_stride, fdst, row0, row1, st );
-		}
-		else
-		{
-			rc = fused_run( p, path, fsrc, AVIRHIP_F32, 4, sstride, fdst,
-				row0, row1, st );
+			// integer / narrow output through the whole-ratio vertical kernel:
+			// it converts and stores into the caller's image itself
+			void* iout2 = ( !direct && !p -> gamma &&
+				(( p -> dither == AVIRHIP_DITHER_DEF &&
+				( p -> out_type == AVIRHIP_U8 || p -> out_type == AVIRHIP_U16 )) ||
+				p -> out_type == AVIRHIP_F32 ) &&
+				!( p -> out_type == AVIRHIP_U8 && p -> io_ch == 4 &&
+				( (uintptr_t) dst & 3 ) != 0 ) &&
+				fused_stores_int( p, path ) &&
+				getenv( "AVIRHIP_NO_FUSED_OUT" ) == nullptr ? dst : nullptr );
+
+			if( raw )
+			{
+				rc = fused_run( p, path, src, p -> in_type, p -> io_ch,
+					p -> src_stride, fdst, row0, row1, st, iout2 );
+			}
+			else
+			{
+				rc = fused_run( p, path, fsrc, AVIRHIP_F32, 4, sstride, fdst,
+					row0, row1, st, iout2 );
+			}
+
+			if( rc == 0 && iout2 != nullptr )
+			{
+				return( AVIRHIP_OK ); // (no epilogue)
+			}
 		}
 
 		if( rc == 1 && p -> path != 0 )

@@ -26,7 +26,7 @@
 //           as coalesced 1-KiB wave loads (L2/MALL resident: it is the small
 //           image), then the FIR7 along y runs over the registers; no LDS.
 
-#include "plan.h"
+#include "gpass_dev.h"
 #include <algorithm>
 #include <string.h>
 #include <type_traits>
@@ -68,6 +68,7 @@ struct DnVParams
 	int width;                     // pixels per row
 	int g_lo, g_hi;                // output groups (of RO rows) to process
 	int row_lo, row_hi, dst_row0;  // rows to store
+	GPOut out;                     // on != 0: integer output stage in the store
 };
 
 __device__ __forceinline__ int dn_clampi( int i, int hi )
@@ -464,8 +465,15 @@ __attribute__(( amdgpu_waves_per_eu( 4, 4 ))) k_dnv( const DnVParams P )
 				a = a + f1 * ( acc[ q + 4 ] + acc[ q + 2 ]);
 				a = a + f2 * ( acc[ q + 5 ] + acc[ q + 1 ]);
 				a = a + f3 * ( acc[ q + 6 ] + acc[ q ]);
-				*(f4*) ( P.dst + (long) ( y - P.dst_row0 ) * P.dst_ss +
-					(long) x * 4 ) = a;
+				if( P.out.on != 0 )
+				{
+					gp_store_int( P.out, y - P.dst_row0, x, a );
+				}
+				else
+				{
+					*(f4*) ( P.dst + (long) ( y - P.dst_row0 ) * P.dst_ss +
+						(long) x * 4 ) = a;
+				}
 			}
 		} );
 	}
@@ -646,7 +654,7 @@ int dn_run_h( void* d, const void* src, int src_type, int src_ch, long src_ss,
 
 // FltBuf [in_len][width] -> destination rows [row0, row1)
 int dn_run_v( void* d, const float* flt, long flt_ss, int width, float* dst,
-	int row0, int row1, hipStream_t st )
+	int row0, int row1, hipStream_t st, const GPOut* out )
 {
 	DnData* D = (DnData*) d;
 
@@ -664,6 +672,13 @@ int dn_run_v( void* d, const float* flt, long flt_ss, int width, float* dst,
 	P.g_lo = row0 / RO;
 	P.g_hi = ( row1 - 1 ) / RO + 1;
 	P.row_lo = row0; P.row_hi = row1; P.dst_row0 = row0;
+	memset( &P.out, 0, sizeof( P.out ));
+
+	if( out != nullptr )
+	{
+		P.out = *out;
+	}
+
 	const dim3 grid(( width + 63 ) / 64, ( P.g_hi - P.g_lo + 3 ) / 4 );
 
 	if( D -> v.K == 3 )

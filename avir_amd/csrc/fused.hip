@@ -28,7 +28,7 @@
 // Arithmetic contract: -ffp-contract=off, separate mul/add in the reference's
 // tap order, sums started from +0.0f (see generic.hip) => bit-identical.
 
-#include "plan.h"
+#include "gpass_dev.h"
 #include <algorithm>
 #include <string.h>
 #include <stdio.h>
@@ -1000,11 +1000,25 @@ bool fused_takes_raw( const avirhip_plan* p, int mode )
 	return( p -> fused != nullptr && ( mode == 2 || mode == 3 ));
 }
 
+// Whether the last pass of this mode stores integer / narrow pixels itself
+// (fused_run's `iout`): the whole-ratio vertical kernel of the two-pass path.
+bool fused_stores_int( const avirhip_plan* p, int mode )
+{
+	const FusedData* F = (const FusedData*) p -> fused;
+	return( F != nullptr && mode == 2 && ( p -> fused_ok & 1 ) &&
+		dn_has_v( F -> dn ));
+}
+
 int fused_run( avirhip_plan* p, int mode, const void* src, int src_type,
 	int src_ch, long src_stride, float* dst, int row0, int row1,
-	hipStream_t st )
+	hipStream_t st, void* iout )
 {
 	FusedData* F = (FusedData*) p -> fused;
+
+	if( iout != nullptr && !fused_stores_int( p, mode ))
+	{
+		return( 1 );
+	}
 
 	if( F == nullptr || ( mode == 3 && !( p -> fused_ok & 2 )) ||
 		( mode == 2 && !( p -> fused_ok & 1 )) || ( mode != 2 && mode != 3 ))
@@ -1085,6 +1099,14 @@ int fused_run( avirhip_plan* p, int mode, const void* src, int src_type,
 
 	if( dn_has_v( F -> dn ))
 	{
+		if( iout != nullptr )
+		{
+			GPOut O;
+			gp_make_out( p, iout, O );
+			return( dn_run_v( F -> dn, F -> fltbuf, dss, p -> new_w, dst, row0,
+				row1, st, &O ));
+		}
+
 		return( dn_run_v( F -> dn, F -> fltbuf, dss, p -> new_w, dst, row0,
 			row1, st ));
 	}

@@ -1050,13 +1050,7 @@ int gpass_run( avirhip_plan* p, const float* src, long src_stride, float* dst,
 			return( 1 );
 		}
 
-		O.on = 1; O.type = p -> out_type; O.ch = p -> io_ch;
-		O.use_tr = ( p -> tr_mul != 1.0 );
-		O.tr_mul = (float) p -> tr_mul;
-		O.tr_muli = (float) ( 1.0 / p -> tr_mul );
-		O.pk_out = (float) p -> pk_out;
-		O.base = iout;
-		O.stride = (long) p -> new_w * p -> io_ch;
+		gp_make_out( p, iout, O );
 		dst = (float*) iout; // (alignment checks below: not written as floats)
 	}
 

@@ -100,6 +100,19 @@ struct GPOut
 	long stride;     // elements per row
 };
 
+// the plan's output stage, for rows stored from `iout` on
+static inline void gp_make_out( const avirhip_plan* p, void* iout, GPOut& O )
+{
+	memset( &O, 0, sizeof( O ));
+	O.on = 1; O.type = p -> out_type; O.ch = p -> io_ch;
+	O.use_tr = ( p -> tr_mul != 1.0 );
+	O.tr_mul = (float) p -> tr_mul;
+	O.tr_muli = (float) ( 1.0 / p -> tr_mul );
+	O.pk_out = (float) p -> pk_out;
+	O.base = iout;
+	O.stride = (long) p -> new_w * p -> io_ch;
+}
+
 __device__ __forceinline__ float gp_round( const float d )
 {
 	return( d < 0.0f ? -(float) (int) ( 0.5f - d ) : (float) (int) ( d + 0.5f ));

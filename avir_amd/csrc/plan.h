@@ -201,7 +201,8 @@ void fused_release( avirhip_plan* p );
 // loader itself -- no pack pass). `src_stride` in elements of that type.
 int fused_run( avirhip_plan* p, int mode, const void* src, int src_type,
 	int src_ch, long src_stride, float* dst, int row0, int row1,
-	hipStream_t st );
+	hipStream_t st, void* iout = nullptr );
+bool fused_stores_int( const avirhip_plan* p, int mode );
 bool fused_takes_raw( const avirhip_plan* p, int mode );
 
 // dn.hip: integer-ratio downsizing passes used by the two-pass tiled path
@@ -211,8 +212,9 @@ bool dn_has_h( const void* d );
 bool dn_has_v( const void* d );
 int dn_run_h( void* d, const void* src, int src_type, int src_ch, long src_ss,
 	float* flt, long flt_ss, int a, int b, hipStream_t st );
+struct GPOut; // gpass_dev.h: the integer output stage fused into a store
 int dn_run_v( void* d, const float* flt, long flt_ss, int width, float* dst,
-	int row0, int row1, hipStream_t st );
+	int row0, int row1, hipStream_t st, const GPOut* out = nullptr );
 
 // gpass.hip: general-ratio pass kernels (path 5), AVIR and LANCIR RGBA float
 int gpass_prepare( avirhip_plan* p );

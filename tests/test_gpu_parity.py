@@ -1262,3 +1262,35 @@ def test_misaligned_device_buffers():
                         bad += 1
                         print("OVERWRITE", (sw, sh, nw, nh), lanc, ch, dt.__name__, off_in, off_out)
     assert bad == 0
+
+
+@pytest.mark.parametrize("ch,tin,bits", [(3, np.uint8, 8), (4, np.uint8, 8),
+                                         (1, np.uint16, 16), (3, np.uint16, 10),
+                                         (3, np.float32, 16)])
+@pytest.mark.parametrize("sw,sh,k", [(600, 400, 2), (601, 403, 2),
+                                     (900, 600, 3), (385, 260, 3)])
+def test_avir_whole_ratio_kernels_read_and_store_integer_images(sw, sh, k, ch,
+                                                               tin, bits):
+    """dn.hip inside path 2 (exact 2x / 3x downsizing): the horizontal kernel
+    reads integer pixels itself (one four-element load per pixel), the vertical
+    one rounds, clamps and stores them; whole frames and row bands."""
+    lib = abi.load()
+    nw, nh = (sw + k - 1) // k, (sh + k - 1) // k
+    if np.dtype(tin).kind == "u":
+        src = rb.lcg_u8((sh, sw, ch, np.dtype(tin).itemsize), seed=sw + ch)
+        src = src.view(tin).reshape(sh, sw, ch)
+    else:
+        src = rb.lcg_f32((sh, sw, ch), seed=sw + ch)
+    want = _checker_avir(src, nw, nh, resbits=bits, k=float(k))
+    got = _run_avir(src, nw, nh, resbits=bits, k=float(k), path=abi.PATH_TILED)
+    _assert_same(got, want, "dn %r" % ((sw, sh, k, ch, tin),))
+    r = avir_amd.CImageResizer(bits)
+    p = r.plan(sw, sh, nw, nh, ch, float(k), None, rb._DT[src.dtype],
+               rb._DT[src.dtype])
+    abi.check(lib.avirhip_plan_set_path(p, abi.PATH_TILED), "set_path")
+    out = np.zeros((nh, nw, ch), tin)
+    for a_, b_ in [(0, nh // 3), (nh // 3, nh // 3 + 2), (nh // 3 + 2, nh)]:
+        abi.check(lib.avirhip_resize_band(
+            p, src.ctypes.data, abi.MEM_HOST, out[a_:b_].ctypes.data,
+            abi.MEM_HOST, a_, b_, None), "band")
+    _assert_same(out, want, "dn bands")
