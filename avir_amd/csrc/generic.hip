@@ -11,6 +11,7 @@
 // is bit-identical to the reference's scalar float path.
 
 #include "plan.h"
+#include <type_traits>
 #include <stdio.h>
 #include <stdlib.h>
 
@@ -264,12 +265,53 @@ __global__ void __launch_bounds__( 256 ) k_pack_px( const Tin* src,
 		return;
 	}
 
-	const Tin* s = src + (long) y * src_stride + (long) x * CH;
 	float v[ 4 ] = { 0.0f, 0.0f, 0.0f, 0.0f };
-#pragma unroll
-	for( int c = 0; c < CH; c++ )
+
+	if( sizeof( Tin ) <= 2 && std::is_integral< Tin > :: value )
 	{
-		v[ c ] = (float) s[ c ];
+		// integer pixels: ONE unaligned load of four elements, shifted down
+		// where it had to start early (the image's last pixel)
+		const long total = (long) ( h - 1 ) * src_stride + (long) w * CH;
+		const long e = (long) y * src_stride + (long) x * CH;
+		const long ea = ( total >= 4 && e > total - 4 ? total - 4 : e );
+		const int sh = (int) ( e - ea );
+		unsigned long long q;
+
+		if( total < 4 )
+		{
+			q = 0;
+
+			for( int c = 0; c < CH; c++ )
+			{
+				q |= (unsigned long long) src[ e + c ] << ( 8 * sizeof( Tin ) * c );
+			}
+		}
+		else
+		if( sizeof( Tin ) == 1 )
+		{
+			typedef unsigned int u32u __attribute__(( aligned( 1 )));
+			q = *(const u32u*) ( src + ea ) >> ( 8 * sh );
+		}
+		else
+		{
+			typedef unsigned long long u64u __attribute__(( aligned( 2 )));
+			q = *(const u64u*) ( src + ea ) >> ( 16 * sh );
+		}
+#pragma unroll
+		for( int c = 0; c < CH; c++ )
+		{
+			v[ c ] = (float) (unsigned int) ( sizeof( Tin ) == 1 ?
+				( q >> ( 8 * c )) & 0xffull : ( q >> ( 16 * c )) & 0xffffull );
+		}
+	}
+	else
+	{
+		const Tin* s = src + (long) y * src_stride + (long) x * CH;
+#pragma unroll
+		for( int c = 0; c < CH; c++ )
+		{
+			v[ c ] = (float) s[ c ];
+		}
 	}
 
 	typedef float f4v __attribute__(( ext_vector_type( 4 )));
