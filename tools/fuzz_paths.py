@@ -32,6 +32,8 @@ def make(sh, sw, ch, dt, seed):
 for it in range(N):
     big = rng.rand() < 0.15
     hi = 900 if big else 260
+    if os.environ.get("FUZZ_BIG"):
+        hi = 3000 if big else 1200
     sw, sh, nw, nh = [int(rng.randint(1, hi)) for _ in range(4)]
     if rng.rand() < 0.3:  # comparable sizes: ratios near 1 .. 3
         nw = max(1, int(sw * rng.uniform(0.3, 3.0)))
