@@ -1309,10 +1309,16 @@ int finalize_avir_plan( avirhip_plan* p )
 		// and write the caller's images themselves, the marching kernel
 		// needs a pack pass before and an epilogue pass behind it
 		// (1920x1080 -> 3840x2160 RGB u8: 0.084 against 0.089 ms)
+		// ... in general: whenever the marching kernel's result needs the
+		// epilogue pass (integer or 1-3 channel pixels out; 1080p -> 4K:
+		// RGB float 0.071 against 0.101 ms, RGB u8 -> float 0.070 / 0.102,
+		// RGBA float -> u8 0.082 / 0.087); RGBA float output keeps it (a
+		// uint8 RGBA source costs it one pack pass: 0.064 against 0.068)
 		if( p -> auto_path == 4 && gpass_preferred( p ) && !p -> gamma &&
 			p -> dither == AVIRHIP_DITHER_DEF &&
-			( p -> in_type == AVIRHIP_U8 || p -> in_type == AVIRHIP_U16 ) &&
-			( p -> out_type == AVIRHIP_U8 || p -> out_type == AVIRHIP_U16 ))
+			!( p -> out_type == AVIRHIP_F32 && p -> io_ch == 4 ) &&
+			( p -> out_type == AVIRHIP_U8 || p -> out_type == AVIRHIP_U16 ||
+			p -> out_type == AVIRHIP_F32 ))
 		{
 			p -> auto_path = 5;
 		}
