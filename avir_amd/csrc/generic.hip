@@ -496,6 +496,73 @@ __global__ void __launch_bounds__( 256 ) k_pack_gamma( const Tin* src,
 	dst[ (long) y * row_elems + x ] = r;
 }
 
+// ech == 4: one thread per pixel, one 16-byte store (the element-wise kernel
+// above spends an integer division and a 4-byte store per float)
+template< typename Tin, int CH >
+__global__ void __launch_bounds__( 256 ) k_pack_gamma_px( const Tin* src,
+	float* dst, int w, int h, long src_stride, int alpha_index, float gm,
+	const float* tbl )
+{
+	const int x = blockIdx.x * blockDim.x + threadIdx.x;
+	const int y = blockIdx.y;
+
+	if( x >= w || y >= h )
+	{
+		return;
+	}
+
+	const Tin* s = src + (long) y * src_stride + (long) x * CH;
+	float v[ 4 ] = { 0.0f, 0.0f, 0.0f, 0.0f };
+#pragma unroll
+	for( int c = 0; c < CH; c++ )
+	{
+		const Tin e = s[ c ];
+
+		if( c == alpha_index )
+		{
+			v[ c ] = (float) e * gm;
+		}
+		else
+		if( sizeof( Tin ) == 1 )
+		{
+			v[ c ] = tbl[ (int) e ];
+		}
+		else
+		{
+			v[ c ] = srgb_to_lin( (float) e, gm );
+		}
+	}
+
+	typedef float f4v __attribute__(( ext_vector_type( 4 )));
+	f4v o; o.x = v[ 0 ]; o.y = v[ 1 ]; o.z = v[ 2 ]; o.w = v[ 3 ];
+	*(f4v*) ( dst + ( (long) y * w + x ) * 4 ) = o;
+}
+
+template< typename Tin >
+static void launch_pack_gamma_px( const void* src, float* dst, int w, int h,
+	int ch, long src_stride, int alpha_index, float gm, const float* tbl,
+	hipStream_t st )
+{
+	const dim3 grd(( w + 255 ) / 256, h );
+	const Tin* s = (const Tin*) src;
+
+	switch( ch )
+	{
+		case 1: hipLaunchKernelGGL(( k_pack_gamma_px< Tin, 1 > ), grd,
+			dim3( 256 ), 0, st, s, dst, w, h, src_stride, alpha_index, gm, tbl );
+			break;
+		case 2: hipLaunchKernelGGL(( k_pack_gamma_px< Tin, 2 > ), grd,
+			dim3( 256 ), 0, st, s, dst, w, h, src_stride, alpha_index, gm, tbl );
+			break;
+		case 3: hipLaunchKernelGGL(( k_pack_gamma_px< Tin, 3 > ), grd,
+			dim3( 256 ), 0, st, s, dst, w, h, src_stride, alpha_index, gm, tbl );
+			break;
+		default: hipLaunchKernelGGL(( k_pack_gamma_px< Tin, 4 > ), grd,
+			dim3( 256 ), 0, st, s, dst, w, h, src_stride, alpha_index, gm, tbl );
+			break;
+	}
+}
+
 int launch_pack_gamma( const void* src, int in_type, float* dst, int w, int h,
 	int ch, int ech, long src_stride, int alpha_index, const float* tbl,
 	hipStream_t st )
@@ -505,6 +572,22 @@ int launch_pack_gamma( const void* src, int in_type, float* dst, int w, int h,
 	// InGammaMult, avir.h:4744-4754
 	const float gm = (float) ( in_type == AVIRHIP_U8 ? 1.0 / 255.0 :
 		( in_type == AVIRHIP_U16 ? 1.0 / 65535.0 : 1.0 ));
+
+	if( ech == 4 && in_type != AVIRHIP_F64 )
+	{
+		if( in_type == AVIRHIP_U8 )
+			launch_pack_gamma_px< uint8_t >( src, dst, w, h, ch, src_stride,
+				alpha_index, gm, tbl, st );
+		else if( in_type == AVIRHIP_U16 )
+			launch_pack_gamma_px< uint16_t >( src, dst, w, h, ch, src_stride,
+				alpha_index, gm, tbl, st );
+		else
+			launch_pack_gamma_px< float >( src, dst, w, h, ch, src_stride,
+				alpha_index, gm, tbl, st );
+
+		AVIRHIP_HIPCHECK( hipGetLastError() );
+		return( AVIRHIP_OK );
+	}
 
 	if( in_type == AVIRHIP_U8 )
 		hipLaunchKernelGGL( k_pack_gamma< uint8_t >, grd, dim3( 256 ), 0, st,
@@ -654,6 +737,56 @@ static void launch_epilogue_px( const float* res, void* dst, long npx, int ch,
 	}
 }
 
+// ech == 4 WITH gamma, integer output: one thread per pixel (applySRGBGamma +
+// the default ditherer + unpackScanline, as k_epilogue spells them out)
+template< typename Tout, int CH >
+__global__ void __launch_bounds__( 256 ) k_epilogue_gamma_px( const float* res,
+	Tout* dst, long npx, int use_tr, float tr_mul, float tr_muli,
+	float pk_out, int alpha_index, float ogm )
+{
+	const long i = (long) blockIdx.x * blockDim.x + threadIdx.x;
+
+	if( i >= npx )
+	{
+		return;
+	}
+
+	typedef float f4v __attribute__(( ext_vector_type( 4 )));
+	const f4v r = *(const f4v*) ( res + i * 4 );
+	const float vv[ 4 ] = { r.x, r.y, r.z, r.w };
+#pragma unroll
+	for( int c = 0; c < CH; c++ )
+	{
+		float v = vv[ c ];
+		v = ( c == alpha_index ? v * ogm : lin_to_srgb( v ) * ogm );
+		v = ( use_tr ? avir_round( v * tr_muli ) * tr_mul : avir_round( v ));
+		v = ( v < 0.0f ? 0.0f : ( v > pk_out ? pk_out : v ));
+		dst[ i * CH + c ] = (Tout) v;
+	}
+}
+
+template< typename Tout >
+static void launch_epilogue_gamma_px( const float* res, void* dst, long npx,
+	int ch, int use_tr, float trm, float trmi, float pk, int alpha_index,
+	float ogm, hipStream_t st )
+{
+	const dim3 grd( (unsigned) (( npx + 255 ) / 256 ));
+	Tout* d = (Tout*) dst;
+
+#define EG( CH ) hipLaunchKernelGGL(( k_epilogue_gamma_px< Tout, CH > ), grd, \
+		dim3( 256 ), 0, st, res, d, npx, use_tr, trm, trmi, pk, alpha_index, ogm )
+
+	switch( ch )
+	{
+		case 1: EG( 1 ); break;
+		case 2: EG( 2 ); break;
+		case 3: EG( 3 ); break;
+		default: EG( 4 ); break;
+	}
+
+#undef EG
+}
+
 int launch_epilogue( const float* res, void* dst, int out_type, long n,
 	double tr_mul, double pk_out, int gamma, int ch, int ech,
 	int alpha_index, hipStream_t st )
@@ -666,6 +799,20 @@ int launch_epilogue( const float* res, void* dst, int out_type, long n,
 	// OutGammaMult, avir.h:4756-4763
 	const float ogm = (float) ( out_type == AVIRHIP_U8 ? 255.0 :
 		( out_type == AVIRHIP_U16 ? 65535.0 : 1.0 ));
+
+	if( ech == 4 && gamma && ( out_type == AVIRHIP_U8 ||
+		out_type == AVIRHIP_U16 ))
+	{
+		if( out_type == AVIRHIP_U8 )
+			launch_epilogue_gamma_px< uint8_t >( res, dst, n / ch, ch, use_tr,
+				trm, trmi, pk, alpha_index, ogm, st );
+		else
+			launch_epilogue_gamma_px< uint16_t >( res, dst, n / ch, ch, use_tr,
+				trm, trmi, pk, alpha_index, ogm, st );
+
+		AVIRHIP_HIPCHECK( hipGetLastError() );
+		return( AVIRHIP_OK );
+	}
 
 	if( ech == 4 && !gamma && ( (uintptr_t) dst & 3 ) == 0 )
 	{
