@@ -862,7 +862,7 @@ static int exec_device( avirhip_plan* p, const void* src, void* dst,
 		rc = launch_epilogue( fdst, dst, p -> out_type,
 			(long) ( row1 - row0 ) * p -> new_w * p -> io_ch, p -> tr_mul,
 			p -> pk_out, ( p -> gamma && p -> out_type != AVIRHIP_F32 ),
-			p -> io_ch, p -> ch, p -> alpha_index, st );
+			p -> io_ch, p -> ch, p -> alpha_index, st, p -> d_gthr );
 	}
 
 	return( rc );
@@ -1135,6 +1135,7 @@ static avirhip_plan* new_plan()
 	p -> shard_src = nullptr; p -> shard_src_bytes = 0;
 	p -> tr_mul = 1.0; p -> pk_out = 0.0;
 	p -> gamma = 0; p -> alpha_index = -1; p -> d_srgb_tbl = nullptr;
+	p -> d_gthr = nullptr;
 	p -> dither = AVIRHIP_DITHER_DEF; p -> errd_line = nullptr;
 	p -> is_spare = 0;
 	p -> ch = 0; p -> io_ch = 0;
@@ -1278,6 +1279,21 @@ int finalize_avir_plan( avirhip_plan* p )
 		std::vector< float > tbl( 256 );
 		srgb_u8_table( tbl.data() );
 		rc = upload( p, tbl, &p -> d_srgb_tbl );
+
+		// uint8 output: the de-linearising output stage as a threshold table
+		// (generic.hip; the default ditherer only)
+		if( rc == 0 && p -> out_type == AVIRHIP_U8 &&
+			p -> dither == AVIRHIP_DITHER_DEF )
+		{
+			std::vector< float > thr( 512 );
+
+			if( gamma_u8_thresholds( 255.0f, p -> tr_mul != 1.0,
+				(float) p -> tr_mul, (float) ( 1.0 / p -> tr_mul ),
+				(float) p -> pk_out, thr.data() ))
+			{
+				rc = upload( p, thr, &p -> d_gthr );
+			}
+		}
 	}
 
 	// 1-3 channel pixels: channels are independent, so executing them as

@@ -11,6 +11,7 @@
 // is bit-identical to the reference's scalar float path.
 
 #include "plan.h"
+#include <string.h>
 #include <type_traits>
 #include <stdio.h>
 #include <stdlib.h>
@@ -396,7 +397,7 @@ __host__ __device__ __forceinline__ double srgb_pow24( const double x )
 		0.231757513261358 * x - 0.0395365717969074 * x4 );
 }
 
-__device__ __forceinline__ double srgb_pow24i( const double x )
+__host__ __device__ __forceinline__ double srgb_pow24i( const double x )
 {
 	const double sx = sqrt( x );
 	const double ssx = sqrt( sx );
@@ -423,7 +424,7 @@ __device__ __forceinline__ float srgb_to_lin( const float s0, const float m )
 }
 
 // convertLin2SRGB< float >, avir.h:301-312
-__device__ __forceinline__ float lin_to_srgb( const float s )
+__host__ __device__ __forceinline__ float lin_to_srgb( const float s )
 {
 	const float a = 0.055f;
 
@@ -611,7 +612,7 @@ int launch_pack_gamma( const void* src, int in_type, float* dst, int w, int h,
 }
 
 // avir::round, avir.h:130-135 (biased, via int cast).
-__device__ __forceinline__ float avir_round( const float d )
+__host__ __device__ __forceinline__ float avir_round( const float d )
 {
 	return( d < 0.0f ? -(float) (int) ( 0.5f - d ) :
 		(float) (int) ( d + 0.5f ));
@@ -737,6 +738,123 @@ static void launch_epilogue_px( const float* res, void* dst, long npx, int ch,
 	}
 }
 
+// The gamma output stage for uint8 as a step function. applySRGBGamma + the
+// default ditherer + unpackScanline map a float v to a byte through operations
+// that are each monotone non-decreasing in v (a double-precision root
+// polynomial, float multiplies by positive constants, round, clamp, cast), so
+// the whole stage is a monotone step function of v: the byte is the number of
+// thresholds thr[ k ] <= v, thr[ k ] = the smallest float whose byte is >= k.
+// The host finds the 255 thresholds by bisection over float bit patterns with
+// the SAME expressions (correctly rounded IEEE double sqrt on both sides), so
+// the table form is bit-exact -- eight comparisons instead of three
+// double-precision square roots per channel.
+static float gamma_stage( const float v0, const bool alpha, const float ogm,
+	const int use_tr, const float trm, const float trmi, const float pk )
+{
+	float v = ( alpha ? v0 * ogm : lin_to_srgb( v0 ) * ogm );
+	v = ( use_tr ? avir_round( v * trmi ) * trm : avir_round( v ));
+	return( v < 0.0f ? 0.0f : ( v > pk ? pk : v ));
+}
+
+// thr[ 0 .. 255 ] colour channels, thr[ 256 .. 511 ] the alpha channel;
+// entry 0 of each is unused (-inf), unreachable bytes hold +inf
+bool gamma_u8_thresholds( const float ogm, const int use_tr, const float trm,
+	const float trmi, const float pk, float* thr )
+{
+	for( int a = 0; a < 2; a++ )
+	{
+		float* const t = thr + a * 256;
+		t[ 0 ] = -INFINITY;
+
+		for( int k = 1; k < 256; k++ )
+		{
+			// non-negative floats order like their bit patterns
+			unsigned int lo = 0, hi; // F( lo ) < k <= F( hi )
+			if( gamma_stage( 0.0f, a == 1, ogm, use_tr, trm, trmi, pk ) >= k )
+			{
+				t[ k ] = 0.0f;
+				continue;
+			}
+
+			// (the search stops at 16.0: far above anything that still changes
+			// the byte, far below the values whose rounding leaves the int range
+			// -- where the host's cast and the device's differ)
+			if( !( gamma_stage( 16.0f, a == 1, ogm, use_tr, trm, trmi,
+				pk ) >= k ))
+			{
+				t[ k ] = INFINITY;
+				continue;
+			}
+
+			hi = 0x41800000u; // 16.0f
+
+			while( hi - lo > 1 )
+			{
+				const unsigned int mid = lo + ( hi - lo ) / 2;
+				union { unsigned int u; float f; } cv; cv.u = mid;
+				const float fm = cv.f;
+
+				if( gamma_stage( fm, a == 1, ogm, use_tr, trm, trmi, pk ) >= k )
+				{
+					hi = mid;
+				}
+				else
+				{
+					lo = mid;
+				}
+			}
+
+			{ union { unsigned int u; float f; } cv; cv.u = hi; t[ k ] = cv.f; }
+		}
+
+		// the stage must be monotone where it was sampled
+		for( int k = 2; k < 256; k++ )
+		{
+			if( t[ k ] < t[ k - 1 ])
+			{
+				return( false );
+			}
+		}
+	}
+
+	return( true );
+}
+
+template< int CH >
+__global__ void __launch_bounds__( 256 ) k_epilogue_gamma_thr( const float* res,
+	unsigned char* dst, long npx, int alpha_index, const float* thr )
+{
+	__shared__ float sthr[ 512 ];
+	sthr[ threadIdx.x ] = thr[ threadIdx.x ];
+	sthr[ threadIdx.x + 256 ] = thr[ threadIdx.x + 256 ];
+	__syncthreads();
+
+	const long i = (long) blockIdx.x * blockDim.x + threadIdx.x;
+
+	if( i >= npx )
+	{
+		return;
+	}
+
+	typedef float f4v __attribute__(( ext_vector_type( 4 )));
+	const f4v r = *(const f4v*) ( res + i * 4 );
+	const float vv[ 4 ] = { r.x, r.y, r.z, r.w };
+#pragma unroll
+	for( int c = 0; c < CH; c++ )
+	{
+		const float v = vv[ c ];
+		const float* const t = sthr + ( c == alpha_index ? 256 : 0 );
+		int lo = 0;
+#pragma unroll
+		for( int s = 128; s >= 1; s >>= 1 )
+		{
+			lo += ( v >= t[ lo + s ] ? s : 0 );
+		}
+
+		dst[ i * CH + c ] = (unsigned char) lo;
+	}
+}
+
 // ech == 4 WITH gamma, integer output: one thread per pixel (applySRGBGamma +
 // the default ditherer + unpackScanline, as k_epilogue spells them out)
 template< typename Tout, int CH >
@@ -789,7 +907,7 @@ static void launch_epilogue_gamma_px( const float* res, void* dst, long npx,
 
 int launch_epilogue( const float* res, void* dst, int out_type, long n,
 	double tr_mul, double pk_out, int gamma, int ch, int ech,
-	int alpha_index, hipStream_t st )
+	int alpha_index, hipStream_t st, const float* gthr )
 {
 	const dim3 grd( (unsigned) (( n + 255 ) / 256 ));
 	const int use_tr = ( tr_mul != 1.0 );
@@ -799,6 +917,27 @@ int launch_epilogue( const float* res, void* dst, int out_type, long n,
 	// OutGammaMult, avir.h:4756-4763
 	const float ogm = (float) ( out_type == AVIRHIP_U8 ? 255.0 :
 		( out_type == AVIRHIP_U16 ? 65535.0 : 1.0 ));
+
+	if( ech == 4 && gamma && out_type == AVIRHIP_U8 && gthr != nullptr )
+	{
+		const long npx = n / ch;
+		const dim3 grd( (unsigned) (( npx + 255 ) / 256 ));
+
+#define ET( CH ) hipLaunchKernelGGL(( k_epilogue_gamma_thr< CH > ), grd, \
+		dim3( 256 ), 0, st, res, (unsigned char*) dst, npx, alpha_index, gthr )
+
+		switch( ch )
+		{
+			case 1: ET( 1 ); break;
+			case 2: ET( 2 ); break;
+			case 3: ET( 3 ); break;
+			default: ET( 4 ); break;
+		}
+
+#undef ET
+		AVIRHIP_HIPCHECK( hipGetLastError() );
+		return( AVIRHIP_OK );
+	}
 
 	if( ech == 4 && gamma && ( out_type == AVIRHIP_U8 ||
 		out_type == AVIRHIP_U16 ))

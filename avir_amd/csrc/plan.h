@@ -103,6 +103,7 @@ struct avirhip_plan
 	int dither;             // AVIRHIP_DITHER_* (integer outputs only)
 	float* errd_line;       // error-diffusion rows handed between row blocks
 	float* d_srgb_tbl;      // 256-entry uint8 linearisation table (gamma plans)
+	float* d_gthr;          // uint8 gamma output stage as 2 x 256 thresholds
 	avirhip::LAxis h, v;
 	// LANCIR
 	avirhip::LancirAxisDev lv, lh;
@@ -179,7 +180,9 @@ int launch_op( const LOp& op, int ch, bool x_is_idx, const Surf& in,
 	hipStream_t st );
 int launch_epilogue( const float* res, void* dst, int out_type, long n,
 	double tr_mul, double pk_out, int gamma, int ch, int ech,
-	int alpha_index, hipStream_t st );
+	int alpha_index, hipStream_t st, const float* gthr = nullptr );
+bool gamma_u8_thresholds( float ogm, int use_tr, float trm, float trmi,
+	float pk, float* thr );
 int launch_errd( const float* res, void* dst, int out_type, int w, int h,
 	int ch, int ech, double tr_mul, double pk_out, int gamma, int alpha_index,
 	float* line, hipStream_t st );
