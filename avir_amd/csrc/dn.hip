@@ -27,6 +27,7 @@
 //           image), then the FIR7 along y runs over the registers; no LDS.
 
 #include "gpass_dev.h"
+#include "dn_dev.h"
 #include <algorithm>
 #include <string.h>
 #include <type_traits>
@@ -37,15 +38,6 @@ namespace avirhip {
 typedef float f4 __attribute__(( ext_vector_type( 4 )));
 typedef unsigned u4 __attribute__(( ext_vector_type( 4 )));
 typedef __attribute__(( address_space( 3 ))) void* ldsptr;
-
-#define DN_MAXNT 40
-
-struct DnAxisP
-{
-	int K, NT, c0;       // offset of output j: K*j + c0
-	int in_len, out_len;
-	const float* coef;   // device: NT resize coefficients, then 4 FIR taps
-};
 
 struct DnHParams
 {
@@ -70,26 +62,6 @@ struct DnVParams
 	int row_lo, row_hi, dst_row0;  // rows to store
 	GPOut out;                     // on != 0: integer output stage in the store
 };
-
-__device__ __forceinline__ int dn_clampi( int i, int hi )
-{
-	return( i < 0 ? 0 : ( i > hi ? hi : i ));
-}
-
-// compile-time loop: every index below must be a constant so that the arrays
-// stay in registers (a rolled loop would index them dynamically -> scratch)
-template< int... I, class F >
-__device__ __forceinline__ void dn_static_for_impl(
-	std::integer_sequence< int, I... >, F&& f )
-{
-	( f( std::integral_constant< int, I >()), ... );
-}
-
-template< int N, class F >
-__device__ __forceinline__ void dn_static_for( F&& f )
-{
-	dn_static_for_impl( std::make_integer_sequence< int, N >(), f );
-}
 
 // input i feeds tap i - K*r of output r
 template< int K, int NT, int R, int I >
@@ -483,19 +455,6 @@ __attribute__(( amdgpu_waves_per_eu( 4, 4 ))) k_dnv( const DnVParams P )
 // host side
 // ---------------------------------------------------------------------
 
-struct DnAxis
-{
-	int K, NT, c0, in_len, out_len;
-	float* d_coef;
-};
-
-struct DnData
-{
-	bool hok, vok;
-	DnAxis h, v;
-	std::vector< void* > allocs;
-};
-
 static bool dn_supported( int K, int NT )
 {
 	return(( K == 2 && NT == 24 ) || ( K == 3 && NT == 38 ));
@@ -580,6 +539,9 @@ int dn_prepare( avirhip_plan* p, void** out )
 		return( rc );
 	}
 
+	hipDeviceProp_t prop;
+	D -> ncu = ( hipGetDeviceProperties( &prop, p -> device ) == hipSuccess ?
+		prop.multiProcessorCount : 256 );
 	*out = D;
 	return( AVIRHIP_OK );
 }

@@ -993,6 +993,14 @@ static int launch_tiles( avirhip_plan* p, const TileGeom& G, bool useh,
 	return( AVIRHIP_OK );
 }
 
+// AVIRHIP_DNF=0 keeps integer-ratio downsizing on the two pass kernels (A/B)
+static bool dnf_enabled()
+{
+	static const int on = []() { const char* e = getenv( "AVIRHIP_DNF" );
+		return( e == nullptr || atoi( e ) != 0 ? 1 : 0 ); }();
+	return( on != 0 );
+}
+
 // mode 3: fused; mode 2: two-pass.
 bool fused_takes_raw( const avirhip_plan* p, int mode )
 {
@@ -1059,6 +1067,26 @@ int fused_run( avirhip_plan* p, int mode, const void* src, int src_type,
 	{
 		return( launch_tiles( p, F -> fused, true, true, src, src_type, src_ch,
 			src_stride, dst, dss, row0, row0, row1, st ));
+	}
+
+	// integer-ratio downsizing on both axes: one marching launch, no FltBuf
+	if( src_type == AVIRHIP_F32 && dn_has_h( F -> dn ) && dn_has_v( F -> dn ) &&
+		dnf_enabled() )
+	{
+		GPOut O;
+
+		if( iout != nullptr )
+		{
+			gp_make_out( p, iout, O );
+		}
+
+		const int rc = dn_run_hv( F -> dn, (const float*) src, src_stride, dst,
+			row0, row1, st, ( iout != nullptr ? &O : nullptr ));
+
+		if( rc != 1 )
+		{
+			return( rc );
+		}
 	}
 
 	// two-pass: which FltBuf rows does the band need?

@@ -218,6 +218,10 @@ int dn_run_h( void* d, const void* src, int src_type, int src_ch, long src_ss,
 struct GPOut; // gpass_dev.h: the integer output stage fused into a store
 int dn_run_v( void* d, const float* flt, long flt_ss, int width, float* dst,
 	int row0, int row1, hipStream_t st, const GPOut* out = nullptr );
+// dnf.hip: both axes of such a plan in one marching launch (no FltBuf);
+// returns 1 when the call cannot take it
+int dn_run_hv( void* d, const float* src, long src_ss, float* dst, int row0,
+	int row1, hipStream_t st, const GPOut* out = nullptr );
 
 // gpass.hip: general-ratio pass kernels (path 5), AVIR and LANCIR RGBA float
 int gpass_prepare( avirhip_plan* p );
