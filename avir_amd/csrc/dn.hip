@@ -500,14 +500,23 @@ static int dn_match( const LAxis& ax, DnData* D, DnAxis& A, bool& ok )
 		}
 	}
 
-	float hc[ DN_MAXNT + 4 ];
+	// [NT resize taps][4 FIR taps][NT + 2K tap pairs V2 of dnf.hip's column
+	// waves: V2[i] = { i < NT ? c[i] : 0, i >= 2K ? c[i - 2K] : 0 }]
+	float hc[ DN_MAXNT + 4 + 2 * ( DN_MAXNT + 6 )];
+	memset( hc, 0, sizeof( hc ));
 	memcpy( hc, &g.h_coef[ 0 ], NT * sizeof( float ));
 	memcpy( hc + NT, &f.h_flt[ 0 ], 4 * sizeof( float ));
+
+	for( int i = 0; i < NT + 2 * K; i++ )
+	{
+		hc[ NT + 4 + 2 * i ] = ( i < NT ? g.h_coef[ i ] : 0.0f );
+		hc[ NT + 4 + 2 * i + 1 ] = ( i >= 2 * K ? g.h_coef[ i - 2 * K ] : 0.0f );
+	}
+
 	void* q = nullptr;
 	AVIRHIP_HIPCHECK( hipMalloc( &q, sizeof( hc )));
 	D -> allocs.push_back( q );
-	AVIRHIP_HIPCHECK( hipMemcpy( q, hc, ( NT + 4 ) * sizeof( float ),
-		hipMemcpyHostToDevice ));
+	AVIRHIP_HIPCHECK( hipMemcpy( q, hc, sizeof( hc ), hipMemcpyHostToDevice ));
 	A.K = K; A.NT = NT; A.c0 = g.h_start[ 0 ];
 	A.in_len = g.in_len; A.out_len = g.out_len;
 	A.d_coef = (float*) q;

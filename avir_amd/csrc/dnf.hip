@@ -70,21 +70,17 @@ struct DnFParams
 	GPOut out;                      // on != 0: integer output stage in the store
 };
 
-// one element (channel c of pixel x) through the integer output stage
-// (gp_store_int's arithmetic per channel)
-__device__ __forceinline__ void df_store_elem( const GPOut& O, const long row,
-	const int x, const int c, const float v )
+// one element (a lane's channel of its pixel, byte offset `voff` inside the
+// row) through the integer output stage (gp_store_int's arithmetic per
+// channel); row `row` of the caller's band
+__device__ __forceinline__ void df_store_elem( const GPOut& O,
+	const __amdgpu_buffer_rsrc_t rs, const int voff, const int row,
+	const float v )
 {
-	if( c >= O.ch )
-	{
-		return;
-	}
-
-	const long e = row * O.stride + (long) x * O.ch + c;
-
 	if( O.type == AVIRHIP_F32 )
 	{
-		((float*) O.base )[ e ] = v;
+		__builtin_amdgcn_raw_buffer_store_b32( __builtin_bit_cast( unsigned,
+			v ), rs, voff, row * (int) O.stride * 4, 0 );
 		return;
 	}
 
@@ -104,11 +100,13 @@ __device__ __forceinline__ void df_store_elem( const GPOut& O, const long row,
 
 	if( O.type == AVIRHIP_U8 )
 	{
-		((unsigned char*) O.base )[ e ] = (unsigned char) q;
+		__builtin_amdgcn_raw_buffer_store_b8( (unsigned char) q, rs, voff,
+			row * (int) O.stride, 0 );
 	}
 	else
 	{
-		((unsigned short*) O.base )[ e ] = (unsigned short) q;
+		__builtin_amdgcn_raw_buffer_store_b16( (unsigned short) q, rs, voff,
+			row * (int) O.stride * 2, 0 );
 	}
 }
 
@@ -234,194 +232,213 @@ __device__ __forceinline__ void df_feed( f2 ( &acc )[ 3 ], const f2 v,
 	}
 }
 
-// Scalar multiply-adds of a column wave: one F value times the taps of N of
-// the outputs alive at its row (FIRST: a0's sum starts here, from +0.0f).
-template< bool FIRST >
-__device__ __forceinline__ void df_v1( float& a0,
-	const float v, const float c0 )
+// ---- column waves: one asm statement per F row.
+// A lane keeps the 16 accumulator slots (output j lives in slot j % 16) as 8
+// register PAIRS {slot 4q + b, slot 4q + b + 2}: the two outputs of a pair,
+// j - 2 and j, are at taps t + 2K and t of the same row, so ONE packed
+// multiply (the F value broadcast, times the register pair V2[t + 2K] =
+// {c[t + 2K], c[t]}) and one packed add serve both. V2 is c[] laid out for
+// that, with zeros where a pair's other output is not alive (the table has
+// NT + 2K entries): a dead half receives +-0 products, and every slot is
+// zeroed on the row its next output starts at. A wave issues an instruction
+// every ~4 cycles whatever it is, and the column waves are the workgroup's
+// longest instruction streams: 13 taps = 26 scalar instructions become 14-16.
+// The F values arrive as pairs of rows {row 2m, row 2m + 1} (ds_read2_b32):
+// RSEL picks the half.
+#define DF_RSEL0 "op_sel:[0,0] op_sel_hi:[0,1]"
+#define DF_RSEL1 "op_sel:[1,0] op_sel_hi:[1,1]"
+#define DF_VP_MULR0( i ) \
+	"v_pk_mul_f32 %[q" #i "], %[vp], %[k" #i "] " DF_RSEL0 "\n\t"
+#define DF_VP_MULR1( i ) \
+	"v_pk_mul_f32 %[q" #i "], %[vp], %[k" #i "] " DF_RSEL1 "\n\t"
+#define DF_VP_ADD( i ) "v_pk_add_f32 %[a" #i "], %[a" #i "], %[q" #i "]\n\t"
+#define DF_VP_OUT( i ) [a##i] "+v"( a##i ), [q##i] "=&v"( q##i ),
+#define DF_VP_IN( i ) [k##i] "v"( k##i ),
+// pairs 1 .. N-1 (pair 0 closes the operand lists: no trailing comma)
+#define DF_PR6( M ) M( 1 ) M( 2 ) M( 3 ) M( 4 ) M( 5 )
+#define DF_PR7( M ) DF_PR6( M ) M( 6 )
+#define DF_PR8( M ) DF_PR7( M ) M( 7 )
+#define DF_VSTMT( PR, MULR ) asm volatile( \
+	MULR( 0 ) PR( MULR ) DF_VP_ADD( 0 ) PR( DF_VP_ADD ) \
+	: PR( DF_VP_OUT ) [a0] "+v"( a0 ), [q0] "=&v"( q0 ) \
+	: PR( DF_VP_IN ) [k0] "v"( k0 ), [vp] "v"( vp ))
+
+template< int N, int R >
+__device__ __forceinline__ void df_vstmt( f2& a0, f2& a1, f2& a2, f2& a3,
+	f2& a4, f2& a5, f2& a6, f2& a7, const f2 vp, const f2 k0, const f2 k1,
+	const f2 k2, const f2 k3, const f2 k4, const f2 k5, const f2 k6,
+	const f2 k7 )
 {
-	float p0;
-	if constexpr( FIRST )
-	{
-		asm volatile( "v_mul_f32 %1, %3, %2\n\t"
-			"v_add_f32 %0, 0, %1\n\t"
-			: "=&v"( a0 ),
-			"=&v"( p0 )
-			: "v"( v ), "s"( c0 ) );
-	}
+	f2 q0, q1, q2, q3, q4, q5, q6, q7;
+
+	if constexpr( N == 8 && R == 0 ) DF_VSTMT( DF_PR8, DF_VP_MULR0 );
+	else if constexpr( N == 8 && R == 1 ) DF_VSTMT( DF_PR8, DF_VP_MULR1 );
+	else if constexpr( N == 7 && R == 0 ) DF_VSTMT( DF_PR7, DF_VP_MULR0 );
+	else if constexpr( N == 7 && R == 1 ) DF_VSTMT( DF_PR7, DF_VP_MULR1 );
+	else if constexpr( N == 6 && R == 0 ) DF_VSTMT( DF_PR6, DF_VP_MULR0 );
+	else if constexpr( N == 6 && R == 1 ) DF_VSTMT( DF_PR6, DF_VP_MULR1 );
 	else
 	{
-		asm volatile( "v_mul_f32 %1, %3, %2\n\t"
-			"v_add_f32 %0, %0, %1"
-			: "+v"( a0 ),
-			"=&v"( p0 )
-			: "v"( v ), "s"( c0 ) );
+		static_assert( N < 0, "6-8 pair registers are alive at a row" );
 	}
 }
 
-template< bool FIRST >
-__device__ __forceinline__ void df_v5( float& a0, float& a1, float& a2, float& a3, float& a4,
-	const float v, const float c0, const float c1, const float c2, const float c3, const float c4 )
+// Row U of the 16-output period: the pair registers with an output alive and
+// their V2 entries; the slot (if any) whose output starts at this row.
+template< int K, int NT, int U >
+struct DfRow
 {
-	float p0, p1, p2, p3, p4;
-	if constexpr( FIRST )
+	int n;
+	int pi[ 8 ], vi[ 8 ];
+	int zslot; // -1: none
+
+	constexpr DfRow() : n( 0 ), pi(), vi(), zslot( -1 )
 	{
-		asm volatile( "v_mul_f32 %5, %11, %10\n\t"
-			"v_mul_f32 %6, %12, %10\n\t"
-			"v_mul_f32 %7, %13, %10\n\t"
-			"v_mul_f32 %8, %14, %10\n\t"
-			"v_mul_f32 %9, %15, %10\n\t"
-			"v_add_f32 %0, 0, %5\n\t"
-			"v_add_f32 %1, %1, %6\n\t"
-			"v_add_f32 %2, %2, %7\n\t"
-			"v_add_f32 %3, %3, %8\n\t"
-			"v_add_f32 %4, %4, %9"
-			: "=&v"( a0 ), "+v"( a1 ), "+v"( a2 ), "+v"( a3 ), "+v"( a4 ),
-			"=&v"( p0 ), "=&v"( p1 ), "=&v"( p2 ), "=&v"( p3 ), "=&v"( p4 )
-			: "v"( v ), "s"( c0 ), "s"( c1 ), "s"( c2 ), "s"( c3 ), "s"( c4 ) );
+		for( int r = 0; r < 8; r++ )
+		{
+			const int slo = ( r >> 1 ) * 4 + ( r & 1 ), shi = slo + 2;
+			int tlo = -1, thi = -1;
+
+			// the alive outputs are j = U / K, U / K - 1, ... (tap U - K * j)
+			for( int d = 0; d < 16; d++ )
+			{
+				const int j = U / K - d;
+				const int t = U - K * j;
+
+				if( t >= 0 && t < NT )
+				{
+					const int sl = (( j % 16 ) + 16 ) % 16;
+					if( sl == slo ) tlo = t;
+					if( sl == shi ) thi = t;
+					if( t == 0 ) zslot = sl;
+				}
+			}
+
+			if( tlo >= 0 || thi >= 0 )
+			{
+				pi[ n ] = r;
+				vi[ n ] = ( thi >= 0 ? thi + 2 * K : tlo );
+				n++;
+			}
+		}
+	}
+};
+
+// ---- row waves: the resize inputs of a lane, ds_read_b64 in batches that
+// are issued one batch ahead of their use (asm: hipcc would merge them into
+// ds_read2_b64, half the LDS rate, and waits for every load it issues between
+// two asm statements on the spot)
+template< int B >
+struct DfBatch
+{
+	f2 v[ B ];
+};
+
+#define DF_LD( i ) "ds_read_b64 %" #i ", %[ad] offset:%[o" #i "]\n\t"
+#define DF_LDO( i ) "=v"( d.v[ i ])
+#define DF_LDI( i ) [o##i] "i"( O##i )
+
+template< int B, int O0, int O1, int O2, int O3, int O4, int O5, int O6,
+	int O7 = 0, int O8 = 0, int O9 = 0, int O10 = 0 >
+__device__ __forceinline__ void df_load( DfBatch< B >& d, const unsigned ad )
+{
+	if constexpr( B == 11 )
+	{
+		asm volatile( DF_LD( 0 ) DF_LD( 1 ) DF_LD( 2 ) DF_LD( 3 ) DF_LD( 4 )
+			DF_LD( 5 ) DF_LD( 6 ) DF_LD( 7 ) DF_LD( 8 ) DF_LD( 9 ) DF_LD( 10 )
+			: DF_LDO( 0 ), DF_LDO( 1 ), DF_LDO( 2 ), DF_LDO( 3 ), DF_LDO( 4 ),
+			DF_LDO( 5 ), DF_LDO( 6 ), DF_LDO( 7 ), DF_LDO( 8 ), DF_LDO( 9 ),
+			DF_LDO( 10 )
+			: [ad] "v"( ad ), DF_LDI( 0 ), DF_LDI( 1 ), DF_LDI( 2 ),
+			DF_LDI( 3 ), DF_LDI( 4 ), DF_LDI( 5 ), DF_LDI( 6 ), DF_LDI( 7 ),
+			DF_LDI( 8 ), DF_LDI( 9 ), DF_LDI( 10 ));
 	}
 	else
 	{
-		asm volatile( "v_mul_f32 %5, %11, %10\n\t"
-			"v_mul_f32 %6, %12, %10\n\t"
-			"v_mul_f32 %7, %13, %10\n\t"
-			"v_mul_f32 %8, %14, %10\n\t"
-			"v_mul_f32 %9, %15, %10\n\t"
-			"v_add_f32 %0, %0, %5\n\t"
-			"v_add_f32 %1, %1, %6\n\t"
-			"v_add_f32 %2, %2, %7\n\t"
-			"v_add_f32 %3, %3, %8\n\t"
-			"v_add_f32 %4, %4, %9"
-			: "+v"( a0 ), "+v"( a1 ), "+v"( a2 ), "+v"( a3 ), "+v"( a4 ),
-			"=&v"( p0 ), "=&v"( p1 ), "=&v"( p2 ), "=&v"( p3 ), "=&v"( p4 )
-			: "v"( v ), "s"( c0 ), "s"( c1 ), "s"( c2 ), "s"( c3 ), "s"( c4 ) );
+		static_assert( B == 7, "batch of 11 (K = 3) or 7 (K = 2) inputs" );
+		asm volatile( DF_LD( 0 ) DF_LD( 1 ) DF_LD( 2 ) DF_LD( 3 ) DF_LD( 4 )
+			DF_LD( 5 ) DF_LD( 6 )
+			: DF_LDO( 0 ), DF_LDO( 1 ), DF_LDO( 2 ), DF_LDO( 3 ), DF_LDO( 4 ),
+			DF_LDO( 5 ), DF_LDO( 6 )
+			: [ad] "v"( ad ), DF_LDI( 0 ), DF_LDI( 1 ), DF_LDI( 2 ),
+			DF_LDI( 3 ), DF_LDI( 4 ), DF_LDI( 5 ), DF_LDI( 6 ));
 	}
 }
 
-template< bool FIRST >
-__device__ __forceinline__ void df_v6( float& a0, float& a1, float& a2, float& a3, float& a4, float& a5,
-	const float v, const float c0, const float c1, const float c2, const float c3, const float c4, const float c5 )
+// batch starting at input I0: byte offsets of its inputs
+template< int K, int NP, int B, int I0 >
+__device__ __forceinline__ void df_load_at( DfBatch< B >& d, const unsigned ad )
 {
-	float p0, p1, p2, p3, p4, p5;
-	if constexpr( FIRST )
+#define DF_O( j ) ( 16 * df_slot< K, NP >( I0 + ( j )))
+	if constexpr( B == 11 )
 	{
-		asm volatile( "v_mul_f32 %6, %13, %12\n\t"
-			"v_mul_f32 %7, %14, %12\n\t"
-			"v_mul_f32 %8, %15, %12\n\t"
-			"v_mul_f32 %9, %16, %12\n\t"
-			"v_mul_f32 %10, %17, %12\n\t"
-			"v_mul_f32 %11, %18, %12\n\t"
-			"v_add_f32 %0, 0, %6\n\t"
-			"v_add_f32 %1, %1, %7\n\t"
-			"v_add_f32 %2, %2, %8\n\t"
-			"v_add_f32 %3, %3, %9\n\t"
-			"v_add_f32 %4, %4, %10\n\t"
-			"v_add_f32 %5, %5, %11"
-			: "=&v"( a0 ), "+v"( a1 ), "+v"( a2 ), "+v"( a3 ), "+v"( a4 ), "+v"( a5 ),
-			"=&v"( p0 ), "=&v"( p1 ), "=&v"( p2 ), "=&v"( p3 ), "=&v"( p4 ), "=&v"( p5 )
-			: "v"( v ), "s"( c0 ), "s"( c1 ), "s"( c2 ), "s"( c3 ), "s"( c4 ), "s"( c5 ) );
+		df_load< B, DF_O( 0 ), DF_O( 1 ), DF_O( 2 ), DF_O( 3 ), DF_O( 4 ),
+			DF_O( 5 ), DF_O( 6 ), DF_O( 7 ), DF_O( 8 ), DF_O( 9 ),
+			DF_O( 10 ) >( d, ad );
 	}
 	else
 	{
-		asm volatile( "v_mul_f32 %6, %13, %12\n\t"
-			"v_mul_f32 %7, %14, %12\n\t"
-			"v_mul_f32 %8, %15, %12\n\t"
-			"v_mul_f32 %9, %16, %12\n\t"
-			"v_mul_f32 %10, %17, %12\n\t"
-			"v_mul_f32 %11, %18, %12\n\t"
-			"v_add_f32 %0, %0, %6\n\t"
-			"v_add_f32 %1, %1, %7\n\t"
-			"v_add_f32 %2, %2, %8\n\t"
-			"v_add_f32 %3, %3, %9\n\t"
-			"v_add_f32 %4, %4, %10\n\t"
-			"v_add_f32 %5, %5, %11"
-			: "+v"( a0 ), "+v"( a1 ), "+v"( a2 ), "+v"( a3 ), "+v"( a4 ), "+v"( a5 ),
-			"=&v"( p0 ), "=&v"( p1 ), "=&v"( p2 ), "=&v"( p3 ), "=&v"( p4 ), "=&v"( p5 )
-			: "v"( v ), "s"( c0 ), "s"( c1 ), "s"( c2 ), "s"( c3 ), "s"( c4 ), "s"( c5 ) );
+		df_load< B, DF_O( 0 ), DF_O( 1 ), DF_O( 2 ), DF_O( 3 ), DF_O( 4 ),
+			DF_O( 5 ), DF_O( 6 ) >( d, ad );
 	}
+#undef DF_O
 }
 
-template< bool FIRST >
-__device__ __forceinline__ void df_v7( float& a0, float& a1, float& a2, float& a3, float& a4, float& a5, float& a6,
-	const float v, const float c0, const float c1, const float c2, const float c3, const float c4, const float c5, const float c6 )
+// the batch's data has landed once at most `LEFT` younger LDS reads are
+// outstanding (LDS returns in order); naming the registers keeps hipcc from
+// touching them before
+template< int B, int LEFT >
+__device__ __forceinline__ void df_wait( DfBatch< B >& d )
 {
-	float p0, p1, p2, p3, p4, p5, p6;
-	if constexpr( FIRST )
+	static_assert( LEFT == 0 || LEFT == 7 || LEFT == 11, "wait count" );
+
+	if constexpr( B == 11 )
 	{
-		asm volatile( "v_mul_f32 %7, %15, %14\n\t"
-			"v_mul_f32 %8, %16, %14\n\t"
-			"v_mul_f32 %9, %17, %14\n\t"
-			"v_mul_f32 %10, %18, %14\n\t"
-			"v_mul_f32 %11, %19, %14\n\t"
-			"v_mul_f32 %12, %20, %14\n\t"
-			"v_mul_f32 %13, %21, %14\n\t"
-			"v_add_f32 %0, 0, %7\n\t"
-			"v_add_f32 %1, %1, %8\n\t"
-			"v_add_f32 %2, %2, %9\n\t"
-			"v_add_f32 %3, %3, %10\n\t"
-			"v_add_f32 %4, %4, %11\n\t"
-			"v_add_f32 %5, %5, %12\n\t"
-			"v_add_f32 %6, %6, %13"
-			: "=&v"( a0 ), "+v"( a1 ), "+v"( a2 ), "+v"( a3 ), "+v"( a4 ), "+v"( a5 ), "+v"( a6 ),
-			"=&v"( p0 ), "=&v"( p1 ), "=&v"( p2 ), "=&v"( p3 ), "=&v"( p4 ), "=&v"( p5 ), "=&v"( p6 )
-			: "v"( v ), "s"( c0 ), "s"( c1 ), "s"( c2 ), "s"( c3 ), "s"( c4 ), "s"( c5 ), "s"( c6 ) );
+		if constexpr( LEFT == 0 )
+		{
+			asm volatile( "s_waitcnt lgkmcnt(0)"
+				: "+v"( d.v[ 0 ]), "+v"( d.v[ 1 ]), "+v"( d.v[ 2 ]),
+				"+v"( d.v[ 3 ]), "+v"( d.v[ 4 ]), "+v"( d.v[ 5 ]),
+				"+v"( d.v[ 6 ]), "+v"( d.v[ 7 ]), "+v"( d.v[ 8 ]),
+				"+v"( d.v[ 9 ]), "+v"( d.v[ 10 ]));
+		}
+		else
+		{
+			asm volatile( "s_waitcnt lgkmcnt(11)"
+				: "+v"( d.v[ 0 ]), "+v"( d.v[ 1 ]), "+v"( d.v[ 2 ]),
+				"+v"( d.v[ 3 ]), "+v"( d.v[ 4 ]), "+v"( d.v[ 5 ]),
+				"+v"( d.v[ 6 ]), "+v"( d.v[ 7 ]), "+v"( d.v[ 8 ]),
+				"+v"( d.v[ 9 ]), "+v"( d.v[ 10 ]));
+		}
 	}
 	else
 	{
-		asm volatile( "v_mul_f32 %7, %15, %14\n\t"
-			"v_mul_f32 %8, %16, %14\n\t"
-			"v_mul_f32 %9, %17, %14\n\t"
-			"v_mul_f32 %10, %18, %14\n\t"
-			"v_mul_f32 %11, %19, %14\n\t"
-			"v_mul_f32 %12, %20, %14\n\t"
-			"v_mul_f32 %13, %21, %14\n\t"
-			"v_add_f32 %0, %0, %7\n\t"
-			"v_add_f32 %1, %1, %8\n\t"
-			"v_add_f32 %2, %2, %9\n\t"
-			"v_add_f32 %3, %3, %10\n\t"
-			"v_add_f32 %4, %4, %11\n\t"
-			"v_add_f32 %5, %5, %12\n\t"
-			"v_add_f32 %6, %6, %13"
-			: "+v"( a0 ), "+v"( a1 ), "+v"( a2 ), "+v"( a3 ), "+v"( a4 ), "+v"( a5 ), "+v"( a6 ),
-			"=&v"( p0 ), "=&v"( p1 ), "=&v"( p2 ), "=&v"( p3 ), "=&v"( p4 ), "=&v"( p5 ), "=&v"( p6 )
-			: "v"( v ), "s"( c0 ), "s"( c1 ), "s"( c2 ), "s"( c3 ), "s"( c4 ), "s"( c5 ), "s"( c6 ) );
+		if constexpr( LEFT == 0 )
+		{
+			asm volatile( "s_waitcnt lgkmcnt(0)"
+				: "+v"( d.v[ 0 ]), "+v"( d.v[ 1 ]), "+v"( d.v[ 2 ]),
+				"+v"( d.v[ 3 ]), "+v"( d.v[ 4 ]), "+v"( d.v[ 5 ]),
+				"+v"( d.v[ 6 ]));
+		}
+		else
+		{
+			asm volatile( "s_waitcnt lgkmcnt(7)"
+				: "+v"( d.v[ 0 ]), "+v"( d.v[ 1 ]), "+v"( d.v[ 2 ]),
+				"+v"( d.v[ 3 ]), "+v"( d.v[ 4 ]), "+v"( d.v[ 5 ]),
+				"+v"( d.v[ 6 ]));
+		}
 	}
 }
 
-// outputs jp0, jp0 - 1, ... jp0 - (N - 1) at row u of the period (taps
-// u - K * jp): one statement
-template< int K, int NT, int U, int JP0, int N >
-__device__ __forceinline__ void df_vrow( float ( &acc )[ 16 ], const float v,
-	const float ( &c )[ NT ])
+template< int K, int NT, int B, int I0 >
+__device__ __forceinline__ void df_feed_batch( f2 ( &acc )[ 3 ],
+	const DfBatch< B >& d, const f2 ( &cp )[ NT / 2 ])
 {
-#define DF_A( k ) acc[ (((( JP0 - ( k )) % 16 ) + 16 ) % 16 ) ]
-#define DF_C( k ) c[ U - K * ( JP0 - ( k )) ]
-	constexpr bool first = ( U - K * JP0 == 0 );
-
-	if constexpr( N == 7 )
+	dn_static_for< B >( [&]( auto jc )
 	{
-		df_v7< first >( DF_A( 0 ), DF_A( 1 ), DF_A( 2 ), DF_A( 3 ), DF_A( 4 ),
-			DF_A( 5 ), DF_A( 6 ), v, DF_C( 0 ), DF_C( 1 ), DF_C( 2 ),
-			DF_C( 3 ), DF_C( 4 ), DF_C( 5 ), DF_C( 6 ));
-	}
-	else if constexpr( N == 6 )
-	{
-		df_v6< first >( DF_A( 0 ), DF_A( 1 ), DF_A( 2 ), DF_A( 3 ), DF_A( 4 ),
-			DF_A( 5 ), v, DF_C( 0 ), DF_C( 1 ), DF_C( 2 ), DF_C( 3 ),
-			DF_C( 4 ), DF_C( 5 ));
-	}
-	else if constexpr( N == 5 )
-	{
-		df_v5< first >( DF_A( 0 ), DF_A( 1 ), DF_A( 2 ), DF_A( 3 ), DF_A( 4 ),
-			v, DF_C( 0 ), DF_C( 1 ), DF_C( 2 ), DF_C( 3 ), DF_C( 4 ));
-	}
-	else if constexpr( N > 0 )
-	{
-		df_v1< first >( DF_A( 0 ), v, DF_C( 0 ));
-		df_vrow< K, NT, U, JP0 - 1, N - 1 >( acc, v, c );
-	}
-#undef DF_A
-#undef DF_C
+		constexpr int j = decltype( jc )::value;
+		df_feed< K, NT, I0 + j >( acc, d.v[ j ], cp );
+	} );
 }
 
 template< int KH, int NTH, int KV, int NTV >
@@ -429,8 +446,10 @@ __global__ void __launch_bounds__( DF_NTHR ) k_dnf( const DnFParams P )
 {
 	constexpr int NPH = ( KH * ( DF_NT1 - 1 ) + NTH + 63 ) / 64; // DMA pieces
 	constexpr int ROWPX = NPH * 64;
+	constexpr int NIN = NTH + 2 * KH; // inputs of a lane's three outputs
+	constexpr int BI = NIN / 4;       // ... in four batches
 	static_assert( KH != 2 || NPH == 2, "plane layout assumes two pieces" );
-	static_assert(( NTH & 1 ) == 0, "tap pairs" );
+	static_assert(( NTH & 1 ) == 0 && BI * 4 == NIN, "tap pairs, batches" );
 
 	__shared__ __attribute__(( aligned( 16 ))) f4
 		sS[ DF_NHW ][ 2 ][ 2 ][ ROWPX ];
@@ -511,6 +530,10 @@ __global__ void __launch_bounds__( DF_NTHR ) k_dnf( const DnFParams P )
 		const unsigned lds_s = (unsigned) (unsigned long) (lds_char*)
 			&sS[ h ][ 0 ][ 0 ][ 0 ];
 
+		// LDS byte address of this lane's first input in buffer 0
+		const unsigned lds_in = lds_s + ( rho * ROWPX +
+			( KH == 2 ? 3 : 9 ) * tri ) * 16 + hf * 8;
+
 		const int vin_last = P.V.in_len - 1;
 
 		auto issue = [&]( const int s )
@@ -533,7 +556,6 @@ __global__ void __launch_bounds__( DF_NTHR ) k_dnf( const DnFParams P )
 
 		issue( 0 );
 
-		// FIR tasks of this lane: (row, pixel, half) of passes 0..2
 		for( int s = 0; s < S; s++ )
 		{
 			if( s + 1 < S )
@@ -558,27 +580,23 @@ __global__ void __launch_bounds__( DF_NTHR ) k_dnf( const DnFParams P )
 
 			// ---- resize: 3 consecutive outputs per lane
 			{
-				const f2* sp = (const f2*) &sS[ h ][ bf ][ rho ][ 0 ] +
-					( KH == 2 ? 3 : 9 ) * 2 * tri + hf;
-
-				// all inputs first (hipcc never moves a load across an asm
-				// statement: read where they are used, every ds_read would be
-				// waited for on the spot)
-				f2 in[ NTH + 2 * KH ];
-#pragma unroll
-				for( int i = 0; i < NTH + 2 * KH; i++ )
-				{
-					in[ i ] = sp[ 2 * df_slot< KH, NPH >( i )];
-				}
-
+				const unsigned ad = lds_in + bf * ( 2 * ROWPX * 16 );
+				DfBatch< BI > d0, d1, d2, d3;
 				f2 acc[ 3 ];
 				acc[ 0 ] = (f2) 0.0f; acc[ 1 ] = (f2) 0.0f; acc[ 2 ] = (f2) 0.0f;
 
-				dn_static_for< NTH + 2 * KH >( [&]( auto ic )
-				{
-					constexpr int i = decltype( ic )::value;
-					df_feed< KH, NTH, i >( acc, in[ i ], cp );
-				} );
+				df_load_at< KH, NPH, BI, 0 >( d0, ad );
+				df_load_at< KH, NPH, BI, BI >( d1, ad );
+				df_wait< BI, BI >( d0 );
+				df_feed_batch< KH, NTH, BI, 0 >( acc, d0, cp );
+				df_load_at< KH, NPH, BI, 2 * BI >( d2, ad );
+				df_wait< BI, BI >( d1 );
+				df_feed_batch< KH, NTH, BI, BI >( acc, d1, cp );
+				df_load_at< KH, NPH, BI, 3 * BI >( d3, ad );
+				df_wait< BI, BI >( d2 );
+				df_feed_batch< KH, NTH, BI, 2 * BI >( acc, d2, cp );
+				df_wait< BI, 0 >( d3 );
+				df_feed_batch< KH, NTH, BI, 3 * BI >( acc, d3, cp );
 
 				f2* tp = (f2*) &sT[ h ][ rho ][ 3 * tri ] + hf;
 				tp[ 0 ] = acc[ 0 ];
@@ -639,27 +657,50 @@ __global__ void __launch_bounds__( DF_NTHR ) k_dnf( const DnFParams P )
 		const int ch = e & 3;
 		const bool st_ok = ( lane_ok && x < P.H.out_len );
 
-		gp_cfloat* const vc = (gp_cfloat*) P.V.coef;
-		float c[ NTV ];
-#pragma unroll
-		for( int t = 0; t < NTV; t++ )
+		// the tap pairs (see DF_VSTMT): one copy per lane, in registers
+		f2 k2[ NTV + 2 * KV ];
 		{
-			c[ t ] = vc[ t ];
+			const f2* const v2 = (const f2*) ( P.V.coef + NTV + 4 );
+#pragma unroll
+			for( int i = 0; i < NTV + 2 * KV; i++ )
+			{
+				k2[ i ] = v2[ i ];
+				asm volatile( "" : "+v"( k2[ i ])); // (no re-loading later)
+			}
 		}
 
+		gp_cfloat* const vc = (gp_cfloat*) P.V.coef;
 		const float f0 = vc[ NTV ], f1 = vc[ NTV + 1 ], f2_ = vc[ NTV + 2 ],
 			f3 = vc[ NTV + 3 ];
 
-		float acc[ 16 ];
-		float wr[ 8 ];
-#pragma unroll
-		for( int i = 0; i < 16; i++ )
+		// destination: lane offset fixed, row offset scalar; lanes that must
+		// not store get an offset the buffer range check drops
+		int st_voff;
+		__amdgpu_buffer_rsrc_t drs;
+
+		if( P.out.on != 0 )
 		{
-			acc[ i ] = 0.0f;
+			const int es = ( P.out.type == AVIRHIP_U8 ? 1 :
+				( P.out.type == AVIRHIP_U16 ? 2 : 4 ));
+
+			drs = __builtin_amdgcn_make_buffer_rsrc( P.out.base, 0,
+				0x7fffffff, 0x00020000 );
+			st_voff = ( st_ok && ch < P.out.ch ?
+				( x * P.out.ch + ch ) * es : (int) 0x80000000 );
 		}
+		else
+		{
+			drs = __builtin_amdgcn_make_buffer_rsrc( (void*) P.dst, 0,
+				0x7fffffff, 0x00020000 );
+			st_voff = ( st_ok ? ( x * 4 + ch ) * 4 : (int) 0x80000000 );
+		}
+
+		f2 accp[ 8 ];
+		float wr[ 8 ];
 #pragma unroll
 		for( int i = 0; i < 8; i++ )
 		{
+			accp[ i ] = (f2) 0.0f;
 			wr[ i ] = 0.0f;
 		}
 
@@ -675,37 +716,60 @@ __global__ void __launch_bounds__( DF_NTHR ) k_dnf( const DnFParams P )
 				if( s < S )
 				{
 					__syncthreads();
-					float v[ DF_RS ];
+					f2 vp[ DF_RS / 2 ];
 #pragma unroll
-					for( int i = 0; i < DF_RS; i++ )
+					for( int m = 0; m < DF_RS / 2; m++ )
 					{
-						v[ i ] = sF[ s & 1 ][ i ][ e ];
+						vp[ m ].x = sF[ s & 1 ][ 2 * m ][ e ];
+						vp[ m ].y = sF[ s & 1 ][ 2 * m + 1 ][ e ];
 					}
 
 					dn_static_for< DF_RS >( [&]( auto ic )
 					{
 						constexpr int i = decltype( ic )::value;
 						constexpr int u = ph * DF_RS + i; // row of the period
-						constexpr int jhi = u / KV;
-						// outputs alive at this row (tap t = u - KV * j): j from
-						// u / KV down while t < NTV -- two statements per row
-						constexpr int na = ( NTV - 1 - ( u % KV )) / KV + 1;
-						constexpr int n1 = ( na > 7 ? 7 : na );
-						df_vrow< KV, NTV, u, jhi, n1 >( acc, v[ i ], c );
-						df_vrow< KV, NTV, u, jhi - n1, na - n1 >( acc, v[ i ], c );
+						constexpr DfRow< KV, NTV, u > R;
+
+						// the sum of an output starts from +0.0f
+						if constexpr( R.zslot >= 0 )
+						{
+							constexpr int zp = ( R.zslot >> 2 ) * 2 +
+								( R.zslot & 1 );
+
+							if constexpr((( R.zslot >> 1 ) & 1 ) == 0 )
+							{
+								accp[ zp ].x = 0.0f;
+							}
+							else
+							{
+								accp[ zp ].y = 0.0f;
+							}
+						}
+
+#define DF_PI( k ) accp[ R.pi[ ( k ) < R.n ? ( k ) : 0 ]]
+#define DF_KI( k ) k2[ R.vi[ ( k ) < R.n ? ( k ) : 0 ]]
+						df_vstmt< R.n, ( i & 1 ) >( DF_PI( 0 ), DF_PI( 1 ),
+							DF_PI( 2 ), DF_PI( 3 ), DF_PI( 4 ), DF_PI( 5 ),
+							DF_PI( 6 ), DF_PI( 7 ), vp[ i >> 1 ], DF_KI( 0 ),
+							DF_KI( 1 ), DF_KI( 2 ), DF_KI( 3 ), DF_KI( 4 ),
+							DF_KI( 5 ), DF_KI( 6 ), DF_KI( 7 ));
+#undef DF_PI
+#undef DF_KI
 
 						// a T row completes with its last tap
 						if constexpr(( u - ( NTV - 1 )) % KV == 0 )
 						{
 							constexpr int jp = ( u - ( NTV - 1 )) / KV;
 							constexpr int slot = (( jp % 16 ) + 16 ) % 16;
+							constexpr int sp = ( slot >> 2 ) * 2 + ( slot & 1 );
 							constexpr int ws = (( jp % 8 ) + 8 ) % 8;
 							const int jl = jl_base + jp;
 
 							if( jl >= 0 )
 							{
 								const int j = jstart + jl;
-								float U = acc[ slot ];
+								float U = ((( slot >> 1 ) & 1 ) == 0 ?
+									accp[ sp ].x : accp[ sp ].y );
 
 								if( j > vlast )
 								{
@@ -734,18 +798,19 @@ __global__ void __launch_bounds__( DF_NTHR ) k_dnf( const DnFParams P )
 									a = a + f3 * ( wr[ ws ] +
 										wr[ ( ws + 2 ) & 7 ]);
 
-									if( st_ok )
+									const int yr = y - P.dst_row0;
+
+									if( P.out.on == 0 )
 									{
-										if( P.out.on != 0 )
-										{
-											df_store_elem( P.out,
-												y - P.dst_row0, x, ch, a );
-										}
-										else
-										{
-											P.dst[ (long) ( y - P.dst_row0 ) *
-												P.dst_ss + (long) x * 4 + ch ] = a;
-										}
+										__builtin_amdgcn_raw_buffer_store_b32(
+											__builtin_bit_cast( unsigned, a ),
+											drs, st_voff,
+											yr * (int) P.dst_ss * 4, 0 );
+									}
+									else
+									{
+										df_store_elem( P.out, drs, st_voff, yr,
+											a );
 									}
 								}
 							}
