@@ -1024,9 +1024,13 @@ static int exec_any( avirhip_plan* p, const void* src, int src_mem, void* dst,
 				hipEventDisableTiming ));
 		}
 		else
+		if( p -> last_stream != (void*) st )
 		{
+			// (calls on one stream are ordered by the stream itself)
 			AVIRHIP_HIPCHECK( hipStreamWaitEvent( st, p -> last_done, 0 ));
 		}
+
+		p -> last_stream = (void*) st;
 	}
 
 	struct Done
@@ -1131,7 +1135,7 @@ static avirhip_plan* new_plan()
 	p -> stage_src = nullptr; p -> stage_dst = nullptr;
 	p -> stage_src_bytes = 0; p -> stage_dst_bytes = 0;
 	p -> shard_band = nullptr; p -> shard_band_bytes = 0;
-	p -> last_done = nullptr;
+	p -> last_done = nullptr; p -> last_stream = nullptr;
 	p -> shard_src = nullptr; p -> shard_src_bytes = 0;
 	p -> tr_mul = 1.0; p -> pk_out = 0.0;
 	p -> gamma = 0; p -> alpha_index = -1; p -> d_srgb_tbl = nullptr;

@@ -48,6 +48,7 @@
 #include "dn_dev.h"
 #include <algorithm>
 #include <string.h>
+#include <stdlib.h>
 
 namespace avirhip {
 
@@ -68,6 +69,9 @@ struct DnFParams
 	int row_lo, row_hi;             // output rows to store
 	int nstrips, nchunks, crows;    // work items, strip fastest; rows per chunk
 	GPOut out;                      // on != 0: integer output stage in the store
+	int dbg;                        // timing ablations (AVIRHIP_DNF_DBG): 1 no
+	                                // column arithmetic, 2 no row arithmetic,
+	                                // 4 no source loads, 8 no FIR in the row waves
 };
 
 // one element (a lane's channel of its pixel, byte offset `voff` inside the
@@ -560,6 +564,7 @@ __global__ void __launch_bounds__( DF_NTHR ) k_dnf( const DnFParams P )
 		{
 			if( s + 1 < S )
 			{
+				if( !( P.dbg & 4 ))
 				issue( s + 1 );
 
 				if( NPH == 3 )
@@ -579,6 +584,7 @@ __global__ void __launch_bounds__( DF_NTHR ) k_dnf( const DnFParams P )
 			const int bf = s & 1;
 
 			// ---- resize: 3 consecutive outputs per lane
+			if( !( P.dbg & 2 ))
 			{
 				const unsigned ad = lds_in + bf * ( 2 * ROWPX * 16 );
 				DfBatch< BI > d0, d1, d2, d3;
@@ -624,6 +630,7 @@ __global__ void __launch_bounds__( DF_NTHR ) k_dnf( const DnFParams P )
 			}
 
 			// ---- correction FIR along x: 2 rows x 42 pixels x 2 halves
+			if( !( P.dbg & 8 ))
 #pragma unroll
 			for( int q = 0; q < 3; q++ )
 			{
@@ -665,6 +672,10 @@ __global__ void __launch_bounds__( DF_NTHR ) k_dnf( const DnFParams P )
 			for( int i = 0; i < NTV + 2 * KV; i++ )
 			{
 				k2[ i ] = v2[ i ];
+			}
+#pragma unroll
+			for( int i = 0; i < NTV + 2 * KV; i++ )
+			{
 				asm volatile( "" : "+v"( k2[ i ])); // (no re-loading later)
 			}
 		}
@@ -724,6 +735,7 @@ __global__ void __launch_bounds__( DF_NTHR ) k_dnf( const DnFParams P )
 						vp[ m ].y = sF[ s & 1 ][ 2 * m + 1 ][ e ];
 					}
 
+					if( !( P.dbg & 1 ))
 					dn_static_for< DF_RS >( [&]( auto ic )
 					{
 						constexpr int i = decltype( ic )::value;
@@ -874,6 +886,10 @@ int dn_run_hv( void* d, const float* src, long src_ss, float* dst, int row0,
 	{
 		P.out = *out;
 	}
+
+	static const int dbg = []() { const char* e = getenv( "AVIRHIP_DNF_DBG" );
+		return( e != nullptr ? atoi( e ) : 0 ); }();
+	P.dbg = dbg;
 
 	// one workgroup per compute unit: a chunk's warm-up (NT + 5K source rows)
 	// is paid per work item, so as few, as tall chunks as fill the chip

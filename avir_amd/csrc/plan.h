@@ -151,6 +151,7 @@ struct avirhip_plan
 	std::mutex exec_mtx;
 	std::mutex shard_mtx; // avirhip_resize_sharded: replicas, band buffers
 	hipEvent_t last_done;
+	void* last_stream; // stream of the call that recorded last_done
 	void* stage_src; // host-pointer staging
 	void* stage_dst;
 	size_t stage_src_bytes, stage_dst_bytes;
