@@ -20,6 +20,7 @@ STEP_NAMES = ["FIR", "UP_ZEROSTUFF", "UP_FILTERED", "RESIZE", "RESIZE2"]
 DITHER_DEF, DITHER_ERRD = 0, 1
 PATH_AUTO, PATH_GENERIC, PATH_TILED, PATH_FUSED, PATH_UP2 = 0, 1, 2, 3, 4
 PATH_GPASS = 5
+VARIANT_UP2_PLAIN_V, VARIANT_DN_TWO_PASS = 1, 2
 
 _fp = C.POINTER(C.c_float)
 _ip = C.POINTER(C.c_int32)
@@ -132,6 +133,7 @@ PROTOTYPES = {
     "avirhip_lancir_plan_create": (_I, [C.POINTER(LancirDesc), C.POINTER(_VP)]),
     "avirhip_plan_destroy": (None, [_VP]),
     "avirhip_plan_set_path": (_I, [_VP, _I]),
+    "avirhip_plan_set_variant": (_I, [_VP, _I]),
     "avirhip_plan_get_path": (_I, [_VP]),
     "avirhip_resize": (_I, [_VP, _VP, _I, _VP, _I, _VP]),
     "avirhip_resize_band": (_I, [_VP, _VP, _I, _VP, _I, _I, _I, _VP]),

@@ -977,7 +977,10 @@ static int exec_any( avirhip_plan* p, const void* src, int src_mem, void* dst,
 	{
 		avirhip_plan* spare = nullptr;
 		{
-			std::lock_guard< std::mutex > sl( p -> shard_mtx );
+			// (its own mutex: avirhip_resize_sharded holds shard_mtx for the
+			// whole call and reaches this point for the band on the plan's
+			// own device)
+			std::lock_guard< std::mutex > sl( p -> spare_mtx );
 
 			for( size_t i = 0; i < p -> spares.size() && spare == nullptr; i++ )
 			{
@@ -993,6 +996,7 @@ static int exec_any( avirhip_plan* p, const void* src, int src_mem, void* dst,
 				{
 					spare -> is_spare = 1;
 					spare -> path = p -> path;
+					spare -> variant = p -> variant;
 					spare -> exec_mtx.lock();
 					p -> spares.push_back( spare );
 				}
@@ -1130,7 +1134,7 @@ static avirhip_plan* new_plan()
 {
 	avirhip_plan* p = new avirhip_plan();
 	p -> is_lancir = 0; p -> device = 0; p -> alloc_bytes = 0;
-	p -> path = 0; p -> fused_ok = 0; p -> auto_path = 1; p -> fused = nullptr; p -> up2 = nullptr; p -> lanc2 = nullptr; p -> gpass = nullptr;
+	p -> path = 0; p -> variant = 0; p -> fused_ok = 0; p -> auto_path = 1; p -> fused = nullptr; p -> up2 = nullptr; p -> lanc2 = nullptr; p -> gpass = nullptr;
 	p -> packed = nullptr; p -> resbuf = nullptr; p -> lres = nullptr;
 	p -> stage_src = nullptr; p -> stage_dst = nullptr;
 	p -> stage_src_bytes = 0; p -> stage_dst_bytes = 0;
@@ -1444,6 +1448,7 @@ static int clone_plan( const avirhip_plan* s, int device, avirhip_plan** out )
 	q -> h = s -> h; q -> v = s -> v;     // host vectors; device pointers are
 	q -> lv = s -> lv; q -> lh = s -> lh; // replaced by the uploads below
 	q -> path = s -> path;
+	q -> variant = s -> variant;
 
 	const int rc = ( s -> is_lancir ? finalize_lancir_plan( q ) :
 		finalize_avir_plan( q ));
@@ -1847,6 +1852,66 @@ int avirhip_plan_set_path( avirhip_plan* p, int path )
 	}
 
 	p -> path = path;
+
+	// the plan's same-device spares and other-device replicas run what it runs
+	{
+		std::lock_guard< std::mutex > sl( p -> spare_mtx );
+
+		for( size_t i = 0; i < p -> spares.size(); i++ )
+		{
+			p -> spares[ i ] -> path = path;
+		}
+	}
+	{
+		std::lock_guard< std::mutex > sl( p -> shard_mtx );
+
+		for( size_t i = 0; i < p -> replicas.size(); i++ )
+		{
+			if( p -> replicas[ i ] != nullptr )
+			{
+				p -> replicas[ i ] -> path = path;
+			}
+		}
+	}
+
+	return( AVIRHIP_OK );
+}
+
+int avirhip_plan_set_variant( avirhip_plan* p, int variant )
+{
+	if( p == nullptr || variant < 0 || variant > 3 )
+	{
+		set_error( "bad variant" );
+		return( AVIRHIP_EINVAL );
+	}
+
+	p -> variant = variant;
+
+	if( p -> inner != nullptr )
+	{
+		p -> inner -> variant = variant;
+	}
+
+	{
+		std::lock_guard< std::mutex > sl( p -> spare_mtx );
+
+		for( size_t i = 0; i < p -> spares.size(); i++ )
+		{
+			p -> spares[ i ] -> variant = variant;
+		}
+	}
+	{
+		std::lock_guard< std::mutex > sl( p -> shard_mtx );
+
+		for( size_t i = 0; i < p -> replicas.size(); i++ )
+		{
+			if( p -> replicas[ i ] != nullptr )
+			{
+				p -> replicas[ i ] -> variant = variant;
+			}
+		}
+	}
+
 	return( AVIRHIP_OK );
 }
 

@@ -1071,7 +1071,7 @@ int fused_run( avirhip_plan* p, int mode, const void* src, int src_type,
 
 	// integer-ratio downsizing on both axes: one marching launch, no FltBuf
 	if( src_type == AVIRHIP_F32 && dn_has_h( F -> dn ) && dn_has_v( F -> dn ) &&
-		dnf_enabled() )
+		dnf_enabled() && !( p -> variant & AVIRHIP_VARIANT_DN_TWO_PASS ))
 	{
 		GPOut O;
 

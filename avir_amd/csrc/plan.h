@@ -121,6 +121,7 @@ struct avirhip_plan
 	struct { int on, type, ch; const void* ptr; long stride; } lraw;
 
 	int path;       // forced path (0 = auto)
+	int variant;    // AVIRHIP_VARIANT_* bits (0 = automatic kernel forms)
 	int fused_ok;   // tiled kernels: bit 0 = two-pass (path 2), bit 1 = fused (3)
 	int auto_path;  // path taken when `path` == 0
 	void* fused;    // tiled-kernel private data
@@ -150,6 +151,7 @@ struct avirhip_plan
 	// previous call's completion event.
 	std::mutex exec_mtx;
 	std::mutex shard_mtx; // avirhip_resize_sharded: replicas, band buffers
+	std::mutex spare_mtx; // the list of spares
 	hipEvent_t last_done;
 	void* last_stream; // stream of the call that recorded last_done
 	void* stage_src; // host-pointer staging

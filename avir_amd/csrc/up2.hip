@@ -1123,7 +1123,8 @@ int up2_run( avirhip_plan* p, const float* src, long src_stride, float* dst,
 	const int ldspad = ( pad != nullptr ? atoi( pad ) : 0 );
 	static const bool novt = ( getenv( "AVIRHIP_UP2_NOVT" ) != nullptr );
 
-	if( U2_RB == 8 && D -> vsym && !novt )
+	if( U2_RB == 8 && D -> vsym && !novt &&
+		!( p -> variant & AVIRHIP_VARIANT_UP2_PLAIN_V ))
 	{
 		hipLaunchKernelGGL( k_up2< U2_RB == 8 >, dim3( items ), dim3( U2_NT ),
 			ldspad, st, P );

@@ -477,6 +477,10 @@ def main():
             "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 4),
             "traffic": read_traffic(),
+            "traffic_source": "profiles/pmc_traffic.json (static: the "
+                              "committed rocprofv3 --pmc passes of this "
+                              "kernel, FETCH_SIZE x2 + WRITE_SIZE; not "
+                              "collected by this run)",
             "algorithmic_bytes": ALGO_BYTES,
             "kernel_ms": round(ev_ms, 4),
             "kernels_per_step": {1: 5, 2: 2, 3: 1, 4: 1, 5: 2}.get(path)}
@@ -506,8 +510,9 @@ def main():
             out["sharded"] = {"error": "%s: %s" % (type(e).__name__, e)}
 
     if rank == 0 and world == 1:
-        # a sustained figure: the default timed region is a few ms
-        n = max(args.steps, int(1.25 / max(t / args.steps, 1e-6)))
+        # a sustained figure: the default timed region is a few ms; >= 5 s
+        # of back-to-back frames is also what a 1 Hz utilisation sampler sees
+        n = max(args.steps, int(5.0 / max(t / args.steps, 1e-6)))
         ts, _ = timed(full_frame, n)
         out["sustained"] = {"steps": n, "seconds": round(ts, 3),
                             "ms_per_step": round(ts / n * 1e3, 4),

@@ -212,6 +212,17 @@ int avirhip_plan_set_path(avirhip_plan* plan, int path);
 /* The path the next execution will take (1..5). */
 int avirhip_plan_get_path(const avirhip_plan* plan);
 
+/* Kernel variants inside a path, for differential tests and A/B timing (every
+ * variant is bit-identical). `variant` is a bit mask, 0 = the automatic choice:
+ * AVIRHIP_VARIANT_UP2_PLAIN_V   path 4 runs the 13-row-window form of the
+ *     vertical phase (the form a plan whose 2x bank phase is not bit-symmetric
+ *     takes) instead of the transposed, product-sharing one;
+ * AVIRHIP_VARIANT_DN_TWO_PASS   integer-ratio downsizing (k = 2, 3) runs its
+ *     two pass kernels through FltBuf instead of the single fused launch. */
+#define AVIRHIP_VARIANT_UP2_PLAIN_V 1
+#define AVIRHIP_VARIANT_DN_TWO_PASS 2
+int avirhip_plan_set_variant(avirhip_plan* plan, int variant);
+
 /* Executes H pass + V pass (+ integer epilogue) of `plan`:
  * src -> dst. `src_mem`/`dst_mem` are AVIRHIP_MEM_HOST or _DEVICE; host
  * buffers are staged through device memory inside the call. `stream` is a

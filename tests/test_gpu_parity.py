@@ -21,11 +21,19 @@ def _device():
 
 
 def _checker_avir(src, nw, nh, **kw):
-    """Reference output: the real reference when its prebuilt .so is here,
-    else the restatement."""
+    """Reference output: the real reference (oracle/_ref, prebuilt where
+    /root/reference exists; it travels to the GPU box). A box without it FAILS
+    -- silently checking against the restatement would downgrade the run --
+    unless AVIRHIP_TEST_ORACLE=restatement asks for the plain-C restatement
+    (itself pinned to the reference by tests/test_oracle.py)."""
     if rb.have_ref():
         return rb.ref_avir(src, nw, nh, **kw)
-    return rb.orc_avir(src, nw, nh, **kw)
+    if os.environ.get("AVIRHIP_TEST_ORACLE") == "restatement":
+        return rb.orc_avir(src, nw, nh, **kw)
+    pytest.fail("oracle/_ref/libavir_ref.so is missing: build it where "
+                "/root/reference exists (make -C oracle ref), or set "
+                "AVIRHIP_TEST_ORACLE=restatement to check against "
+                "oracle/liboracle.so instead")
 
 
 def _bits(a):
@@ -48,7 +56,7 @@ def _assert_same(got, want, what):
 
 
 def _run_avir(src, nw, nh, resbits=8, out_dtype=None, build_mode=-1, k=0.0,
-              path=0, **kw):
+              path=0, variant=0, **kw):
     r = avir_amd.CImageResizer(resbits, kw.get("srcbits", 0))
     v = avir_amd.CImageResizerVars()
     v.BuildMode = build_mode
@@ -57,11 +65,13 @@ def _run_avir(src, nw, nh, resbits=8, out_dtype=None, build_mode=-1, k=0.0,
     v.AlphaIndex = kw.get("alpha", -1)
     h, w, ch = src.shape
     out_dtype = np.dtype(out_dtype or src.dtype)
-    if path:
+    if path or variant:
         lib = abi.load()
         p = r.plan(w, h, nw, nh, ch, k, v, rb._DT[src.dtype],
                    rb._DT[out_dtype])
-        abi.check(lib.avirhip_plan_set_path(p, path), "set_path")
+        if path:
+            abi.check(lib.avirhip_plan_set_path(p, path), "set_path")
+        abi.check(lib.avirhip_plan_set_variant(p, variant), "set_variant")
     return r.resize(src, nw, nh, k=k, out_dtype=out_dtype, aVars=v)
 
 
@@ -133,6 +143,35 @@ def test_avir_exact_2x_marching_kernel(sw, sh, bits):
             assert "cannot run this plan" in str(e) and mode == -1
             continue
         _assert_same(got, want, "up2 %dx%d mode %d" % (sw, sh, mode))
+
+
+@pytest.mark.parametrize("sw,sh", UP2 + [(1000, 700)])
+def test_avir_exact_2x_plain_vertical_phase(sw, sh):
+    """k_up2<false> (up2.hip): the 13-row-window vertical phase that a plan
+    takes when its 2x bank phase is not bit-symmetric -- no shipped preset
+    is, so the form is selected through the ABI
+    (AVIRHIP_VARIANT_UP2_PLAIN_V); whole frames and row bands."""
+    lib = abi.load()
+    src = rb.lcg_f32((sh, sw, 4), seed=77 + sw)
+    want = _checker_avir(src, 2 * sw, 2 * sh, resbits=16, build_mode=1)
+    got = _run_avir(src, 2 * sw, 2 * sh, resbits=16, build_mode=1,
+                    path=abi.PATH_UP2, variant=abi.VARIANT_UP2_PLAIN_V)
+    _assert_same(got, want, "up2 plain V %dx%d" % (sw, sh))
+    if sh >= 21:
+        r = avir_amd.CImageResizer(16)
+        v = avir_amd.CImageResizerVars()
+        v.BuildMode = 1
+        p = r.plan(sw, sh, 2 * sw, 2 * sh, 4, 0.0, v)
+        abi.check(lib.avirhip_plan_set_path(p, abi.PATH_UP2), "set_path")
+        abi.check(lib.avirhip_plan_set_variant(p, abi.VARIANT_UP2_PLAIN_V),
+                  "set_variant")
+        nh = 2 * sh
+        for a, b in [(0, nh // 3), (nh // 3, nh // 3 + 5), (nh // 3 + 5, nh)]:
+            band = np.empty((b - a, 2 * sw, 4), np.float32)
+            abi.check(lib.avirhip_resize_band(
+                p, src.ctypes.data, abi.MEM_HOST, band.ctypes.data,
+                abi.MEM_HOST, a, b, None), "band")
+            _assert_same(band, want[a:b], "plain V band [%d,%d)" % (a, b))
 
 
 def test_avir_exact_2x_random_shapes_agree_with_generic_kernels():
@@ -360,6 +399,33 @@ def test_avir_integer_downsizing_passes(sw, sh, nw, nh, bits):
     _assert_same(_run_avir(src, nw, nh, resbits=bits), want, "auto path")
     _assert_same(_run_avir(src, nw, nh, resbits=bits, path=abi.PATH_TILED),
                  want, "two-pass path")
+
+
+@pytest.mark.parametrize("sw,sh,nw,nh", DOWN_INT + [
+    (3840, 400, 1280, 134), (500, 2160, 250, 720), (2600, 1000, 1300, 334)])
+def test_avir_integer_downsizing_fused_and_two_pass_kernels(sw, sh, nw, nh):
+    """dnf.hip (both axes in one marching launch, the automatic form for float
+    RGBA) and dn.hip's two pass kernels (AVIRHIP_VARIANT_DN_TWO_PASS) against
+    the reference; row bands of the fused form against the whole frame."""
+    lib = abi.load()
+    src = rb.lcg_f32((sh, sw, 4), seed=5 + sw + nh)
+    want = _checker_avir(src, nw, nh, resbits=16)
+    _assert_same(_run_avir(src, nw, nh, resbits=16, path=abi.PATH_TILED),
+                 want, "fused downsizing")
+    _assert_same(_run_avir(src, nw, nh, resbits=16, path=abi.PATH_TILED,
+                           variant=abi.VARIANT_DN_TWO_PASS),
+                 want, "two-pass downsizing")
+    r = avir_amd.CImageResizer(16)
+    p = r.plan(sw, sh, nw, nh, 4)
+    abi.check(lib.avirhip_plan_set_path(p, abi.PATH_TILED), "set_path")
+    for g in (3, 5):
+        cuts = [nh * i // g for i in range(g + 1)]
+        for a, b in zip(cuts[:-1], cuts[1:]):
+            band = np.empty((b - a, nw, 4), np.float32)
+            abi.check(lib.avirhip_resize_band(
+                p, src.ctypes.data, abi.MEM_HOST, band.ctypes.data,
+                abi.MEM_HOST, a, b, None), "band")
+            _assert_same(band, want[a:b], "band [%d,%d)" % (a, b))
 
 
 def test_avir_integer_downsizing_bands():
