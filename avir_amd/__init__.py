@@ -111,12 +111,13 @@ class CImageResizer(object):
     aSrcBitDepth=0, aParams=CImageResizerParamsDef())`. `aDitherer` stands
     for the reference's third fpclass_def template parameter (avir.h:4569):
     "def" = CImageResizerDithererDefINL, "errd" = CImageResizerDithererErrdINL
-    (README.md:135-142)."""
+    (README.md:135-142); `aFpPack=4` stands for avir::fpclass_float4 of
+    avir_float4_sse.h (README.md:174-186)."""
 
     DITHERERS = {"def": abi.DITHER_DEF, "errd": abi.DITHER_ERRD}
 
     def __init__(self, aResBitDepth=8, aSrcBitDepth=0, aParams=None,
-                 aDitherer="def"):
+                 aDitherer="def", aFpPack=1):
         self._lib = abi.load()
         self._h = C.c_void_p()
         abi.check(self._lib.avirhip_resizer_create(
@@ -127,6 +128,11 @@ class CImageResizer(object):
             abi.check(self._lib.avirhip_resizer_set_ditherer(
                 self._h, self.DITHERERS[aDitherer]),
                 "avirhip_resizer_set_ditherer")
+        if aFpPack != 1:
+            # fpclass_float4 of avir_float4_sse.h (fppack 4): its cost model,
+            # nearest-even ditherer and float-output path
+            abi.check(self._lib.avirhip_resizer_set_fpclass(self._h, aFpPack),
+                      "avirhip_resizer_set_fpclass")
 
     def __del__(self):
         h, self._h = getattr(self, "_h", None), None

@@ -148,6 +148,7 @@ PROTOTYPES = {
     "avirhip_resizer_create": (_I, [_I, _I, C.POINTER(Params), C.POINTER(_VP)]),
     "avirhip_resizer_destroy": (None, [_VP]),
     "avirhip_resizer_set_ditherer": (_I, [_VP, _I]),
+    "avirhip_resizer_set_fpclass": (_I, [_VP, _I]),
     "avirhip_resizer_build_desc": (_I, [_VP, _I, _I, _I, _I, _I, _I, _D,
                                         C.POINTER(Vars), _I, _I,
                                         C.POINTER(C.POINTER(PlanDesc))]),

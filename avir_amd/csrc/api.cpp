@@ -432,8 +432,8 @@ static int ensure_scratch( avirhip_plan* p )
 		p -> packed = (float*) q;
 	}
 
-	if(( p -> out_type != AVIRHIP_F32 || p -> ch != p -> io_ch ) &&
-		p -> resbuf == nullptr )
+	if(( p -> out_type != AVIRHIP_F32 || p -> ch != p -> io_ch ||
+		( p -> fp4 && p -> gamma )) && p -> resbuf == nullptr )
 	{
 		if(( rc = dev_alloc( p, (size_t) p -> new_w * p -> new_h * p -> ch *
 			sizeof( float ), &q )) != 0 ) return( rc );
@@ -738,8 +738,10 @@ static int exec_device( avirhip_plan* p, const void* src, void* dst,
 	// float output is the vertical pass' in-place result (avir.h:4956-4979):
 	// with gamma it stays linear, only the other output types are
 	// de-linearised in the epilogue
+	// (fpclass_float4 has no in-place output: its float results pass through
+	// the output stage like every other type, which matters with gamma)
 	const bool direct = ( p -> out_type == AVIRHIP_F32 &&
-		p -> ch == p -> io_ch );
+		p -> ch == p -> io_ch && !( p -> fp4 && p -> gamma ));
 
 	float* fdst = ( direct ? (float*) dst : p -> resbuf );
 
@@ -861,8 +863,9 @@ static int exec_device( avirhip_plan* p, const void* src, void* dst,
 	{
 		rc = launch_epilogue( fdst, dst, p -> out_type,
 			(long) ( row1 - row0 ) * p -> new_w * p -> io_ch, p -> tr_mul,
-			p -> pk_out, ( p -> gamma && p -> out_type != AVIRHIP_F32 ),
-			p -> io_ch, p -> ch, p -> alpha_index, st, p -> d_gthr );
+			p -> pk_out, ( p -> gamma && ( p -> out_type != AVIRHIP_F32 ||
+			p -> fp4 )), p -> io_ch, p -> ch, p -> alpha_index, st,
+			p -> d_gthr, ( p -> dither == AVIRHIP_DITHER_DEF_RNE ));
 	}
 
 	return( rc );
@@ -1144,7 +1147,7 @@ static avirhip_plan* new_plan()
 	p -> tr_mul = 1.0; p -> pk_out = 0.0;
 	p -> gamma = 0; p -> alpha_index = -1; p -> d_srgb_tbl = nullptr;
 	p -> d_gthr = nullptr;
-	p -> dither = AVIRHIP_DITHER_DEF; p -> errd_line = nullptr;
+	p -> dither = AVIRHIP_DITHER_DEF; p -> fp4 = 0; p -> errd_line = nullptr;
 	p -> is_spare = 0;
 	p -> ch = 0; p -> io_ch = 0;
 	p -> l_out_mul = 1.0f; p -> l_clamp = 0.0f; p -> l_unity = 1;
@@ -1243,7 +1246,8 @@ int avirhip_plan_create( const avirhip_plan_desc* d, avirhip_plan** out )
 	p -> alpha_index = ( d -> channels == 4 && ( d -> alpha_index == 0 ||
 		d -> alpha_index == 3 ) ? d -> alpha_index : -1 );
 
-	if( d -> dither != AVIRHIP_DITHER_DEF && d -> dither != AVIRHIP_DITHER_ERRD )
+	if( d -> dither != AVIRHIP_DITHER_DEF && d -> dither != AVIRHIP_DITHER_ERRD &&
+		d -> dither != AVIRHIP_DITHER_DEF_RNE )
 	{
 		set_error( "unknown ditherer %d", d -> dither );
 		avirhip_plan_destroy( p );
@@ -1253,6 +1257,8 @@ int avirhip_plan_create( const avirhip_plan_desc* d, avirhip_plan** out )
 	// float / double output skips the dither stage (avir.h:5002-5025)
 	p -> dither = ( d -> out_type == AVIRHIP_U8 || d -> out_type == AVIRHIP_U16 ?
 		d -> dither : AVIRHIP_DITHER_DEF );
+	// fpclass_float4 (AVIRHIP_DITHER_DEF_RNE): no in-place float output
+	p -> fp4 = ( d -> dither == AVIRHIP_DITHER_DEF_RNE ? 1 : 0 );
 
 	int rc = lower_axis( d -> h, d -> src_w, d -> new_w, p -> h );
 
@@ -1442,6 +1448,7 @@ static int clone_plan( const avirhip_plan* s, int device, avirhip_plan** out )
 	q -> tr_mul = s -> tr_mul; q -> pk_out = s -> pk_out;
 	q -> gamma = s -> gamma; q -> alpha_index = s -> alpha_index;
 	q -> dither = s -> dither;
+	q -> fp4 = s -> fp4;
 	q -> l_out_mul = s -> l_out_mul; q -> l_clamp = s -> l_clamp;
 	q -> l_unity = s -> l_unity;
 	q -> l_order = s -> l_order;

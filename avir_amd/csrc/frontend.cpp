@@ -115,9 +115,10 @@ struct avirhip_resizer
 {
 	AvirPlanner* planner;
 	int dither; // AVIRHIP_DITHER_*: fpclass::CDitherer of the mirrored object
+	int fppack; // fpclass::fppack of the mirrored object (1 or 4)
 	std::mutex mtx;
 	typedef std::tuple< int, int, int, int, int, int, double, double, double,
-		int, int, int, int, int, int, int > Key; // ..., ditherer, device
+		int, int, int, int, int, int, int > Key; // ..., ditherer + fppack, device
 	PlanCache< Key > cache;
 	std::map< Key, avirhip_vars_base > vbcache;
 };
@@ -241,6 +242,7 @@ int avirhip_resizer_create( int res_bit_depth, int src_bit_depth,
 	avirhip_resizer* r = new avirhip_resizer();
 	r -> planner = new AvirPlanner( res_bit_depth, src_bit_depth, P );
 	r -> dither = AVIRHIP_DITHER_DEF;
+	r -> fppack = 1;
 	*out = r;
 	return( AVIRHIP_OK );
 }
@@ -256,6 +258,19 @@ int avirhip_resizer_set_ditherer( avirhip_resizer* r, int dither )
 
 	std::lock_guard< std::mutex > lock( r -> mtx );
 	r -> dither = dither;
+	return( AVIRHIP_OK );
+}
+
+int avirhip_resizer_set_fpclass( avirhip_resizer* r, int fppack )
+{
+	if( r == nullptr || ( fppack != 1 && fppack != 4 ))
+	{
+		set_error( "set_fpclass: fppack 1 (float) or 4 (float4) only" );
+		return( AVIRHIP_EINVAL );
+	}
+
+	std::lock_guard< std::mutex > lock( r -> mtx );
+	r -> fppack = fppack;
 	return( AVIRHIP_OK );
 }
 
@@ -284,14 +299,22 @@ int avirhip_resizer_build_desc( avirhip_resizer* r, int src_w, int src_h,
 
 	const avirhip_vars& V = ( vars == nullptr ? g_defvars : *vars );
 	DescStore* S = r -> planner -> build( src_w, src_h, src_scanline_size,
-		new_w, new_h, el_count_io, k, V, in_type, out_type );
+		new_w, new_h, el_count_io, k, V, in_type, out_type, r -> fppack );
 
 	if( S == nullptr )
 	{
 		return( AVIRHIP_EINVAL );
 	}
 
-	S -> d.dither = r -> dither;
+	if( r -> fppack == 4 && r -> dither != AVIRHIP_DITHER_DEF )
+	{
+		delete S;
+		set_error( "fpclass_float4: only the default ditherer is built" );
+		return( AVIRHIP_EUNSUPPORTED );
+	}
+
+	S -> d.dither = ( r -> fppack == 4 ? AVIRHIP_DITHER_DEF_RNE :
+		r -> dither );
 	*out = &S -> d;
 	return( AVIRHIP_OK );
 }
@@ -324,7 +347,8 @@ static int resizer_acquire( avirhip_resizer* r, int src_w, int src_h,
 	std::lock_guard< std::mutex > lock( r -> mtx );
 	const avirhip_resizer::Key key( src_w, src_h, src_scanline_size, new_w,
 		new_h, el_count_io, k, V.ox, V.oy, V.BuildMode, in_type, out_type,
-		( V.UseSRGBGamma ? 1 : 0 ), V.AlphaIndex, r -> dither, dev );
+		( V.UseSRGBGamma ? 1 : 0 ), V.AlphaIndex,
+		r -> dither + 16 * r -> fppack, dev );
 
 	auto* e = r -> cache.find( key );
 
@@ -515,7 +539,7 @@ int avirhip_resizer_vars_base( avirhip_resizer* r, int src_w, int src_h,
 
 	const avirhip_resizer::Key key( src_w, src_h, src_scanline_size, new_w,
 		new_h, el_count_io, k, V.ox, V.oy, V.BuildMode, in_type, out_type,
-		( V.UseSRGBGamma ? 1 : 0 ), V.AlphaIndex, 0, 0 );
+		( V.UseSRGBGamma ? 1 : 0 ), V.AlphaIndex, 16 * r -> fppack, 0 );
 
 	{
 		std::lock_guard< std::mutex > lock( r -> mtx );
@@ -538,6 +562,22 @@ int avirhip_resizer_vars_base( avirhip_resizer* r, int src_w, int src_h,
 	}
 
 	fill_vars_base( *d, k, V, out );
+
+	if( d -> dither == AVIRHIP_DITHER_DEF_RNE )
+	{
+		// fpclass_float4: a pixel is one 16-byte fptype (avir.h:4576-4579,
+		// 4786-4787); buffer lengths count fptype elements
+		const int ch = d -> channels;
+		out -> ElCount = ( ch + 3 ) / 4;
+		out -> fppack = 4; out -> fpalign = 16;
+
+		for( int i = 0; i < 2; i++ )
+		{
+			out -> BufLen[ i ] = out -> BufLen[ i ] / ch * out -> ElCount;
+			out -> BufOffs[ i ] = out -> BufOffs[ i ] / ch * out -> ElCount;
+		}
+	}
+
 	avirhip_plan_desc_free( d );
 
 	std::lock_guard< std::mutex > lock( r -> mtx );

@@ -618,6 +618,15 @@ __host__ __device__ __forceinline__ float avir_round( const float d )
 		(float) (int) ( d + 0.5f ));
 }
 
+// round() of avir_float4_sse.h:303-313 (the ditherer of fpclass_float4):
+// _mm_cvtps_epi32 under round-to-nearest-even, back to float; values the
+// 32-bit conversion cannot hold become the "integer indefinite" -2^31.
+__device__ __forceinline__ float avir_round_rne( const float d )
+{
+	const float r = rintf( d );
+	return( fabsf( r ) < 2147483648.0f ? r : -2147483648.0f );
+}
+
 // CImageResizerDithererDefINL::dither (avir.h:4392-4419) + unpackScanline
 // (avir.h:3155-3215): round, clamp, optional bit-depth truncation, C cast.
 // With gamma, applySRGBGamma (avir.h:2982-3068) runs first: colour channels are
@@ -625,7 +634,7 @@ __host__ __device__ __forceinline__ float avir_round( const float d )
 template< typename Tout, bool IsInt >
 __global__ void __launch_bounds__( 256 ) k_epilogue( const float* res,
 	Tout* dst, long n, int use_tr, float tr_mul, float tr_muli, float pk_out,
-	int gamma, int ch, int ech, int alpha_index, float ogm )
+	int gamma, int ch, int ech, int alpha_index, float ogm, int rne )
 {
 	const long i = (long) blockIdx.x * blockDim.x + threadIdx.x;
 
@@ -653,6 +662,14 @@ __global__ void __launch_bounds__( 256 ) k_epilogue( const float* res,
 
 	if( IsInt )
 	{
+		if( rne )
+		{
+			// fpclass_float4: nearest-even, and clamp() is min(max(v, 0), pk)
+			// of SSE (avir_float4_sse.h:325-329) -- the same values
+			v = ( use_tr ? avir_round_rne( v * tr_muli ) * tr_mul :
+				avir_round_rne( v ));
+		}
+		else
 		if( use_tr )
 		{
 			v = avir_round( v * tr_muli ) * tr_mul;
@@ -907,7 +924,7 @@ static void launch_epilogue_gamma_px( const float* res, void* dst, long npx,
 
 int launch_epilogue( const float* res, void* dst, int out_type, long n,
 	double tr_mul, double pk_out, int gamma, int ch, int ech,
-	int alpha_index, hipStream_t st, const float* gthr )
+	int alpha_index, hipStream_t st, const float* gthr, bool rne )
 {
 	const dim3 grd( (unsigned) (( n + 255 ) / 256 ));
 	const int use_tr = ( tr_mul != 1.0 );
@@ -918,7 +935,7 @@ int launch_epilogue( const float* res, void* dst, int out_type, long n,
 	const float ogm = (float) ( out_type == AVIRHIP_U8 ? 255.0 :
 		( out_type == AVIRHIP_U16 ? 65535.0 : 1.0 ));
 
-	if( ech == 4 && gamma && out_type == AVIRHIP_U8 && gthr != nullptr )
+	if( !rne && ech == 4 && gamma && out_type == AVIRHIP_U8 && gthr != nullptr )
 	{
 		const long npx = n / ch;
 		const dim3 grd( (unsigned) (( npx + 255 ) / 256 ));
@@ -939,7 +956,7 @@ int launch_epilogue( const float* res, void* dst, int out_type, long n,
 		return( AVIRHIP_OK );
 	}
 
-	if( ech == 4 && gamma && ( out_type == AVIRHIP_U8 ||
+	if( !rne && ech == 4 && gamma && ( out_type == AVIRHIP_U8 ||
 		out_type == AVIRHIP_U16 ))
 	{
 		if( out_type == AVIRHIP_U8 )
@@ -953,7 +970,7 @@ int launch_epilogue( const float* res, void* dst, int out_type, long n,
 		return( AVIRHIP_OK );
 	}
 
-	if( ech == 4 && !gamma && ( (uintptr_t) dst & 3 ) == 0 )
+	if( !rne && ech == 4 && !gamma && ( (uintptr_t) dst & 3 ) == 0 )
 	{
 		const long npx = n / ch;
 
@@ -977,19 +994,19 @@ int launch_epilogue( const float* res, void* dst, int out_type, long n,
 	if( out_type == AVIRHIP_U8 )
 		hipLaunchKernelGGL(( k_epilogue< uint8_t, true > ), grd, dim3( 256 ),
 			0, st, res, (uint8_t*) dst, n, use_tr, trm, trmi, pk, gamma, ch,
-			ech, alpha_index, ogm );
+			ech, alpha_index, ogm, ( rne ? 1 : 0 ));
 	else if( out_type == AVIRHIP_U16 )
 		hipLaunchKernelGGL(( k_epilogue< uint16_t, true > ), grd, dim3( 256 ),
 			0, st, res, (uint16_t*) dst, n, use_tr, trm, trmi, pk, gamma, ch,
-			ech, alpha_index, ogm );
+			ech, alpha_index, ogm, ( rne ? 1 : 0 ));
 	else if( out_type == AVIRHIP_F64 )
 		hipLaunchKernelGGL(( k_epilogue< double, false > ), grd, dim3( 256 ),
 			0, st, res, (double*) dst, n, use_tr, trm, trmi, pk, gamma, ch,
-			ech, alpha_index, ogm );
+			ech, alpha_index, ogm, ( rne ? 1 : 0 ));
 	else
 		hipLaunchKernelGGL(( k_epilogue< float, false > ), grd, dim3( 256 ),
 			0, st, res, (float*) dst, n, use_tr, trm, trmi, pk, gamma, ch,
-			ech, alpha_index, ogm );
+			ech, alpha_index, ogm, ( rne ? 1 : 0 ));
 
 	AVIRHIP_HIPCHECK( hipGetLastError() );
 	return( AVIRHIP_OK );

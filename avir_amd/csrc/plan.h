@@ -101,6 +101,7 @@ struct avirhip_plan
 	double tr_mul, pk_out;
 	int gamma, alpha_index; // sRGB gamma stages (avir.h:2841-2930, 2982-3068)
 	int dither;             // AVIRHIP_DITHER_* (integer outputs only)
+	int fp4;                // plan of an fpclass_float4 object (no in-place float output)
 	float* errd_line;       // error-diffusion rows handed between row blocks
 	float* d_srgb_tbl;      // 256-entry uint8 linearisation table (gamma plans)
 	float* d_gthr;          // uint8 gamma output stage as 2 x 256 thresholds
@@ -183,7 +184,8 @@ int launch_op( const LOp& op, int ch, bool x_is_idx, const Surf& in,
 	hipStream_t st );
 int launch_epilogue( const float* res, void* dst, int out_type, long n,
 	double tr_mul, double pk_out, int gamma, int ch, int ech,
-	int alpha_index, hipStream_t st, const float* gthr = nullptr );
+	int alpha_index, hipStream_t st, const float* gthr = nullptr,
+	bool rne = false );
 bool gamma_u8_thresholds( float ogm, int use_tr, float trm, float trmi,
 	float pk, float* thr );
 int launch_errd( const float* res, void* dst, int out_type, int w, int h,

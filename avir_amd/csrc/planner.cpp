@@ -1452,7 +1452,8 @@ AvirPlanner::~AvirPlanner()
 }
 
 DescStore* AvirPlanner::build( int sw, int sh, int sstride, int nw, int nh,
-	int ch, double k, const avirhip_vars& vars, int in_type, int out_type )
+	int ch, double k, const avirhip_vars& vars, int in_type, int out_type,
+	int fppack )
 {
 	if( sw < 1 || sh < 1 || nw < 1 || nh < 1 || ch < 1 || ch > 4 ||
 		in_type < 0 || in_type > 3 || out_type < 0 || out_type > 3 )
@@ -1524,7 +1525,10 @@ DescStore* AvirPlanner::build( int sw, int sh, int sstride, int nw, int nh,
 	}
 
 	AxisVars V;
-	V.elCount = ch;
+	// ElCount counts `fptype` values per pixel (avir.h:4786-4787): with a
+	// 4-float SIMD fptype (fpclass_float4) a pixel of 1-4 channels is ONE
+	// element, and the build-mode cost model weighs the steps differently
+	V.elCount = ( ch + fppack - 1 ) / fppack;
 	V.k = 0.0; V.o = 0.0; V.resizeStep = 0; V.isResize2 = false;
 
 	FracBank bank;

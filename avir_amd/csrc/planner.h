@@ -37,7 +37,7 @@ public:
 	// Returns nullptr (and sets the error string) on an unsupported request.
 	DescStore* build( int src_w, int src_h, int src_scanline_size, int new_w,
 		int new_h, int el_count_io, double k, const avirhip_vars& vars,
-		int in_type, int out_type );
+		int in_type, int out_type, int fppack = 1 );
 
 private:
 	AvirPlannerImpl* impl;

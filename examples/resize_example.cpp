@@ -13,6 +13,7 @@
 #include <cstdint>
 #include <vector>
 #include "avir.h"
+#include "avir_float4_sse.h"
 #include "lancir.h"
 
 static uint64_t fnv1a64( const void* p, size_t n )
@@ -98,6 +99,29 @@ int main()
 
 		printf( "errd %016llx\n", (unsigned long long) fnv1a64( Out8.data(),
 			Out8.size() ));
+
+		// the SIMD value type, exactly as the reference's README enables it
+		// (README.md:174-186): 8-bit RGB up, 16-bit RGBA-float down, and the
+		// variables it writes back
+		avir :: CImageResizer< avir :: fpclass_float4 > ImageResizerF4( 8 );
+		avir :: CImageResizerVars VarsF4;
+		ImageResizerF4.resizeImage( In8.data(), 640, 480, 0, Out8.data(),
+			1024, 768, 3, 0, &VarsF4 );
+
+		printf( "float4_u8 %016llx\n", (unsigned long long) fnv1a64(
+			Out8.data(), Out8.size() ));
+
+		printf( "float4_vars %d %d %d %d %d %d %d\n", VarsF4.ElCount,
+			VarsF4.fppack, VarsF4.fpalign, VarsF4.BufLen[ 0 ],
+			VarsF4.BufLen[ 1 ], VarsF4.BufOffs[ 0 ], VarsF4.BufOffs[ 1 ]);
+
+		std :: vector< uint16_t > Out16( 400 * 300 * 4 );
+		avir :: CImageResizer< avir :: fpclass_float4 > ImageResizerF4b( 12 );
+		ImageResizerF4b.resizeImage( InF.data(), 640, 480, 0, Out16.data(),
+			400, 300, 4, 0 );
+
+		printf( "float4_u16 %016llx\n", (unsigned long long) fnv1a64(
+			Out16.data(), Out16.size() * 2 ));
 
 		// CImageResizerVarsBase is written back (avir.h:4663-4669)
 		avir :: CImageResizerVars Vars2;

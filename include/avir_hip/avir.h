@@ -220,8 +220,11 @@ public:
 		const CImageResizerParams& aParams = CImageResizerParamsDef() )
 		: h( nullptr )
 	{
-		static_assert( sizeof( typename fpclass :: fptype ) == sizeof( float ),
-			"avir_hip: only the float pipeline (fpclass_def<float>) exists" );
+		static_assert( sizeof( typename fpclass :: fptypeatom ) ==
+			sizeof( float ) && ( fpclass :: fppack == 1 ||
+			fpclass :: fppack == 4 ) && fpclass :: packmode == 0,
+			"avir_hip: the float pipeline only -- fpclass_def<float> or "
+			"fpclass_float4 (avir_float4_sse.h)" );
 
 		avirhip_params p;
 		p.CorrFltAlpha = aParams.CorrFltAlpha; p.CorrFltLen = aParams.CorrFltLen;
@@ -239,6 +242,12 @@ public:
 		hipdetail :: check( avirhip_resizer_set_ditherer( h,
 			fpclass :: CDitherer :: avirhip_dither ),
 			"avirhip_resizer_set_ditherer" );
+
+		if( fpclass :: fppack != 1 )
+		{
+			hipdetail :: check( avirhip_resizer_set_fpclass( h,
+				fpclass :: fppack ), "avirhip_resizer_set_fpclass" );
+		}
 	}
 
 	~CImageResizer()
@@ -264,12 +273,13 @@ public:
 			v.AlphaIndex = aVars -> AlphaIndex;
 			v.BuildMode = aVars -> BuildMode;
 			v.RndSeed = aVars -> RndSeed;
-			aVars -> ElCount = ElCountIO;
+			aVars -> ElCount = ( ElCountIO + fpclass :: fppack - 1 ) /
+				fpclass :: fppack;
 			aVars -> ElCountIO = ElCountIO;
-			aVars -> fppack = 1;
-			aVars -> fpalign = 4;
-			aVars -> elalign = 1;
-			aVars -> packmode = 0;
+			aVars -> fppack = fpclass :: fppack;
+			aVars -> fpalign = fpclass :: fpalign;
+			aVars -> elalign = fpclass :: elalign;
+			aVars -> packmode = fpclass :: packmode;
 		}
 
 		hipdetail :: check( avirhip_resizer_resize( h, SrcBuf,

@@ -144,6 +144,13 @@ typedef struct avirhip_plan_desc {
 
 #define AVIRHIP_DITHER_DEF 0
 #define AVIRHIP_DITHER_ERRD 1
+/* CImageResizerDithererDefINL over the SSE value type of fpclass_float4: its
+ * round() is cvtps_epi32 under nearest-even (avir_float4_sse.h:303-313)
+ * instead of avir::round's (int)(d + 0.5) (avir.h:130-135). Such a plan also
+ * has no in-place float output (avir.h:4956: sizeof(fptype) != sizeof(Tout)),
+ * i.e. float / double results pass through the output stage, and with sRGB
+ * gamma they ARE de-linearised. */
+#define AVIRHIP_DITHER_DEF_RNE 2
 
 /* ---------------------------------------------------------------------
  * LANCIR plan description (CLancIR internals, lancir.h:840-1381).
@@ -320,6 +327,16 @@ void avirhip_resizer_destroy(avirhip_resizer* r);
  * following resize of this object: AVIRHIP_DITHER_DEF (default) or
  * AVIRHIP_DITHER_ERRD. */
 int avirhip_resizer_set_ditherer(avirhip_resizer* r, int dither);
+/* Selects the `fptype` packing of the mirrored fpclass (avir.h:4569-4592):
+ * 1 = fpclass_def<float> (default), 4 = fpclass_float4 of
+ * avir_float4_sse.h (fpclass_def<float4, float>). The arithmetic per channel
+ * is the same; what changes is what the reference derives from fppack:
+ * ElCount = ceil(ElCountIO / fppack) in the build-mode cost model
+ * (avir.h:4786, 6206-6270 -- the automatic BuildMode can differ), the
+ * ditherer's rounding and the float-output path (AVIRHIP_DITHER_DEF_RNE),
+ * and the CImageResizerVarsBase write-back. The error-diffusion ditherer is
+ * only built for fppack 1. */
+int avirhip_resizer_set_fpclass(avirhip_resizer* r, int fppack);
 
 /* Host-only: runs the planner exactly as resizeImage() would for this call
  * and returns the plan description (owned by the library; release with

@@ -44,6 +44,18 @@ def test_reference_style_program_matches_reference():
     chk = rb.ref_avir if rb.have_ref() else rb.orc_avir
     assert got["errd"] == rb.fnv(chk(rb.lcg_u8((480, 640, 3)), 1024, 768,
                                      errd=True))
+    # README.md:174-186: avir_float4_sse.h + CImageResizer<fpclass_float4>
+    if rb.have_ref():
+        assert got["float4_u8"] == rb.fnv(rb.ref_avir(
+            rb.lcg_u8((480, 640, 3)), 1024, 768, variant=1))
+        import numpy as np
+        assert got["float4_u16"] == rb.fnv(rb.ref_avir(
+            src, 400, 300, resbits=12, out_dtype=np.uint16, variant=1))
+        import ctypes as C
+        w = (C.c_double * 16)()
+        rb.ref().ref_avir_vars_base_f4(640, 480, 1024, 768, 3, 0.0, 1, 8, w)
+        assert got["float4_vars"] == "%d %d %d %d %d %d %d" % (
+            w[0], w[2], w[3], w[6], w[7], w[8], w[9])
     if rb.have_ref():
         import ctypes as C
         w = (C.c_double * 16)()

@@ -57,7 +57,8 @@ def _assert_same(got, want, what):
 
 def _run_avir(src, nw, nh, resbits=8, out_dtype=None, build_mode=-1, k=0.0,
               path=0, variant=0, **kw):
-    r = avir_amd.CImageResizer(resbits, kw.get("srcbits", 0))
+    r = avir_amd.CImageResizer(resbits, kw.get("srcbits", 0),
+                               aFpPack=kw.get("fppack", 1))
     v = avir_amd.CImageResizerVars()
     v.BuildMode = build_mode
     v.ox, v.oy = kw.get("ox", 0.0), kw.get("oy", 0.0)
@@ -264,6 +265,49 @@ def test_avir_exact_2x_other_io_types():
         got = _run_avir(src, 300, 200, resbits=8, out_dtype=tout,
                         build_mode=1, path=abi.PATH_UP2)
         _assert_same(got, want, "up2 %s->%s" % (np.dtype(tin), np.dtype(tout)))
+
+
+F4_SHAPES = [(64, 48, 100, 77, 4), (64, 48, 128, 96, 3), (300, 200, 100, 67, 4),
+             (50, 40, 37, 90, 1), (90, 60, 45, 30, 2), (37, 21, 74, 42, 4),
+             (640, 480, 1024, 768, 3), (200, 150, 130, 90, 3), (64, 48, 70, 48, 4)]
+
+
+@pytest.mark.parametrize("sw,sh,nw,nh,ch", F4_SHAPES)
+def test_avir_fpclass_float4(sw, sh, nw, nh, ch):
+    """avir::CImageResizer<fpclass_float4> (avir_float4_sse.h, README.md:174-186)
+    against the reference's own SSE class: the automatic build mode its cost
+    model picks with ElCount = 1 (it differs from the scalar class for most
+    upsizing plans), nearest-even rounding of integer outputs with and without
+    bit-depth truncation, float / double outputs, sRGB gamma (de-linearised
+    float output included), alpha."""
+    if not rb.have_ref():
+        pytest.fail("oracle/_ref is needed: the restatement has no float4 class")
+    f32 = rb.lcg_f32((sh, sw, ch), seed=31 + sw)
+    u8 = rb.lcg_u8((sh, sw, ch), seed=32 + sw)
+    u16 = rb.lcg_u8((sh, sw, ch, 2), seed=33 + sw).view(np.uint16).reshape(sh, sw, ch)
+    cases = [(f32, np.float32, 16, {}), (f32, np.float64, 16, {}),
+             (u8, np.uint8, 8, {}), (f32, np.uint8, 8, {}),
+             (u8, np.uint8, 6, {}), (u16, np.uint16, 16, {}),
+             (u16, np.uint16, 10, {}), (f32, np.uint16, 12, {}),
+             (u8, np.uint8, 8, {"gamma": True}),
+             (u8, np.float32, 8, {"gamma": True}),
+             (u16, np.uint16, 16, {"gamma": True}),
+             (f32, np.float32, 16, {"gamma": True})]
+    if ch == 4:
+        cases += [(u8, np.uint8, 8, {"gamma": True, "alpha": 3}),
+                  (u8, np.float32, 8, {"gamma": True, "alpha": 0})]
+    for src, tout, bits, kw in cases:
+        want = rb.ref_avir(src, nw, nh, resbits=bits, out_dtype=tout,
+                           variant=1, **kw)
+        got = _run_avir(src, nw, nh, resbits=bits, out_dtype=tout, fppack=4,
+                        **kw)
+        _assert_same(got, want, "float4 %s->%s bits %d %r" % (
+            src.dtype, np.dtype(tout), bits, kw))
+    # forced build modes: the same float results as the scalar class
+    for mode in (0, 1):
+        want = rb.ref_avir(f32, nw, nh, resbits=16, variant=1, build_mode=mode)
+        _assert_same(_run_avir(f32, nw, nh, resbits=16, build_mode=mode,
+                               fppack=4), want, "float4 mode %d" % mode)
 
 
 @pytest.mark.parametrize("bits", [8, 16])
