@@ -11,6 +11,8 @@
 #include <stdlib.h>
 #include <algorithm>
 #include <chrono>
+#include <atomic>
+#include <thread>
 
 namespace avirhip {
 
@@ -897,6 +899,242 @@ namespace avirhip {
 
 static int clone_plan( const avirhip_plan* s, int device, avirhip_plan** out );
 
+// The last source row the output rows [row0, row1) read (inclusive): the
+// vertical axis' op chain walked backwards (AVIR), the vertical filter
+// positions (LANCIR).
+static int band_last_src_row( const avirhip_plan* p, int row0, int row1 )
+{
+	if( p -> is_lancir )
+	{
+		return( std::max( 0, std::min( p -> lv.h_start[ row1 - 1 ] +
+			p -> lv.kernel_len - 1, p -> src_h - 1 )));
+	}
+
+	int a = row0, b = row1 - 1;
+
+	for( int i = (int) p -> v.ops.size() - 1; i >= 0; i-- )
+	{
+		int ia, ib;
+		const LOp& op = p -> v.ops[ i ];
+		need_range( op, std::max( 0, std::min( a, op.out_len - 1 )),
+			std::max( 0, std::min( b, op.out_len - 1 )), ia, ib );
+		a = ia;
+		b = ib;
+	}
+
+	return( std::max( 0, std::min( b, p -> src_h - 1 )));
+}
+
+// Host-pointer call, pipelined (the call every existing caller of the
+// reference makes, avir.h:4680-4684): the frame in row bands, the source rows
+// of band b + 1 travelling host -> device (an uploader thread: a copy from
+// pageable memory holds its thread until the data is staged) while band b is
+// computed and band b - 1 travels device -> host. PCIe is full duplex, so the
+// call costs the longer direction instead of the sum (cfg3: 531 MB down,
+// 133 MB up). Returns 1 when the call should take the serial path.
+static int exec_device( avirhip_plan* p, const void* src, void* dst,
+	int row0, int row1, hipStream_t st );
+
+static int exec_host_pipelined( avirhip_plan* p, const void* src, void* dst,
+	size_t src_bytes, size_t dst_bytes, size_t row_bytes, hipStream_t st )
+{
+	static const bool off = ( getenv( "AVIRHIP_NO_HOST_PIPELINE" ) != nullptr );
+	enum { NBMAX = 32 };
+	static const int NB = []() { const char* e = getenv( "AVIRHIP_HOST_BANDS" );
+		const int n = ( e != nullptr ? atoi( e ) : 16 );
+		return( n < 2 ? 2 : ( n > NBMAX ? (int) NBMAX : n )); }();
+
+	if( off || p -> new_h < 4 * NB || src_bytes + dst_bytes < ( 16u << 20 ) ||
+		( !p -> is_lancir && p -> dither == AVIRHIP_DITHER_ERRD &&
+		( p -> out_type == AVIRHIP_U8 || p -> out_type == AVIRHIP_U16 )))
+	{
+		return( 1 );
+	}
+
+	if( p -> pipe_in == nullptr )
+	{
+		hipStream_t a, b;
+		AVIRHIP_HIPCHECK( hipStreamCreateWithFlags( &a, hipStreamNonBlocking ));
+		AVIRHIP_HIPCHECK( hipStreamCreateWithFlags( &b, hipStreamNonBlocking ));
+		p -> pipe_in = a; p -> pipe_out = b;
+
+		for( int i = 0; i < 2 * NB + 1; i++ )
+		{
+			hipEvent_t e;
+			AVIRHIP_HIPCHECK( hipEventCreateWithFlags( &e,
+				hipEventDisableTiming ));
+			p -> pipe_ev.push_back( e );
+		}
+	}
+
+	hipStream_t s_in = (hipStream_t) p -> pipe_in;
+	hipStream_t s_out = (hipStream_t) p -> pipe_out;
+	static const bool do_reg = ( getenv( "AVIRHIP_HOST_REGISTER" ) != nullptr );
+	bool reg_s = false, reg_d = false;
+
+	if( do_reg )
+	{
+		reg_s = ( hipHostRegister( (void*) src, src_bytes,
+			hipHostRegisterDefault ) == hipSuccess );
+		reg_d = ( hipHostRegister( dst, dst_bytes, hipHostRegisterDefault ) ==
+			hipSuccess );
+		(void) hipGetLastError();
+	}
+
+	const size_t es = dtype_size( p -> in_type );
+	const size_t srow = (size_t) p -> src_stride * es;
+	int cut[ NBMAX + 1 ], last[ NBMAX ];
+
+	for( int b = 0; b <= NB; b++ )
+	{
+		cut[ b ] = (int) ( (long) p -> new_h * b / NB );
+	}
+
+	for( int b = 0; b < NB; b++ )
+	{
+		last[ b ] = band_last_src_row( p, cut[ b ], cut[ b + 1 ]);
+
+		if( b > 0 )
+		{
+			last[ b ] = std::max( last[ b ], last[ b - 1 ]);
+		}
+	}
+
+	last[ NB - 1 ] = p -> src_h - 1;
+
+	// the copy streams start behind whatever the caller's stream holds
+	hipEvent_t e0 = p -> pipe_ev[ 2 * NB ];
+	AVIRHIP_HIPCHECK( hipEventRecord( e0, st ));
+	AVIRHIP_HIPCHECK( hipStreamWaitEvent( s_in, e0, 0 ));
+	AVIRHIP_HIPCHECK( hipStreamWaitEvent( s_out, e0, 0 ));
+
+	std::atomic< int > ready( -1 );
+	std::atomic< int > up_err( 0 );
+	const int dev = p -> device;
+	char* const dsrc = (char*) p -> stage_src;
+
+	std::thread uploader( [&]()
+	{
+		if( hipSetDevice( dev ) != hipSuccess )
+		{
+			up_err.store( 1 );
+			ready.store( NB );
+			return;
+		}
+
+		int done = 0; // source rows on their way
+
+		for( int b = 0; b < NB; b++ )
+		{
+			const int upto = last[ b ] + 1;
+
+			if( upto > done )
+			{
+				const size_t o0 = (size_t) done * srow;
+				const size_t o1 = std::min( src_bytes, (size_t) upto * srow );
+
+				if( o1 > o0 && hipMemcpyAsync( dsrc + o0, (const char*) src + o0,
+					o1 - o0, hipMemcpyHostToDevice, s_in ) != hipSuccess )
+				{
+					up_err.store( 1 );
+				}
+
+				done = upto;
+			}
+
+			if( hipEventRecord( p -> pipe_ev[ b ], s_in ) != hipSuccess )
+			{
+				up_err.store( 1 );
+			}
+
+			ready.store( b );
+		}
+	} );
+
+	int rc = AVIRHIP_OK;
+
+	// band b's copy down holds this thread (pageable memory), so band b + 1's
+	// kernels are enqueued BEFORE it: the device never waits for the host
+	auto copy_down = [&]( const int b )
+	{
+		const size_t off_b = (size_t) cut[ b ] * row_bytes;
+		const size_t len_b = std::min( dst_bytes,
+			(size_t) cut[ b + 1 ] * row_bytes ) - off_b;
+
+		if( hipStreamWaitEvent( s_out, p -> pipe_ev[ NB + b ], 0 ) != hipSuccess ||
+			hipMemcpyAsync( (char*) dst + off_b, (char*) p -> stage_dst + off_b,
+			len_b, hipMemcpyDeviceToHost, s_out ) != hipSuccess )
+		{
+			rc = AVIRHIP_EHIP;
+		}
+	};
+
+	int enq = 0; // bands whose kernels are enqueued
+
+	for( int b = 0; b < NB && rc == AVIRHIP_OK; b++ )
+	{
+		while( ready.load() < b )
+		{
+			std::this_thread::yield();
+		}
+
+		if( up_err.load() != 0 )
+		{
+			break;
+		}
+
+		if( hipStreamWaitEvent( st, p -> pipe_ev[ b ], 0 ) != hipSuccess )
+		{
+			rc = AVIRHIP_EHIP;
+			break;
+		}
+
+		rc = exec_device( p, dsrc, (char*) p -> stage_dst +
+			(size_t) cut[ b ] * row_bytes, cut[ b ], cut[ b + 1 ], st );
+
+		if( rc != AVIRHIP_OK )
+		{
+			break;
+		}
+
+		if( hipEventRecord( p -> pipe_ev[ NB + b ], st ) != hipSuccess )
+		{
+			rc = AVIRHIP_EHIP;
+			break;
+		}
+
+		enq = b + 1;
+
+		if( b >= 1 )
+		{
+			copy_down( b - 1 );
+		}
+	}
+
+	if( rc == AVIRHIP_OK && enq == NB )
+	{
+		copy_down( NB - 1 );
+	}
+
+	uploader.join();
+	(void) hipStreamSynchronize( s_in );
+	(void) hipStreamSynchronize( s_out );
+	(void) hipStreamSynchronize( st );
+
+	if( reg_s ) (void) hipHostUnregister( (void*) src );
+	if( reg_d ) (void) hipHostUnregister( dst );
+
+	if( up_err.load() != 0 && rc == AVIRHIP_OK )
+	{
+		set_error( "host-pointer call: the source upload failed: %s",
+			hipGetErrorString( hipGetLastError() ));
+		rc = AVIRHIP_EHIP;
+	}
+
+	return( rc );
+}
+
+
 static int exec_any( avirhip_plan* p, const void* src, int src_mem, void* dst,
 	int dst_mem, int row0, int row1, void* stream, bool have_lock = false )
 {
@@ -1061,8 +1299,6 @@ static int exec_any( avirhip_plan* p, const void* src, int src_mem, void* dst,
 			p -> stage_src_bytes = src_bytes;
 		}
 
-		AVIRHIP_HIPCHECK( hipMemcpyAsync( p -> stage_src, src, src_bytes,
-			hipMemcpyHostToDevice, st ));
 		dsrc = p -> stage_src;
 	}
 
@@ -1100,7 +1336,28 @@ static int exec_any( avirhip_plan* p, const void* src, int src_mem, void* dst,
 		ddst = p -> stage_dst;
 	}
 
-	int rc = exec_device( p, dsrc, ddst, row0, row1, st );
+	int rc = 1;
+
+	if( src_mem == AVIRHIP_MEM_HOST && dst_mem == AVIRHIP_MEM_HOST &&
+		row0 == 0 && row1 == p -> new_h && (size_t) p -> new_w * p -> io_ch *
+		dtype_size( p -> out_type ) == row_bytes )
+	{
+		rc = exec_host_pipelined( p, src, dst, src_bytes, dst_bytes, row_bytes,
+			st );
+
+		if( rc != 1 )
+		{
+			return( rc );
+		}
+	}
+
+	if( src_mem == AVIRHIP_MEM_HOST )
+	{
+		AVIRHIP_HIPCHECK( hipMemcpyAsync( p -> stage_src, src, src_bytes,
+			hipMemcpyHostToDevice, st ));
+	}
+
+	rc = exec_device( p, dsrc, ddst, row0, row1, st );
 	if( rc != 0 ) return( rc );
 
 	if( dst_mem == AVIRHIP_MEM_HOST )
@@ -1143,6 +1400,7 @@ static avirhip_plan* new_plan()
 	p -> stage_src_bytes = 0; p -> stage_dst_bytes = 0;
 	p -> shard_band = nullptr; p -> shard_band_bytes = 0;
 	p -> last_done = nullptr; p -> last_stream = nullptr;
+	p -> pipe_in = nullptr; p -> pipe_out = nullptr;
 	p -> shard_src = nullptr; p -> shard_src_bytes = 0;
 	p -> tr_mul = 1.0; p -> pk_out = 0.0;
 	p -> gamma = 0; p -> alpha_index = -1; p -> d_srgb_tbl = nullptr;
@@ -1823,6 +2081,19 @@ void avirhip_plan_destroy( avirhip_plan* p )
 	if( p -> last_done != nullptr )
 	{
 		(void) hipEventDestroy( p -> last_done );
+	}
+
+	for( size_t i = 0; i < p -> pipe_ev.size(); i++ )
+	{
+		(void) hipEventDestroy( p -> pipe_ev[ i ]);
+	}
+
+	p -> pipe_ev.clear();
+
+	if( p -> pipe_in != nullptr )
+	{
+		(void) hipStreamDestroy( (hipStream_t) p -> pipe_in );
+		(void) hipStreamDestroy( (hipStream_t) p -> pipe_out );
 	}
 
 	avirhip_plan_destroy( p -> inner );

@@ -155,6 +155,9 @@ struct avirhip_plan
 	std::mutex spare_mtx; // the list of spares
 	hipEvent_t last_done;
 	void* last_stream; // stream of the call that recorded last_done
+	// host-pointer calls: copy streams and events of the band pipeline
+	void* pipe_in; void* pipe_out;
+	std::vector< hipEvent_t > pipe_ev;
 	void* stage_src; // host-pointer staging
 	void* stage_dst;
 	size_t stage_src_bytes, stage_dst_bytes;

@@ -534,8 +534,9 @@ def main():
         out["host_pointer_call"] = {
             "ms": round(min(ts[1:]) * 1e3, 2),
             "value": round(mpix / min(ts[1:]), 1), "unit": "Mpixels/s",
-            "note": "pageable host src/dst, H2D + kernel + D2H inside "
-                    "avirhip_resize; 663.6 MB over PCIe",
+            "note": "pageable host src/dst; source rows up, band kernels and "
+                    "result rows down pipelined inside avirhip_resize "
+                    "(16 bands, PCIe both ways at once); 663.6 MB over PCIe",
             "parity_ok": synth.fnv(hdst) == "38d7739587151f6e"}
         out["cpu_baseline"] = cpu_baseline(src_np, os.cpu_count() or 1)
 

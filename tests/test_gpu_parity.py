@@ -1404,3 +1404,38 @@ def test_avir_whole_ratio_kernels_read_and_store_integer_images(sw, sh, k, ch,
             p, src.ctypes.data, abi.MEM_HOST, out[a_:b_].ctypes.data,
             abi.MEM_HOST, a_, b_, None), "band")
     _assert_same(out, want, "dn bands")
+
+
+@pytest.mark.parametrize("case", [
+    ("avir", 1000, 700, 2000, 1400, 4, np.float32, np.float32),
+    ("avir", 3000, 2000, 1000, 667, 4, np.float32, np.float32),
+    ("avir", 2000, 1500, 3000, 2250, 3, np.uint8, np.uint8),
+    ("avir", 1920, 1080, 2500, 1400, 4, np.float32, np.uint16),
+    ("lancir", 1500, 1000, 2200, 1500, 4, np.float32, np.float32),
+    ("lancir", 2400, 1600, 1200, 800, 3, np.uint8, np.uint8)])
+def test_host_pointer_calls_run_the_band_pipeline(case):
+    """A host-pointer call of a large frame is pipelined inside the library
+    (api.cpp::exec_host_pipelined: source rows up, band kernels, result rows
+    down, all in flight at once): the result must be the device-resident
+    call's, bit for bit, and a second call on the same plan too."""
+    import torch
+    api, sw, sh, nw, nh, ch, tin, tout = case
+    if np.dtype(tin).kind == "u":
+        src = rb.lcg_u8((sh, sw, ch), seed=sw)
+    else:
+        src = rb.lcg_f32((sh, sw, ch), seed=sw)
+    obj = avir_amd.CImageResizer(16 if tout == np.uint16 else 8) \
+        if api == "avir" else avir_amd.CLancIR()
+    dsrc = torch.from_numpy(src).to("cuda:0")
+    if api == "avir":
+        want = obj.resize(dsrc, nw, nh, out_dtype={
+            np.float32: torch.float32, np.uint8: torch.uint8,
+            np.uint16: torch.uint16}[tout]).cpu().numpy()
+        got = obj.resize(src, nw, nh, out_dtype=tout)
+        again = obj.resize(src, nw, nh, out_dtype=tout)
+    else:
+        want = obj.resize(dsrc, nw, nh).cpu().numpy()
+        got = obj.resize(src, nw, nh)
+        again = obj.resize(src, nw, nh)
+    _assert_same(got, want, "pipelined host call %r" % (case,))
+    _assert_same(again, want, "second pipelined host call %r" % (case,))
