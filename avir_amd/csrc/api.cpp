@@ -1398,7 +1398,7 @@ static avirhip_plan* new_plan()
 	p -> packed = nullptr; p -> resbuf = nullptr; p -> lres = nullptr;
 	p -> stage_src = nullptr; p -> stage_dst = nullptr;
 	p -> stage_src_bytes = 0; p -> stage_dst_bytes = 0;
-	p -> shard_band = nullptr; p -> shard_band_bytes = 0;
+	p -> shard_band = nullptr; p -> shard_band_bytes = 0; p -> shard_ldev = -1;
 	p -> last_done = nullptr; p -> last_stream = nullptr;
 	p -> pipe_in = nullptr; p -> pipe_out = nullptr;
 	p -> shard_src = nullptr; p -> shard_src_bytes = 0;
@@ -1785,6 +1785,24 @@ int avirhip_resize_sharded( avirhip_plan* p, int n_gpus, const int* devices,
 
 	const bool force_replica =
 		( getenv( "AVIRHIP_SHARDED_FORCE_REPLICA" ) != nullptr );
+	// test aid: AVIRHIP_SHARDED_DEVMAP="0,0,0" maps the LOGICAL devices of
+	// `devices[]` (0, 1, 2) onto physical ones, so that the multi-device
+	// branches -- one replica and one set of buffers per logical device, the
+	// source copied to each, stores / copies into a peer's memory at the
+	// band's offset -- execute on a box with a single GPU
+	std::vector< int > devmap;
+	{
+		const char* dm = getenv( "AVIRHIP_SHARDED_DEVMAP" );
+
+		while( dm != nullptr && *dm != 0 )
+		{
+			devmap.push_back( atoi( dm ));
+			dm = strchr( dm, ',' );
+			if( dm != nullptr ) dm++;
+		}
+	}
+
+	const bool mocked = !devmap.empty();
 	// test aid: always go through the band buffers + peer copies
 	const bool force_staged =
 		( getenv( "AVIRHIP_SHARDED_STAGED" ) != nullptr );
@@ -1814,18 +1832,21 @@ int avirhip_resize_sharded( avirhip_plan* p, int n_gpus, const int* devices,
 	// ---- compute: every band on its device's default stream
 	for( int g = 0; g < n_gpus && rc == 0; g++ )
 	{
-		const int d = ( devices != nullptr ? devices[ g ] : p -> device );
+		// ld: the device as the caller names it; d: where it really is
+		const int ld = ( devices != nullptr ? devices[ g ] : p -> device );
+		const int d = ( mocked && ld >= 0 && ld < (int) devmap.size() ?
+			devmap[ ld ] : ld );
 
-		if( d < 0 || d >= ndev )
+		if( d < 0 || d >= ndev || ld < 0 )
 		{
-			set_error( "resize_sharded: device %d does not exist", d );
+			set_error( "resize_sharded: device %d does not exist", ld );
 			rc = AVIRHIP_EINVAL;
 			break;
 		}
 
 		avirhip_plan* q = nullptr;
 
-		if( d == p -> device && !force_replica )
+		if( ld == p -> device && !force_replica )
 		{
 			q = p;
 		}
@@ -1833,7 +1854,7 @@ int avirhip_resize_sharded( avirhip_plan* p, int n_gpus, const int* devices,
 		{
 			for( size_t i = 0; i < p -> replicas.size(); i++ )
 			{
-				if( p -> replicas[ i ] -> device == d )
+				if( p -> replicas[ i ] -> shard_ldev == ld )
 				{
 					q = p -> replicas[ i ];
 				}
@@ -1842,6 +1863,7 @@ int avirhip_resize_sharded( avirhip_plan* p, int n_gpus, const int* devices,
 			if( q == nullptr )
 			{
 				if(( rc = clone_plan( p, d, &q )) != 0 ) break;
+				q -> shard_ldev = ld;
 				p -> replicas.push_back( q );
 			}
 		}
@@ -1855,7 +1877,8 @@ int avirhip_resize_sharded( avirhip_plan* p, int n_gpus, const int* devices,
 		const void* s = src;
 		int smem = src_mem;
 
-		if( src_mem == AVIRHIP_MEM_DEVICE && src_dev != d )
+		// (mocked: the buffers live on logical device 0)
+		if( src_mem == AVIRHIP_MEM_DEVICE && ( mocked ? ld != 0 : src_dev != d ))
 		{
 			if(( rc = grow( q, &q -> shard_src, &q -> shard_src_bytes,
 				src_bytes )) != 0 ) break;
@@ -1873,9 +1896,14 @@ int avirhip_resize_sharded( avirhip_plan* p, int n_gpus, const int* devices,
 
 		if( dst_mem == AVIRHIP_MEM_DEVICE && !force_staged )
 		{
-			if( d == dst_dev )
+			if( mocked ? ld == 0 : d == dst_dev )
 			{
 				direct = true;
+			}
+			else
+			if( mocked )
+			{
+				direct = true; // "peer" memory on the same physical device
 			}
 			else
 			{

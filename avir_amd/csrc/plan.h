@@ -145,6 +145,7 @@ struct avirhip_plan
 	std::vector< avirhip_plan* > spares;
 	int is_spare;
 	void* shard_band; size_t shard_band_bytes;
+	int shard_ldev; // replica: the device id its owner's caller named
 	void* shard_src; size_t shard_src_bytes;
 	// A plan owns scratch buffers (packed source, float result, FltBuf, op
 	// outputs, staging): calls that use them are serialised -- host side by

@@ -77,7 +77,14 @@ class BandPipeline(object):
     avirhip_resize_band() with a device destination. Frames alternate between
     two slots; step() only waits for the transfers of the frame that used the
     slot before (two frames ago), finish() drains everything. On the root,
-    frame(slot) is the stitched image of the last frame stepped into `slot`."""
+    frame(slot) is the stitched image of the last frame stepped into `slot`.
+
+    Stream contract: torch.distributed orders a send / receive after the work
+    enqueued on the CURRENT stream at the time it is posted, so `resize_rows`
+    must launch on that stream -- step() checks that the current stream is
+    the one the pipeline was built on. A stitched frame may only be read
+    after wait_slot(slot) (or finish()): until then its transfers may still
+    be in flight on RCCL's stream."""
 
     def __init__(self, new_h, new_w, ch, dtype, device, rank, world, dist,
                  resize_rows, nsub=4, root=0, slots=2):
@@ -92,6 +99,8 @@ class BandPipeline(object):
         self.pending = [[] for _ in range(slots)]
         self.after = [[] for _ in range(slots)]  # host-staging copies (gloo)
         self.nframe = 0
+        self.stream = (torch.cuda.current_stream(device)
+                       if torch.device(device).type == "cuda" else None)
         if rank == root:
             self.full = [torch.empty((new_h, new_w, ch), dtype=dtype,
                                      device=device) for _ in range(slots)]
@@ -113,9 +122,22 @@ class BandPipeline(object):
             fn()
         self.after[slot] = []
 
+    def wait_slot(self, slot):
+        """Blocks until every transfer of the frame last stepped into `slot`
+        has completed; on the root, frame(slot) is then safe to read (on the
+        pipeline's stream)."""
+        self._wait(slot)
+
     def step(self):
         """Enqueues one frame; returns the slot it used."""
         dist, root = self.dist, self.root
+        if self.stream is not None:
+            import torch
+            if torch.cuda.current_stream(self.stream.device) != self.stream:
+                raise RuntimeError(
+                    "BandPipeline.step(): the current stream is not the one "
+                    "the pipeline was built on (transfers are ordered after "
+                    "the kernels through it)")
         slot = self.nframe % self.slots
         self.nframe += 1
         self._wait(slot)

@@ -289,6 +289,10 @@ def main():
     ap.add_argument("--backend", default="nccl",
                     help="torch.distributed backend for --gpus > 1 (nccl = "
                          "RCCL; gloo only for dry runs of the rank logic)")
+    ap.add_argument("--pg-smoke", action="store_true",
+                    help="with --gpus 1: run the step through a one-rank "
+                         "process group and the band pipeline (the N > 1 code "
+                         "path, on the one GPU this box has)")
     ap.add_argument("--sub-bands", type=int, default=4,
                     help="N > 1: sub-bands per rank (transfer of sub-band i "
                          "overlaps the resize of sub-band i+1)")
@@ -324,12 +328,22 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
 
-    if world > 1:
+    if world > 1 or args.pg_smoke:
+        import datetime
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if args.pg_smoke and world == 1:
+            # a one-rank process group: the band pipeline's code path through
+            # torch.distributed / RCCL on a box with a single GPU
+            os.environ.setdefault("MASTER_PORT", "29617")
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
+        # a transfer that never completes must end the run with an error,
+        # not hang the node until the driver's limit
+        tmo = datetime.timedelta(seconds=180)
         if args.backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
+            dist.init_process_group("nccl", device_id=dev, timeout=tmo)
         else:
-            dist.init_process_group(args.backend)
+            dist.init_process_group(args.backend, timeout=tmo)
         # pay RCCL's communicator set-up now: the barrier that brackets the
         # timed region must be a ~100 us one, not seconds of idle GPU (clocks
         # would ramp down right before the measurement)
@@ -366,7 +380,7 @@ def main():
 
     def barrier():
         torch.cuda.synchronize(dev)
-        if world > 1:
+        if dist.is_initialized():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
@@ -384,13 +398,13 @@ def main():
             finish()
         barrier()
         t = time.perf_counter() - t0
-        if world > 1:
+        if dist.is_initialized():
             t = sharding.max_over_ranks(t, dist, dev)
         return t, e0.elapsed_time(e1) / steps
 
     pipe = None
     sharded_error = None
-    if world > 1:
+    if world > 1 or args.pg_smoke:
         from avir_amd import sharding
         try:
             pipe = sharding.BandPipeline(NEW_H, NEW_W, CH, torch.float32, dev,
@@ -420,7 +434,14 @@ def main():
     if finish is not None:
         finish()
 
-    t, ev_ms = timed(step, args.steps, finish)
+    try:
+        t, ev_ms = timed(step, args.steps, finish)
+    except Exception as e:  # noqa: BLE001 -- the stitch failed under load
+        if pipe is None:
+            raise
+        sharded_error = "%s: %s" % (type(e).__name__, e)
+        pipe, step, finish = None, full_frame, None
+        t, ev_ms = timed(step, args.steps, finish)
     frames = args.steps if pipe is not None else world * args.steps
     value = frames * mpix / t
 
@@ -497,7 +518,7 @@ def main():
                 "note": "instruction count from the committed PMC pass; peak "
                         "= measured packed mul+add rate of the chip"}
 
-    if world > 1:
+    if world > 1 or args.pg_smoke:
         # secondary measurements: must never take the headline line down
         try:
             extra = sharded_extras(lib, plan, src, dst, dev, world, rank, dist,
@@ -506,8 +527,18 @@ def main():
             if sharded_error:
                 extra["pipeline_error"] = sharded_error
             out["sharded"] = extra
+            # first-class beside `value` (ONE frame in bands, stitched on the
+            # root): the same bands with the output left where it was
+            # computed -- no link-bound stitch -- and whole frames per GPU
+            out["value_distributed"] = extra["compute_only"]["value"]
+            out["value_independent_frames"] = \
+                extra["independent_frames"]["value"]
         except Exception as e:  # noqa: BLE001
             out["sharded"] = {"error": "%s: %s" % (type(e).__name__, e)}
+
+    if world == 1 and "value_distributed" not in out:
+        out["value_distributed"] = out["value"]
+        out["value_independent_frames"] = out["value"]
 
     if rank == 0 and world == 1:
         # a sustained figure: the default timed region is a few ms; >= 5 s
@@ -543,7 +574,7 @@ def main():
     if rank == 0:
         print(json.dumps(out), flush=True)
 
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
 
@@ -572,7 +603,7 @@ def sharded_extras(lib, plan, src, dst, dev, world, rank, dist, torch, pipe,
         "ms_per_frame": round(t / iters * 1e3, 4),
         "bytes_into_root": int(inbound), "achieved_gbs": round(gbs, 1),
         "links": world - 1, "link_peak_gbs": XGMI_LINK_GBS,
-        "frac_of_links": round(gbs / ((world - 1) * XGMI_LINK_GBS), 4),
+        "frac_of_links": round(gbs / (max(1, world - 1) * XGMI_LINK_GBS), 4),
         "note": "xGMI is point-to-point: the root receives over world-1 of its "
                 "7 links; 153 GB/s is a link's two-way peak (one way: half)"}
     if rank == 0:

@@ -49,3 +49,24 @@ def test_bench_two_ranks_band_pipeline_gloo_dry_run():
     assert "error" not in s, s
     assert s["gather_only"]["stitched_ok"]
     assert s["compute_only"]["value"] > 0 and s["independent_frames"]["value"] > 0
+    assert d["value_distributed"] == s["compute_only"]["value"]
+    assert d["value_independent_frames"] == s["independent_frames"]["value"]
+
+
+def test_bench_one_rank_process_group_on_rccl():
+    """The N > 1 code path (process group on the nccl backend = RCCL, barriers,
+    the max-over-ranks all-reduce, the band pipeline and the sharded extras)
+    with the one rank this box can host."""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1",
+               MASTER_PORT=str(29500 + os.getpid() % 150))
+    r = subprocess.run([sys.executable, "bench.py", "--steps", "5", "--warmup",
+                        "2", "--settle-ms", "50", "--no-cpu", "--pg-smoke",
+                        "--backend", "nccl"], cwd=ROOT, env=env,
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-3000:])
+    d = _last_json(r.stdout)
+    assert d["n_gpus"] == 1 and d["parity"]["ok"], d
+    assert "row bands of ONE frame" in d["config"]["sharding"] or \
+        d["config"]["sharding"].startswith("one GPU"), d["config"]
+    assert "error" not in d["sharded"], d["sharded"]
+    assert d["sharded"]["gather_only"]["stitched_ok"]

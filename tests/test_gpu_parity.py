@@ -748,6 +748,45 @@ def test_single_process_sharded_resize(force_replica, staged, monkeypatch):
                                       dst.ctypes.data, 0, None, None) != 0
 
 
+@pytest.mark.parametrize("staged", [False, True])
+def test_sharded_resize_with_a_mocked_device_table(staged, monkeypatch):
+    """avirhip_resize_sharded's multi-device branches on the 1-GPU box: the
+    caller names LOGICAL devices 0..3, AVIRHIP_SHARDED_DEVMAP maps all of them
+    onto GPU 0 -- one plan replica and one set of buffers per logical device,
+    the source copied to each, and the bands stored into "peer" memory at
+    their offsets (or, staged, copied there from the band buffers)."""
+    import ctypes as C
+    import torch
+    lib = abi.load()
+    monkeypatch.setenv("AVIRHIP_SHARDED_DEVMAP", "0,0,0,0")
+    if staged:
+        monkeypatch.setenv("AVIRHIP_SHARDED_STAGED", "1")
+    for (sw, sh, nw, nh, ch, dt) in [(300, 200, 600, 400, 4, np.float32),
+                                     (301, 203, 100, 67, 3, np.uint8),
+                                     (640, 431, 320, 144, 4, np.float32)]:
+        src = (rb.lcg_u8((sh, sw, ch), seed=18) if dt == np.uint8 else
+               rb.lcg_f32((sh, sw, ch), seed=18))
+        r = avir_amd.CImageResizer(16)
+        want = r.resize(src, nw, nh)
+        code = rb._DT[np.dtype(dt)]
+        p = r.plan(sw, sh, nw, nh, ch, 0.0, None, code, code)
+        for devs in ((0, 1), (0, 1, 2, 3), (3, 1, 0), (2, 2, 1)):
+            n = len(devs)
+            cd = (C.c_int * n)(*devs)
+            dsrc = torch.from_numpy(src).to("cuda:0")
+            ddst = torch.zeros((nh, nw, ch), dtype=dsrc.dtype, device="cuda:0")
+            abi.check(lib.avirhip_resize_sharded(
+                p, n, cd, dsrc.data_ptr(), ddst.data_ptr(), 0, None, None),
+                "sharded device")
+            torch.cuda.synchronize()
+            _assert_same(ddst.cpu().numpy(), want, "mocked devices %r" % (devs,))
+            dst = np.zeros((nh, nw, ch), dt)
+            abi.check(lib.avirhip_resize_sharded(
+                p, n, cd, src.ctypes.data, dst.ctypes.data, 0, None, None),
+                "sharded host")
+            _assert_same(dst, want, "mocked devices %r, host" % (devs,))
+
+
 def test_in_place_device_resize():
     """NewBuf may alias SrcBuf when the result is not larger
     (avir.h:4650-4652); with device buffers the library copies the
