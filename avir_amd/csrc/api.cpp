@@ -851,8 +851,13 @@ static int exec_device( avirhip_plan* p, const void* src, void* dst,
 		if( p -> errd_line == nullptr )
 		{
 			void* q;
-			if(( rc = dev_alloc( p, (size_t) 2 * p -> new_w * 4 *
-				sizeof( float ), &q )) != 0 ) return( rc );
+			// one row of diffusion values per pass of 448 rows (generic.hip:
+			// k_errd_mp; the single-workgroup kernels use two), then the
+			// passes' progress flags
+			const size_t np = (size_t) ( p -> new_h + 447 ) / 448 + 2;
+
+			if(( rc = dev_alloc( p, np * p -> new_w * 4 * sizeof( float ) +
+				np * sizeof( unsigned ) + 64, &q )) != 0 ) return( rc );
 			p -> errd_line = (float*) q;
 		}
 

@@ -11,6 +11,7 @@
 // is bit-identical to the reference's scalar float path.
 
 #include "plan.h"
+#include <atomic>
 #include <string.h>
 #include <type_traits>
 #include <stdio.h>
@@ -1030,6 +1031,8 @@ int launch_epilogue( const float* res, void* dst, int out_type, long n,
 // with c1 = 0.364842, c2 = 0.207305, c3 = 0.063011 (float).
 // ---------------------------------------------------------------------
 
+#define ED_PF 8 // pixels a lane reads ahead of its step
+
 template< typename Tout >
 __global__ void __launch_bounds__( 1024 ) k_errd( const float* res, Tout* dst,
 	const int w, const int h, const int ch, const int ech, const float tr_mul,
@@ -1066,9 +1069,90 @@ __global__ void __launch_bounds__( 1024 ) k_errd( const float* res, Tout* dst,
 
 		const int nsteps = w + 2 * ( prow - 1 ) + 2;
 
-		for( int t = 0; t < nsteps; t++ )
+		// A lane's pixels are read ED_PF steps ahead into a register ring (the
+		// step loop is unrolled over it): a step is a barrier plus a few dozen
+		// flops, and without the prefetch every one of the w + 2 * rows steps
+		// exposed the latency of a load that nothing else could hide (one
+		// workgroup on the chip) -- 45.7 -> ms per 4K RGB frame, see
+		// profiles/r03_errd. The diffusion values handed over from the
+		// previous pass (lane 0 of wave 0) travel the same way.
+		float pf[ ED_PF ][ 4 ], lf[ ED_PF ][ 4 ];
+
+		auto fetch = [&]( const int pn, float ( &o )[ 4 ], float ( &lo )[ 4 ])
 		{
+#pragma unroll
+			for( int c = 0; c < 4; c++ )
+			{
+				o[ c ] = 0.0f;
+				lo[ c ] = 0.0f;
+			}
+
+			if( pn >= 0 && pn < w )
+			{
+				if( rowok )
+				{
+					if( ech == 4 )
+					{
+						typedef float f4v __attribute__(( ext_vector_type( 4 )));
+						const f4v v = *(const f4v*) ( rp + (size_t) pn * 4 );
+						o[ 0 ] = v.x; o[ 1 ] = v.y; o[ 2 ] = v.z; o[ 3 ] = v.w;
+					}
+					else
+					{
+#pragma unroll
+						for( int c = 0; c < 4; c++ )
+						{
+							if( c < ch )
+							{
+								o[ c ] = rp[ (size_t) pn * ech + c ];
+							}
+						}
+					}
+				}
+
+				if( rr == 0 && pass > 0 )
+				{
+					// written by another wave of this workgroup in the
+					// previous pass: read past the L1
+#pragma unroll
+					for( int c = 0; c < 4; c++ )
+					{
+						lo[ c ] = __hip_atomic_load( &lin[ pn * 4 + c ],
+							__ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT );
+					}
+				}
+			}
+		};
+
+#pragma unroll
+		for( int k = 0; k < ED_PF; k++ )
+		{
+			fetch( k - 2 * rr, pf[ k ], lf[ k ]);
+		}
+
+		for( int t0 = 0; t0 < nsteps; t0 += ED_PF )
+		{
+#pragma unroll
+		for( int k = 0; k < ED_PF; k++ )
+		{
+			const int t = t0 + k;
+
+			if( t >= nsteps )
+			{
+				break;
+			}
+
 			const int p = t - 2 * rr;
+			float cur[ 4 ], lcur[ 4 ];
+#pragma unroll
+			for( int c = 0; c < 4; c++ )
+			{
+				cur[ c ] = pf[ k ][ c ];
+				lcur[ c ] = lf[ k ][ c ];
+			}
+
+			fetch( p + ED_PF, pf[ k ], lf[ k ]);
+
 			float din[ 4 ];
 #pragma unroll
 			for( int c = 0; c < 4; c++ )
@@ -1086,16 +1170,8 @@ __global__ void __launch_bounds__( 1024 ) k_errd( const float* res, Tout* dst,
 						din[ c ] = xch[( t + 1 ) & 1 ][ wave - 1 ][ c ];
 					}
 					else
-					if( pass > 0 && p >= 0 && p < w )
 					{
-						// written by another wave of this workgroup in the
-						// previous pass: read past the L1
-						din[ c ] = __hip_atomic_load( &lin[ p * 4 + c ],
-							__ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT );
-					}
-					else
-					{
-						din[ c ] = 0.0f;
+						din[ c ] = lcur[ c ]; // 0 in the first pass
 					}
 				}
 			}
@@ -1107,7 +1183,7 @@ __global__ void __launch_bounds__( 1024 ) k_errd( const float* res, Tout* dst,
 				{
 					if( c < ch )
 					{
-						float v = rp[ (size_t) p * ech + c ];
+						float v = cur[ c ];
 
 						if( gamma )
 						{
@@ -1167,8 +1243,405 @@ __global__ void __launch_bounds__( 1024 ) k_errd( const float* res, Tout* dst,
 
 			__syncthreads();
 		}
+		}
 
 		__threadfence();
+		__syncthreads();
+	}
+}
+
+// A lane's output bytes collect in a 16-byte block (the aligned block of the
+// destination they belong to) and leave as ONE 16-byte store when the lane's
+// write position moves on: element-wide stores from 896 lanes that each walk
+// their own image row are 2688 one-byte write requests per step, and those
+// requests, not the arithmetic or the loads, set the step time (31.7 ms per
+// 4K RGB frame before). Blocks a lane filled only in part -- the two ends of a
+// row -- leave as byte stores of exactly the bytes it owns.
+struct ErrdOut
+{
+	unsigned long long lo, hi;
+	unsigned long long blk; // address >> 4 of the block being filled, 0: none
+	unsigned mask;          // bytes of the block written so far
+};
+
+__device__ __forceinline__ void eo_flush( ErrdOut& o )
+{
+	if( o.mask == 0 )
+	{
+		return;
+	}
+
+	unsigned char* const q = (unsigned char*) ( o.blk << 4 );
+
+	if( o.mask == 0xffffu )
+	{
+		typedef unsigned long long ull2 __attribute__(( ext_vector_type( 2 )));
+		ull2 v; v.x = o.lo; v.y = o.hi;
+		*(ull2*) q = v;
+	}
+	else
+	{
+		for( int i = 0; i < 16; i++ )
+		{
+			if(( o.mask >> i ) & 1 )
+			{
+				q[ i ] = (unsigned char) (( i < 8 ? o.lo >> ( 8 * i ) :
+					o.hi >> ( 8 * ( i - 8 ))) & 0xff );
+			}
+		}
+	}
+
+	o.mask = 0;
+}
+
+// `n` bytes (one pixel: 1-4 elements, <= 8 bytes) at address `a`; they may
+// run over the end of the block being filled
+__device__ __forceinline__ void eo_put( ErrdOut& o, const unsigned long long a,
+	const unsigned long long v, const int n )
+{
+	const unsigned long long b = a >> 4;
+
+	if( b != o.blk )
+	{
+		eo_flush( o );
+		o.blk = b; o.lo = 0; o.hi = 0;
+	}
+
+	const int k = (int) ( a & 15 );
+	const int n1 = min( n, 16 - k ); // bytes that fit into this block
+
+	if( k < 8 )
+	{
+		o.lo |= v << ( 8 * k );
+
+		if( k > 0 && k + n > 8 )
+		{
+			o.hi |= v >> ( 8 * ( 8 - k ));
+		}
+	}
+	else
+	{
+		o.hi |= v << ( 8 * ( k - 8 ));
+	}
+
+	o.mask |= (( 1u << n1 ) - 1u ) << k;
+
+	if( n1 < n )
+	{
+		eo_flush( o );
+		o.blk = b + 1; o.hi = 0;
+		o.lo = v >> ( 8 * n1 );
+		o.mask = ( 1u << ( n - n1 )) - 1u;
+	}
+}
+
+// ---------------------------------------------------------------------
+// The same ditherer for padded RGBA float results (ech == 4), frames of any
+// height, on several compute units: the frame is cut into PASSES of 448 rows,
+// one workgroup each, chained through the diffusion values of a pass' last
+// row -- pass k + 1 starts as soon as pass k has published the first few of
+// them (a flag per pass in global memory, write-through stores + drained flag
+// on the producing side, L1-bypassing loads on the consuming side), so the
+// whole frame costs about width + 2 * height steps instead of the sum over
+// the passes. A pass only ever waits for the pass before it, i.e. for a
+// workgroup with a lower index.
+//
+// Inside a workgroup 7 waves compute (lane = row) and an eighth does nothing
+// but LDS-DMA: a lane's pixel t - 2 rr sits in ITS row, 448 cache lines apart
+// from its neighbours', and per-lane loads (in the compute lanes, or by DMA
+// one pixel per lane) made the texture path look up ~900 lines per step --
+// that, not the arithmetic, set the step time (profiles/r03_errd). The I/O
+// wave instead moves whole 128-byte lines: one instruction = 8 rows x 8 pixels,
+// the 8 rows chosen 4 apart so that their skewed pixel positions share a
+// phase, 15 instructions every second step, landing 8 steps before use in a
+// two-slot LDS ring (vmcnt counts the bursts in: loads retire in order).
+// ---------------------------------------------------------------------
+#define EJ_CW 7                 // compute waves
+#define EJ_ROWS ( EJ_CW * 64 )  // rows per pass
+#define EJ_NG ( EJ_ROWS / 8 )   // row groups (one DMA instruction each)
+#define EJ_LDS ( 2 * EJ_NG * 1024 + 2 * 8 * 16 + 2 * 8 * 4 * 4 )
+
+__device__ __forceinline__ void ej_dma( const __amdgpu_buffer_rsrc_t rs,
+	const unsigned lds, const int voff )
+{
+	asm volatile( "s_mov_b32 m0, %0\n\t"
+		"s_nop 0\n\t"
+		"buffer_load_dwordx4 %1, %2, 0 offen lds"
+		:: "s"( lds ), "v"( voff ), "s"( rs ) : "memory" );
+}
+
+// (past the L1 and the L2: another compute unit has just written the line)
+__device__ __forceinline__ void ej_dma_sc( const __amdgpu_buffer_rsrc_t rs,
+	const unsigned lds, const int voff )
+{
+	asm volatile( "s_mov_b32 m0, %0\n\t"
+		"s_nop 0\n\t"
+		"buffer_load_dwordx4 %1, %2, 0 offen sc0 sc1 lds"
+		:: "s"( lds ), "v"( voff ), "s"( rs ) : "memory" );
+}
+
+template< typename Tout >
+__global__ void __launch_bounds__( 512 ) k_errd_mp( const float* res,
+	Tout* dst, const int w, const int h, const int ch, const float tr_mul,
+	const float tr_muli, const float pk_out, const int gamma,
+	const int alpha_index, const float ogm, float* line, unsigned* flags,
+	const unsigned epoch, const int pass0 )
+{
+	typedef float f4v __attribute__(( ext_vector_type( 4 )));
+	typedef __attribute__(( address_space( 3 ))) char lchar;
+	extern __shared__ __attribute__(( aligned( 16 ))) char smem[];
+	f4v* const sIn = (f4v*) smem;                        // [2][EJ_NG][64]
+	f4v* const sL = (f4v*) ( smem + 2 * EJ_NG * 1024 );  // [2][8]
+	float ( * const xch )[ 8 ][ 4 ] = (float (*)[ 8 ][ 4 ])
+		( smem + 2 * EJ_NG * 1024 + 256 );               // [2][8][4]
+	const unsigned lds0 = (unsigned) (unsigned long) (lchar*) smem;
+	const unsigned ldsL = lds0 + 2 * EJ_NG * 1024;
+
+	const int tid = threadIdx.x;
+	const int lane = tid & 63;
+	const int wave = __builtin_amdgcn_readfirstlane( tid >> 6 );
+	const int pass = pass0 + blockIdx.x;
+	const int row0 = pass * EJ_ROWS;
+	const int prow = min( EJ_ROWS, h - row0 );
+	const int nsteps = w + 2 * ( prow - 1 ) + 2;
+	const bool last_pass = ( row0 + EJ_ROWS >= h );
+	// the diffusion values a pass hands down: row `pass` of `line`
+	float* const lout = line + (size_t) pass * w * 4;
+	const float c1 = (float) 0.364842;
+	const float c2 = (float) 0.207305;
+	const float c3 = (float) 0.063011;
+
+	if( wave == EJ_CW )
+	{
+		// ---- the I/O wave
+		const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+			(void*) ( res + (size_t) row0 * w * 4 ), 0, 0x7fffffff, 0x00020000 );
+		const __amdgpu_buffer_rsrc_t rl = __builtin_amdgcn_make_buffer_rsrc(
+			(void*) ( pass > 0 ? line + (size_t) ( pass - 1 ) * w * 4 : line ),
+			0, 0x7fffffff, 0x00020000 );
+		const int li = lane >> 3; // row of the group
+		const int lk = lane & 7;  // pixel of the segment
+		int have = ( pass > 0 ? 0 : 0x7fffffff ); // values the pass above published
+
+		// burst of step T (even): the 14 groups whose rows start a segment
+		// at step T + 8, and the segment of values from the pass above
+		auto burst = [&]( const int T )
+		{
+			// (the ring slot goes by the step the segments are first read at,
+			// T + 8, the same for every row of the burst)
+			const int r0 = ( T >> 1 ) & 3;
+			const int slot = (( T + 8 ) >> 3 ) & 1;
+#pragma unroll 1
+			for( int a = 0; a < EJ_NG / 4; a++ )
+			{
+				const int g = a * 4 + r0;
+				const int rr = 32 * a + 4 * li + r0;
+				const int px = max( 0, min( T + 8 - 2 * rr + lk, w - 1 ));
+				ej_dma( rs, lds0 + ( slot * EJ_NG + g ) * 1024,
+					min( rr, prow - 1 ) * w * 16 + px * 16 );
+			}
+
+			// (an instruction at every burst: the wait counts are constants)
+			const int ps = ( T + 8 ) & ~7;
+
+			if( pass > 0 && ( T & 7 ) == 0 && ps < w )
+			{
+				const int need = min( ps + 8, w );
+
+				while( have < need )
+				{
+					const unsigned f = __hip_atomic_load( &flags[ pass - 1 ],
+						__ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT );
+
+					have = ( ( f >> 20 ) == epoch ? (int) ( f & 0xfffffu ) : 0 );
+
+					if( have < need )
+					{
+						__builtin_amdgcn_s_sleep( 8 );
+					}
+				}
+			}
+
+			if( lane < 8 )
+			{
+				const int px = max( 0, min( ps + lane, w - 1 ));
+
+				if( pass > 0 )
+				{
+					ej_dma_sc( rl, ldsL + slot * 128, px * 16 );
+				}
+				else
+				{
+					ej_dma( rs, ldsL + slot * 128, 0 );
+				}
+			}
+		};
+
+		for( int T = -8; T < 0; T += 2 )
+		{
+			burst( T );
+		}
+
+		__syncthreads(); // (the compute waves' set-up)
+
+		for( int t = 0; t < nsteps; t++ )
+		{
+			if(( t & 1 ) == 0 )
+			{
+				burst( t );
+				// bursts t, t - 2, t - 4 may be in flight: t - 6 (first read
+				// at step t + 2) has landed
+				asm volatile( "s_waitcnt vmcnt(45)" ::: "memory" );
+			}
+
+			__syncthreads();
+		}
+
+		asm volatile( "s_waitcnt vmcnt(0)" ::: "memory" );
+		return;
+	}
+
+	// ---- compute waves: one row per lane
+	const int rr = tid;
+	const int row = row0 + rr;
+	const bool rowok = ( row < h );
+	const bool feeds = ( rr == prow - 1 && !last_pass );
+	Tout* const dp = dst + (size_t) row * w * ch;
+	// where this row's pixels sit in the ring: group, row of the group
+	const int grp = ( rr >> 5 ) * 4 + ( rr & 3 );
+	const int gi = ( rr & 31 ) >> 2;
+	float A[ 4 ], B[ 4 ], nm1[ 4 ], dout[ 4 ];
+#pragma unroll
+	for( int c = 0; c < 4; c++ )
+	{
+		A[ c ] = B[ c ] = nm1[ c ] = dout[ c ] = 0.0f;
+	}
+
+	ErrdOut eo;
+	eo.lo = 0; eo.hi = 0; eo.blk = 0; eo.mask = 0;
+
+	__syncthreads();
+
+	for( int t = 0; t < nsteps; t++ )
+	{
+		const int p = t - 2 * rr;
+		const f4v px = sIn[ (((( rr >> 2 ) + ( p >> 3 )) & 1 ) * EJ_NG + grp ) *
+			64 + gi * 8 + ( p & 7 )];
+		const float cur[ 4 ] = { px.x, px.y, px.z, px.w };
+		float din[ 4 ];
+#pragma unroll
+		for( int c = 0; c < 4; c++ )
+		{
+			din[ c ] = __shfl_up( dout[ c ], 1 );
+		}
+
+		if( lane == 0 )
+		{
+			if( wave > 0 )
+			{
+#pragma unroll
+				for( int c = 0; c < 4; c++ )
+				{
+					din[ c ] = xch[( t + 1 ) & 1 ][ wave - 1 ][ c ];
+				}
+			}
+			else
+			if( pass > 0 && p < w )
+			{
+				const f4v l = sL[ (( p >> 3 ) & 1 ) * 8 + ( p & 7 )];
+				din[ 0 ] = l.x; din[ 1 ] = l.y; din[ 2 ] = l.z; din[ 3 ] = l.w;
+			}
+			else
+			{
+#pragma unroll
+				for( int c = 0; c < 4; c++ )
+				{
+					din[ c ] = 0.0f;
+				}
+			}
+		}
+
+		if( rowok && p >= 0 && p < w )
+		{
+			unsigned long long opx = 0; // the pixel's elements, packed
+#pragma unroll
+			for( int c = 0; c < 4; c++ )
+			{
+				if( c < ch )
+				{
+					float v = cur[ c ];
+
+					if( gamma )
+					{
+						v = ( c == alpha_index ? v * ogm :
+							lin_to_srgb( v ) * ogm );
+					}
+
+					v = v + din[ c ];
+
+					if( p > 0 )
+					{
+						v = v + nm1[ c ];
+					}
+
+					const float z0 = avir_round( v * tr_muli ) * tr_mul;
+					const float noise = v - z0;
+					const float o = ( z0 < 0.0f ? 0.0f :
+						( z0 > pk_out ? pk_out : z0 ));
+
+					opx |= (unsigned long long) (Tout) o <<
+						( 8 * sizeof( Tout ) * c );
+					const float m1 = noise * c1;
+					dout[ c ] = A[ c ] + noise * c2; // D[p-1] complete
+					A[ c ] = B[ c ] + m1;            // D[p]: two of three
+					B[ c ] = 0.0f + noise * c3;      // D[p+1]: first term
+					nm1[ c ] = m1;
+				}
+			}
+
+			eo_put( eo, (unsigned long long) ( dp + (size_t) p * ch ), opx,
+				ch * (int) sizeof( Tout ));
+		}
+		else
+		if( rowok && p == w )
+		{
+			// the last pixel's D has no right-hand neighbour term
+#pragma unroll
+			for( int c = 0; c < 4; c++ )
+			{
+				dout[ c ] = A[ c ];
+			}
+
+			eo_flush( eo ); // the row's last, partly filled block
+		}
+
+		if( feeds && p >= 1 && p <= w )
+		{
+			// write-through: the pass below reads them on another compute unit
+#pragma unroll
+			for( int c = 0; c < 4; c++ )
+			{
+				__hip_atomic_store( &lout[ ( p - 1 ) * 4 + c ], dout[ c ],
+					__ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT );
+			}
+
+			if(( p & 7 ) == 0 || p == w )
+			{
+				asm volatile( "s_waitcnt vmcnt(0)" ::: "memory" );
+				__hip_atomic_store( &flags[ pass ], ( epoch << 20 ) |
+					(unsigned) p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT );
+			}
+		}
+
+		if( lane == 63 )
+		{
+#pragma unroll
+			for( int c = 0; c < 4; c++ )
+			{
+				xch[ t & 1 ][ wave ][ c ] = dout[ c ];
+			}
+		}
+
 		__syncthreads();
 	}
 }
@@ -1182,6 +1655,50 @@ int launch_errd( const float* res, void* dst, int out_type, int w, int h,
 	const float pk = (float) pk_out;
 	const float ogm = (float) ( out_type == AVIRHIP_U8 ? 255.0 : 65535.0 );
 	const int nt = std::min( 1024, (( h + 63 ) / 64 ) * 64 );
+
+	// padded RGBA results of frames worth the set-up: one workgroup per pass
+	// of 448 rows, chained (k_errd_mp)
+	if( ech == 4 && ( (uintptr_t) res & 15 ) == 0 && (long) w * h >= 65536 &&
+		w < ( 1 << 20 ) && (long) w * 16 * EJ_ROWS < 0x7fffffffL &&
+		( out_type == AVIRHIP_U8 || out_type == AVIRHIP_U16 ) &&
+		getenv( "AVIRHIP_ERRD_PLAIN" ) == nullptr )
+	{
+		static std::atomic< unsigned > calls( 0 );
+		const unsigned epoch = ( ++calls ) & 0xfffu;
+		const int npass = ( h + EJ_ROWS - 1 ) / EJ_ROWS;
+		// (launch_errd's caller sized `line` for npass rows of values + flags)
+		unsigned* const flags = (unsigned*) ( line + (size_t) npass * w * 4 );
+		// AVIRHIP_ERRD_SERIAL: one launch per pass (stream order instead of
+		// the flags; debugging aid)
+		const bool serial = ( getenv( "AVIRHIP_ERRD_SERIAL" ) != nullptr );
+
+		for( int p0 = 0; p0 < npass; p0 += ( serial ? 1 : npass ))
+		{
+			const dim3 grid( serial ? 1 : npass );
+
+			if( out_type == AVIRHIP_U8 )
+			{
+				AVIRHIP_HIPCHECK( hipFuncSetAttribute(
+					(const void*) k_errd_mp< uint8_t >,
+					hipFuncAttributeMaxDynamicSharedMemorySize, EJ_LDS ));
+				hipLaunchKernelGGL(( k_errd_mp< uint8_t > ), grid, dim3( 512 ),
+					EJ_LDS, st, res, (uint8_t*) dst, w, h, ch, trm, trmi, pk,
+					gamma, alpha_index, ogm, line, flags, epoch, p0 );
+			}
+			else
+			{
+				AVIRHIP_HIPCHECK( hipFuncSetAttribute(
+					(const void*) k_errd_mp< uint16_t >,
+					hipFuncAttributeMaxDynamicSharedMemorySize, EJ_LDS ));
+				hipLaunchKernelGGL(( k_errd_mp< uint16_t > ), grid, dim3( 512 ),
+					EJ_LDS, st, res, (uint16_t*) dst, w, h, ch, trm, trmi, pk,
+					gamma, alpha_index, ogm, line, flags, epoch, p0 );
+			}
+		}
+
+		AVIRHIP_HIPCHECK( hipGetLastError() );
+		return( AVIRHIP_OK );
+	}
 
 	if( out_type == AVIRHIP_U8 )
 	{

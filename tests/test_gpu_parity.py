@@ -1029,6 +1029,13 @@ ERRD = [
     (20, 1100, 3, 1025, 4, np.uint8, np.uint8, 8, False),
     (16, 700, 1, 1400, 1, np.uint8, np.uint16, 16, False),
     (300, 200, 600, 400, 4, np.uint8, np.uint8, 8, False),
+    # frames of the kernel with I/O waves (generic.hip::k_errd_io, 896 rows per
+    # pass): one, two and three passes, 1-4 channels, gamma, 16-bit
+    (640, 480, 1024, 768, 3, np.uint8, np.uint8, 8, False),
+    (700, 500, 1400, 1000, 4, np.uint8, np.uint8, 8, True),
+    (200, 500, 100, 1900, 3, np.uint8, np.uint16, 16, False),
+    (300, 1000, 150, 897, 1, np.float32, np.uint8, 8, False),
+    (1200, 300, 400, 100, 2, np.uint16, np.uint16, 10, False),
 ]
 
 
