@@ -49,16 +49,22 @@
 #include <algorithm>
 #include <string.h>
 #include <stdlib.h>
+#include <stdio.h>
+#include <vector>
 
 namespace avirhip {
 
 #define DF_W 42     // output columns per strip
 #define DF_NT1 48   // resize (T) outputs per row: 16 triples
-#define DF_NHW 8    // row waves
-#define DF_NVW 4    // column waves
-#define DF_RS 16    // source rows per step: 2 per row wave
-#define DF_LPV 42   // lanes (elements) per column wave
-#define DF_NTHR (( DF_NHW + DF_NVW ) * 64 )
+// 12 waves per workgroup: NHW row waves + the column waves of the strip's 168
+// elements. 8 + 4 (42 elements each): 16 rows per step, every SIMD hosts two
+// row waves and a column wave. 9 + 3 (56 each): 18 rows per step, one SIMD
+// hosts three row waves instead -- the column waves' share of the vector ALU
+// shrinks with their idle lanes (K = 3: 209 -> 194 SIMD cycles per row), at
+// the price of a longer static unroll of the column waves (the step must
+// divide a whole number of 16-output periods: 8 phases instead of 3).
+#define DF_NTHR 768
+#define DF_MAXRS 18
 
 struct DnFParams
 {
@@ -69,6 +75,8 @@ struct DnFParams
 	int row_lo, row_hi;             // output rows to store
 	int nstrips, nchunks, crows;    // work items, strip fastest; rows per chunk
 	GPOut out;                      // on != 0: integer output stage in the store
+	unsigned long long* clk;        // dbg & 16: per wave {total, dma wait, barrier
+	                                // wait, 0} shader clocks
 	int dbg;                        // timing ablations (AVIRHIP_DNF_DBG): 1 no
 	                                // column arithmetic, 2 no row arithmetic,
 	                                // 4 no source loads, 8 no FIR in the row waves
@@ -445,9 +453,23 @@ __device__ __forceinline__ void df_feed_batch( f2 ( &acc )[ 3 ],
 	} );
 }
 
-template< int KH, int NTH, int KV, int NTV >
+// (instrumented barrier / wait: the clocks only tick when dbg & 16)
+#define DF_TIMED( acc, stmt ) do { if( P.dbg & 16 ) { \
+	const unsigned long long t0_ = __builtin_readcyclecounter(); stmt; \
+	acc += __builtin_readcyclecounter() - t0_; } else { stmt; } } while( 0 )
+
+template< int KH, int NTH, int KV, int NTV, int DF_NHW >
 __global__ void __launch_bounds__( DF_NTHR ) k_dnf( const DnFParams P )
 {
+	unsigned long long tk_total = ( P.dbg & 16 ? __builtin_readcyclecounter() :
+		0 ), tk_dma = 0, tk_bar = 0;
+	constexpr int DF_NVW = 12 - DF_NHW;         // column waves
+	constexpr int DF_RS = 2 * DF_NHW;           // source rows per step
+	constexpr int DF_LPV = DF_W * 4 / DF_NVW;   // elements per column wave
+	// phases of the column waves' unroll: steps per whole number of periods
+	constexpr int DF_NPH = ( DF_RS == 16 ? KV : ( KV == 3 ? 8 : 16 ));
+	static_assert( DF_NVW * DF_LPV == DF_W * 4 && ( DF_NPH * DF_RS ) %
+		( 16 * KV ) == 0, "column wave geometry" );
 	constexpr int NPH = ( KH * ( DF_NT1 - 1 ) + NTH + 63 ) / 64; // DMA pieces
 	constexpr int ROWPX = NPH * 64;
 	constexpr int NIN = NTH + 2 * KH; // inputs of a lane's three outputs
@@ -569,16 +591,16 @@ __global__ void __launch_bounds__( DF_NTHR ) k_dnf( const DnFParams P )
 
 				if( NPH == 3 )
 				{
-					GP_WAIT_VM( 6 );
+					DF_TIMED( tk_dma, GP_WAIT_VM( 6 ));
 				}
 				else
 				{
-					GP_WAIT_VM( 4 );
+					DF_TIMED( tk_dma, GP_WAIT_VM( 4 ));
 				}
 			}
 			else
 			{
-				GP_WAIT_VM( 0 );
+				DF_TIMED( tk_dma, GP_WAIT_VM( 0 ));
 			}
 
 			const int bf = s & 1;
@@ -649,7 +671,7 @@ __global__ void __launch_bounds__( DF_NTHR ) k_dnf( const DnFParams P )
 				}
 			}
 
-			__syncthreads();
+			DF_TIMED( tk_bar, __syncthreads());
 		}
 	}
 	else
@@ -657,6 +679,12 @@ __global__ void __launch_bounds__( DF_NTHR ) k_dnf( const DnFParams P )
 		// ------------------------------------------------------------
 		// column waves
 		// ------------------------------------------------------------
+		// (Raising the column waves' priority, s_setprio 3, moves the barrier
+		// wait from the row waves -- 28 % of their time at equal priority,
+		// in-kernel clocks of AVIRHIP_DNF_DBG=16 -- to the column waves, 47 %,
+		// and the launch takes as long: the step is bound by the SIMDs' total
+		// issue, not by one role. Skewing the row waves of a SIMD against each
+		// other with s_sleep costs 3-5 %.)
 		const int vi = wave - DF_NHW;
 		const bool lane_ok = ( lane < DF_LPV );
 		const int e = DF_LPV * vi + ( lane_ok ? lane : DF_LPV - 1 );
@@ -720,13 +748,13 @@ __global__ void __launch_bounds__( DF_NTHR ) k_dnf( const DnFParams P )
 
 		while( s < S )
 		{
-			dn_static_for< KV >( [&]( auto phc )
+			dn_static_for< DF_NPH >( [&]( auto phc )
 			{
 				constexpr int ph = decltype( phc )::value;
 
 				if( s < S )
 				{
-					__syncthreads();
+					DF_TIMED( tk_bar, __syncthreads());
 					f2 vp[ DF_RS / 2 ];
 #pragma unroll
 					for( int m = 0; m < DF_RS / 2; m++ )
@@ -833,8 +861,15 @@ __global__ void __launch_bounds__( DF_NTHR ) k_dnf( const DnFParams P )
 				}
 			} );
 
-			jl_base += 16;
+			jl_base += DF_NPH * DF_RS / KV;
 		}
+	}
+
+	if(( P.dbg & 16 ) && lane == 0 && P.clk != nullptr )
+	{
+		unsigned long long* const q = P.clk + ( (size_t) item * 12 + wave ) * 4;
+		q[ 0 ] = __builtin_readcyclecounter() - tk_total;
+		q[ 1 ] = tk_dma; q[ 2 ] = tk_bar; q[ 3 ] = (unsigned long long) S;
 	}
 }
 
@@ -890,6 +925,19 @@ int dn_run_hv( void* d, const float* src, long src_ss, float* dst, int row0,
 	static const int dbg = []() { const char* e = getenv( "AVIRHIP_DNF_DBG" );
 		return( e != nullptr ? atoi( e ) : 0 ); }();
 	P.dbg = dbg;
+	P.clk = nullptr;
+	static unsigned long long* dclk = nullptr;
+	static int dcalls = 0;
+
+	if( dbg & 16 )
+	{
+		if( dclk == nullptr )
+		{
+			(void) hipMalloc( &dclk, 4096 * 12 * 32 );
+		}
+
+		P.clk = dclk;
+	}
 
 	// one workgroup per compute unit: a chunk's warm-up (NT + 5K source rows)
 	// is paid per work item, so as few, as tall chunks as fill the chip
@@ -900,29 +948,65 @@ int dn_run_hv( void* d, const float* src, long src_ss, float* dst, int row0,
 	P.nchunks = ( rows + P.crows - 1 ) / P.crows;
 	const dim3 grid( P.nstrips * P.nchunks );
 	const int kk = D -> h.K * 10 + D -> v.K;
+	// K = 3 along y: 9 row waves + 3 column waves (AVIRHIP_DNF_NHW=8: the 8 + 4
+	// split, for A/B timing)
+	static const int nhw3 = []() { const char* e = getenv( "AVIRHIP_DNF_NHW" );
+		return( e != nullptr && atoi( e ) == 8 ? 8 : 9 ); }();
+
+#define DF_LAUNCH( ... ) hipLaunchKernelGGL(( k_dnf< __VA_ARGS__ > ), grid, \
+	dim3( DF_NTHR ), 0, st, P )
 
 	switch( kk )
 	{
 		case 33:
-			hipLaunchKernelGGL(( k_dnf< 3, 38, 3, 38 > ), grid, dim3( DF_NTHR ),
-				0, st, P );
+			if( nhw3 == 9 ) DF_LAUNCH( 3, 38, 3, 38, 9 );
+			else DF_LAUNCH( 3, 38, 3, 38, 8 );
 			break;
 		case 22:
-			hipLaunchKernelGGL(( k_dnf< 2, 24, 2, 24 > ), grid, dim3( DF_NTHR ),
-				0, st, P );
+			DF_LAUNCH( 2, 24, 2, 24, 8 );
 			break;
 		case 32:
-			hipLaunchKernelGGL(( k_dnf< 3, 38, 2, 24 > ), grid, dim3( DF_NTHR ),
-				0, st, P );
+			DF_LAUNCH( 3, 38, 2, 24, 8 );
 			break;
 		case 23:
-			hipLaunchKernelGGL(( k_dnf< 2, 24, 3, 38 > ), grid, dim3( DF_NTHR ),
-				0, st, P );
+			if( nhw3 == 9 ) DF_LAUNCH( 2, 24, 3, 38, 9 );
+			else DF_LAUNCH( 2, 24, 3, 38, 8 );
 			break;
 		default:
 			return( 1 );
 	}
 
+#undef DF_LAUNCH
+
+	if(( dbg & 16 ) && ++dcalls == 100 && grid.x <= 4096 )
+	{
+		// in-kernel clocks of a launch in the middle of a timing loop
+		std::vector< unsigned long long > hc( (size_t) grid.x * 12 * 4 );
+		(void) hipStreamSynchronize( st );
+		(void) hipMemcpy( hc.data(), dclk, hc.size() * 8, hipMemcpyDeviceToHost );
+		const int nh = ( D -> v.K == 3 ? nhw3 : 8 );
+		double tot[ 2 ] = { 0, 0 }, dma[ 2 ] = { 0, 0 }, bar[ 2 ] = { 0, 0 };
+		double mx = 0.0;
+
+		for( unsigned i = 0; i < grid.x; i++ )
+		{
+			for( int wv = 0; wv < 12; wv++ )
+			{
+				const unsigned long long* q = &hc[ ( (size_t) i * 12 + wv ) * 4 ];
+				const int r = ( wv < nh ? 0 : 1 );
+				tot[ r ] += (double) q[ 0 ]; dma[ r ] += (double) q[ 1 ];
+				bar[ r ] += (double) q[ 2 ];
+				mx = std::max( mx, (double) q[ 0 ]);
+			}
+		}
+
+		const double nr = (double) grid.x * nh, nc = (double) grid.x * ( 12 - nh );
+		fprintf( stderr, "k_dnf clocks (%u items, %d row waves): row waves total "
+			"%.0f, DMA wait %.0f, barrier %.0f | column waves total %.0f, "
+			"barrier %.0f | longest wave %.0f cycles, %llu steps\n", grid.x, nh,
+			tot[ 0 ] / nr, dma[ 0 ] / nr, bar[ 0 ] / nr, tot[ 1 ] / nc,
+			bar[ 1 ] / nc, mx, hc[ 3 ]);
+	}
 	AVIRHIP_HIPCHECK( hipGetLastError() );
 	return( AVIRHIP_OK );
 }
