@@ -289,6 +289,9 @@ def main():
     ap.add_argument("--backend", default="nccl",
                     help="torch.distributed backend for --gpus > 1 (nccl = "
                          "RCCL; gloo only for dry runs of the rank logic)")
+    ap.add_argument("--no-sustained", action="store_true",
+                    help="skip the 5-second sustained leg (counter-collection "
+                         "runs serialise every launch)")
     ap.add_argument("--pg-smoke", action="store_true",
                     help="with --gpus 1: run the step through a one-rank "
                          "process group and the band pipeline (the N > 1 code "
@@ -540,7 +543,7 @@ def main():
         out["value_distributed"] = out["value"]
         out["value_independent_frames"] = out["value"]
 
-    if rank == 0 and world == 1:
+    if rank == 0 and world == 1 and not args.no_sustained:
         # a sustained figure: the default timed region is a few ms; >= 5 s
         # of back-to-back frames is also what a 1 Hz utilisation sampler sees
         n = max(args.steps, int(5.0 / max(t / args.steps, 1e-6)))
