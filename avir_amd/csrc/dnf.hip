@@ -685,6 +685,16 @@ __global__ void __launch_bounds__( DF_NTHR ) k_dnf( const DnFParams P )
 		// and the launch takes as long: the step is bound by the SIMDs' total
 		// issue, not by one role. Skewing the row waves of a SIMD against each
 		// other with s_sleep costs 3-5 %.)
+		// K = 2 along y: the column waves are the step's longest instruction
+		// streams (12 taps and a correction-filter row every second source
+		// row) and the row waves spend 40 % of their time in the barrier;
+		// raised, a column wave issues whenever it can (3840x2160 ->
+		// 1920x1080: 0.0636 -> 0.0615 ms)
+		if( KV == 2 )
+		{
+			__builtin_amdgcn_s_setprio( 3 );
+		}
+
 		const int vi = wave - DF_NHW;
 		const bool lane_ok = ( lane < DF_LPV );
 		const int e = DF_LPV * vi + ( lane_ok ? lane : DF_LPV - 1 );
