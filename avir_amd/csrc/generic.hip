@@ -840,7 +840,8 @@ bool gamma_u8_thresholds( const float ogm, const int use_tr, const float trm,
 
 template< int CH >
 __global__ void __launch_bounds__( 256 ) k_epilogue_gamma_thr( const float* res,
-	unsigned char* dst, long npx, int alpha_index, const float* thr )
+	unsigned char* dst, long npx, int alpha_index, const float* thr,
+	int use_tr, float tr_mul, float tr_muli, float pk_out, float ogm )
 {
 	__shared__ float sthr[ 512 ];
 	sthr[ threadIdx.x ] = thr[ threadIdx.x ];
@@ -867,6 +868,18 @@ __global__ void __launch_bounds__( 256 ) k_epilogue_gamma_thr( const float* res,
 		for( int s = 128; s >= 1; s >>= 1 )
 		{
 			lo += ( v >= t[ lo + s ] ? s : 0 );
+		}
+
+		// above the range the thresholds were searched in (16.0: nothing an
+		// image holds) the direct expressions decide -- +inf, for one, is NOT
+		// the largest byte: the power approximation turns it into a NaN
+		// (found by the all-floats sweep of tests/test_gpu_parity.py)
+		if( v > 16.0f )
+		{
+			float d = ( c == alpha_index ? v * ogm : lin_to_srgb( v ) * ogm );
+			d = ( use_tr ? avir_round( d * tr_muli ) * tr_mul : avir_round( d ));
+			d = ( d < 0.0f ? 0.0f : ( d > pk_out ? pk_out : d ));
+			lo = (int) (unsigned char) d;
 		}
 
 		dst[ i * CH + c ] = (unsigned char) lo;
@@ -942,7 +955,8 @@ int launch_epilogue( const float* res, void* dst, int out_type, long n,
 		const dim3 grd( (unsigned) (( npx + 255 ) / 256 ));
 
 #define ET( CH ) hipLaunchKernelGGL(( k_epilogue_gamma_thr< CH > ), grd, \
-		dim3( 256 ), 0, st, res, (unsigned char*) dst, npx, alpha_index, gthr )
+		dim3( 256 ), 0, st, res, (unsigned char*) dst, npx, alpha_index, gthr, \
+		use_tr, trm, trmi, pk, ogm )
 
 		switch( ch )
 		{
@@ -2247,3 +2261,63 @@ int launch_lancir_out( const avirhip_plan* p, const float* res, long rstride,
 }
 
 } // namespace avirhip
+
+// Test hook (include/avirhip.h): the uint8 gamma output stage over caller-chosen
+// float values, once as the threshold table and once as the direct expressions.
+extern "C" int avirhip_debug_gamma_u8( const float* dev_rgba, long npx,
+	double tr_mul, int alpha_index, unsigned char* dev_out_table,
+	unsigned char* dev_out_direct, void* stream )
+{
+	using namespace avirhip;
+
+	if( dev_rgba == nullptr || dev_out_table == nullptr ||
+		dev_out_direct == nullptr || npx < 1 || !( tr_mul >= 1.0 ))
+	{
+		set_error( "debug_gamma_u8: bad arguments" );
+		return( AVIRHIP_EINVAL );
+	}
+
+	const int use_tr = ( tr_mul != 1.0 );
+	const float trm = (float) tr_mul;
+	const float trmi = (float) ( 1.0 / tr_mul );
+	float thr[ 512 ];
+
+	if( !gamma_u8_thresholds( 255.0f, use_tr, trm, trmi, 255.0f, thr ))
+	{
+		set_error( "debug_gamma_u8: the stage is not monotone for these "
+			"parameters (plans then keep the direct kernel)" );
+		return( AVIRHIP_EUNSUPPORTED );
+	}
+
+	float* dthr = nullptr;
+	AVIRHIP_HIPCHECK( hipMalloc( (void**) &dthr, sizeof( thr )));
+	hipStream_t st = (hipStream_t) stream;
+	hipError_t e = hipMemcpyAsync( dthr, thr, sizeof( thr ),
+		hipMemcpyHostToDevice, st );
+	const dim3 grd( (unsigned) (( npx + 255 ) / 256 ));
+
+	if( e == hipSuccess )
+	{
+		hipLaunchKernelGGL(( k_epilogue_gamma_thr< 4 > ), grd, dim3( 256 ), 0,
+			st, dev_rgba, dev_out_table, npx, alpha_index, dthr, use_tr, trm,
+			trmi, 255.0f, 255.0f );
+		launch_epilogue_gamma_px< uint8_t >( dev_rgba, dev_out_direct, npx, 4,
+			use_tr, trm, trmi, 255.0f, alpha_index, 255.0f, st );
+		e = hipGetLastError();
+	}
+
+	if( e == hipSuccess )
+	{
+		e = hipStreamSynchronize( st );
+	}
+
+	(void) hipFree( dthr );
+
+	if( e != hipSuccess )
+	{
+		set_error( "debug_gamma_u8: %s", hipGetErrorString( e ));
+		return( AVIRHIP_EHIP );
+	}
+
+	return( AVIRHIP_OK );
+}

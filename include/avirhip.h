@@ -413,6 +413,17 @@ int avirhip_lancir_get_plan(avirhip_lancir* l, int src_w, int src_h,
 	int new_w, int new_h, int el_count, const avirhip_lancir_params* params,
 	int in_type, int out_type, avirhip_plan** out);
 
+/* Test hook: the uint8 sRGB-gamma output stage (applySRGBGamma + default
+ * ditherer + unpackScanline, avir.h:2982-3068, 4392-4419, 3155-3215) applied to
+ * `npx` float RGBA pixels in device memory, once in the form plans use (the
+ * 2 x 256 threshold table, a monotone step function found by bisection on the
+ * host) and once as the direct expressions: tests/test_gpu_parity.py sweeps
+ * every float bit pattern through both. `tr_mul` >= 1 (1: no bit-depth
+ * truncation), `alpha_index` 0..3 or -1. */
+int avirhip_debug_gamma_u8(const float* dev_rgba, long npx, double tr_mul,
+	int alpha_index, unsigned char* dev_out_table,
+	unsigned char* dev_out_direct, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

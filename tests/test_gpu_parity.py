@@ -1485,3 +1485,45 @@ def test_host_pointer_calls_run_the_band_pipeline(case):
         again = obj.resize(src, nw, nh)
     _assert_same(got, want, "pipelined host call %r" % (case,))
     _assert_same(again, want, "second pipelined host call %r" % (case,))
+
+
+@pytest.mark.parametrize("tr_mul,alpha", [(1.0, -1), (1.0, 3), (255.0 / 63.0, 0)])
+def test_gamma_threshold_table_equals_the_direct_stage_for_every_float(tr_mul,
+                                                                        alpha):
+    """The uint8 gamma output stage runs as a threshold table found by
+    bisection (generic.hip::gamma_u8_thresholds), which assumes the stage is
+    monotone. Sweep it: every float bit pattern in [0, 16], the negative
+    floats down to -16, infinities and NaNs, through the table form and the
+    direct expressions -- colour and alpha channels, with and without
+    bit-depth truncation -- must give the same byte."""
+    import torch
+    lib = abi.load()
+    dev = "cuda:0"
+    top = 0x41800000  # 16.0f
+    chunk = 1 << 26   # values per call (x 4 channels = one RGBA pixel each)
+    start = 0
+    while start <= top:
+        n = min(chunk, top + 1 - start)
+        bits = torch.arange(start, start + n, dtype=torch.int64, device=dev)
+        vals = bits.to(torch.int32).view(torch.float32)
+        # channels: +v, -v, v again, and a channel of specials / repeats
+        px = torch.empty((n, 4), dtype=torch.float32, device=dev)
+        px[:, 0] = vals
+        px[:, 1] = -vals
+        px[:, 2] = vals
+        px[:, 3] = vals
+        px[0, 3] = float("inf")
+        px[min(1, n - 1), 3] = float("-inf")
+        px[min(2, n - 1), 3] = float("nan")
+        a = torch.empty((n, 4), dtype=torch.uint8, device=dev)
+        b = torch.empty((n, 4), dtype=torch.uint8, device=dev)
+        abi.check(lib.avirhip_debug_gamma_u8(
+            px.data_ptr(), n, float(tr_mul), alpha, a.data_ptr(), b.data_ptr(),
+            torch.cuda.current_stream().cuda_stream), "debug_gamma_u8")
+        if not torch.equal(a, b):
+            bad = (a != b).nonzero()[0]
+            i, c = int(bad[0]), int(bad[1])
+            raise AssertionError(
+                "value %r (bits %#x, channel %d): table %d, direct %d" % (
+                    float(px[i, c]), start + i, c, int(a[i, c]), int(b[i, c])))
+        start += n
