@@ -1395,6 +1395,39 @@ static int exec_any( avirhip_plan* p, const void* src, int src_mem, void* dst,
 	return( AVIRHIP_OK );
 }
 
+size_t plan_device_bytes( avirhip_plan* p )
+{
+	if( p == nullptr )
+	{
+		return( 0 );
+	}
+
+	size_t b = p -> alloc_bytes + plan_device_bytes( p -> inner );
+
+	{
+		std::lock_guard< std::mutex > sl( p -> spare_mtx );
+
+		for( size_t i = 0; i < p -> spares.size(); i++ )
+		{
+			b += plan_device_bytes( p -> spares[ i ]);
+		}
+	}
+
+	// (replicas are only touched under shard_mtx, which a sharded call holds
+	// for its whole duration: do not wait for it, count what can be seen)
+	if( p -> shard_mtx.try_lock())
+	{
+		for( size_t i = 0; i < p -> replicas.size(); i++ )
+		{
+			b += plan_device_bytes( p -> replicas[ i ]);
+		}
+
+		p -> shard_mtx.unlock();
+	}
+
+	return( b );
+}
+
 static avirhip_plan* new_plan()
 {
 	avirhip_plan* p = new avirhip_plan();

@@ -77,9 +77,7 @@ struct PlanCache
 
 			for( auto it = m.begin(); it != m.end(); ++it )
 			{
-				bytes += it -> second.p -> alloc_bytes +
-					( it -> second.p -> inner != nullptr ?
-					it -> second.p -> inner -> alloc_bytes : 0 );
+				bytes += avirhip::plan_device_bytes( it -> second.p );
 
 				if( &it -> second != keep && it -> second.busy == 0 &&
 					!it -> second.pinned && ( victim == m.end() ||

@@ -174,6 +174,9 @@ void set_error( const char* fmt, ... );
 
 size_t dtype_size( int t );
 int finalize_avir_plan( avirhip_plan* p ); // api.cpp
+// device bytes a plan holds, with its inner plan, same-device spares and
+// other-device replicas (the plan caches' byte bound)
+size_t plan_device_bytes( avirhip_plan* p );
 
 // generic.hip
 // `ch` = channels in `src`, `ech` >= ch = channels written (zero padded)
