@@ -1527,3 +1527,52 @@ def test_gamma_threshold_table_equals_the_direct_stage_for_every_float(tr_mul,
                 "value %r (bits %#x, channel %d): table %d, direct %d" % (
                     float(px[i, c]), start + i, c, int(a[i, c]), int(b[i, c])))
         start += n
+
+
+def _frtest_stats(resize, th, k, w=700, h=3, bias=1.0, offs=80):
+    """other/frtest.cpp:129-250 for one frequency and one resizing step: a
+    de-biased, power-normalised cosine row (plus Bias), resized by k and back;
+    returns (frequency response dB, two-way distortion dB, peak error dB)."""
+    i = np.arange(w, dtype=np.float64)
+    row = np.cos(i * th).astype(np.float32).astype(np.float64)
+    row -= row.mean()
+    row *= 1.0 / np.sqrt((row * row).mean())
+    src = np.repeat((row + bias).astype(np.float32)[None, :, None], h, axis=0)
+    nw, nh = int(np.ceil(w / k)), int(np.ceil(h / k))
+    mid = resize(src, nw, max(nh, 1), -k)
+    back = resize(mid, w, h, -1.0 / k)
+
+    def rms(a):
+        return float(np.sqrt(((a.astype(np.float64) - bias) ** 2).mean()))
+
+    s0, m0, b0 = src[0, offs:w - offs, 0], mid[0, offs:nw - offs, 0], \
+        back[0, offs:w - offs, 0]
+    p1g, p2g = 1.0 / rms(s0), 1.0 / rms(b0)
+    d = (s0.astype(np.float64) - bias) * p1g - (b0.astype(np.float64) - bias) * p2g
+    return (20 * np.log10(rms(m0)), 10 * np.log10((d * d).mean()),
+            20 * np.log10(np.abs(d).max()))
+
+
+def test_frequency_response_and_two_way_distortion_like_frtest():
+    """The reference's own quality methodology (other/frtest.cpp): sinusoids
+    through a resize by k and back. With bit-exact kernels the figures must be
+    the reference's to the last digit; beside that, the pass band is flat and
+    the round trip is clean for frequencies the smaller image can hold."""
+    lib = abi.load()
+
+    def gpu(src, nw, nh, k):
+        return avir_amd.CImageResizer(16).resize(src, nw, nh, k=k)
+
+    def ref(src, nw, nh, k):
+        return _checker_avir(src, nw, nh, resbits=16, k=k)
+
+    for th_pi, k in [(0.05, 1.0 / 0.7), (0.2, 1.0 / 0.45), (0.1, 2.0),
+                     (0.3, 0.62), (0.6, 0.37), (0.02, 3.3)]:
+        g = _frtest_stats(gpu, np.pi * th_pi, k)
+        r = _frtest_stats(ref, np.pi * th_pi, k)
+        assert g == r, (th_pi, k, g, r)
+        # a frequency well inside the smaller image's band (and enough periods
+        # in the measured window): |gain| < 0.1 dB, two-way distortion < -60 dB
+        if th_pi >= 0.05 and th_pi * max(k, 1.0) < 0.3:
+            assert abs(g[0]) < 0.1, (th_pi, k, g)
+            assert g[1] < -60.0, (th_pi, k, g)
