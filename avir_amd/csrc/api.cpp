@@ -1343,9 +1343,16 @@ static int exec_any( avirhip_plan* p, const void* src, int src_mem, void* dst,
 
 	int rc = 1;
 
+	// (NewBuf may alias SrcBuf, avir.h:4650-4652: result rows copied down while
+	// source rows still travel up would overwrite them -- such calls keep the
+	// serial order, whole source up first)
+	const bool host_alias = ( (const char*) src < (const char*) dst + dst_bytes &&
+		(const char*) dst < (const char*) src + src_bytes );
+
 	if( src_mem == AVIRHIP_MEM_HOST && dst_mem == AVIRHIP_MEM_HOST &&
-		row0 == 0 && row1 == p -> new_h && (size_t) p -> new_w * p -> io_ch *
-		dtype_size( p -> out_type ) == row_bytes )
+		!host_alias && row0 == 0 && row1 == p -> new_h &&
+		(size_t) p -> new_w * p -> io_ch * dtype_size( p -> out_type ) ==
+		row_bytes )
 	{
 		rc = exec_host_pipelined( p, src, dst, src_bytes, dst_bytes, row_bytes,
 			st );

@@ -1576,3 +1576,17 @@ def test_frequency_response_and_two_way_distortion_like_frtest():
         if th_pi >= 0.05 and th_pi * max(k, 1.0) < 0.3:
             assert abs(g[0]) < 0.1, (th_pi, k, g)
             assert g[1] < -60.0, (th_pi, k, g)
+
+
+def test_in_place_host_resize_of_a_large_frame():
+    """NewBuf may alias SrcBuf when the result is not larger
+    (avir.h:4650-4652). A host-pointer call of this size would otherwise run the
+    band pipeline, whose copies down would overwrite source rows still on
+    their way up: aliased host buffers keep the serial order."""
+    src = rb.lcg_f32((1500, 2000, 4), seed=4)
+    want = avir_amd.CImageResizer(16).resize(src.copy(), 1000, 750)
+    buf = src.copy().reshape(-1)
+    r = avir_amd.CImageResizer(16)
+    r.resizeImage(buf, 2000, 1500, 0, buf, 1000, 750, 4, 0.0)
+    _assert_same(buf[:1000 * 750 * 4].reshape(750, 1000, 4), want,
+                 "in-place host resize")
