@@ -286,6 +286,73 @@ __attribute__(( amdgpu_waves_per_eu( 4, 4 ))) k_up2( const Up2Params P )
 #pragma unroll
 	for( int i = 0; i < ( VT ? 12 : 1 ); i++ ) ea[ i ] = oa[ i ] = (f2) 0.0f;
 
+	// ---- VT: per-lane addresses, computed ONCE per work item and carried
+	// through all phases in 6 registers (LDS byte addresses packed two to a
+	// register, unpacked by one volatile instruction where a phase needs one:
+	// opaque to the compiler, which would otherwise keep every derived address
+	// alive next to the 64 registers of vertical state -- or, as before this
+	// change, had to rebuild them from the lane id in every phase: 13 % of the
+	// vector instructions of a marching step).
+	constexpr int RPI0 = U2_NT / U2_SW;
+	constexpr int CN0 = U2_RB * U2_CW;
+	unsigned pkA = 0; // lo: H2 window start in sC; hi: this half pixel in sT
+	unsigned pkB = 0; // H1 iterations 0 / 1: first source pixel in sS
+	unsigned pkC = 0; // H1 iteration 2: source in sS / destination in sC
+	unsigned t16 = 0; // thread index * 16 (flat pixel slot in sC / sT)
+	int pvoff = -1;   // source byte offset of this lane's DMA pixel (< 0: none)
+	int dlv = 0;      // destination byte offset within a row
+
+	if constexpr( VT )
+	{
+		typedef __attribute__(( address_space( 3 ))) void* lp;
+		auto la = []( const void* q ) -> unsigned
+			{ return( (unsigned) (unsigned long long) (lp) q ); };
+
+		{
+			const int r = tid / U2_SW;
+			const int sx = clampi( qx0 - 9 + ( tid - r * U2_SW ), P.sw - 1 );
+			pvoff = ( tid < RPI0 * U2_SW ? r * srow_b + sx * 16 : -1 );
+		}
+
+		dlv = ( xo < P.nw ? ( xo * 4 + hf * 2 ) * 4 : (int) 0x80000000u );
+		t16 = (unsigned) tid * 16;
+		pkA = la( &sC[ ( tid / ( U2_TW / 2 )) * U2_CW +
+			( tid & ( U2_TW / 2 - 1 ))]) |
+			( la( (const f2*) sT + ((( col & 1 ) * U2_TPL + ( col >> 1 )) * 2 +
+			hf )) << 16 );
+
+		unsigned ha[ 3 ], hd = 0;
+#pragma unroll
+		for( int k = 0; k < 3; k++ )
+		{
+			const int i = min( tid + k * U2_NT, CN0 - 1 );
+			const int r = (int) ((unsigned) i / U2_CW );
+			ha[ k ] = la( &sS[ i + r * ( U2_SW - U2_CW )]);
+			hd = la( &sC[ i ]);
+		}
+
+		pkB = ha[ 0 ] | ( ha[ 1 ] << 16 );
+		pkC = ha[ 2 ] | ( hd << 16 );
+		asm volatile( "" : "+v"( pkA ), "+v"( pkB ), "+v"( pkC ), "+v"( t16 ),
+			"+v"( pvoff ), "+v"( dlv ));
+	}
+
+	typedef const __attribute__(( address_space( 3 ))) f4* lds_cf4;
+	typedef __attribute__(( address_space( 3 ))) f4* lds_f4;
+	typedef const __attribute__(( address_space( 3 ))) f2* lds_cf2;
+	auto lo16 = []( const unsigned v ) -> unsigned
+	{
+		unsigned r;
+		asm volatile( "v_and_b32 %0, 0xffff, %1" : "=v"( r ) : "v"( v ));
+		return( r );
+	};
+	auto hi16 = []( const unsigned v ) -> unsigned
+	{
+		unsigned r;
+		asm volatile( "v_lshrrev_b32 %0, 16, %1" : "=v"( r ) : "v"( v ));
+		return( r );
+	};
+
 	// ---- source tiles: LDS-DMA (buffer_load_dwordx4 ... lds), HBM -> LDS
 	// without passing through registers. One instruction moves whole pixels
 	// of U2_RPI consecutive tile rows: lane f takes pixel f % U2_SW of row
@@ -302,6 +369,24 @@ __attribute__(( amdgpu_waves_per_eu( 4, 4 ))) k_up2( const Up2Params P )
 
 	auto prefetch = [&]( const int ub )
 	{
+		if( VT && ub >= 0 && ub + U2_RB <= P.sh )
+		{
+			// (interior rows: the lane offset is the persistent one)
+			if( pvoff >= 0 )
+			{
+#pragma unroll
+				for( int k = 0; k < NDMA; k++ )
+				{
+					__builtin_amdgcn_raw_ptr_buffer_load_lds( rsrc,
+						(ldsptr) ((char*) sS + k * RPI * U2_SW * 16 + wave_b ),
+						16, pvoff, ( ub - ubase + k * RPI ) * srow_b, 0,
+						U2_LDAUX );
+				}
+			}
+
+			return;
+		}
+
 		const int tid = ( VT ? fresh_tid( wave ) : (int) threadIdx.x );
 		const int pr_r = tid / U2_SW;
 		const int pr_sx = clampi( qx0 - 9 + ( tid - pr_r * U2_SW ), P.sw - 1 );
@@ -343,6 +428,7 @@ __attribute__(( amdgpu_waves_per_eu( 4, 4 ))) k_up2( const Up2Params P )
 	constexpr int NH1 = ( CN + U2_NT - 1 ) / U2_NT;
 	constexpr int H1EVERY = U2_RB / NH1; // woven into every H1EVERY-th V step
 	static_assert( NH1 <= U2_RB, "H1 iterations must fit into the marching steps" );
+	static_assert( !VT || ( NH1 == 3 && CN == CN0 && RPI == RPI0 ), "VT: packed H1 addresses" );
 
 	auto h1_iter = [&]( const int k, const f2 ( &h )[ 4 ])
 	{
@@ -362,29 +448,84 @@ __attribute__(( amdgpu_waves_per_eu( 4, 4 ))) k_up2( const Up2Params P )
 		}
 	};
 
-	// the same without a lane condition (no control flow inside a vertical
+	// the VT form, without a lane condition (no control flow inside a vertical
 	// step: basic-block boundaries let the compiler sink accumulation chains
-	// across them): lanes past the tile's end redo its last pixel
-	auto h1_iter_nb = [&]( const int k, const f2 ( &h )[ 4 ])
+	// across them; lanes past the tile's end redo its last pixel), addresses
+	// from the persistent packed registers
+	auto h1_iter_p = [&]( const int k, const f2 ( &h )[ 4 ])
 	{
-		const int tid = fresh_tid( wave );
-		const int i = (( k + 1 ) * U2_NT <= CN ? tid + k * U2_NT :
-			min( tid + k * U2_NT, CN - 1 ));
-		const int r = (int) ((unsigned) i / U2_CW );
-		const f4* s = &sS[ i + r * ( U2_SW - U2_CW )];
+		const unsigned sa = ( k == 0 ? lo16( pkB ) : k == 1 ? hi16( pkB ) :
+			lo16( pkC ));
+		const unsigned da = ( k == 2 ? hi16( pkC ) : t16 + k * U2_NT * 16 +
+			(unsigned) (unsigned long long) (ldsptr) sC );
+		const lds_cf4 s = (lds_cf4) (unsigned long long) sa;
 		const f4 s0 = s[ 0 ], s1 = s[ 1 ], s2 = s[ 2 ], s3 = s[ 3 ];
 		const f4 s4 = s[ 4 ], s5 = s[ 5 ], s6 = s[ 6 ];
 		f4 a = tmul( h[ 0 ], s3 );
 		a = a + tmul( h[ 1 ], s4 + s2 );
 		a = a + tmul( h[ 2 ], s5 + s1 );
 		a = a + tmul( h[ 3 ], s6 + s0 );
-		sC[ i ] = a;
+		*(lds_f4) (unsigned long long) da = a;
 	};
 
 	// ---- H2: T[2q], T[2q+1] from the 13-px window C[qq .. qq+12], one source
 	// pixel (two whole output pixels) per thread and iteration
 	auto h2_phase = [&]()
 	{
+		if( VT && U2_ON( 2 ))
+		{
+			const Taps H = load_taps( P.coef );
+			const lds_cf4 c0 = (lds_cf4) (unsigned long long) lo16( pkA );
+			const lds_f4 t0 = (lds_f4) (unsigned long long)
+				( t16 + (unsigned) (unsigned long long) (ldsptr) sT );
+			constexpr int RS = U2_NT / ( U2_TW / 2 ); // rows per iteration
+
+#pragma unroll
+			for( int it = 0; it < U2_RB / RS; it++ )
+			{
+				const lds_cf4 c = c0 + it * RS * U2_CW;
+				f4 e = (f4) 0.0f;
+				f4 o = (f4) 0.0f;
+				f4 w[ 13 ];
+
+				// the window in three parts of 5 + 4 + 4 pixels: the
+				// transposed vertical phase keeps 64 registers live
+				// across this phase
+#pragma unroll
+				for( int t = 0; t < 5; t++ ) w[ t ] = c[ t ];
+#pragma unroll
+				for( int t = 0; t < 4; t++ )
+				{
+					e = e + tmul( H.fe( t ), w[ t ]);
+					o = o + tmul( H.fo( t ), w[ t + 1 ]);
+				}
+
+				__builtin_amdgcn_sched_barrier( 0 );
+#pragma unroll
+				for( int t = 5; t < 9; t++ ) w[ t ] = c[ t ];
+#pragma unroll
+				for( int t = 4; t < 8; t++ )
+				{
+					e = e + tmul( H.fe( t ), w[ t ]);
+					o = o + tmul( H.fo( t ), w[ t + 1 ]);
+				}
+
+				__builtin_amdgcn_sched_barrier( 0 );
+#pragma unroll
+				for( int t = 9; t < 13; t++ ) w[ t ] = c[ t ];
+#pragma unroll
+				for( int t = 8; t < 12; t++ )
+				{
+					e = e + tmul( H.fe( t ), w[ t ]);
+					o = o + tmul( H.fo( t ), w[ t + 1 ]);
+				}
+
+				t0[ it * U2_NT ] = e;
+				t0[ U2_TPL + it * U2_NT ] = o;
+				__builtin_amdgcn_sched_barrier( 0 );
+			}
+		}
+		else
 		if( U2_ON( 2 ))
 		{
 			const Taps H = load_taps( P.coef );
@@ -653,14 +794,8 @@ __attribute__(( amdgpu_waves_per_eu( 4, 4 ))) k_up2( const Up2Params P )
 
 			const int yb = ( ub - 9 ) * 2;
 			int so = ( yb - qy0 * 2 ) * drow_b; // scalar byte offset of row yb
-			const int tid = fresh_tid( wave );
-			const int hf = tid & 1;
-			const int col = tid >> 1;
-			const int xo = qx0 * 2 + col;
-			const int dlane_v = ( xo < P.nw ? ( xo * 4 + hf * 2 ) * 4 :
-				(int) 0x80000000u );
-			const f2* sT2 = (const f2*) sT +
-				((( col & 1 ) * U2_TPL + ( col >> 1 )) * 2 + hf );
+			const int dlane_v = dlv;
+			const lds_cf2 sT2 = (lds_cf2) (unsigned long long) hi16( pkA );
 			// rows yb + 1 .. yb + 16 that lie in [ylo, yhi)
 			const int rlo = min( max( ylo - ( yb + 1 ), 0 ), 2 * U2_RB );
 			const int rhi = min( max( yhi - ( yb + 1 ), 0 ), 2 * U2_RB );
@@ -782,7 +917,7 @@ __attribute__(( amdgpu_waves_per_eu( 4, 4 ))) k_up2( const Up2Params P )
 				// stale tiles and nobody reads its result)
 				if( rr % H1EVERY == 0 && rr / H1EVERY < NH1 && U2_ON( 2 ))
 				{
-					h1_iter_nb( rr / H1EVERY, hv );
+					h1_iter_p( rr / H1EVERY, hv );
 				}
 			}
 		};
