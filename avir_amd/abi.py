@@ -20,7 +20,7 @@ STEP_NAMES = ["FIR", "UP_ZEROSTUFF", "UP_FILTERED", "RESIZE", "RESIZE2"]
 DITHER_DEF, DITHER_ERRD = 0, 1
 PATH_AUTO, PATH_GENERIC, PATH_TILED, PATH_FUSED, PATH_UP2 = 0, 1, 2, 3, 4
 PATH_GPASS = 5
-VARIANT_UP2_PLAIN_V, VARIANT_DN_TWO_PASS = 1, 2
+VARIANT_UP2_PLAIN_V, VARIANT_DN_TWO_PASS, VARIANT_SACC_LADDER = 1, 2, 4
 
 _fp = C.POINTER(C.c_float)
 _ip = C.POINTER(C.c_int32)

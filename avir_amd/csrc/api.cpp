@@ -2230,7 +2230,7 @@ int avirhip_plan_set_path( avirhip_plan* p, int path )
 
 int avirhip_plan_set_variant( avirhip_plan* p, int variant )
 {
-	if( p == nullptr || variant < 0 || variant > 3 )
+	if( p == nullptr || variant < 0 || variant > 7 )
 	{
 		set_error( "bad variant" );
 		return( AVIRHIP_EINVAL );

@@ -366,7 +366,8 @@ void sacc_release_axis( SAData* D );
 int sacc_run_axis( const SAData* D, bool rows, const void* src, int src_type,
 	int src_ch, int live_ch, long s_lane, long s_step, float* dst, long d_lane,
 	long d_step, int lane_lo, int lane_hi, int out_lo, int out_hi,
-	hipStream_t st, const GPOut* out = nullptr );
+	hipStream_t st, const GPOut* out = nullptr, bool finite = false,
+	bool ladder = false );
 
 struct GPData
 {
@@ -1134,6 +1135,11 @@ int gpass_run( avirhip_plan* p, const float* src, long src_stride, float* dst,
 	v_source_rows( D, row0, row1, a, b );
 
 	rc = 1;
+	// an integer image is finite, and so is the FltBuf made from it: both
+	// passes may take the branch-free form of the accumulation kernel
+	const bool int_src = ( raw != nullptr && ( raw_type == AVIRHIP_U8 ||
+		raw_type == AVIRHIP_U16 ));
+	const bool ladder = (( p -> variant & AVIRHIP_VARIANT_SACC_LADDER ) != 0 );
 
 	if( D -> sa_h != nullptr )
 	{
@@ -1144,7 +1150,7 @@ int gpass_run( avirhip_plan* p, const float* src, long src_stride, float* dst,
 
 			rc = sacc_run_axis( D -> sa_h, true, raw, raw_type, raw_ch, raw_ch,
 				raw_stride * es, raw_ch * es, D -> mid, mid_ss, 4, a, b + 1, 0,
-				p -> new_w, st );
+				p -> new_w, st, nullptr, int_src, ladder );
 		}
 		else
 		{
@@ -1173,7 +1179,7 @@ int gpass_run( avirhip_plan* p, const float* src, long src_stride, float* dst,
 	{
 		rc = sacc_run_axis( D -> sa_v, false, D -> mid, AVIRHIP_F32, 4,
 			p -> io_ch, 16, mid_ss * 4, dst - (long) row0 * dst_ss, 4, dst_ss,
-			0, p -> new_w, row0, row1, st, out );
+			0, p -> new_w, row0, row1, st, out, int_src, ladder );
 	}
 
 	if( rc == 1 )

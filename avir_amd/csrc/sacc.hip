@@ -33,13 +33,16 @@
 // the source. Row lanes collect four outputs in LDS and store 64 contiguous
 // bytes per row.
 
-#include "gpass_dev.h"
+#include "dnf_dev.h"
 #include <algorithm>
 #include <type_traits>
 #include <stdint.h>
 #include <string.h>
 #include <stdlib.h>
 #include <math.h>
+#include <map>
+#include <array>
+#include <vector>
 
 namespace avirhip {
 
@@ -55,6 +58,13 @@ struct SAAxis
 	const int* first;   // [rows] first output alive at the sample
 	const float* tab;   // [rows][16]: coefficients of the outputs alive at the
 	                    // sample, first alive output first; [15] = their count
+	const float* tab2;  // k_sacc2 (nullptr: not available): rows of 16, entry s
+	                    // = the coefficient of the alive output g with g % 16 == s,
+	                    // 0 elsewhere; addressed through ridx
+	int tbase;          // (a multiple of 4, <= u_min)
+	const int* ridx;    // k_sacc2: byte offset into tab2 of sample ( tbase + i )'s
+	                    // row -- equal rows are stored once (a ratio like 27/10
+	                    // has 216 distinct ones: the scalar cache holds them)
 };
 
 struct SAParams
@@ -700,6 +710,573 @@ __global__ void __launch_bounds__( 64 ) k_sacc( const SAParams P )
 }
 
 // ---------------------------------------------------------------------
+// k_sacc2 -- the same pass, branch-free per sample, for sources known to be
+// FINITE (integer images, and the FltBuf made from one).
+//
+// k_sacc spends ~1000 cycles per sample on ~210 cycles of arithmetic: a
+// compare ladder over the outputs alive (one wave-uniform branch per output),
+// a v_readlane per coefficient, samples and table rows through LDS FIFOs.
+// Here a table row holds one coefficient per accumulator SLOT (output g lives
+// in slot g % 16) and zeros for the slots whose output is not alive, so a
+// sample is multiplied into ALL 16 slots unconditionally: x * 0 = +-0 leaves a
+// finite accumulator as it is (an accumulator is never -0: it starts from +0
+// and (+0) + (-0) = +0), which is why the sources must be finite -- a 0 * inf
+// would put a NaN into a slot between two of its outputs. What this buys:
+//   * no branch and no LDS access per sample: the row is ONE s_load_dwordx16
+//     per two samples, issued two samples ahead (lgkmcnt counts nothing else),
+//     its entries are the scalar operands of the packed multiplies (op_sel
+//     picks a half of an SGPR pair);
+//   * RGB: the third channel of TWO slots shares one packed multiply-add (the
+//     coefficient pair as it lies x the channel broadcast): 3 instead of 4
+//     instructions per slot -- a packed instruction takes a SIMD as long as a
+//     scalar one;
+//   * samples arrive by per-lane loads of eight pixels of the lane's row (RGB
+//     uint8: two dwordx3), one group in flight while the other is used; the
+//     four samples up next always sit in the same registers, so every position
+//     is compile-time and nothing goes through LDS;
+//   * an output leaves its accumulator AFTER the group in which its last tap
+//     fell (its later coefficients are zeros): one wave-uniform switch over the
+//     slot per output, outside the sample code. The host checks that the slot's
+//     next output starts after that group (sa2_tables).
+// Same order of operations per output as k_sacc => the same bits.
+// ---------------------------------------------------------------------
+
+typedef float f16v __attribute__(( ext_vector_type( 16 )));
+
+#define SA2_LGKM_WAIT() asm volatile( "s_waitcnt lgkmcnt(0)" ::: "memory" )
+
+// W dwords as one register tuple
+template< int W > struct SA2Vec
+{
+	typedef unsigned int T __attribute__(( ext_vector_type( W )));
+	__device__ __forceinline__ static unsigned int get( const T& v, const int i )
+		{ return( v[ i ]); }
+	__device__ __forceinline__ static void orr( T& v, const int i,
+		const unsigned int x ) { v[ i ] |= x; }
+};
+
+// A per-lane global load whose destination the compiler does not treat as a
+// load result ("+v": the group in flight lives in ONE register tuple across
+// the loop; as a plain load its loop-carried copies were made right after the
+// load went out, at full memory latency). sa2_landed() is the wait: every use
+// of the group depends on it.
+template< int W, int OFF, class V >
+__device__ __forceinline__ void sa2_gload( V& d, const unsigned char* const p )
+{
+	if constexpr( W == 1 )
+		asm volatile( "global_load_dword %0, %1, off offset:%2"
+			: "+v"( d ) : "v"( p ), "n"( OFF ) : "memory" );
+	else if constexpr( W == 2 )
+		asm volatile( "global_load_dwordx2 %0, %1, off offset:%2"
+			: "+v"( d ) : "v"( p ), "n"( OFF ) : "memory" );
+	else if constexpr( W == 3 )
+		asm volatile( "global_load_dwordx3 %0, %1, off offset:%2"
+			: "+v"( d ) : "v"( p ), "n"( OFF ) : "memory" );
+	else
+		asm volatile( "global_load_dwordx4 %0, %1, off offset:%2"
+			: "+v"( d ) : "v"( p ), "n"( OFF ) : "memory" );
+}
+
+template< class V >
+__device__ __forceinline__ void sa2_landed( V& a, V& b )
+{
+	asm volatile( "s_waitcnt vmcnt(0)" : "+v"( a ), "+v"( b ) :: "memory" );
+}
+
+template<> struct SA2Vec< 1 >
+{
+	typedef unsigned int T;
+	__device__ __forceinline__ static unsigned int get( const T& v, const int )
+		{ return( v ); }
+	__device__ __forceinline__ static void orr( T& v, const int,
+		const unsigned int x ) { v |= x; }
+};
+
+template< int NC >
+struct SA2Acc
+{
+	f2 A[ 16 ];  // channels 0, 1 of slot s            (NC >= 2)
+	f2 B[ 16 ];  // channels 2, 3 of slot s            (NC == 4)
+	f2 BB[ 8 ];  // the odd channel of slots 2i, 2i + 1 (NC == 3: 2; NC == 1: 0)
+};
+
+// four slots 4q .. 4q + 3 of one sample; c0 = { c[4q], c[4q+1] }, c1 the next two
+template< int NC >
+__device__ __forceinline__ void sa2_quad( f2* const A, f2* const B,
+	f2* const BB, const f2 xa, const f2 xb, const f2 c0, const f2 c1 )
+{
+	f2 p0, p1, p2, p3, p4, p5, p6, p7;
+
+	if constexpr( NC == 4 )
+	{
+		asm volatile(
+			"v_pk_mul_f32 %[p0], %[xa], %[c0]" DF_SEL0 "\n\t"
+			"v_pk_mul_f32 %[p1], %[xb], %[c0]" DF_SEL0 "\n\t"
+			"v_pk_mul_f32 %[p2], %[xa], %[c0]" DF_SEL1 "\n\t"
+			"v_pk_mul_f32 %[p3], %[xb], %[c0]" DF_SEL1 "\n\t"
+			"v_pk_mul_f32 %[p4], %[xa], %[c1]" DF_SEL0 "\n\t"
+			"v_pk_mul_f32 %[p5], %[xb], %[c1]" DF_SEL0 "\n\t"
+			"v_pk_mul_f32 %[p6], %[xa], %[c1]" DF_SEL1 "\n\t"
+			"v_pk_mul_f32 %[p7], %[xb], %[c1]" DF_SEL1 "\n\t"
+			"v_pk_add_f32 %[a0], %[a0], %[p0]\n\t"
+			"v_pk_add_f32 %[b0], %[b0], %[p1]\n\t"
+			"v_pk_add_f32 %[a1], %[a1], %[p2]\n\t"
+			"v_pk_add_f32 %[b1], %[b1], %[p3]\n\t"
+			"v_pk_add_f32 %[a2], %[a2], %[p4]\n\t"
+			"v_pk_add_f32 %[b2], %[b2], %[p5]\n\t"
+			"v_pk_add_f32 %[a3], %[a3], %[p6]\n\t"
+			"v_pk_add_f32 %[b3], %[b3], %[p7]"
+			: [a0] "+v"( A[ 0 ]), [a1] "+v"( A[ 1 ]), [a2] "+v"( A[ 2 ]),
+			[a3] "+v"( A[ 3 ]), [b0] "+v"( B[ 0 ]), [b1] "+v"( B[ 1 ]),
+			[b2] "+v"( B[ 2 ]), [b3] "+v"( B[ 3 ]),
+			[p0] "=&v"( p0 ), [p1] "=&v"( p1 ), [p2] "=&v"( p2 ),
+			[p3] "=&v"( p3 ), [p4] "=&v"( p4 ), [p5] "=&v"( p5 ),
+			[p6] "=&v"( p6 ), [p7] "=&v"( p7 )
+			: [xa] "v"( xa ), [xb] "v"( xb ), [c0] "s"( c0 ), [c1] "s"( c1 ));
+	}
+	else
+	if constexpr( NC == 3 )
+	{
+		asm volatile(
+			"v_pk_mul_f32 %[p0], %[xa], %[c0]" DF_SEL0 "\n\t"
+			"v_pk_mul_f32 %[p1], %[xa], %[c0]" DF_SEL1 "\n\t"
+			"v_pk_mul_f32 %[p2], %[c0], %[xb] op_sel_hi:[1,0]\n\t"
+			"v_pk_mul_f32 %[p3], %[xa], %[c1]" DF_SEL0 "\n\t"
+			"v_pk_mul_f32 %[p4], %[xa], %[c1]" DF_SEL1 "\n\t"
+			"v_pk_mul_f32 %[p5], %[c1], %[xb] op_sel_hi:[1,0]\n\t"
+			"v_pk_add_f32 %[a0], %[a0], %[p0]\n\t"
+			"v_pk_add_f32 %[a1], %[a1], %[p1]\n\t"
+			"v_pk_add_f32 %[q0], %[q0], %[p2]\n\t"
+			"v_pk_add_f32 %[a2], %[a2], %[p3]\n\t"
+			"v_pk_add_f32 %[a3], %[a3], %[p4]\n\t"
+			"v_pk_add_f32 %[q1], %[q1], %[p5]"
+			: [a0] "+v"( A[ 0 ]), [a1] "+v"( A[ 1 ]), [a2] "+v"( A[ 2 ]),
+			[a3] "+v"( A[ 3 ]), [q0] "+v"( BB[ 0 ]), [q1] "+v"( BB[ 1 ]),
+			[p0] "=&v"( p0 ), [p1] "=&v"( p1 ), [p2] "=&v"( p2 ),
+			[p3] "=&v"( p3 ), [p4] "=&v"( p4 ), [p5] "=&v"( p5 )
+			: [xa] "v"( xa ), [xb] "v"( xb ), [c0] "s"( c0 ), [c1] "s"( c1 ));
+	}
+	else
+	if constexpr( NC == 2 )
+	{
+		asm volatile(
+			"v_pk_mul_f32 %[p0], %[xa], %[c0]" DF_SEL0 "\n\t"
+			"v_pk_mul_f32 %[p1], %[xa], %[c0]" DF_SEL1 "\n\t"
+			"v_pk_mul_f32 %[p3], %[xa], %[c1]" DF_SEL0 "\n\t"
+			"v_pk_mul_f32 %[p4], %[xa], %[c1]" DF_SEL1 "\n\t"
+			"v_pk_add_f32 %[a0], %[a0], %[p0]\n\t"
+			"v_pk_add_f32 %[a1], %[a1], %[p1]\n\t"
+			"v_pk_add_f32 %[a2], %[a2], %[p3]\n\t"
+			"v_pk_add_f32 %[a3], %[a3], %[p4]"
+			: [a0] "+v"( A[ 0 ]), [a1] "+v"( A[ 1 ]), [a2] "+v"( A[ 2 ]),
+			[a3] "+v"( A[ 3 ]),
+			[p0] "=&v"( p0 ), [p1] "=&v"( p1 ), [p3] "=&v"( p3 ), [p4] "=&v"( p4 )
+			: [xa] "v"( xa ), [c0] "s"( c0 ), [c1] "s"( c1 ));
+	}
+	else
+	{
+		asm volatile(
+			"v_pk_mul_f32 %[p2], %[c0], %[xa] op_sel_hi:[1,0]\n\t"
+			"v_pk_mul_f32 %[p5], %[c1], %[xa] op_sel_hi:[1,0]\n\t"
+			"v_pk_add_f32 %[q0], %[q0], %[p2]\n\t"
+			"v_pk_add_f32 %[q1], %[q1], %[p5]"
+			: [q0] "+v"( BB[ 0 ]), [q1] "+v"( BB[ 1 ]),
+			[p2] "=&v"( p2 ), [p5] "=&v"( p5 )
+			: [xa] "v"( xa ), [c0] "s"( c0 ), [c1] "s"( c1 ));
+	}
+}
+
+// SRC 1 / 2: uint8 / uint16 pixels of CH channels; lanes are image ROWS (the
+// caller's image: the first pass of a plan with an integer source)
+template< int SRC, int CH, int NC >
+__global__ void __launch_bounds__( 64 ) k_sacc2( const SAParams P )
+{
+	typedef SAV< NC > PV;
+	typedef typename SAElem< SRC > :: T Tin;
+	const SAAxis& A = P.ax;
+
+	const int lane = threadIdx.x;
+	const int strip = blockIdx.x % P.nstrips;
+	const int chunk = blockIdx.x / P.nstrips;
+	const int l0 = P.lane_lo + strip * 64;
+	const int li = l0 + lane;
+	const bool lok = ( li < P.lane_hi );
+	const int lc = min( li, P.lane_hi - 1 );
+	const int n0 = P.out_lo + chunk * P.chunk;
+	const int n1 = min( n0 + P.chunk, P.out_hi );
+
+	if( n0 >= n1 )
+	{
+		return;
+	}
+
+	gp_cint* const a_start = (gp_cint*) (unsigned long) A.start;
+	gp_cint* const a_first = (gp_cint*) (unsigned long) A.first;
+	const int nt = A.nt;
+	const int glast = A.g_len - 1;
+	const int slast = A.in_len - 1;
+
+	// accumulated outputs the chunk's correction FIR reads: [ga, gb], virtual
+	// repeats of the last one up to gbv (see k_sacc)
+	const int ga = gp_clamp( n0 - A.e - 3, glast );
+	const int gb = gp_clamp( n1 - 1 - A.e + 3, glast );
+	const int gbv = n1 - 1 - A.e + 3;
+	const int u_a = a_start[ ga ];
+	const int q_a = u_a >> 2; // blocks of four samples, absolute coordinates
+
+	// ---- the sample feed. A lane loads EIGHT samples of its row at a time
+	// (2 * NDW dwords, one group ahead: `nxt` is in flight while `cur` is
+	// used); the four samples up next always sit in cur[ 0 .. NDW ), so their
+	// positions are compile-time: after a block the upper half moves down or
+	// the next group takes over.
+	constexpr int NDW = CH * (int) sizeof( Tin ); // dwords per four samples
+	constexpr int EPD = 4 / (int) sizeof( Tin );  // elements per dword
+	// (vector-typed so that a half group is one register tuple from the load
+	// on: with single dwords the loop-carried copies of the group in flight
+	// were made right after its load went out -- at full memory latency)
+	constexpr int NV = ( NDW > 4 ? 2 : 1 );
+	constexpr int VW = NDW / NV;
+	typedef typename SA2Vec< VW > :: T HV;
+	struct Half { HV v[ NV ]; };
+	Half curA, curB, nxtA, nxtB; // cur: A = the block up next; nxt: in flight
+	const unsigned char* const lrow = (const unsigned char*) P.src +
+		(long) lc * P.s_lane;
+
+	auto g_load = [&]( const int q8 ) // unconditional: a group on the image's
+	{                                 // edge reads a clamped address, g_fix
+		const int gs = max( 0, min( q8 * 8, slast + 1 - 8 )); // replaces it
+		const unsigned char* const gp = lrow + (long) gs * CH * sizeof( Tin );
+		sa2_gload< VW, 0 >( nxtA.v[ 0 ], gp );
+		sa2_gload< VW, NDW * 4 >( nxtB.v[ 0 ], gp );
+
+		if constexpr( NV == 2 )
+		{
+			sa2_gload< VW, VW * 4 >( nxtA.v[ NV - 1 ], gp );
+			sa2_gload< VW, ( NDW + VW ) * 4 >( nxtB.v[ NV - 1 ], gp );
+		}
+	};
+
+	auto g_take = [&]() // the group in flight becomes the current one
+	{
+		sa2_landed( nxtA.v[ 0 ], nxtB.v[ 0 ]);
+
+		if constexpr( NV == 2 )
+		{
+			sa2_landed( nxtA.v[ NV - 1 ], nxtB.v[ NV - 1 ]);
+		}
+
+		curA = nxtA;
+		curB = nxtB;
+	};
+
+	auto h_get = [&]( const Half& h, const int k ) -> unsigned int
+	{
+		return( SA2Vec< VW > :: get( h.v[ k / VW ], k % VW ));
+	};
+
+	auto h_or = [&]( Half& h, const int k, const unsigned int x )
+	{
+		SA2Vec< VW > :: orr( h.v[ k / VW ], k % VW, x );
+	};
+
+	// A group that is not the eight samples as they lie in memory: the view
+	// repeats the edge sample beyond the image; the samples before the chunk's
+	// first one count as zeros (their table rows belong to earlier outputs,
+	// whose slots must stay clean -- 0 * c changes nothing). Rare: element loads.
+	auto g_fix = [&]( const int q8 )
+	{
+		if( q8 * 8 >= 0 && q8 * 8 + 7 <= slast && q8 * 8 >= u_a )
+		{
+			return;
+		}
+
+#pragma unroll
+		for( int i = 0; i < NV; i++ )
+		{
+			curA.v[ i ] = (HV) 0u;
+			curB.v[ i ] = (HV) 0u;
+		}
+
+#pragma unroll
+		for( int j = 0; j < 8; j++ )
+		{
+			const int u = q8 * 8 + j;
+			const Tin* const px = (const Tin*) lrow + (long) gp_clamp( u, slast ) *
+				CH;
+#pragma unroll
+			for( int c = 0; c < CH; c++ )
+			{
+				const int ei = ( j & 3 ) * CH + c;
+				const unsigned int v = ( u >= u_a ? (unsigned int) px[ c ] : 0u );
+
+				if( j < 4 ) h_or( curA, ei / EPD, v << (( ei % EPD ) * ( 32 / EPD )));
+				else h_or( curB, ei / EPD, v << (( ei % EPD ) * ( 32 / EPD )));
+			}
+		}
+	};
+
+	auto x_of = [&]( const int j ) -> PV // sample j of the block up next
+	{
+		float v[ 4 ] = { 0.0f, 0.0f, 0.0f, 0.0f };
+#pragma unroll
+		for( int c = 0; c < CH; c++ )
+		{
+			const int ei = j * CH + c;
+			v[ c ] = (float) (( h_get( curA, ei / EPD ) >> (( ei % EPD ) *
+				( 32 / EPD ))) & ( SRC == 1 ? 0xffu : 0xffffu ));
+		}
+
+		f4 o; o.x = v[ 0 ]; o.y = v[ 1 ]; o.z = v[ 2 ]; o.w = v[ 3 ];
+		return( PV::from( o ));
+	};
+
+	// ---- the accumulators, the correction FIR's window, pending outputs
+	SA2Acc< NC > R;
+#pragma unroll
+	for( int i = 0; i < 16; i++ )
+	{
+		R.A[ i ] = (f2) 0.0f; R.B[ i ] = (f2) 0.0f; R.BB[ i >> 1 ] = (f2) 0.0f;
+	}
+
+	PV w[ 8 ];
+#pragma unroll
+	for( int i = 0; i < 8; i++ )
+	{
+		w[ i ] = PV::zero();
+	}
+
+	f4 pend[ 4 ]; // four consecutive outputs leave as 64 bytes per row
+#pragma unroll
+	for( int i = 0; i < 4; i++ )
+	{
+		pend[ i ] = (f4) 0.0f;
+	}
+
+	const float f0 = A.f[ 0 ], f1c = A.f[ 1 ], f2c = A.f[ 2 ], f3c = A.f[ 3 ];
+	int g = a_first[ u_a - A.u_min ]; // the next output to complete (<= ga)
+	int endg = a_start[ g ] + nt - 1; // its last sample
+	int n_out = n0;
+
+	// the first group: loaded, fixed up, the block of u_a at the bottom
+#pragma unroll
+	for( int i = 0; i < NV; i++ )
+	{
+		nxtA.v[ i ] = (HV) 0u;
+		nxtB.v[ i ] = (HV) 0u;
+	}
+
+	g_load( q_a >> 1 );
+	g_take();
+	g_fix( q_a >> 1 );
+
+	if( q_a & 1 )
+	{
+		curA = curB;
+	}
+
+	g_load(( q_a >> 1 ) + 1 );
+
+	// ---- the table feed: the rows of TWO samples per scalar load batch, one
+	// batch ahead. Scalar loads return out of order, so a wait is a wait for
+	// all of them: a batch is waited for BEFORE the next one goes out (the
+	// compiler would wait at the first use, after it), and nothing else in the
+	// loop counts on lgkmcnt.
+	gp_cfloat* const tabu = (gp_cfloat*) (unsigned long) A.tab2;
+	gp_cint* ip = (gp_cint*) (unsigned long) A.ridx + ( q_a * 4 - A.tbase );
+
+	// (the loads are asm so that the compiler's own counter bookkeeping does
+	// not see them: it would add a second lgkmcnt(0) at the first use of a
+	// batch -- after the next batch has gone out)
+	auto rows2 = [&]( f16v& lo, f16v& hi, const int o0, const int o1 )
+	{
+		asm volatile( "s_load_dwordx16 %0, %2, %3\n\t"
+			"s_load_dwordx16 %1, %2, %4"
+			: "=&s"( lo ), "=&s"( hi ) : "s"( tabu ), "s"( o0 ), "s"( o1 )
+			: "memory" );
+	};
+
+	typedef int i4v __attribute__(( ext_vector_type( 4 )));
+	auto idx4 = [&]( i4v& d, gp_cint* const q )
+	{
+		asm volatile( "s_load_dwordx4 %0, %1, 0x0" : "=&s"( d ) : "s"( q )
+			: "memory" );
+	};
+
+	// row offsets of this block's samples (ia), the next block's (ib), and the
+	// one after it (ic, in flight)
+	i4v ia, ib, ic;
+	idx4( ia, ip );
+	idx4( ib, ip + 4 );
+	ic = ib;
+	SA2_LGKM_WAIT();
+	f16v ca0, ca1, cb0, cb1;
+	rows2( ca0, ca1, ia[ 0 ], ia[ 1 ]);
+	cb0 = ca0; cb1 = ca1;
+	ip += 8;
+
+	int qn = q_a;              // the next block of samples
+	int ulast = q_a * 4 - 1;   // the last sample multiplied in
+	const int s0 = g & 15;     // slot of the first output to complete
+	bool started = false;
+
+	auto step = [&]( const int j, const f16v& c )
+	{
+		const PV x = x_of( j );
+#pragma unroll
+		for( int k = 0; k < 4; k++ )
+		{
+			f2 c0, c1;
+			c0.x = c[ k * 4 ]; c0.y = c[ k * 4 + 1 ];
+			c1.x = c[ k * 4 + 2 ]; c1.y = c[ k * 4 + 3 ];
+			sa2_quad< NC >( &R.A[ k * 4 ], &R.B[ k * 4 ], &R.BB[ k * 2 ], x.a,
+				x.b, c0, c1 );
+		}
+	};
+
+	// One output: the blocks of samples up to the one its last tap falls into,
+	// then it leaves its accumulator. SC = its slot g % 16, compile-time: the
+	// loop over the outputs is unrolled 16 times, the trip into it starts at
+	// slot s0 (the copies before it are skipped once). Returns true after the
+	// last output.
+	auto body = [&]( auto SC ) -> bool
+	{
+		constexpr int S = decltype( SC )::value;
+
+		if( !started )
+		{
+			if( S != s0 )
+			{
+				return( false );
+			}
+
+			started = true;
+		}
+
+#pragma clang loop unroll( disable )
+		while( g <= gb && endg > ulast )
+		{
+			SA2_LGKM_WAIT();
+			rows2( cb0, cb1, ia[ 2 ], ia[ 3 ]);
+			idx4( ic, ip );
+			step( 0, ca0 );
+			step( 1, ca1 );
+			SA2_LGKM_WAIT();
+			rows2( ca0, ca1, ib[ 0 ], ib[ 1 ]);
+			step( 2, cb0 );
+			step( 3, cb1 );
+			ia = ib;
+			ib = ic;
+			ip += 4;
+			qn++;
+			ulast += 4;
+
+			if( qn & 1 )
+			{
+				curA = curB;
+			}
+			else
+			{
+				g_take();
+				g_fix( qn >> 1 );
+				g_load(( qn >> 1 ) + 1 );
+			}
+		}
+
+		PV val = PV::zero();
+
+		if( NC >= 2 ) val.a = R.A[ S ];
+		else val.a.x = R.BB[ S >> 1 ][ S & 1 ];
+
+		if( NC == 4 ) val.b = R.B[ S ];
+		else if( NC == 3 ) val.b.x = R.BB[ S >> 1 ][ S & 1 ];
+
+		R.A[ S ] = (f2) 0.0f;
+		R.B[ S ] = (f2) 0.0f;
+		R.BB[ S >> 1 ][ S & 1 ] = 0.0f;
+
+		if( g >= ga ) // (else: alive at the chunk's first sample, not its own)
+		{
+			if( g > gb )
+			{
+				val = w[ ( S + 7 ) & 7 ]; // past the last one the edge repeats
+			}
+
+			w[ S & 7 ] = val;
+
+			if( g == ga && n0 - A.e - 3 < 0 )
+			{
+#pragma unroll
+				for( int i = 0; i < 8; i++ )
+				{
+					w[ i ] = val;
+				}
+			}
+
+			// output n = g + e - 3: f0*G[c] + sum f_i*( G[c+i] + G[c-i] ),
+			// c = g - 3
+			if( g >= n0 - A.e + 3 )
+			{
+				PV r = w[ ( S + 5 ) & 7 ].scale( f0 );
+				r = r.madd( f1c, w[ ( S + 6 ) & 7 ].madd1( w[ ( S + 4 ) & 7 ]));
+				r = r.madd( f2c, w[ ( S + 7 ) & 7 ].madd1( w[ ( S + 3 ) & 7 ]));
+				r = r.madd( f3c, w[ S & 7 ].madd1( w[ ( S + 2 ) & 7 ]));
+
+				// pend[ k ] holds the output n with n % 4 == ( k + dsh ) % 4
+				pend[ S & 3 ] = r.to4();
+
+				if(( n_out & 3 ) == 3 || n_out == n1 - 1 )
+				{
+					const int dsh = ( n_out - S ) & 3;
+					const int nb = n_out & ~3;
+#pragma unroll
+					for( int k = 0; k < 4; k++ )
+					{
+						const int n = nb + (( k + dsh ) & 3 );
+
+						if( n >= n0 && n <= n_out && lok )
+						{
+							*(f4*) ( P.dst + (long) li * P.d_lane +
+								(long) n * 4 ) = pend[ k ];
+						}
+					}
+				}
+
+				n_out++;
+			}
+		}
+
+		g++;
+
+		if( g <= gb )
+		{
+			endg = a_start[ g ] + nt - 1;
+		}
+
+		return( g > gbv );
+	};
+
+	for( ; ; )
+	{
+		if( body( std::integral_constant< int, 0 >() )) break;
+		if( body( std::integral_constant< int, 1 >() )) break;
+		if( body( std::integral_constant< int, 2 >() )) break;
+		if( body( std::integral_constant< int, 3 >() )) break;
+		if( body( std::integral_constant< int, 4 >() )) break;
+		if( body( std::integral_constant< int, 5 >() )) break;
+		if( body( std::integral_constant< int, 6 >() )) break;
+		if( body( std::integral_constant< int, 7 >() )) break;
+		if( body( std::integral_constant< int, 8 >() )) break;
+		if( body( std::integral_constant< int, 9 >() )) break;
+		if( body( std::integral_constant< int, 10 >() )) break;
+		if( body( std::integral_constant< int, 11 >() )) break;
+		if( body( std::integral_constant< int, 12 >() )) break;
+		if( body( std::integral_constant< int, 13 >() )) break;
+		if( body( std::integral_constant< int, 14 >() )) break;
+		if( body( std::integral_constant< int, 15 >() )) break;
+	}
+}
+
+// ---------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------
 
@@ -807,6 +1384,94 @@ int sacc_prepare_axis( const GPAxisHost& H, std::vector< void* >& allocs,
 		return( rc );
 	}
 
+	// k_sacc2's table: one coefficient per accumulator slot. Usable when an
+	// output can leave its slot at the end of the 4-sample group its last tap
+	// falls into, i.e. the slot's next output (16 later) starts after it.
+	{
+		const int tbase = (int) ( floor( u_min / 4.0 ) * 4.0 );
+		const int rows2 = u_max - tbase + 1;
+		bool ok2 = ( getenv( "AVIRHIP_NO_SACC2" ) == nullptr );
+
+		for( int g = 0; ok2 && g + 1 < A.g_len; g++ )
+		{
+			ok2 = ( st[ g + 1 ] > st[ g ]);
+		}
+
+		for( int g = 0; ok2 && g + 16 < A.g_len; g++ )
+		{
+			const int e = st[ g ] + nt - 1;
+			const int gend = (int) ( floor( e / 4.0 ) * 4.0 ) + 3;
+			ok2 = ( st[ g + 16 ] > gend );
+		}
+
+		if( ok2 )
+		{
+			std::vector< float > t2( (size_t) ( rows2 + 16 ) * 16, 0.0f );
+			int fi = 0, la = 0;
+
+			for( int r = 0; r < rows; r++ )
+			{
+				const int u = u_min + r;
+
+				while( fi < A.g_len - 1 && st[ fi ] + nt - 1 < u ) fi++;
+				while( la < A.g_len - 1 && st[ la + 1 ] <= u ) la++;
+
+				for( int g = fi; g <= la; g++ )
+				{
+					const float* const cr = H.h_coef + (size_t) (
+						H.h_fidx != nullptr ? H.h_fidx[ g ] : g ) * nt;
+
+					t2[ (size_t) ( u - tbase ) * 16 + ( g & 15 )] = cr[ u - st[ g ]];
+				}
+			}
+
+			// equal rows once (bit patterns), samples address them by offset
+			const size_t nr = (size_t) rows2 + 16;
+			std::vector< float > tu;
+			std::vector< int > ri( nr + 16, 0 );
+			std::map< std::array< uint32_t, 16 >, int > seen;
+
+			for( size_t r = 0; r < nr; r++ )
+			{
+				std::array< uint32_t, 16 > key;
+				memcpy( key.data(), &t2[ r * 16 ], 64 );
+				auto it = seen.find( key );
+
+				if( it == seen.end() )
+				{
+					it = seen.insert( std::make_pair( key,
+						(int) ( tu.size() * sizeof( float )))).first;
+
+					tu.insert( tu.end(), &t2[ r * 16 ], &t2[ r * 16 ] + 16 );
+				}
+
+				ri[ r ] = it -> second;
+			}
+
+			for( size_t r = nr; r < ri.size(); r++ )
+			{
+				ri[ r ] = ri[ nr - 1 ]; // (an all-zero row)
+			}
+
+			rc = sa_upload( allocs, tu.data(), tu.size() * sizeof( float ), &q );
+
+			if( rc == 0 )
+			{
+				D -> a.tab2 = (const float*) q;
+				rc = sa_upload( allocs, ri.data(), ri.size() * sizeof( int ), &q );
+			}
+
+			if( rc != 0 )
+			{
+				delete D;
+				return( rc );
+			}
+
+			D -> a.ridx = (const int*) q;
+			D -> a.tbase = tbase;
+		}
+	}
+
 	*out = D;
 	return( AVIRHIP_OK );
 }
@@ -814,6 +1479,25 @@ int sacc_prepare_axis( const GPAxisHost& H, std::vector< void* >& allocs,
 void sacc_release_axis( SAData* D )
 {
 	delete D;
+}
+
+template< int SRC, int CH, int NC >
+static void sa2_launch( const SAParams& P, int items, hipStream_t st )
+{
+	hipLaunchKernelGGL(( k_sacc2< SRC, CH, NC > ), dim3( items ), dim3( 64 ), 0,
+		st, P );
+}
+
+template< int SRC >
+static void sa2_launch1( const SAParams& P, int ch, int items, hipStream_t st )
+{
+	switch( ch )
+	{
+		case 1: sa2_launch< SRC, 1, 1 >( P, items, st ); break;
+		case 2: sa2_launch< SRC, 2, 2 >( P, items, st ); break;
+		case 3: sa2_launch< SRC, 3, 3 >( P, items, st ); break;
+		default: sa2_launch< SRC, 4, 4 >( P, items, st ); break;
+	}
 }
 
 template< int SRC, int CH, bool HOR, int NC >
@@ -847,7 +1531,7 @@ static void sa_launch1( const SAParams& P, int ch, int items, size_t lds,
 int sacc_run_axis( const SAData* D, bool rows, const void* src, int src_type,
 	int src_ch, int live_ch, long s_lane, long s_step, float* dst, long d_lane,
 	long d_step, int lane_lo, int lane_hi, int out_lo, int out_hi,
-	hipStream_t st, const GPOut* out )
+	hipStream_t st, const GPOut* out, bool finite, bool ladder )
 {
 	if( lane_hi <= lane_lo || out_hi <= out_lo )
 	{
@@ -894,8 +1578,14 @@ int sacc_run_axis( const SAData* D, bool rows, const void* src, int src_type,
 	// samples before its first output completes (they are multiplied into
 	// this chunk's outputs only: no arithmetic is repeated). The kernel is
 	// ALU-bound: whole rounds of the 1024 SIMDs, two or more waves on each.
-	const size_t lds = (size_t) ( dma ? 3 * 4096 : 8 * 1024 ) + SA_TQ * 256 + 64 +
-		( rows ? 4096 : 0 );
+	// k_sacc2: sources known to be finite -- the caller's integer image (row
+	// lanes) or the FltBuf made from one (column lanes)
+	const bool two = ( finite && !ladder && D -> a.tab2 != nullptr &&
+		P.ax.in_len >= 8 && rows && !dma && out == nullptr &&
+		( src_type == AVIRHIP_U8 || src_type == AVIRHIP_U16 ));
+
+	const size_t lds = ( two ? 0 : (size_t) ( dma ? 3 * 4096 : 8 * 1024 ) +
+		SA_TQ * 256 + 64 + ( rows ? 4096 : 0 ));
 
 	const double cap = 256.0 * std::max( 1, std::min( 16,
 		(int) ( 160 * 1024 / ( lds + 512 ))));
@@ -941,6 +1631,21 @@ int sacc_run_axis( const SAData* D, bool rows, const void* src, int src_type,
 	if( !dma && ( !rows || P.ax.in_len < 4 ))
 	{
 		return( 1 );
+	}
+
+	if( two )
+	{
+		if( src_type == AVIRHIP_U8 )
+		{
+			sa2_launch1< 1 >( P, src_ch, items, st );
+		}
+		else
+		{
+			sa2_launch1< 2 >( P, src_ch, items, st );
+		}
+
+		AVIRHIP_HIPCHECK( hipGetLastError() );
+		return( AVIRHIP_OK );
 	}
 
 	if( dma )

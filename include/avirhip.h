@@ -225,9 +225,14 @@ int avirhip_plan_get_path(const avirhip_plan* plan);
  *     vertical phase (the form a plan whose 2x bank phase is not bit-symmetric
  *     takes) instead of the transposed, product-sharing one;
  * AVIRHIP_VARIANT_DN_TWO_PASS   integer-ratio downsizing (k = 2, 3) runs its
- *     two pass kernels through FltBuf instead of the single fused launch. */
+ *     two pass kernels through FltBuf instead of the single fused launch;
+ * AVIRHIP_VARIANT_SACC_LADDER   the streaming-accumulation kernel of
+ *     downsizing axes runs its general form (one branch per alive output, the
+ *     form float sources take) where the branch-free form for integer sources
+ *     would run. */
 #define AVIRHIP_VARIANT_UP2_PLAIN_V 1
 #define AVIRHIP_VARIANT_DN_TWO_PASS 2
+#define AVIRHIP_VARIANT_SACC_LADDER 4
 int avirhip_plan_set_variant(avirhip_plan* plan, int variant);
 
 /* Executes H pass + V pass (+ integer epilogue) of `plan`:
