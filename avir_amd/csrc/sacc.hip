@@ -886,6 +886,135 @@ __device__ __forceinline__ void sa2_quad( f2* const A, f2* const B,
 	}
 }
 
+// The running state of a chunk's outputs
+struct SA2State
+{
+	int g;      // the next output to complete
+	int n_out;  // the next final output
+	int ga, gb; // accumulated outputs the chunk's correction FIR reads
+	int n0, n1; // the chunk's final outputs
+	int e, li;
+	bool lok;
+	float f0, f1, f2, f3;
+	float* dp;  // column lanes: the next output's pixel
+};
+
+// Output T.g leaves slot S (compile-time): through the correction FIR's
+// window into the destination. ROWS: four consecutive outputs are collected
+// and leave as 64 contiguous bytes of the lane's row (see k_sacc); column
+// lanes store a pixel per output, or go through the integer output stage.
+template< int NC, int S, bool ROWS >
+__device__ __forceinline__ void sa2_emit( SA2Acc< NC >& R, SAV< NC > ( &w )[ 8 ],
+	f4 ( &pend )[ 4 ], SA2State& T, const SAParams& P0 )
+{
+	typedef SAV< NC > PV;
+	// (column lanes: the parameters are read from the kernel argument segment
+	// HERE, through a pointer the compiler cannot see through: hoisted out of
+	// the sample loop they sat in scalar registers the coefficient rows need
+	// and came back from their spill slots by dozens of v_readlanes per
+	// output. Row lanes use few of them: there the reloads cost more.)
+	(void) P0;
+	typedef const __attribute__(( address_space( 4 ))) SAParams CP;
+	CP* Pq = (CP*) __builtin_amdgcn_kernarg_segment_ptr(); // (the only argument)
+
+	if( !ROWS )
+	{
+		asm volatile( "" : "+s"( Pq ));
+	}
+
+	CP& P = *Pq;
+	PV val = PV::zero();
+
+	if( NC >= 2 ) val.a = R.A[ S ];
+	else val.a.x = R.BB[ S >> 1 ][ S & 1 ];
+
+	if( NC == 4 ) val.b = R.B[ S ];
+	else if( NC == 3 ) val.b.x = R.BB[ S >> 1 ][ S & 1 ];
+
+	R.A[ S ] = (f2) 0.0f;
+	R.B[ S ] = (f2) 0.0f;
+	R.BB[ S >> 1 ][ S & 1 ] = 0.0f;
+
+	if( T.g < T.ga )
+	{
+		return; // alive at the chunk's first sample, not the chunk's own
+	}
+
+	if( T.g > T.gb )
+	{
+		val = w[ ( S + 7 ) & 7 ]; // past the last one the edge value repeats
+	}
+
+	w[ S & 7 ] = val;
+
+	if( T.g == T.ga && T.n0 - T.e - 3 < 0 )
+	{
+#pragma unroll
+		for( int i = 0; i < 8; i++ )
+		{
+			w[ i ] = val;
+		}
+	}
+
+	// output n = g + e - 3: f0*G[c] + sum f_i*( G[c+i] + G[c-i] ), c = g - 3
+	if( T.g < T.n0 - T.e + 3 )
+	{
+		return;
+	}
+
+	PV r = w[ ( S + 5 ) & 7 ].scale( T.f0 );
+	r = r.madd( T.f1, w[ ( S + 6 ) & 7 ].madd1( w[ ( S + 4 ) & 7 ]));
+	r = r.madd( T.f2, w[ ( S + 7 ) & 7 ].madd1( w[ ( S + 3 ) & 7 ]));
+	r = r.madd( T.f3, w[ S & 7 ].madd1( w[ ( S + 2 ) & 7 ]));
+
+	if( ROWS )
+	{
+		// pend[ k ] holds the output n with n % 4 == ( k + dsh ) % 4
+		pend[ S & 3 ] = r.to4();
+
+		if(( T.n_out & 3 ) == 3 || T.n_out == T.n1 - 1 )
+		{
+			const int dsh = ( T.n_out - S ) & 3;
+			const int nb = T.n_out & ~3;
+#pragma unroll
+			for( int k = 0; k < 4; k++ )
+			{
+				const int n = nb + (( k + dsh ) & 3 );
+
+				if( n >= T.n0 && n <= T.n_out && T.lok )
+				{
+					*(f4*) ( P.dst + (long) T.li * P.d_lane + (long) n * 4 ) =
+						pend[ k ];
+				}
+			}
+		}
+	}
+	else
+	if( P.out.on != 0 )
+	{
+		if( T.lok )
+		{
+			GPOut O;
+			O.on = 1; O.type = P.out.type; O.ch = P.out.ch;
+			O.use_tr = P.out.use_tr; O.tr_mul = P.out.tr_mul;
+			O.tr_muli = P.out.tr_muli; O.pk_out = P.out.pk_out;
+			O.base = P.out.base; O.stride = P.out.stride;
+			gp_store_int( O, T.n_out - P.out_lo, T.li, r.to4() );
+		}
+	}
+	else
+	{
+		if( T.lok )
+		{
+			*(f4*) T.dp = r.to4();
+		}
+
+		T.dp += P.d_step;
+	}
+
+	T.n_out++;
+}
+
 // SRC 1 / 2: uint8 / uint16 pixels of CH channels; lanes are image ROWS (the
 // caller's image: the first pass of a plan with an integer source)
 template< int SRC, int CH, int NC >
@@ -1052,10 +1181,12 @@ __global__ void __launch_bounds__( 64 ) k_sacc2( const SAParams P )
 		pend[ i ] = (f4) 0.0f;
 	}
 
-	const float f0 = A.f[ 0 ], f1c = A.f[ 1 ], f2c = A.f[ 2 ], f3c = A.f[ 3 ];
-	int g = a_first[ u_a - A.u_min ]; // the next output to complete (<= ga)
-	int endg = a_start[ g ] + nt - 1; // its last sample
-	int n_out = n0;
+	SA2State T;
+	T.g = a_first[ u_a - A.u_min ]; // (<= ga)
+	T.n_out = n0; T.ga = ga; T.gb = gb; T.n0 = n0; T.n1 = n1; T.e = A.e;
+	T.li = li; T.lok = lok; T.dp = nullptr;
+	T.f0 = A.f[ 0 ]; T.f1 = A.f[ 1 ]; T.f2 = A.f[ 2 ]; T.f3 = A.f[ 3 ];
+	int endg = a_start[ T.g ] + nt - 1; // the last sample of output T.g
 
 	// the first group: loaded, fixed up, the block of u_a at the bottom
 #pragma unroll
@@ -1116,7 +1247,7 @@ __global__ void __launch_bounds__( 64 ) k_sacc2( const SAParams P )
 
 	int qn = q_a;              // the next block of samples
 	int ulast = q_a * 4 - 1;   // the last sample multiplied in
-	const int s0 = g & 15;     // slot of the first output to complete
+	const int s0 = T.g & 15;     // slot of the first output to complete
 	bool started = false;
 
 	auto step = [&]( const int j, const f16v& c )
@@ -1153,7 +1284,7 @@ __global__ void __launch_bounds__( 64 ) k_sacc2( const SAParams P )
 		}
 
 #pragma clang loop unroll( disable )
-		while( g <= gb && endg > ulast )
+		while( T.g <= gb && endg > ulast )
 		{
 			SA2_LGKM_WAIT();
 			rows2( cb0, cb1, ia[ 2 ], ia[ 3 ]);
@@ -1182,77 +1313,15 @@ __global__ void __launch_bounds__( 64 ) k_sacc2( const SAParams P )
 			}
 		}
 
-		PV val = PV::zero();
+		sa2_emit< NC, S, true >( R, w, pend, T, P );
+		T.g++;
 
-		if( NC >= 2 ) val.a = R.A[ S ];
-		else val.a.x = R.BB[ S >> 1 ][ S & 1 ];
-
-		if( NC == 4 ) val.b = R.B[ S ];
-		else if( NC == 3 ) val.b.x = R.BB[ S >> 1 ][ S & 1 ];
-
-		R.A[ S ] = (f2) 0.0f;
-		R.B[ S ] = (f2) 0.0f;
-		R.BB[ S >> 1 ][ S & 1 ] = 0.0f;
-
-		if( g >= ga ) // (else: alive at the chunk's first sample, not its own)
+		if( T.g <= gb )
 		{
-			if( g > gb )
-			{
-				val = w[ ( S + 7 ) & 7 ]; // past the last one the edge repeats
-			}
-
-			w[ S & 7 ] = val;
-
-			if( g == ga && n0 - A.e - 3 < 0 )
-			{
-#pragma unroll
-				for( int i = 0; i < 8; i++ )
-				{
-					w[ i ] = val;
-				}
-			}
-
-			// output n = g + e - 3: f0*G[c] + sum f_i*( G[c+i] + G[c-i] ),
-			// c = g - 3
-			if( g >= n0 - A.e + 3 )
-			{
-				PV r = w[ ( S + 5 ) & 7 ].scale( f0 );
-				r = r.madd( f1c, w[ ( S + 6 ) & 7 ].madd1( w[ ( S + 4 ) & 7 ]));
-				r = r.madd( f2c, w[ ( S + 7 ) & 7 ].madd1( w[ ( S + 3 ) & 7 ]));
-				r = r.madd( f3c, w[ S & 7 ].madd1( w[ ( S + 2 ) & 7 ]));
-
-				// pend[ k ] holds the output n with n % 4 == ( k + dsh ) % 4
-				pend[ S & 3 ] = r.to4();
-
-				if(( n_out & 3 ) == 3 || n_out == n1 - 1 )
-				{
-					const int dsh = ( n_out - S ) & 3;
-					const int nb = n_out & ~3;
-#pragma unroll
-					for( int k = 0; k < 4; k++ )
-					{
-						const int n = nb + (( k + dsh ) & 3 );
-
-						if( n >= n0 && n <= n_out && lok )
-						{
-							*(f4*) ( P.dst + (long) li * P.d_lane +
-								(long) n * 4 ) = pend[ k ];
-						}
-					}
-				}
-
-				n_out++;
-			}
+			endg = a_start[ T.g ] + nt - 1;
 		}
 
-		g++;
-
-		if( g <= gb )
-		{
-			endg = a_start[ g ] + nt - 1;
-		}
-
-		return( g > gbv );
+		return( T.g > gbv );
 	};
 
 	for( ; ; )
@@ -1274,6 +1343,265 @@ __global__ void __launch_bounds__( 64 ) k_sacc2( const SAParams P )
 		if( body( std::integral_constant< int, 14 >() )) break;
 		if( body( std::integral_constant< int, 15 >() )) break;
 	}
+}
+
+// The same for the SECOND pass of such a plan: lanes are pixel COLUMNS of the
+// float RGBA intermediate (FltBuf), a sample is one of its rows. The rows
+// travel HBM -> LDS by LDS-DMA (1 KiB per row and instruction, no registers),
+// three blocks of four rows ahead of the block being multiplied in; a block's
+// four pixels are read from LDS while the block before it runs. Rows outside
+// [ulo, uhi] -- not written by this call's first pass, possibly not finite --
+// are never touched: the nearest row inside stands in (its taps are zeros or
+// belong to outputs of other chunks).
+// (A lane per CHANNEL of a pixel column -- three times the strips, so three
+// times longer chunks and less of the 36-sample run-in per chunk -- was built
+// and measured: 59.9 us against 51.0 us for the README photo case. A sample
+// is then only 128 cycles of arithmetic, too little to hide a scalar load
+// behind, and every output costs its own trip through the correction filter
+// and the output stage three times.)
+#define SA2V_PF 3    // blocks of four rows in flight or landed ahead of use
+#define SA2V_RB 4    // blocks in the LDS ring (a power of two > SA2V_PF)
+#define SA2V_RING ( SA2V_RB * 4 ) // rows in the ring
+#define SA2V_WAIT() GP_WAIT_VM( 8 ) // ( SA2V_PF - 1 ) * 4 younger operations
+
+template< int NC >
+__global__ void __launch_bounds__( 64 ) k_sacc2v( const SAParams P )
+{
+	typedef SAV< NC > PV;
+	extern __shared__ __attribute__(( aligned( 16 ))) char smem[];
+	const f4* const ring = (const f4*) smem;
+	const SAAxis& A = P.ax;
+
+	const int lane = threadIdx.x;
+	const int strip = blockIdx.x % P.nstrips;
+	const int chunk = blockIdx.x / P.nstrips;
+	const int l0 = P.lane_lo + strip * 64;
+	const int li = l0 + lane;
+	const bool lok = ( li < P.lane_hi );
+	const int lc = min( li, P.lane_hi - 1 );
+	const int n0 = P.out_lo + chunk * P.chunk;
+	const int n1 = min( n0 + P.chunk, P.out_hi );
+
+	if( n0 >= n1 )
+	{
+		return;
+	}
+
+	gp_cint* const a_start = (gp_cint*) (unsigned long) A.start;
+	gp_cint* const a_first = (gp_cint*) (unsigned long) A.first;
+	const int nt = A.nt;
+	const int glast = A.g_len - 1;
+	const int slast = A.in_len - 1;
+	const int ga = gp_clamp( n0 - A.e - 3, glast );
+	const int gb = gp_clamp( n1 - 1 - A.e + 3, glast );
+	const int gbv = n1 - 1 - A.e + 3;
+	const int u_a = a_start[ ga ];
+	const int u_e = a_start[ gb ] + nt - 1;
+	const int ulo = max( u_a, 0 );
+	const int uhi = min( u_e, slast );
+	const int q_a = u_a >> 2;
+
+	const unsigned lds0 = (unsigned) (unsigned long) (lds_char*) smem;
+	const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+		(void*) P.src, 0, 0x7fffffff, 0x00020000 );
+	const int voff = lc * (int) P.s_lane;
+	const unsigned sstep = (unsigned) P.s_step;
+
+	auto d_issue = [&]( const int qb ) // the four rows of block qb
+	{
+#pragma unroll
+		for( int j = 0; j < 4; j++ )
+		{
+			const int uu = min( max( qb * 4 + j, ulo ), uhi );
+			df_dma( rsrc, lds0 + (unsigned) ((( qb & ( SA2V_RB - 1 )) * 4 + j ) *
+				1024 ), voff, (unsigned) uu * sstep );
+		}
+	};
+
+	PV x[ 4 ];
+	auto x_read = [&]( const int qb )
+	{
+#pragma unroll
+		for( int j = 0; j < 4; j++ )
+		{
+			x[ j ] = PV::from( ring[ (( qb & ( SA2V_RB - 1 )) * 4 + j ) * 64 +
+				lane ]);
+		}
+
+		if( qb == q_a )
+		{
+			// the samples before the chunk's first one count as zeros (their
+			// table rows belong to earlier outputs, whose slots stay clean)
+#pragma unroll
+			for( int j = 0; j < 3; j++ )
+			{
+				if( qb * 4 + j < u_a )
+				{
+					x[ j ] = PV::zero();
+				}
+			}
+		}
+	};
+
+	SA2Acc< NC > R;
+#pragma unroll
+	for( int i = 0; i < 16; i++ )
+	{
+		R.A[ i ] = (f2) 0.0f; R.B[ i ] = (f2) 0.0f; R.BB[ i >> 1 ] = (f2) 0.0f;
+	}
+
+	PV w[ 8 ];
+#pragma unroll
+	for( int i = 0; i < 8; i++ )
+	{
+		w[ i ] = PV::zero();
+	}
+
+	f4 pend[ 4 ]; // (row lanes only)
+
+	SA2State T;
+	T.g = a_first[ u_a - A.u_min ]; // (<= ga)
+	T.n_out = n0; T.ga = ga; T.gb = gb; T.n0 = n0; T.n1 = n1; T.e = A.e;
+	T.li = li; T.lok = lok;
+	T.dp = P.dst + (long) li * P.d_lane + (long) n0 * P.d_step;
+	T.f0 = A.f[ 0 ]; T.f1 = A.f[ 1 ]; T.f2 = A.f[ 2 ]; T.f3 = A.f[ 3 ];
+	int endg = a_start[ T.g ] + nt - 1; // the last sample of output T.g
+
+#pragma unroll
+	for( int i = 0; i < SA2V_PF; i++ )
+	{
+		d_issue( q_a + i );
+	}
+
+	SA2V_WAIT(); // loads retire in order: block q_a has landed
+	x_read( q_a );
+
+	// ---- the table feed (see k_sacc2)
+	gp_cfloat* const tabu = (gp_cfloat*) (unsigned long) A.tab2;
+	gp_cint* ip = (gp_cint*) (unsigned long) A.ridx + ( q_a * 4 - A.tbase );
+
+	auto rows2 = [&]( f16v& lo, f16v& hi, const int o0, const int o1 )
+	{
+		asm volatile( "s_load_dwordx16 %0, %2, %3\n\t"
+			"s_load_dwordx16 %1, %2, %4"
+			: "=&s"( lo ), "=&s"( hi ) : "s"( tabu ), "s"( o0 ), "s"( o1 )
+			: "memory" );
+	};
+
+	typedef int i4v __attribute__(( ext_vector_type( 4 )));
+	auto idx4 = [&]( i4v& d, gp_cint* const q )
+	{
+		asm volatile( "s_load_dwordx4 %0, %1, 0x0" : "=&s"( d ) : "s"( q )
+			: "memory" );
+	};
+
+	// row offsets of this block's samples (ia), the next block's (ib), and the
+	// one after it (ic, in flight)
+	i4v ia, ib, ic;
+	idx4( ia, ip );
+	idx4( ib, ip + 4 );
+	ic = ib;
+	SA2_LGKM_WAIT();
+	f16v ca0, ca1, cb0, cb1;
+	rows2( ca0, ca1, ia[ 0 ], ia[ 1 ]);
+	cb0 = ca0; cb1 = ca1;
+	ip += 8;
+
+	int qn = q_a;
+	int ulast = q_a * 4 - 1;
+	const int s0 = T.g & 15;
+	bool started = false;
+
+	auto step = [&]( const int j, const f16v& c )
+	{
+#pragma unroll
+		for( int k = 0; k < 4; k++ )
+		{
+			f2 c0, c1;
+			c0.x = c[ k * 4 ]; c0.y = c[ k * 4 + 1 ];
+			c1.x = c[ k * 4 + 2 ]; c1.y = c[ k * 4 + 3 ];
+			sa2_quad< NC >( &R.A[ k * 4 ], &R.B[ k * 4 ], &R.BB[ k * 2 ],
+				x[ j ].a, x[ j ].b, c0, c1 );
+		}
+	};
+
+	auto body = [&]( auto SC ) -> bool
+	{
+		constexpr int S = decltype( SC )::value;
+
+		if( !started )
+		{
+			if( S != s0 )
+			{
+				return( false );
+			}
+
+			started = true;
+		}
+
+#pragma clang loop unroll( disable )
+		while( T.g <= gb && endg > ulast )
+		{
+			SA2_LGKM_WAIT();
+			// (the block's pixels, read from LDS a block ago: used HERE as far
+			// as the compiler is concerned, so that its own wait for them
+			// comes before the next scalar loads go out, not after)
+			asm volatile( "" : "+v"( x[ 0 ].a ), "+v"( x[ 1 ].a ), "+v"( x[ 2 ].a ),
+				"+v"( x[ 3 ].a ), "+v"( x[ 0 ].b ), "+v"( x[ 1 ].b ),
+				"+v"( x[ 2 ].b ), "+v"( x[ 3 ].b ));
+			rows2( cb0, cb1, ia[ 2 ], ia[ 3 ]);
+			idx4( ic, ip );
+			step( 0, ca0 );
+			step( 1, ca1 );
+			SA2_LGKM_WAIT();
+			rows2( ca0, ca1, ib[ 0 ], ib[ 1 ]);
+			step( 2, cb0 );
+			step( 3, cb1 );
+			ia = ib;
+			ib = ic;
+			ip += 4;
+			qn++;
+			ulast += 4;
+			// the next block goes out into slots read long ago; with only
+			// the operations of the SA2V_PF - 1 blocks after qn (or fewer:
+			// stores) outstanding, block qn has landed
+			d_issue( qn + SA2V_PF - 1 );
+			SA2V_WAIT();
+			x_read( qn );
+		}
+
+		sa2_emit< NC, S, false >( R, w, pend, T, P );
+		T.g++;
+
+		if( T.g <= gb )
+		{
+			endg = a_start[ T.g ] + nt - 1;
+		}
+
+		return( T.g > gbv );
+	};
+
+	for( ; ; )
+	{
+		if( body( std::integral_constant< int, 0 >() )) break;
+		if( body( std::integral_constant< int, 1 >() )) break;
+		if( body( std::integral_constant< int, 2 >() )) break;
+		if( body( std::integral_constant< int, 3 >() )) break;
+		if( body( std::integral_constant< int, 4 >() )) break;
+		if( body( std::integral_constant< int, 5 >() )) break;
+		if( body( std::integral_constant< int, 6 >() )) break;
+		if( body( std::integral_constant< int, 7 >() )) break;
+		if( body( std::integral_constant< int, 8 >() )) break;
+		if( body( std::integral_constant< int, 9 >() )) break;
+		if( body( std::integral_constant< int, 10 >() )) break;
+		if( body( std::integral_constant< int, 11 >() )) break;
+		if( body( std::integral_constant< int, 12 >() )) break;
+		if( body( std::integral_constant< int, 13 >() )) break;
+		if( body( std::integral_constant< int, 14 >() )) break;
+		if( body( std::integral_constant< int, 15 >() )) break;
+	}
+
+	GP_WAIT_VM( 0 ); // no LDS-DMA may outlive the workgroup's LDS
 }
 
 // ---------------------------------------------------------------------
@@ -1570,9 +1898,7 @@ int sacc_run_axis( const SAData* D, bool rows, const void* src, int src_type,
 		return( 1 );
 	}
 
-	const int lanes = lane_hi - lane_lo;
 	const int nout = out_hi - out_lo;
-	P.nstrips = ( lanes + 63 ) / 64;
 
 	// Outputs per work item: a chunk's only overhead is feeding the NT
 	// samples before its first output completes (they are multiplied into
@@ -1581,11 +1907,17 @@ int sacc_run_axis( const SAData* D, bool rows, const void* src, int src_type,
 	// k_sacc2: sources known to be finite -- the caller's integer image (row
 	// lanes) or the FltBuf made from one (column lanes)
 	const bool two = ( finite && !ladder && D -> a.tab2 != nullptr &&
-		P.ax.in_len >= 8 && rows && !dma && out == nullptr &&
-		( src_type == AVIRHIP_U8 || src_type == AVIRHIP_U16 ));
+		P.ax.in_len >= 8 && (( rows && !dma && out == nullptr &&
+		( src_type == AVIRHIP_U8 || src_type == AVIRHIP_U16 )) ||
+		( !rows && dma && s_lane == 16 &&
+		(double) s_step * P.ax.in_len < 2147483648.0 )));
 
-	const size_t lds = ( two ? 0 : (size_t) ( dma ? 3 * 4096 : 8 * 1024 ) +
-		SA_TQ * 256 + 64 + ( rows ? 4096 : 0 ));
+	const size_t lds = ( two ? ( rows ? 0 : SA2V_RING * 1024 ) :
+		(size_t) ( dma ? 3 * 4096 : 8 * 1024 ) + SA_TQ * 256 + 64 +
+		( rows ? 4096 : 0 ));
+
+	const int lanes = P.lane_hi - P.lane_lo;
+	P.nstrips = ( lanes + 63 ) / 64;
 
 	const double cap = 256.0 * std::max( 1, std::min( 16,
 		(int) ( 160 * 1024 / ( lds + 512 ))));
@@ -1627,6 +1959,11 @@ int sacc_run_axis( const SAData* D, bool rows, const void* src, int src_type,
 		P.chunk = std::max( 1, atoi( getenv( "AVIRHIP_SA_CHUNK" )));
 	}
 
+	if( !rows && getenv( "AVIRHIP_SA_CHUNK_V" ) != nullptr )
+	{
+		P.chunk = std::max( 1, atoi( getenv( "AVIRHIP_SA_CHUNK_V" )));
+	}
+
 	const int items = P.nstrips * (( nout + P.chunk - 1 ) / P.chunk );
 	if( !dma && ( !rows || P.ax.in_len < 4 ))
 	{
@@ -1635,6 +1972,20 @@ int sacc_run_axis( const SAData* D, bool rows, const void* src, int src_type,
 
 	if( two )
 	{
+		if( !rows )
+		{
+			if( live_ch == 3 )
+			{
+				hipLaunchKernelGGL(( k_sacc2v< 3 > ), dim3( items ), dim3( 64 ),
+					lds, st, P );
+			}
+			else
+			{
+				hipLaunchKernelGGL(( k_sacc2v< 4 > ), dim3( items ), dim3( 64 ),
+					lds, st, P );
+			}
+		}
+		else
 		if( src_type == AVIRHIP_U8 )
 		{
 			sa2_launch1< 1 >( P, src_ch, items, st );
