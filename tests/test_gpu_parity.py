@@ -1267,6 +1267,47 @@ def test_avir_streaming_accumulation_kernel(sw, sh, nw, nh, ch, tin):
     _assert_same(out, want, "sacc bands")
 
 
+@pytest.mark.parametrize("ch,tin,tout", [(3, np.uint8, np.uint8),
+                                         (4, np.uint8, np.float32),
+                                         (1, np.uint16, np.uint16),
+                                         (2, np.uint8, np.uint8),
+                                         (3, np.uint16, np.uint8)])
+def test_avir_streaming_accumulation_both_forms_on_integer_sources(ch, tin, tout):
+    """Integer sources take the branch-free form of the accumulation kernels
+    (k_sacc2 / k_sacc2v: a table entry per accumulator slot, every sample
+    multiplied into all 16 slots -- which is why the source has to be finite);
+    AVIRHIP_VARIANT_SACC_LADDER runs the general form (the one float sources
+    take) on the same plan. Both against the reference, frames and bands: a
+    band's second pass must not touch FltBuf rows its first pass did not
+    write."""
+    lib = abi.load()
+    for (sw, sh, nw, nh) in SACC[:8] + [(1300, 900, 481, 333)]:
+        src = rb.lcg_u8((sh, sw, ch, np.dtype(tin).itemsize), seed=sw + ch)
+        src = src.view(tin).reshape(sh, sw, ch)
+        bits = 8 * np.dtype(tin).itemsize
+        want = _checker_avir(src, nw, nh, resbits=bits, out_dtype=tout)
+        for var in (0, abi.VARIANT_SACC_LADDER):
+            r = avir_amd.CImageResizer(bits)
+            p = r.plan(sw, sh, nw, nh, ch, 0.0, None, rb._DT[src.dtype],
+                       rb._DT[np.dtype(tout)])
+            if lib.avirhip_plan_set_path(p, abi.PATH_GPASS) != 0:
+                continue
+            abi.check(lib.avirhip_plan_set_variant(p, var), "set_variant")
+            out = np.zeros((nh, nw, ch), tout)
+            abi.check(lib.avirhip_resize_band(
+                p, src.ctypes.data, abi.MEM_HOST, out.ctypes.data,
+                abi.MEM_HOST, 0, nh, None), "frame")
+            _assert_same(out, want, "sacc form %d %r" % (var, (sw, sh, nw, nh)))
+            out = np.full((nh, nw, ch), 7, tout)
+            for a_, b_ in [(0, nh // 3), (nh // 3, nh // 3 + 1),
+                           (nh // 3 + 1, nh)]:
+                if b_ > a_:
+                    abi.check(lib.avirhip_resize_band(
+                        p, src.ctypes.data, abi.MEM_HOST, out[a_:b_].ctypes.data,
+                        abi.MEM_HOST, a_, b_, None), "band")
+            _assert_same(out, want, "sacc form %d bands" % var)
+
+
 @pytest.mark.parametrize("ch", [1, 3, 4])
 @pytest.mark.parametrize("tin,tout,bits", [
     (np.uint8, np.uint8, 8), (np.uint16, np.uint16, 16),
