@@ -896,7 +896,7 @@ struct SA2State
 	int e, li;
 	bool lok;
 	float f0, f1, f2, f3;
-	float* dp;  // column lanes: the next output's pixel
+	float* dp;  // column lanes: the next output's pixel; row lanes: the lane's row
 };
 
 // Output T.g leaves slot S (compile-time): through the correction FIR's
@@ -983,8 +983,7 @@ __device__ __forceinline__ void sa2_emit( SA2Acc< NC >& R, SAV< NC > ( &w )[ 8 ]
 
 				if( n >= T.n0 && n <= T.n_out && T.lok )
 				{
-					*(f4*) ( P.dst + (long) T.li * P.d_lane + (long) n * 4 ) =
-						pend[ k ];
+					*(f4*) ( T.dp + (long) n * 4 ) = pend[ k ]; // (dp: the lane's row)
 				}
 			}
 		}
@@ -1184,7 +1183,7 @@ __global__ void __launch_bounds__( 64 ) k_sacc2( const SAParams P )
 	SA2State T;
 	T.g = a_first[ u_a - A.u_min ]; // (<= ga)
 	T.n_out = n0; T.ga = ga; T.gb = gb; T.n0 = n0; T.n1 = n1; T.e = A.e;
-	T.li = li; T.lok = lok; T.dp = nullptr;
+	T.li = li; T.lok = lok; T.dp = P.dst + (long) li * P.d_lane;
 	T.f0 = A.f[ 0 ]; T.f1 = A.f[ 1 ]; T.f2 = A.f[ 2 ]; T.f3 = A.f[ 3 ];
 	int endg = a_start[ T.g ] + nt - 1; // the last sample of output T.g
 
@@ -1283,6 +1282,9 @@ __global__ void __launch_bounds__( 64 ) k_sacc2( const SAParams P )
 			started = true;
 		}
 
+		// (the next output's first sample: loaded here, used after this one left)
+		const int nst = a_start[ min( T.g + 1, gb )];
+
 #pragma clang loop unroll( disable )
 		while( T.g <= gb && endg > ulast )
 		{
@@ -1318,7 +1320,7 @@ __global__ void __launch_bounds__( 64 ) k_sacc2( const SAParams P )
 
 		if( T.g <= gb )
 		{
-			endg = a_start[ T.g ] + nt - 1;
+			endg = nst + nt - 1;
 		}
 
 		return( T.g > gbv );
@@ -1539,6 +1541,9 @@ __global__ void __launch_bounds__( 64 ) k_sacc2v( const SAParams P )
 			started = true;
 		}
 
+		// (the next output's first sample: loaded here, used after this one left)
+		const int nst = a_start[ min( T.g + 1, gb )];
+
 #pragma clang loop unroll( disable )
 		while( T.g <= gb && endg > ulast )
 		{
@@ -1575,7 +1580,7 @@ __global__ void __launch_bounds__( 64 ) k_sacc2v( const SAParams P )
 
 		if( T.g <= gb )
 		{
-			endg = a_start[ T.g ] + nt - 1;
+			endg = nst + nt - 1;
 		}
 
 		return( T.g > gbv );
@@ -1779,6 +1784,15 @@ int sacc_prepare_axis( const GPAxisHost& H, std::vector< void* >& allocs,
 			for( size_t r = nr; r < ri.size(); r++ )
 			{
 				ri[ r ] = ri[ nr - 1 ]; // (an all-zero row)
+			}
+
+			if( getenv( "AVIRHIP_SA2_SAMEROW" ) != nullptr ) // timing experiment
+			{
+				for( size_t r = 0; r < ri.size(); r++ )
+				{
+					ri[ r ] = ( atoi( getenv( "AVIRHIP_SA2_SAMEROW" )) == 2 ?
+						(int) ( r % 8 ) * 64 : 0 );
+				}
 			}
 
 			rc = sa_upload( allocs, tu.data(), tu.size() * sizeof( float ), &q );
