@@ -42,6 +42,12 @@ template<int MODE> __global__ void __launch_bounds__(64) k(float* out, f2 c0, f2
 			"v_add_f32 %0, %0, %6\n v_add_f32 %1, %1, %7\n v_add_f32 %2, %2, %8\n v_add_f32 %3, %3, %9\n v_add_f32 %4, %4, %10\n v_add_f32 %5, %5, %11"
 			: "+v"(a[0].x), "+v"(a[1].x), "+v"(a[2].x), "+v"(a[3].x), "+v"(a[4].x), "+v"(a[5].x), "=&v"(p[0].x), "=&v"(p[1].x), "=&v"(p[2].x), "=&v"(p[3].x), "=&v"(p[4].x), "=&v"(p[5].x)
 			: "s"(c0.x), "s"(c0.y), "v"(x0.x), "v"(x1.x));
+		if (MODE == 11) asm volatile( // the quad with the scalar pair as src1 everywhere
+			"v_pk_mul_f32 %6, %12, %14 op_sel_hi:[1,0]\n v_pk_mul_f32 %7, %12, %14 op_sel:[0,1] op_sel_hi:[1,1]\n v_pk_mul_f32 %8, %13, %14 op_sel_hi:[0,1]\n"
+			"v_pk_mul_f32 %9, %12, %15 op_sel_hi:[1,0]\n v_pk_mul_f32 %10, %12, %15 op_sel:[0,1] op_sel_hi:[1,1]\n v_pk_mul_f32 %11, %13, %15 op_sel_hi:[0,1]\n"
+			"v_pk_add_f32 %0, %0, %6\n v_pk_add_f32 %1, %1, %7\n v_pk_add_f32 %2, %2, %8\n v_pk_add_f32 %3, %3, %9\n v_pk_add_f32 %4, %4, %10\n v_pk_add_f32 %5, %5, %11"
+			: "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "=&v"(p[0]), "=&v"(p[1]), "=&v"(p[2]), "=&v"(p[3]), "=&v"(p[4]), "=&v"(p[5])
+			: "v"(x0), "v"(x1), "s"(c0), "s"(c1));
 		if (MODE == 6) asm volatile(
 			"v_pk_mul_f32 %0, %0, %6\n v_pk_mul_f32 %1, %1, %6\n v_pk_mul_f32 %2, %2, %6\n v_pk_mul_f32 %3, %3, %6\n v_pk_mul_f32 %4, %4, %6\n v_pk_mul_f32 %5, %5, %6\n"
 			"v_pk_mul_f32 %0, %0, %7\n v_pk_mul_f32 %1, %1, %7\n v_pk_mul_f32 %2, %2, %7\n v_pk_mul_f32 %3, %3, %7\n v_pk_mul_f32 %4, %4, %7\n v_pk_mul_f32 %5, %5, %7"
@@ -103,6 +109,42 @@ template<int D> __global__ void __launch_bounds__(64) k12(float* out, f2 c0, f2 
 	float s = 0; for (int i = 0; i < 12; i++) s += a[i].x + a[i].y;
 	out[blockIdx.x * 64 + threadIdx.x] = s;
 }
+// the row-wave statement of dnf.hip: one input, NA taps: NA v_pk_mul_f32 (SGPR pair, op_sel) then NA v_pk_add_f32
+// into NA accumulators; the statement repeats for the next input on the SAME accumulators
+template<int NA> __global__ void __launch_bounds__(64) kna(float* out, f2 c0, f2 c1, int iters)
+{
+	f2 a[6], p[6], x0 = {1.0f + threadIdx.x, 2.0f};
+	for (int i = 0; i < 6; i++) { a[i] = (f2) (float) i; p[i] = (f2) 0.0f; }
+	for (int it = 0; it < iters; it++) {
+#pragma unroll
+		for (int r = 0; r < 12 / NA; r++) {
+			if (NA == 2) asm volatile("v_pk_mul_f32 %2, %4, %5 op_sel_hi:[1,0]\n v_pk_mul_f32 %3, %4, %6 op_sel:[0,1] op_sel_hi:[1,1]\n v_pk_add_f32 %0, %0, %2\n v_pk_add_f32 %1, %1, %3"
+				: "+v"(a[0]), "+v"(a[1]), "=&v"(p[0]), "=&v"(p[1]) : "v"(x0), "s"(c0), "s"(c1));
+			if (NA == 3) asm volatile("v_pk_mul_f32 %3, %6, %7 op_sel_hi:[1,0]\n v_pk_mul_f32 %4, %6, %8 op_sel:[0,1] op_sel_hi:[1,1]\n v_pk_mul_f32 %5, %6, %8 op_sel_hi:[1,0]\n"
+				"v_pk_add_f32 %0, %0, %3\n v_pk_add_f32 %1, %1, %4\n v_pk_add_f32 %2, %2, %5"
+				: "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "=&v"(p[0]), "=&v"(p[1]), "=&v"(p[2]) : "v"(x0), "s"(c0), "s"(c1));
+			if (NA == 6) asm volatile("v_pk_mul_f32 %6, %12, %13 op_sel_hi:[1,0]\n v_pk_mul_f32 %7, %12, %14 op_sel:[0,1] op_sel_hi:[1,1]\n v_pk_mul_f32 %8, %12, %14 op_sel_hi:[1,0]\n"
+				"v_pk_mul_f32 %9, %12, %13 op_sel:[0,1] op_sel_hi:[1,1]\n v_pk_mul_f32 %10, %12, %14 op_sel_hi:[1,0]\n v_pk_mul_f32 %11, %12, %13 op_sel_hi:[1,0]\n"
+				"v_pk_add_f32 %0, %0, %6\n v_pk_add_f32 %1, %1, %7\n v_pk_add_f32 %2, %2, %8\n v_pk_add_f32 %3, %3, %9\n v_pk_add_f32 %4, %4, %10\n v_pk_add_f32 %5, %5, %11"
+				: "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "=&v"(p[0]), "=&v"(p[1]), "=&v"(p[2]), "=&v"(p[3]), "=&v"(p[4]), "=&v"(p[5]) : "v"(x0), "s"(c0), "s"(c1));
+		}
+	}
+	float s = 0; for (int i = 0; i < 6; i++) s += a[i].x + a[i].y;
+	out[blockIdx.x * 64 + threadIdx.x] = s;
+}
+template<int NA> static int runna(const char* label, float* out)
+{
+	hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+	const int iters = 50000;
+	for (int wps = 1; wps <= 4; wps++) {
+		const int grid = 1024 * wps; f2 c0 = {1.0001f, 0.9999f}, c1 = {1.00001f, 0.99999f};
+		hipLaunchKernelGGL(kna<NA>, dim3(grid), dim3(64), 0, 0, out, c0, c1, iters); CK(hipDeviceSynchronize());
+		CK(hipEventRecord(e0)); hipLaunchKernelGGL(kna<NA>, dim3(grid), dim3(64), 0, 0, out, c0, c1, iters); CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+		float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+		printf("%-46s %d wave(s)/SIMD: %7.3f ms  %6.3f ns per wave-instruction per SIMD\n", label, wps, ms, ms * 1e6 / (24.0 * iters * wps));
+	}
+	return 0;
+}
 template<int D> static int run12(const char* label, float* out)
 {
 	hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
@@ -143,6 +185,10 @@ int main()
 	run<8>("12 v_add_f32 v,s,v", out);
 	run<9>("12 v_pk_add_f32 v,v,s", out);
 	run<10>("quad with the coefficients in VGPRs", out);
+	run<11>("quad, scalar pair as src1 in all six multiplies", out);
+	runna<2>("statement of 2 taps on 2 accumulators", out);
+	runna<3>("statement of 3 taps on 3 accumulators", out);
+	runna<6>("statement of 6 taps on 6 accumulators", out);
 	run12<0>("2 x (6 pk_mul + 6 pk_add): add 6 after its mul", out);
 	run12<1>("12 pk_mul, then 12 pk_add: add 12 after its mul", out);
 	return 0;
