@@ -134,6 +134,7 @@ PROTOTYPES = {
     "avirhip_plan_destroy": (None, [_VP]),
     "avirhip_plan_set_path": (_I, [_VP, _I]),
     "avirhip_plan_set_variant": (_I, [_VP, _I]),
+    "avirhip_plan_device_bytes": (C.c_ulonglong, [_VP]),
     "avirhip_debug_gamma_u8": (_I, [_VP, C.c_long, C.c_double, _I, _VP, _VP, _VP]),
     "avirhip_plan_get_path": (_I, [_VP]),
     "avirhip_resize": (_I, [_VP, _VP, _I, _VP, _I, _VP]),

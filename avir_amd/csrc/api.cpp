@@ -575,24 +575,29 @@ static int exec_device( avirhip_plan* p, const void* src, void* dst,
 		const LancirAxisDev& V = p -> lv;
 		void* m;
 
-		if( p -> packed == nullptr )
-		{
-			if(( rc = dev_alloc( p, (size_t) p -> src_w * p -> src_h * 4 *
-				sizeof( float ), &m )) != 0 ) return( rc );
-			p -> packed = (float*) m;
-		}
-
-		if( p -> lres == nullptr )
-		{
-			if(( rc = dev_alloc( p, (size_t) p -> new_w * p -> new_h * 4 *
-				sizeof( float ), &m )) != 0 ) return( rc );
-			p -> lres = (float*) m;
-		}
-
 		if( row1 <= row0 )
 		{
 			return( AVIRHIP_OK );
 		}
+
+		// The float RGBA copy of the source and the float result are only
+		// allocated when a pass needs them: with the raw loader and the fused
+		// output stage (the automatic path of uint8 / uint16 images) neither
+		// is touched -- 16 bytes per source and per destination pixel, per
+		// plan, spare and replica, that also count against the plan cache.
+		auto need_lres = [&]() -> int
+		{
+			if( p -> lres == nullptr )
+			{
+				const int r = dev_alloc( p, (size_t) p -> new_w * p -> new_h * 4 *
+					sizeof( float ), &m );
+
+				if( r != 0 ) return( r );
+				p -> lres = (float*) m;
+			}
+
+			return( AVIRHIP_OK );
+		};
 
 		// the source rows this band's vertical windows read
 		const int sa = std::max( 0, std::min( V.h_start[ row0 ],
@@ -612,10 +617,20 @@ static int exec_device( avirhip_plan* p, const void* src, void* dst,
 		q -> lraw.ptr = src; q -> lraw.type = p -> in_type;
 		q -> lraw.ch = p -> io_ch; q -> lraw.stride = p -> src_stride;
 
-		if( !q -> lraw.on && ( rc = launch_pack( (const char*) src +
-			(size_t) sa * p -> src_stride * es, p -> in_type, p -> packed +
-			(size_t) sa * p -> src_w * 4, p -> src_w, sb - sa + 1, p -> io_ch,
-			4, p -> src_stride, st )) != 0 ) return( rc );
+		if( !q -> lraw.on )
+		{
+			if( p -> packed == nullptr )
+			{
+				if(( rc = dev_alloc( p, (size_t) p -> src_w * p -> src_h * 4 *
+					sizeof( float ), &m )) != 0 ) return( rc );
+				p -> packed = (float*) m;
+			}
+
+			if(( rc = launch_pack( (const char*) src +
+				(size_t) sa * p -> src_stride * es, p -> in_type, p -> packed +
+				(size_t) sa * p -> src_w * 4, p -> src_w, sb - sa + 1,
+				p -> io_ch, 4, p -> src_stride, st )) != 0 ) return( rc );
+		}
 
 		q -> lfuse.on = ( getenv( "AVIRHIP_NO_FUSED_OUT" ) == nullptr );
 		q -> lfuse.done = 0;
@@ -623,7 +638,20 @@ static int exec_device( avirhip_plan* p, const void* src, void* dst,
 		q -> lfuse.unity = p -> l_unity; q -> lfuse.out_mul = p -> l_out_mul;
 		q -> lfuse.clampv = p -> l_clamp;
 		q -> lfuse.dst = dst; q -> lfuse.stride = p -> new_stride;
+
+		// (a null result buffer: only the fused store may run; a pass that
+		// would write the float result returns AVIRHIP_NEED_DST first)
+		if( !q -> lfuse.on && ( rc = need_lres() ) != 0 ) return( rc );
+
 		rc = exec_device( q, p -> packed, p -> lres, row0, row1, st );
+
+		if( rc == AVIRHIP_NEED_DST )
+		{
+			if(( rc = need_lres() ) != 0 ) return( rc );
+			q -> lfuse.done = 0;
+			rc = exec_device( q, p -> packed, p -> lres, row0, row1, st );
+		}
+
 		q -> lfuse.on = 0;
 		q -> lraw.on = 0;
 
@@ -644,6 +672,11 @@ static int exec_device( avirhip_plan* p, const void* src, void* dst,
 	if( p -> is_lancir )
 	{
 		const int lpath = ( p -> path != 0 ? p -> path : p -> auto_path );
+
+		if( lpath == 4 && dst == nullptr )
+		{
+			return( AVIRHIP_NEED_DST );
+		}
 
 		if( lpath == 4 )
 		{
@@ -678,6 +711,11 @@ static int exec_device( avirhip_plan* p, const void* src, void* dst,
 				set_error( "path 5 cannot run this call (unaligned buffers?)" );
 				return( AVIRHIP_EUNSUPPORTED );
 			}
+		}
+
+		if( dst == nullptr )
+		{
+			return( AVIRHIP_NEED_DST );
 		}
 
 		if(( rc = ensure_scratch( p )) != 0 ) return( rc );
@@ -2226,6 +2264,11 @@ int avirhip_plan_set_path( avirhip_plan* p, int path )
 	}
 
 	return( AVIRHIP_OK );
+}
+
+unsigned long long avirhip_plan_device_bytes( avirhip_plan* p )
+{
+	return( (unsigned long long) plan_device_bytes( p ));
 }
 
 int avirhip_plan_set_variant( avirhip_plan* p, int variant )

@@ -1091,6 +1091,11 @@ int gpass_run( avirhip_plan* p, const float* src, long src_stride, float* dst,
 			return( 1 );
 		}
 
+		if( dst == nullptr && !p -> lfuse.on )
+		{
+			return( AVIRHIP_NEED_DST );
+		}
+
 		// vertical first (lancir.h:601-646): mid = [new_h][src_w], only the
 		// rows of the band
 		const long mid_ss = (long) p -> src_w * 4;
@@ -1119,9 +1124,16 @@ int gpass_run( avirhip_plan* p, const float* src, long src_stride, float* dst,
 			L.clampv = p -> lfuse.clampv;
 			L.l4 = ( p -> new_w * p -> lfuse.ch ) & ~3;
 			L.base = p -> lfuse.dst; L.stride = p -> lfuse.stride;
-			p -> lfuse.done = 1;
-			return( run_h( D, D -> mid, mid_ss, p -> src_w, dst, dst_ss, row0,
-				p -> new_w, row0, row1, st, nullptr, 0, 0, 0, &L ));
+			rc = run_h( D, D -> mid, mid_ss, p -> src_w, dst, dst_ss, row0,
+				p -> new_w, row0, row1, st, nullptr, 0, 0, 0, &L );
+
+			p -> lfuse.done = ( rc == 0 );
+			return( rc );
+		}
+
+		if( dst == nullptr )
+		{
+			return( AVIRHIP_NEED_DST ); // (an inner plan run without a result buffer)
 		}
 
 		return( run_h( D, D -> mid, mid_ss, p -> src_w, dst, dst_ss, row0,

@@ -22,6 +22,10 @@
 #include <mutex>
 #include "../../include/avirhip.h"
 
+// internal: an inner plan was run without a float result buffer and its path
+// would have written one (exec_device allocates it and runs again)
+#define AVIRHIP_NEED_DST 1001
+
 namespace avirhip {
 
 enum { OP_FIR = 0, OP_GATHER = 1, OP_UPF = 2 };

@@ -235,6 +235,11 @@ int avirhip_plan_get_path(const avirhip_plan* plan);
 #define AVIRHIP_VARIANT_SACC_LADDER 4
 int avirhip_plan_set_variant(avirhip_plan* plan, int variant);
 
+/* Device memory the plan holds right now, in bytes: tables, scratch buffers
+ * (allocated when a path first needs them), its inner plan, spares and
+ * replicas -- what the front ends' plan caches count against their bound. */
+unsigned long long avirhip_plan_device_bytes(avirhip_plan* plan);
+
 /* Executes H pass + V pass (+ integer epilogue) of `plan`:
  * src -> dst. `src_mem`/`dst_mem` are AVIRHIP_MEM_HOST or _DEVICE; host
  * buffers are staged through device memory inside the call. `stream` is a

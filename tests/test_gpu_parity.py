@@ -1631,3 +1631,32 @@ def test_in_place_host_resize_of_a_large_frame():
     r.resizeImage(buf, 2000, 1500, 0, buf, 1000, 750, 4, 0.0)
     _assert_same(buf[:1000 * 750 * 4].reshape(750, 1000, 4), want,
                  "in-place host resize")
+
+
+def test_lancir_integer_plans_allocate_no_float_copies():
+    """A CLancIR plan for uint8 / uint16 images on the pass kernels reads the
+    caller's image in its first pass and stores the caller's result in its
+    last: the float RGBA copy of the source and the float result (16 bytes per
+    pixel each) are not allocated -- plan_device_bytes stays far below them --
+    and a plan that cannot fuse (forced generic kernels) still works."""
+    lib = abi.load()
+    sw, sh, nw, nh, ch = 1200, 800, 1700, 1100, 3
+    src = rb.lcg_u8((sh, sw, ch), seed=5)
+    want = (rb.ref_lancir if rb.have_ref() else rb.orc_lancir)(src, nw, nh)
+    l = avir_amd.CLancIR()
+    got = l.resize(src, nw, nh)
+    _assert_same(got, want, "lancir u8")
+    p = l.plan(sw, sh, nw, nh, ch, None, abi.U8, abi.U8)
+    used = lib.avirhip_plan_device_bytes(p)
+    # what is left: the pass kernels' intermediate [new_h][src_w] float RGBA,
+    # the staging copies of the two host images, tables
+    allowed = nh * sw * 16 + (sw * sh + nw * nh) * ch + (2 << 20)
+    assert 0 < used < allowed < used + min(sw * sh, nw * nh) * 16, used
+    l2 = avir_amd.CLancIR()
+    p2 = l2.plan(sw, sh, nw, nh, ch, None, abi.U8, abi.U8)
+    abi.check(lib.avirhip_plan_set_path(p2, abi.PATH_GENERIC), "set_path")
+    out = np.zeros((nh, nw, ch), np.uint8)
+    abi.check(lib.avirhip_resize_band(p2, src.ctypes.data, abi.MEM_HOST,
+                                      out.ctypes.data, abi.MEM_HOST, 0, nh,
+                                      None), "generic")
+    _assert_same(out, want, "lancir u8 generic")
