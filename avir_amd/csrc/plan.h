@@ -159,7 +159,8 @@ struct avirhip_plan
 	std::mutex shard_mtx; // avirhip_resize_sharded: replicas, band buffers
 	std::mutex spare_mtx; // the list of spares
 	hipEvent_t last_done;
-	void* last_stream; // stream of the call that recorded last_done
+	void* last_stream; // stream of the last call that used the scratch buffers
+	bool last_used;    // (there was one)
 	// host-pointer calls: copy streams and events of the band pipeline
 	void* pipe_in; void* pipe_out;
 	std::vector< hipEvent_t > pipe_ev;
