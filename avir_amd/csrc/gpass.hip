@@ -949,7 +949,7 @@ static int run_h( const GPData* D, const float* src, long src_ss, int src_w,
 
 	// (a chunk's fixed cost: its coefficient row load and three rows of DMA
 	// lead, about two rows of work)
-	P.chunk = balanced_chunk( rows, P.nstrips, 8, rows, 2, wpc, false );
+	P.chunk = balanced_chunk( rows, P.nstrips, 4, rows, 2, wpc, false );
 	const int nch = ( rows + P.chunk - 1 ) / P.chunk;
 	const int items = P.nstrips * nch;
 	const size_t lds = lds_h;

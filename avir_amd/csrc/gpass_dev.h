@@ -605,7 +605,8 @@ __device__ __forceinline__ f4 gp_load_raw( const void* const base,
 // launch by < 10 %): a launch takes as long as its busiest SIMD, that is
 // ceil( waves / 1024 SIMDs ) waves of ( chunk + warm ) rows each, where `warm`
 // = the rows of work a chunk spends before its first output. A single wave
-// per SIMD has nobody to hide its latencies behind (x 1.26, measured), and
+// per SIMD has nobody to hide its latencies behind (x 1.6: a lone wave issues
+// its dependent multiply-adds at half the rate of two, tools/pk_bench.hip), and
 // more waves than the chip holds (`wpc` per CU) run in residency rounds.
 // Fits the k_gv sweep profiles/r02_gpass/chunk_sweep.txt within 10 %.
 static inline int balanced_chunk( int rows, int nstrips, int min_chunk, int max_chunk,
@@ -614,6 +615,16 @@ static inline int balanced_chunk( int rows, int nstrips, int min_chunk, int max_
 	const double cap = 256.0 * wpc;
 	double best = -1.0;
 	int best_chunk = std::max( 1, std::min( rows, max_chunk ));
+	static const double solo = ( getenv( "AVIRHIP_GP_SOLO" ) != nullptr ?
+		atof( getenv( "AVIRHIP_GP_SOLO" )) : 1.6 ); // tuning aids
+	static const int minc = ( getenv( "AVIRHIP_GP_MINCHUNK" ) != nullptr ?
+		atoi( getenv( "AVIRHIP_GP_MINCHUNK" )) : 0 );
+
+	if( minc > 0 )
+	{
+		min_chunk = minc;
+	}
+
 	min_chunk = std::max( 1, std::min( min_chunk, best_chunk ));
 
 	for( int nch = 1; nch <= rows; nch++ )
@@ -637,7 +648,7 @@ static inline int balanced_chunk( int rows, int nstrips, int min_chunk, int max_
 		// (k_gh is not ALU-bound: there whole rounds of resident waves is
 		// the model that fits -- 4661 waves on 4608 slots ran as long as 9216)
 		const double cost = ( valu_bound ?
-			res * per * ( chunk + (double) warm ) * ( per < 2.0 ? 1.26 : 1.0 ) :
+			res * per * ( chunk + (double) warm ) * ( per < 2.0 ? solo : 1.0 ) :
 			res * cap / items * ( chunk + (double) warm ) / chunk );
 
 		if( best < 0.0 || cost < best )

@@ -136,7 +136,10 @@ int gpass_run_v( const GPAxis& A_, int v_blk, int v_rs, int v_rc,
 	const int wpc = std::max( 1, std::min( 16, (int) ( 160 * 1024 /
 		( lds_guess + 512 ))));
 
-	P.chunk = balanced_chunk( rows, P.nstrips, 8, maxg - gextra, warm, wpc,
+	// (chunks down to 4 rows: a small frame -- 640x480 -> 1024x768 -- runs
+	// faster as two short waves per SIMD than as one of 12 rows, 0.0231 ->
+	// 0.0193 ms; tools/gp_solo_sweep.sh)
+	P.chunk = balanced_chunk( rows, P.nstrips, 4, maxg - gextra, warm, wpc,
 		true );
 
 	if( getenv( "AVIRHIP_GV_CHUNK" ) != nullptr ) // tuning aid
