@@ -23,6 +23,7 @@ PATH_GPASS = 5
 VARIANT_UP2_PLAIN_V, VARIANT_DN_TWO_PASS, VARIANT_SACC_LADDER = 1, 2, 4
 
 _fp = C.POINTER(C.c_float)
+_dp = C.POINTER(C.c_double)
 _ip = C.POINTER(C.c_int32)
 
 
@@ -30,7 +31,7 @@ class RPos(C.Structure):
     _fields_ = [("src_pos_int", C.c_int32), ("fti", C.c_int32),
                 ("phase", C.c_int32), ("x", C.c_float),
                 ("src_offs_px", C.c_int32), ("fl", C.c_int32),
-                ("ftp_off", C.c_int32)]
+                ("ftp_off", C.c_int32), ("x64", C.c_double)]
 
 
 class Step(C.Structure):
@@ -46,7 +47,9 @@ class Step(C.Structure):
                 ("bank_filter_len", C.c_int32), ("bank_order", C.c_int32),
                 ("bank_frac_count", C.c_int32), ("n_phases", C.c_int32),
                 ("phase_fti", _ip), ("phase_taps", _fp),
-                ("rpos", C.POINTER(RPos))]
+                ("rpos", C.POINTER(RPos)),
+                ("flt64", _dp), ("prefix_dc64", _dp), ("suffix_dc64", _dp),
+                ("phase_taps64", _dp)]
 
 
 class Axis(C.Structure):
@@ -63,7 +66,7 @@ class PlanDesc(C.Structure):
                 ("h", Axis), ("v", Axis),
                 ("tr_mul", C.c_double), ("pk_out", C.c_double),
                 ("use_srgb_gamma", C.c_int32), ("alpha_index", C.c_int32),
-                ("dither", C.c_int32)]
+                ("dither", C.c_int32), ("work_f64", C.c_int32)]
 
 
 class LancirPos(C.Structure):

@@ -15,6 +15,7 @@ namespace avirhip {
 struct DescStore
 {
 	std::vector< std::unique_ptr< std::vector< float > > > f;
+	std::vector< std::unique_ptr< std::vector< double > > > fd;
 	std::vector< std::unique_ptr< std::vector< int32_t > > > i;
 	std::vector< std::unique_ptr< std::vector< avirhip_rpos > > > r;
 	std::vector< std::unique_ptr< std::vector< avirhip_step > > > s;
@@ -23,7 +24,8 @@ struct DescStore
 	avirhip_lancir_desc ld;
 };
 
-class AvirPlannerImpl;
+namespace pl32 { class AvirPlannerImpl; } // float pipeline (fpclass_def<float>, fpclass_float4)
+namespace pl64 { class AvirPlannerImpl; } // double pipeline (fpclass_def<double>)
 
 // Mirror of avir::CImageResizer's planning half (ctor avir.h:4630-4639).
 class AvirPlanner
@@ -37,10 +39,11 @@ public:
 	// Returns nullptr (and sets the error string) on an unsupported request.
 	DescStore* build( int src_w, int src_h, int src_scanline_size, int new_w,
 		int new_h, int el_count_io, double k, const avirhip_vars& vars,
-		int in_type, int out_type, int fppack = 1 );
+		int in_type, int out_type, int fppack = 1, bool f64 = false );
 
 private:
-	AvirPlannerImpl* impl;
+	pl32::AvirPlannerImpl* impl;
+	pl64::AvirPlannerImpl* impl64; // (made when the first double plan is asked for)
 };
 
 // Mirror of avir::CLancIR's planning half (lancir.h:430-483).

@@ -73,6 +73,7 @@ typedef struct avirhip_rpos {
 	int32_t src_offs_px; /* SrcOffs / ElCount: first source pixel read */
 	int32_t fl;          /* taps walked (RESIZE2: FilterLen - fo, step 2) */
 	int32_t ftp_off;     /* fo: offset of the first tap inside the phase */
+	double x64;          /* double pipeline: the coefficient in double (x unused) */
 } avirhip_rpos;
 
 typedef struct avirhip_step {
@@ -104,6 +105,14 @@ typedef struct avirhip_step {
 	const int32_t* phase_fti; /* [n_phases], ascending */
 	const float* phase_taps;  /* [n_phases][filter_len * (order + 1)] */
 	const avirhip_rpos* rpos; /* [out_len] */
+
+	/* Double pipeline (avirhip_plan_desc::work_f64, the reference's
+	 * fpclass_def<double>): the same tables in double precision -- the
+	 * float fields above are null then, and rpos[].x64 replaces rpos[].x. */
+	const double* flt64;
+	const double* prefix_dc64;
+	const double* suffix_dc64;
+	const double* phase_taps64;
 } avirhip_step;
 
 typedef struct avirhip_axis {
@@ -140,6 +149,10 @@ typedef struct avirhip_plan_desc {
 	 * (error diffusion along and across rows, avir.h:4441-4537; "recursive":
 	 * rows depend on each other, so such a plan cannot execute row bands). */
 	int32_t dither;
+	/* 1: the double pipeline (the reference's fpclass_def<double>,
+	 * avir.h:4553-4560): tables in the steps' ...64 fields, every pass computes
+	 * in double. 0: float (fpclass_def<float>, fpclass_float4). */
+	int32_t work_f64;
 } avirhip_plan_desc;
 
 #define AVIRHIP_DITHER_DEF 0
