@@ -66,7 +66,7 @@ static int dev_alloc( avirhip_plan* p, size_t bytes, void** out )
 // ---- lowering of one AVIR axis (see plan.h for the view semantics) ----
 
 static int lower_axis( const avirhip_axis& ax, int src_len, int dst_len,
-	LAxis& L )
+	LAxis& L, const bool f64 = false )
 {
 	L.ops.clear();
 	L.src_len = src_len;
@@ -108,6 +108,8 @@ static int lower_axis( const avirhip_axis& ax, int src_len, int dst_len,
 		op.zs_mmax = 0x7fffffff;
 		op.out_len = s.out_len; op.out_prefix = 0; op.out_total = s.out_len;
 		op.rf = 1; op.lat = 0; op.e = 0; op.d_flt = nullptr;
+		op.d_flt64 = nullptr; op.d_coef64 = nullptr; op.d_sdc64 = nullptr;
+		op.d_pdc64 = nullptr;
 		op.maxtaps = 0; op.d_start = nullptr; op.d_ntaps = nullptr;
 		op.d_coef = nullptr;
 		op.flen = 0; op.up_inprefix = 0; op.up_R = 0; op.sdc_len = 0;
@@ -115,7 +117,8 @@ static int lower_axis( const avirhip_axis& ax, int src_len, int dst_len,
 
 		if( s.kind == AVIRHIP_STEP_FIR )
 		{
-			if( s.resample_factor < 1 || s.flt == nullptr ||
+			if( s.resample_factor < 1 ||
+				( f64 ? (const void*) s.flt64 : (const void*) s.flt ) == nullptr ||
 				s.flt_latency < 0 || s.flt_len != 2 * s.flt_latency + 1 )
 			{
 				set_error( "step %d: malformed FIR (len %d, latency %d)", si,
@@ -127,7 +130,15 @@ static int lower_axis( const avirhip_axis& ax, int src_len, int dst_len,
 			op.rf = s.resample_factor;
 			op.lat = s.flt_latency;
 			op.e = s.edge_pixel_count;
-			op.h_flt.assign( s.flt + s.flt_latency, s.flt + s.flt_len );
+
+			if( f64 )
+			{
+				op.h_flt64.assign( s.flt64 + s.flt_latency, s.flt64 + s.flt_len );
+			}
+			else
+			{
+				op.h_flt.assign( s.flt + s.flt_latency, s.flt + s.flt_len );
+			}
 
 			if( prev_upf )
 			{
@@ -165,8 +176,9 @@ static int lower_axis( const avirhip_axis& ax, int src_len, int dst_len,
 		else
 		if( s.kind == AVIRHIP_STEP_UP_FILTERED )
 		{
-			if( s.resample_factor < 2 || s.flt == nullptr || s.flt_len < 1 ||
-				prev_upf )
+			if( s.resample_factor < 2 ||
+				( f64 ? (const void*) s.flt64 : (const void*) s.flt ) == nullptr ||
+				s.flt_len < 1 || prev_upf )
 			{
 				set_error( "step %d: malformed filtered upsample", si );
 				return( AVIRHIP_EINVAL );
@@ -176,7 +188,16 @@ static int lower_axis( const avirhip_axis& ax, int src_len, int dst_len,
 			op.view = VIEW_CLAMP;
 			op.rf = s.resample_factor;
 			op.flen = s.flt_len;
-			op.h_flt.assign( s.flt, s.flt + s.flt_len );
+
+			if( f64 )
+			{
+				op.h_flt64.assign( s.flt64, s.flt64 + s.flt_len );
+			}
+			else
+			{
+				op.h_flt.assign( s.flt, s.flt + s.flt_len );
+			}
+
 			op.up_inprefix = s.in_prefix;
 			op.up_R = s.in_prefix + s.in_len + s.in_suffix;
 			op.sdc_len = s.suffix_dc_len;
@@ -195,12 +216,24 @@ static int lower_axis( const avirhip_axis& ax, int src_len, int dst_len,
 			}
 
 			// stash DC tails behind the filter taps: [flt | sdc | pdc]
-			if( s.suffix_dc_len > 0 )
-				op.h_flt.insert( op.h_flt.end(), s.suffix_dc,
-					s.suffix_dc + s.suffix_dc_len );
-			if( s.prefix_dc_len > 0 )
-				op.h_flt.insert( op.h_flt.end(), s.prefix_dc,
-					s.prefix_dc + s.prefix_dc_len );
+			if( f64 )
+			{
+				if( s.suffix_dc_len > 0 )
+					op.h_flt64.insert( op.h_flt64.end(), s.suffix_dc64,
+						s.suffix_dc64 + s.suffix_dc_len );
+				if( s.prefix_dc_len > 0 )
+					op.h_flt64.insert( op.h_flt64.end(), s.prefix_dc64,
+						s.prefix_dc64 + s.prefix_dc_len );
+			}
+			else
+			{
+				if( s.suffix_dc_len > 0 )
+					op.h_flt.insert( op.h_flt.end(), s.suffix_dc,
+						s.suffix_dc + s.suffix_dc_len );
+				if( s.prefix_dc_len > 0 )
+					op.h_flt.insert( op.h_flt.end(), s.prefix_dc,
+						s.prefix_dc + s.prefix_dc_len );
+			}
 
 			L.ops.push_back( op );
 			prev_upf = true;
@@ -219,7 +252,8 @@ static int lower_axis( const avirhip_axis& ax, int src_len, int dst_len,
 				return( AVIRHIP_EUNSUPPORTED );
 			}
 
-			if( s.rpos == nullptr || s.phase_taps == nullptr ||
+			if( s.rpos == nullptr || ( f64 ? (const void*) s.phase_taps64 :
+				(const void*) s.phase_taps ) == nullptr ||
 				s.bank_filter_len < 2 || s.n_phases < 1 ||
 				( s.bank_order != 0 && s.bank_order != 1 ))
 			{
@@ -233,7 +267,15 @@ static int lower_axis( const avirhip_axis& ax, int src_len, int dst_len,
 			op.maxtaps = ( r2 ? ( fl + 1 ) / 2 : fl );
 			op.h_start.resize( s.out_len );
 			op.h_ntaps.resize( s.out_len );
-			op.h_coef.assign( (size_t) s.out_len * op.maxtaps, 0.0f );
+
+			if( f64 )
+			{
+				op.h_coef64.assign( (size_t) s.out_len * op.maxtaps, 0.0 );
+			}
+			else
+			{
+				op.h_coef.assign( (size_t) s.out_len * op.maxtaps, 0.0f );
+			}
 
 			if( r2 )
 			{
@@ -253,14 +295,40 @@ static int lower_axis( const avirhip_axis& ax, int src_len, int dst_len,
 					return( AVIRHIP_EINVAL );
 				}
 
-				const float* ftp = s.phase_taps + (size_t) rp.phase * fsz +
-					rp.ftp_off;
-				const float* ftp2 = ftp + fl;
-				float* cf = &op.h_coef[ (size_t) j * op.maxtaps ];
 				const int stp = ( r2 ? 2 : 1 );
 				int nt = 0;
 
-				for( int i = 0; i < rp.fl; i += stp )
+				if( f64 )
+				{
+					// (the same in double: xx = ftp[i] + ftp2[i]*x)
+					const double* ftp = s.phase_taps64 + (size_t) rp.phase * fsz +
+						rp.ftp_off;
+					const double* ftp2 = ftp + fl;
+					double* cf = &op.h_coef64[ (size_t) j * op.maxtaps ];
+
+					for( int i = 0; i < rp.fl; i += stp )
+					{
+						if( s.bank_order == 1 )
+						{
+							const double t = ftp2[ i ] * rp.x64;
+							cf[ nt ] = ftp[ i ] + t;
+						}
+						else
+						{
+							cf[ nt ] = ftp[ i ];
+						}
+
+						nt++;
+					}
+				}
+
+				const float* ftp = ( f64 ? nullptr : s.phase_taps +
+					(size_t) rp.phase * fsz + rp.ftp_off );
+				const float* ftp2 = ( f64 ? nullptr : ftp + fl );
+				float* cf = ( f64 ? nullptr :
+					&op.h_coef[ (size_t) j * op.maxtaps ]);
+
+				for( int i = 0; !f64 && i < rp.fl; i += stp )
 				{
 					// xx = ftp[i] + ftp2[i]*x in float (avir.h:3945, 4177);
 					// this TU is compiled -ffp-contract=off.
@@ -350,11 +418,15 @@ static int upload_axis( avirhip_plan* p, LAxis& L )
 		if(( rc = upload( p, op.h_start, &op.d_start )) != 0 ) return( rc );
 		if(( rc = upload( p, op.h_ntaps, &op.d_ntaps )) != 0 ) return( rc );
 		if(( rc = upload( p, op.h_coef, &op.d_coef )) != 0 ) return( rc );
+		if(( rc = upload( p, op.h_flt64, &op.d_flt64 )) != 0 ) return( rc );
+		if(( rc = upload( p, op.h_coef64, &op.d_coef64 )) != 0 ) return( rc );
 
 		if( op.type == OP_UPF )
 		{
 			op.d_sdc = op.d_flt + op.flen;
 			op.d_pdc = op.d_sdc + op.sdc_len;
+			op.d_sdc64 = op.d_flt64 + op.flen;
+			op.d_pdc64 = op.d_sdc64 + op.sdc_len;
 		}
 	}
 
@@ -362,7 +434,7 @@ static int upload_axis( avirhip_plan* p, LAxis& L )
 }
 
 // Needed logical input range of `op` for logical outputs [a, b].
-static void need_range( const LOp& op, int a, int b, int& ia, int& ib )
+void need_range( const LOp& op, int a, int b, int& ia, int& ib )
 {
 	if( op.type == OP_FIR )
 	{
@@ -564,6 +636,11 @@ static int exec_device( avirhip_plan* p, const void* src, void* dst,
 	int row0, int row1, hipStream_t st )
 {
 	int rc;
+
+	if( p -> f64 )
+	{
+		return( exec_f64( p, src, dst, row0, row1, st ));
+	}
 
 	// LANCIR: the exact-2x kernel needs no scratch; the generic kernels'
 	// intermediate is only allocated when they actually run
@@ -1609,9 +1686,20 @@ int avirhip_plan_create( const avirhip_plan_desc* d, avirhip_plan** out )
 	// fpclass_float4 (AVIRHIP_DITHER_DEF_RNE): no in-place float output
 	p -> fp4 = ( d -> dither == AVIRHIP_DITHER_DEF_RNE ? 1 : 0 );
 
-	int rc = lower_axis( d -> h, d -> src_w, d -> new_w, p -> h );
+	p -> f64 = ( d -> work_f64 ? 1 : 0 );
 
-	if( rc == 0 ) rc = lower_axis( d -> v, d -> src_h, d -> new_h, p -> v );
+	if( p -> f64 && ( p -> dither != AVIRHIP_DITHER_DEF || p -> fp4 ))
+	{
+		set_error( "the double pipeline runs the default ditherer only" );
+		avirhip_plan_destroy( p );
+		return( AVIRHIP_EUNSUPPORTED );
+	}
+
+	int rc = lower_axis( d -> h, d -> src_w, d -> new_w, p -> h, p -> f64 != 0 );
+
+	if( rc == 0 ) rc = lower_axis( d -> v, d -> src_h, d -> new_h, p -> v,
+		p -> f64 != 0 );
+
 	if( rc == 0 ) rc = finalize_avir_plan( p );
 
 	if( rc != 0 )
@@ -1657,6 +1745,14 @@ int finalize_avir_plan( avirhip_plan* p )
 				rc = upload( p, thr, &p -> d_gthr );
 			}
 		}
+	}
+
+	if( rc == 0 && p -> f64 )
+	{
+		// the double pipeline: the generic kernels in double (generic64.hip),
+		// no fast paths
+		p -> auto_path = 1;
+		return( rc );
 	}
 
 	// 1-3 channel pixels: channels are independent, so executing them as
@@ -1798,6 +1894,7 @@ static int clone_plan( const avirhip_plan* s, int device, avirhip_plan** out )
 	q -> gamma = s -> gamma; q -> alpha_index = s -> alpha_index;
 	q -> dither = s -> dither;
 	q -> fp4 = s -> fp4;
+	q -> f64 = s -> f64;
 	q -> l_out_mul = s -> l_out_mul; q -> l_clamp = s -> l_clamp;
 	q -> l_unity = s -> l_unity;
 	q -> l_order = s -> l_order;

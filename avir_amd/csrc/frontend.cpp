@@ -114,6 +114,7 @@ struct avirhip_resizer
 	AvirPlanner* planner;
 	int dither; // AVIRHIP_DITHER_*: fpclass::CDitherer of the mirrored object
 	int fppack; // fpclass::fppack of the mirrored object (1 or 4)
+	int f64;    // fpclass_def< double >: the double pipeline
 	std::mutex mtx;
 	typedef std::tuple< int, int, int, int, int, int, double, double, double,
 		int, int, int, int, int, int, int > Key; // ..., ditherer + fppack, device
@@ -241,6 +242,7 @@ int avirhip_resizer_create( int res_bit_depth, int src_bit_depth,
 	r -> planner = new AvirPlanner( res_bit_depth, src_bit_depth, P );
 	r -> dither = AVIRHIP_DITHER_DEF;
 	r -> fppack = 1;
+	r -> f64 = 0;
 	*out = r;
 	return( AVIRHIP_OK );
 }
@@ -261,14 +263,17 @@ int avirhip_resizer_set_ditherer( avirhip_resizer* r, int dither )
 
 int avirhip_resizer_set_fpclass( avirhip_resizer* r, int fppack )
 {
-	if( r == nullptr || ( fppack != 1 && fppack != 4 ))
+	if( r == nullptr || ( fppack != 1 && fppack != 4 &&
+		fppack != AVIRHIP_FPCLASS_DOUBLE ))
 	{
-		set_error( "set_fpclass: fppack 1 (float) or 4 (float4) only" );
+		set_error( "set_fpclass: fppack 1 (float), 4 (float4) or "
+			"AVIRHIP_FPCLASS_DOUBLE only" );
 		return( AVIRHIP_EINVAL );
 	}
 
 	std::lock_guard< std::mutex > lock( r -> mtx );
-	r -> fppack = fppack;
+	r -> f64 = ( fppack == AVIRHIP_FPCLASS_DOUBLE ? 1 : 0 );
+	r -> fppack = ( r -> f64 ? 1 : fppack );
 	return( AVIRHIP_OK );
 }
 
@@ -297,17 +302,19 @@ int avirhip_resizer_build_desc( avirhip_resizer* r, int src_w, int src_h,
 
 	const avirhip_vars& V = ( vars == nullptr ? g_defvars : *vars );
 	DescStore* S = r -> planner -> build( src_w, src_h, src_scanline_size,
-		new_w, new_h, el_count_io, k, V, in_type, out_type, r -> fppack );
+		new_w, new_h, el_count_io, k, V, in_type, out_type, r -> fppack,
+		r -> f64 != 0 );
 
 	if( S == nullptr )
 	{
 		return( AVIRHIP_EINVAL );
 	}
 
-	if( r -> fppack == 4 && r -> dither != AVIRHIP_DITHER_DEF )
+	if(( r -> fppack == 4 || r -> f64 ) && r -> dither != AVIRHIP_DITHER_DEF )
 	{
 		delete S;
-		set_error( "fpclass_float4: only the default ditherer is built" );
+		set_error( "fpclass_float4 / fpclass_def<double>: only the default "
+			"ditherer is built" );
 		return( AVIRHIP_EUNSUPPORTED );
 	}
 
@@ -346,7 +353,7 @@ static int resizer_acquire( avirhip_resizer* r, int src_w, int src_h,
 	const avirhip_resizer::Key key( src_w, src_h, src_scanline_size, new_w,
 		new_h, el_count_io, k, V.ox, V.oy, V.BuildMode, in_type, out_type,
 		( V.UseSRGBGamma ? 1 : 0 ), V.AlphaIndex,
-		r -> dither + 16 * r -> fppack, dev );
+		r -> dither + 16 * r -> fppack + 1024 * r -> f64, dev );
 
 	auto* e = r -> cache.find( key );
 
@@ -537,7 +544,8 @@ int avirhip_resizer_vars_base( avirhip_resizer* r, int src_w, int src_h,
 
 	const avirhip_resizer::Key key( src_w, src_h, src_scanline_size, new_w,
 		new_h, el_count_io, k, V.ox, V.oy, V.BuildMode, in_type, out_type,
-		( V.UseSRGBGamma ? 1 : 0 ), V.AlphaIndex, 16 * r -> fppack, 0 );
+		( V.UseSRGBGamma ? 1 : 0 ), V.AlphaIndex,
+		16 * r -> fppack + 1024 * r -> f64, 0 );
 
 	{
 		std::lock_guard< std::mutex > lock( r -> mtx );
@@ -560,6 +568,11 @@ int avirhip_resizer_vars_base( avirhip_resizer* r, int src_w, int src_h,
 	}
 
 	fill_vars_base( *d, k, V, out );
+
+	if( d -> work_f64 )
+	{
+		out -> fpalign = 8; // sizeof( double ), avir.h:4578
+	}
 
 	if( d -> dither == AVIRHIP_DITHER_DEF_RNE )
 	{

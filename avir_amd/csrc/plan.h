@@ -48,6 +48,10 @@ struct LOp
 	int rf, lat, e;
 	float* d_flt; // FIR: &Flt[FltLatency] (lat+1 taps); UPF: whole Flt
 	std::vector< float > h_flt;
+	// (double pipeline, plan -> f64: the same tables in double; the float ones
+	// stay empty)
+	double* d_flt64;
+	std::vector< double > h_flt64;
 
 	// OP_GATHER: out[j] = 0 + sum_{t<ntaps[j]} coef[j][t]*in[start[j]+t]
 	// (doResize / doResize2, avir.h:3884-4328). coef is pre-expanded per
@@ -58,11 +62,15 @@ struct LOp
 	float* d_coef; // [out_len][maxtaps]
 	std::vector< int > h_start, h_ntaps;
 	std::vector< float > h_coef;
+	double* d_coef64;
+	std::vector< double > h_coef64;
 
 	// OP_UPF (filtered upsample, avir.h:3404-3733)
 	int flen, up_inprefix, up_R, sdc_len, pdc_len, pdc_d0;
 	float* d_sdc;
 	float* d_pdc;
+	double* d_sdc64;
+	double* d_pdc64;
 };
 
 struct LAxis
@@ -106,6 +114,10 @@ struct avirhip_plan
 	int gamma, alpha_index; // sRGB gamma stages (avir.h:2841-2930, 2982-3068)
 	int dither;             // AVIRHIP_DITHER_* (integer outputs only)
 	int fp4;                // plan of an fpclass_float4 object (no in-place float output)
+	int f64;                // double pipeline (fpclass_def<double>): generic64.hip runs it
+	double* packed64;       // its copy of the source, its result, its intermediates
+	double* resbuf64;
+	std::vector< double* > hbuf64, vbuf64;
 	float* errd_line;       // error-diffusion rows handed between row blocks
 	float* d_srgb_tbl;      // 256-entry uint8 linearisation table (gamma plans)
 	float* d_gthr;          // uint8 gamma output stage as 2 x 256 thresholds
@@ -200,6 +212,13 @@ int launch_epilogue( const float* res, void* dst, int out_type, long n,
 	bool rne = false );
 bool gamma_u8_thresholds( float ogm, int use_tr, float trm, float trmi,
 	float pk, float* thr );
+// the input range [ia, ib] an op reads for outputs [a, b] (api.cpp)
+void need_range( const LOp& op, int a, int b, int& ia, int& ib );
+
+// generic64.hip: the double pipeline (plan -> f64), output rows [row0, row1)
+int exec_f64( avirhip_plan* p, const void* src, void* dst, int row0, int row1,
+	hipStream_t st );
+
 int launch_errd( const float* res, void* dst, int out_type, int w, int h,
 	int ch, int ech, double tr_mul, double pk_out, int gamma, int alpha_index,
 	float* line, hipStream_t st );

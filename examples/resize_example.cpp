@@ -123,6 +123,24 @@ int main()
 		printf( "float4_u16 %016llx\n", (unsigned long long) fnv1a64(
 			Out16.data(), Out16.size() * 2 ));
 
+		// the double pipeline (avir.h:4553-4560): double in, double out (the
+		// vertical pass' in-place result), and 8-bit RGB through it
+		std :: vector< double > InD( InF.begin(), InF.end() );
+		std :: vector< double > OutD( 400 * 300 * 4 );
+		avir :: CImageResizer< avir :: fpclass_def< double > > ImageResizerD( 16 );
+		ImageResizerD.resizeImage( InD.data(), 640, 480, 0, OutD.data(), 400,
+			300, 4, 0 );
+
+		printf( "double_f64 %016llx\n", (unsigned long long) fnv1a64(
+			OutD.data(), OutD.size() * 8 ));
+
+		avir :: CImageResizer< avir :: fpclass_def< double > > ImageResizerD8( 8 );
+		ImageResizerD8.resizeImage( In8.data(), 640, 480, 0, Out8.data(), 1024,
+			768, 3, 0 );
+
+		printf( "double_u8 %016llx\n", (unsigned long long) fnv1a64(
+			Out8.data(), Out8.size() ));
+
 		// CImageResizerVarsBase is written back (avir.h:4663-4669)
 		avir :: CImageResizerVars Vars2;
 		Vars2.UseSRGBGamma = true;

@@ -220,11 +220,13 @@ public:
 		const CImageResizerParams& aParams = CImageResizerParamsDef() )
 		: h( nullptr )
 	{
-		static_assert( sizeof( typename fpclass :: fptypeatom ) ==
+		static_assert((( sizeof( typename fpclass :: fptypeatom ) ==
 			sizeof( float ) && ( fpclass :: fppack == 1 ||
-			fpclass :: fppack == 4 ) && fpclass :: packmode == 0,
-			"avir_hip: the float pipeline only -- fpclass_def<float> or "
-			"fpclass_float4 (avir_float4_sse.h)" );
+			fpclass :: fppack == 4 )) ||
+			( sizeof( typename fpclass :: fptypeatom ) == sizeof( double ) &&
+			fpclass :: fppack == 1 )) && fpclass :: packmode == 0,
+			"avir_hip: fpclass_def<float>, fpclass_float4 "
+			"(avir_float4_sse.h) or fpclass_def<double>" );
 
 		avirhip_params p;
 		p.CorrFltAlpha = aParams.CorrFltAlpha; p.CorrFltLen = aParams.CorrFltLen;
@@ -243,6 +245,12 @@ public:
 			fpclass :: CDitherer :: avirhip_dither ),
 			"avirhip_resizer_set_ditherer" );
 
+		if( sizeof( typename fpclass :: fptypeatom ) == sizeof( double ))
+		{
+			hipdetail :: check( avirhip_resizer_set_fpclass( h,
+				AVIRHIP_FPCLASS_DOUBLE ), "avirhip_resizer_set_fpclass" );
+		}
+		else
 		if( fpclass :: fppack != 1 )
 		{
 			hipdetail :: check( avirhip_resizer_set_fpclass( h,

@@ -358,7 +358,12 @@ int avirhip_resizer_set_ditherer(avirhip_resizer* r, int dither);
  * (avir.h:4786, 6206-6270 -- the automatic BuildMode can differ), the
  * ditherer's rounding and the float-output path (AVIRHIP_DITHER_DEF_RNE),
  * and the CImageResizerVarsBase write-back. The error-diffusion ditherer is
- * only built for fppack 1. */
+ * only built for fppack 1.
+ * AVIRHIP_FPCLASS_DOUBLE = fpclass_def<double> (avir.h:4553-4560): the double
+ * pipeline -- tables designed and stored in double, every pass computes in
+ * double (the generic kernels; default ditherer only), double output is the
+ * vertical pass' in-place result. */
+#define AVIRHIP_FPCLASS_DOUBLE 64
 int avirhip_resizer_set_fpclass(avirhip_resizer* r, int fppack);
 
 /* Host-only: runs the planner exactly as resizeImage() would for this call

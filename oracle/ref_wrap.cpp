@@ -233,6 +233,8 @@ int doResize( const void* src, int sw, int sh, int sstride, void* dst,
 
 typedef avir::CImageResizer< avir::fpclass_def< float > > RDef;
 typedef avir::CImageResizer< avir::fpclass_float4 > RF4;
+/* avir.h:4553-4560: the double pipeline */
+typedef avir::CImageResizer< avir::fpclass_def< double > > RDbl;
 /* README.md:135-142: the error-diffusion ditherer */
 typedef avir::CImageResizer< avir::fpclass_def< float, float,
 	avir::CImageResizerDithererErrdINL< float > > > RErrd;
@@ -373,7 +375,8 @@ extern "C" {
  * variant 0 = fpclass_def<float> (the parity oracle), 1 = fpclass_float4
  * (SSE), 2 = fpclass_float8_dil (AVX, de-interleaved; only in the REF_SIMD
  * speed build, which is a CPU-baseline timing aid and not a parity oracle),
- * 3 = fpclass_def<float,float,CImageResizerDithererErrdINL<float>>. */
+ * 3 = fpclass_def<float,float,CImageResizerDithererErrdINL<float>>,
+ * 4 = fpclass_def<double>. */
 /* UseSRGBGamma / AlphaIndex for subsequent ref_avir_resize() calls. */
 void ref_set_gamma( int use, int alpha_index )
 {
@@ -475,6 +478,13 @@ int ref_avir_resize( const void* src, int sw, int sh, int sstride, void* dst,
 	if( variant == 3 )
 	{
 		return( doResize< RErrd >( src, sw, sh, sstride, dst, nw, nh, ch, k,
+			in_type, out_type, resbits, srcbits, params, ox, oy, build_mode,
+			threads ));
+	}
+
+	if( variant == 4 )
+	{
+		return( doResize< RDbl >( src, sw, sh, sstride, dst, nw, nh, ch, k,
 			in_type, out_type, resbits, srcbits, params, ox, oy, build_mode,
 			threads ));
 	}

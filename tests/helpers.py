@@ -6,7 +6,7 @@ from avir_amd import abi
 
 def product_desc(sw, sh, nw, nh, ch, k=0.0, in_type=abi.F32, out_type=abi.F32,
                  resbits=8, srcbits=0, build_mode=-1, ox=0.0, oy=0.0,
-                 params=None, sstride=0):
+                 params=None, sstride=0, fpclass=1):
     """Runs the product planner; returns (resizer_handle, POINTER(PlanDesc)).
     Free with free_product_desc()."""
     lib = abi.load()
@@ -22,6 +22,8 @@ def product_desc(sw, sh, nw, nh, ch, k=0.0, in_type=abi.F32, out_type=abi.F32,
     abi.check(lib.avirhip_resizer_create(
         resbits, srcbits, C.byref(P) if P is not None else None,
         C.byref(r)), "resizer_create")
+    if fpclass != 1:
+        abi.check(lib.avirhip_resizer_set_fpclass(r, fpclass), "set_fpclass")
     v = abi.Vars()
     lib.avirhip_vars_default(C.byref(v))
     v.BuildMode, v.ox, v.oy = build_mode, ox, oy

@@ -56,6 +56,13 @@ def test_reference_style_program_matches_reference():
         rb.ref().ref_avir_vars_base_f4(640, 480, 1024, 768, 3, 0.0, 1, 8, w)
         assert got["float4_vars"] == "%d %d %d %d %d %d %d" % (
             w[0], w[2], w[3], w[6], w[7], w[8], w[9])
+    # avir.h:4553-4560: CImageResizer< fpclass_def< double > >
+    if rb.have_ref():
+        import numpy as np
+        assert got["double_f64"] == rb.fnv(rb.ref_avir(
+            src.astype(np.float64), 400, 300, resbits=16, variant=4))
+        assert got["double_u8"] == rb.fnv(rb.ref_avir(
+            rb.lcg_u8((480, 640, 3)), 1024, 768, variant=4))
     if rb.have_ref():
         import ctypes as C
         w = (C.c_double * 16)()

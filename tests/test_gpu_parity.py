@@ -1660,3 +1660,58 @@ def test_lancir_integer_plans_allocate_no_float_copies():
                                       out.ctypes.data, abi.MEM_HOST, 0, nh,
                                       None), "generic")
     _assert_same(out, want, "lancir u8 generic")
+
+
+F64_CASES = [
+    # (sw, sh, nw, nh): every build mode the automatic choice reaches, up and
+    # down, integer and other ratios, tiny images
+    (64, 48, 100, 77), (300, 200, 100, 67), (640, 480, 1024, 768),
+    (120, 100, 45, 77), (9, 7, 31, 5), (257, 131, 514, 262), (90, 300, 41, 61),
+    (200, 150, 67, 50), (33, 65, 200, 67), (50, 40, 50, 40),
+]
+
+
+@pytest.mark.parametrize("tin,tout,bits,gamma,alpha", [
+    (np.float64, np.float64, 16, False, -1), (np.float32, np.float32, 16, False, -1),
+    (np.uint8, np.uint8, 8, False, -1), (np.uint16, np.uint16, 16, False, -1),
+    (np.uint16, np.uint16, 10, False, -1), (np.float64, np.uint8, 8, False, -1),
+    (np.uint8, np.float64, 8, False, -1), (np.uint8, np.uint8, 8, True, -1),
+    (np.float64, np.float64, 16, True, 3), (np.uint16, np.float32, 16, True, 0),
+    (np.float32, np.uint16, 16, True, -1)])
+def test_avir_fpclass_def_double(tin, tout, bits, gamma, alpha):
+    """avir::CImageResizer< fpclass_def< double > > (avir.h:4553-4560): tables
+    designed and stored in double by the planner's double instantiation, every
+    pass in double (generic64.hip), double output in place, other types
+    through the output stage. Bit for bit against the reference built the
+    same way (oracle/_ref, variant 4); whole frames and row bands."""
+    if not rb.have_ref():
+        pytest.skip("oracle/_ref not built")
+    lib = abi.load()
+    for (sw, sh, nw, nh) in F64_CASES:
+        for ch in ((4,) if alpha >= 0 else (1, 3, 4)):
+            if np.dtype(tin).kind == "u":
+                src = rb.lcg_u8((sh, sw, ch, np.dtype(tin).itemsize), seed=sw + ch)
+                src = src.view(tin).reshape(sh, sw, ch)
+            else:
+                src = (rb.lcg_f32((sh, sw, ch), seed=sw * 5 + ch) * 1.2 - 0.1
+                       ).astype(tin)
+                if gamma:
+                    src = np.clip(src, 0.0, 1.0).astype(tin)
+                if np.dtype(tout).kind == "u" and not gamma:
+                    src = (src * float(np.iinfo(tout).max)).astype(tin)
+            want = rb.ref_avir(src, nw, nh, resbits=bits, out_dtype=tout,
+                               variant=4, gamma=gamma, alpha=alpha)
+            v = avir_amd.CImageResizerVars()
+            v.UseSRGBGamma, v.AlphaIndex = gamma, alpha
+            r = avir_amd.CImageResizer(bits, aFpPack=abi.FPCLASS_DOUBLE)
+            got = r.resize(src, nw, nh, 0.0, tout, v)
+            _assert_same(got, want, "f64 %r" % ((sw, sh, nw, nh, ch),))
+            p = r.plan(sw, sh, nw, nh, ch, 0.0, v, rb._DT[src.dtype],
+                       rb._DT[np.dtype(tout)])
+            out = np.zeros((nh, nw, ch), tout)
+            for a_, b_ in [(0, nh // 3), (nh // 3, nh)]:
+                if b_ > a_:
+                    abi.check(lib.avirhip_resize_band(
+                        p, src.ctypes.data, abi.MEM_HOST, out[a_:b_].ctypes.data,
+                        abi.MEM_HOST, a_, b_, None), "band")
+            _assert_same(out, want, "f64 bands")

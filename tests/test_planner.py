@@ -133,3 +133,59 @@ def test_vars_base_write_back_matches_reference():
         assert b.gamma_valid == gamma
         if gamma:
             assert [b.InGammaMult, b.OutGammaMult] == list(want)[14:16]
+
+
+@pytest.mark.parametrize("sw,sh,nw,nh,bits", [
+    (64, 48, 100, 77, 8), (300, 200, 100, 67, 16), (640, 480, 1024, 768, 8),
+    (257, 131, 514, 262, 16), (1000, 700, 250, 175, 10)])
+def test_double_planner_tables(sw, sh, nw, nh, bits):
+    """The planner's double instantiation (fpclass_def<double>): the same step
+    structure as the float plan of a forced build mode, tables in the ...64
+    fields, and NOT the float tables widened -- the reference designs its
+    correction filter from the taps as stored (avir.h:5616-5739), so only the
+    first filters agree to float precision. (End-to-end parity against the
+    reference's double class is a GPU test: test_avir_fpclass_def_double.)"""
+    import numpy as np
+    rf, df = product_desc(sw, sh, nw, nh, 3, in_type=abi.U8, out_type=abi.U8,
+                          resbits=bits)
+    try:
+        mh, mv = df.contents.h.build_mode, df.contents.v.build_mode
+    finally:
+        free_product_desc(rf, df)
+    assert mh == mv
+    rf, df = product_desc(sw, sh, nw, nh, 3, in_type=abi.U8, out_type=abi.U8,
+                          resbits=bits, build_mode=mh)
+    rd, dd = product_desc(sw, sh, nw, nh, 3, in_type=abi.U8, out_type=abi.U8,
+                          resbits=bits, build_mode=mh,
+                          fpclass=abi.FPCLASS_DOUBLE)
+    try:
+        assert df.contents.work_f64 == 0 and dd.contents.work_f64 == 1
+        widened_everywhere = True
+        for af, ad in ((df.contents.h, dd.contents.h),
+                       (df.contents.v, dd.contents.v)):
+            assert af.n_steps == ad.n_steps
+            for i in range(af.n_steps):
+                sf, sd = af.steps[i], ad.steps[i]
+                for f in ("kind", "resample_factor", "in_len", "out_len",
+                          "flt_len", "flt_latency", "bank_filter_len",
+                          "bank_order", "n_phases"):
+                    assert getattr(sf, f) == getattr(sd, f), (i, f)
+                assert not sd.flt and not sd.phase_taps
+                if sf.flt_len:
+                    a = np.array(sf.flt[:sf.flt_len])
+                    b = np.array(sd.flt64[:sd.flt_len])
+                    assert np.allclose(a, b, rtol=0, atol=2e-6)
+                    widened_everywhere &= bool(
+                        (a == b.astype(np.float32)).all())
+                if sf.n_phases:
+                    n = sf.n_phases * sf.bank_filter_len * (sf.bank_order + 1)
+                    a = np.array(sf.phase_taps[:n])
+                    b = np.array(sd.phase_taps64[:n])
+                    assert np.allclose(a, b, rtol=0, atol=2e-6)
+                    assert sd.rpos[0].x == 0.0
+                    for j in range(0, sf.out_len, max(1, sf.out_len // 50)):
+                        assert sf.rpos[j].src_offs_px == sd.rpos[j].src_offs_px
+                        assert abs(sf.rpos[j].x - sd.rpos[j].x64) < 1e-6
+    finally:
+        free_product_desc(rf, df)
+        free_product_desc(rd, dd)
