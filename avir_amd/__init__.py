@@ -112,7 +112,8 @@ class CImageResizer(object):
     for the reference's third fpclass_def template parameter (avir.h:4569):
     "def" = CImageResizerDithererDefINL, "errd" = CImageResizerDithererErrdINL
     (README.md:135-142); `aFpPack=4` stands for avir::fpclass_float4 of
-    avir_float4_sse.h (README.md:174-186)."""
+    avir_float4_sse.h (README.md:174-186), `aFpPack=abi.FPCLASS_DOUBLE` for
+    avir::fpclass_def<double> (avir.h:4553-4560: the double pipeline)."""
 
     DITHERERS = {"def": abi.DITHER_DEF, "errd": abi.DITHER_ERRD}
 
