@@ -94,6 +94,11 @@ def ref():
             lib.ref_avir_vars_base_f4.argtypes = [
                 C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double,
                 C.c_int, C.c_int, C.POINTER(C.c_double)]
+        if hasattr(lib, "ref_avir_vars_base_f64"):
+            lib.ref_avir_vars_base_f64.restype = C.c_int
+            lib.ref_avir_vars_base_f64.argtypes = [
+                C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double,
+                C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double)]
         lib.ref_avir_plan_free.restype = None
         lib.ref_avir_plan_free.argtypes = [C.POINTER(abi.PlanDesc)]
         lib.ref_lancir_plan_dump.restype = C.POINTER(abi.LancirDesc)

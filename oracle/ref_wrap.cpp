@@ -461,6 +461,37 @@ int ref_avir_vars_base_f4( int sw, int sh, int nw, int nh, int ch, double k,
 	return( 0 );
 }
 
+/* The same for avir::CImageResizer<fpclass_def<double>>, with an explicit
+ * build mode (uint8 or double images). */
+int ref_avir_vars_base_f64( int sw, int sh, int nw, int nh, int ch, double k,
+	int is_u8, int resbits, int build_mode, double* out )
+{
+	RDbl r( resbits );
+	avir::CImageResizerVars V;
+	V.BuildMode = build_mode;
+
+	if( is_u8 )
+	{
+		std::vector< uint8_t > a( (size_t) sw * sh * ch, 7 ),
+			b( (size_t) nw * nh * ch );
+		r.resizeImage( a.data(), sw, sh, 0, b.data(), nw, nh, ch, k, &V );
+	}
+	else
+	{
+		std::vector< double > a( (size_t) sw * sh * ch, 0.5 ),
+			b( (size_t) nw * nh * ch );
+		r.resizeImage( a.data(), sw, sh, 0, b.data(), nw, nh, ch, k, &V );
+	}
+
+	out[ 0 ] = V.ElCount; out[ 1 ] = V.ElCountIO; out[ 2 ] = V.fppack;
+	out[ 3 ] = V.fpalign; out[ 4 ] = V.elalign; out[ 5 ] = V.packmode;
+	out[ 6 ] = V.BufLen[ 0 ]; out[ 7 ] = V.BufLen[ 1 ];
+	out[ 8 ] = V.BufOffs[ 0 ]; out[ 9 ] = V.BufOffs[ 1 ];
+	out[ 10 ] = V.k; out[ 11 ] = V.o; out[ 12 ] = V.ResizeStep;
+	out[ 13 ] = V.IsResize2;
+	return( 0 );
+}
+
 int ref_avir_resize( const void* src, int sw, int sh, int sstride, void* dst,
 	int nw, int nh, int ch, double k, int in_type, int out_type, int resbits,
 	int srcbits, const double* params, double ox, double oy, int build_mode,

@@ -189,3 +189,35 @@ def test_double_planner_tables(sw, sh, nw, nh, bits):
     finally:
         free_product_desc(rf, df)
         free_product_desc(rd, dd)
+
+
+def test_double_class_vars_base_and_build_modes_match_reference():
+    """CImageResizer<fpclass_def<double>>: the CImageResizerVarsBase write-back
+    (fpalign 8, buffer lengths and offsets of the chosen build mode) equals the
+    reference's -- automatic and forced build modes, host only."""
+    import ctypes as C
+    lib = abi.load()
+    cases = [(64, 48, 128, 96, 4, 0.0, 0, 16, -1), (64, 48, 100, 77, 3, 0.0, 1, 8, -1),
+             (300, 200, 100, 67, 4, 0.0, 0, 8, -1), (300, 200, 40, 31, 1, 0.0, 1, 8, -1),
+             (90, 60, 120, 100, 2, 0.61, 0, 16, -1), (37, 21, 74, 42, 4, 0.0, 0, 8, 0),
+             (37, 21, 74, 42, 4, 0.0, 0, 8, 2), (16, 9, 5, 7, 2, 0.0, 0, 8, 3),
+             (640, 480, 1024, 768, 3, 0.0, 1, 8, -1), (1000, 700, 250, 175, 3, 0.0, 1, 10, 1)]
+    for (sw, sh, nw, nh, ch, k, u8, bits, mode) in cases:
+        want = (C.c_double * 16)()
+        assert rb.ref().ref_avir_vars_base_f64(sw, sh, nw, nh, ch, k, u8, bits,
+                                               mode, want) == 0
+        r = C.c_void_p()
+        abi.check(lib.avirhip_resizer_create(bits, 0, None, C.byref(r)), "c")
+        abi.check(lib.avirhip_resizer_set_fpclass(r, abi.FPCLASS_DOUBLE), "f")
+        v = abi.Vars()
+        lib.avirhip_vars_default(C.byref(v))
+        v.BuildMode = mode
+        b = abi.VarsBase()
+        t = abi.U8 if u8 else abi.F64
+        abi.check(lib.avirhip_resizer_vars_base(
+            r, sw, sh, 0, nw, nh, ch, k, C.byref(v), t, t, C.byref(b)), "vb")
+        lib.avirhip_resizer_destroy(r)
+        got = [b.ElCount, b.ElCountIO, b.fppack, b.fpalign, b.elalign,
+               b.packmode, b.BufLen[0], b.BufLen[1], b.BufOffs[0],
+               b.BufOffs[1], b.k, b.o, b.ResizeStep, b.IsResize2]
+        assert got == list(want)[:14], (sw, sh, nw, nh, got, list(want))
