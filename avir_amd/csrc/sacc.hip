@@ -728,16 +728,17 @@ __global__ void __launch_bounds__( 64 ) k_sacc( const SAParams P )
 //     picks a half of an SGPR pair);
 //   * RGB: the third channel of TWO slots shares one packed multiply-add (the
 //     coefficient pair as it lies x the channel broadcast): 3 instead of 4
-//     instructions per slot -- a packed instruction takes a SIMD as long as a
-//     scalar one;
+//     instructions per slot;
 //   * samples arrive by per-lane loads of eight pixels of the lane's row (RGB
 //     uint8: two dwordx3), one group in flight while the other is used; the
 //     four samples up next always sit in the same registers, so every position
 //     is compile-time and nothing goes through LDS;
-//   * an output leaves its accumulator AFTER the group in which its last tap
-//     fell (its later coefficients are zeros): one wave-uniform switch over the
-//     slot per output, outside the sample code. The host checks that the slot's
-//     next output starts after that group (sa2_tables).
+//   * an output leaves its accumulator AFTER the block of four samples in
+//     which its last tap fell (its later coefficients are zeros), outside the
+//     sample code: the loop over outputs is unrolled 16 times with the slot
+//     compile-time (a 16-way switch in one copy of the sample loop copied all
+//     48 accumulator registers in and out of every case). The host checks
+//     that the slot's next output starts after that block (sacc_prepare_axis).
 // Same order of operations per output as k_sacc => the same bits.
 // ---------------------------------------------------------------------
 
