@@ -13,6 +13,7 @@
 #include <chrono>
 #include <atomic>
 #include <thread>
+#include <system_error>
 
 namespace avirhip {
 
@@ -1064,6 +1065,17 @@ static int exec_host_pipelined( avirhip_plan* p, const void* src, void* dst,
 		const int n = ( e != nullptr ? atoi( e ) : 16 );
 		return( n < 2 ? 2 : ( n > NBMAX ? (int) NBMAX : n )); }();
 
+	// Every band is one exec_device call. Stages that are not limited to the
+	// band's rows would be repeated NB times: the double pipeline and the
+	// generic kernels run whole axes through a filtered upsample, and the
+	// gamma pack pass converts the whole source -- such calls stay serial.
+	const int xp = ( p -> path != 0 ? p -> path : p -> auto_path );
+
+	if( p -> f64 || ( !p -> is_lancir && ( p -> gamma || xp == 1 )))
+	{
+		return( 1 );
+	}
+
 	if( off || p -> new_h < 4 * NB || src_bytes + dst_bytes < ( 16u << 20 ) ||
 		( !p -> is_lancir && p -> dither == AVIRHIP_DITHER_ERRD &&
 		( p -> out_type == AVIRHIP_U8 || p -> out_type == AVIRHIP_U16 )))
@@ -1073,18 +1085,42 @@ static int exec_host_pipelined( avirhip_plan* p, const void* src, void* dst,
 
 	if( p -> pipe_in == nullptr )
 	{
-		hipStream_t a, b;
-		AVIRHIP_HIPCHECK( hipStreamCreateWithFlags( &a, hipStreamNonBlocking ));
-		AVIRHIP_HIPCHECK( hipStreamCreateWithFlags( &b, hipStreamNonBlocking ));
-		p -> pipe_in = a; p -> pipe_out = b;
+		// built aside and committed to the plan only when complete: a plan
+		// must never hold half a set (the next call would index past pipe_ev)
+		hipStream_t a = nullptr, b = nullptr;
+		std::vector< hipEvent_t > evs;
+		bool ok = ( hipStreamCreateWithFlags( &a, hipStreamNonBlocking ) ==
+			hipSuccess );
 
-		for( int i = 0; i < 2 * NB + 1; i++ )
+		ok = ok && ( hipStreamCreateWithFlags( &b, hipStreamNonBlocking ) ==
+			hipSuccess );
+
+		for( int i = 0; ok && i < 2 * NB + 1; i++ )
 		{
 			hipEvent_t e;
-			AVIRHIP_HIPCHECK( hipEventCreateWithFlags( &e,
-				hipEventDisableTiming ));
-			p -> pipe_ev.push_back( e );
+			ok = ( hipEventCreateWithFlags( &e, hipEventDisableTiming ) ==
+				hipSuccess );
+
+			if( ok ) evs.push_back( e );
 		}
+
+		if( !ok )
+		{
+			(void) hipGetLastError();
+
+			for( size_t i = 0; i < evs.size(); i++ )
+			{
+				(void) hipEventDestroy( evs[ i ]);
+			}
+
+			if( a != nullptr ) (void) hipStreamDestroy( a );
+			if( b != nullptr ) (void) hipStreamDestroy( b );
+
+			return( 1 ); // (the serial path needs none of this)
+		}
+
+		p -> pipe_in = a; p -> pipe_out = b;
+		p -> pipe_ev.swap( evs );
 	}
 
 	hipStream_t s_in = (hipStream_t) p -> pipe_in;
@@ -1133,11 +1169,13 @@ static int exec_host_pipelined( avirhip_plan* p, const void* src, void* dst,
 	const int dev = p -> device;
 	char* const dsrc = (char*) p -> stage_src;
 
-	std::thread uploader( [&]()
+	auto upload_rows = [&]()
 	{
-		if( hipSetDevice( dev ) != hipSuccess )
+		hipError_t he = hipSetDevice( dev );
+
+		if( he != hipSuccess )
 		{
-			up_err.store( 1 );
+			up_err.store( (int) he );
 			ready.store( NB );
 			return;
 		}
@@ -1153,23 +1191,37 @@ static int exec_host_pipelined( avirhip_plan* p, const void* src, void* dst,
 				const size_t o0 = (size_t) done * srow;
 				const size_t o1 = std::min( src_bytes, (size_t) upto * srow );
 
-				if( o1 > o0 && hipMemcpyAsync( dsrc + o0, (const char*) src + o0,
-					o1 - o0, hipMemcpyHostToDevice, s_in ) != hipSuccess )
+				if( o1 > o0 && ( he = hipMemcpyAsync( dsrc + o0,
+					(const char*) src + o0, o1 - o0, hipMemcpyHostToDevice,
+					s_in )) != hipSuccess )
 				{
-					up_err.store( 1 );
+					up_err.store( (int) he );
 				}
 
 				done = upto;
 			}
 
-			if( hipEventRecord( p -> pipe_ev[ b ], s_in ) != hipSuccess )
+			if(( he = hipEventRecord( p -> pipe_ev[ b ], s_in )) != hipSuccess )
 			{
-				up_err.store( 1 );
+				up_err.store( (int) he );
 			}
 
 			ready.store( b );
 		}
-	} );
+	};
+
+	// (a thread that cannot be started must not throw through extern "C":
+	// the rows then go up from this thread, band after band, before the loop)
+	std::thread uploader;
+
+	try
+	{
+		uploader = std::thread( upload_rows );
+	}
+	catch( const std::system_error& )
+	{
+		upload_rows();
+	}
 
 	int rc = AVIRHIP_OK;
 
@@ -1236,7 +1288,7 @@ static int exec_host_pipelined( avirhip_plan* p, const void* src, void* dst,
 		copy_down( NB - 1 );
 	}
 
-	uploader.join();
+	if( uploader.joinable() ) uploader.join();
 	(void) hipStreamSynchronize( s_in );
 	(void) hipStreamSynchronize( s_out );
 	(void) hipStreamSynchronize( st );
@@ -1247,7 +1299,7 @@ static int exec_host_pipelined( avirhip_plan* p, const void* src, void* dst,
 	if( up_err.load() != 0 && rc == AVIRHIP_OK )
 	{
 		set_error( "host-pointer call: the source upload failed: %s",
-			hipGetErrorString( hipGetLastError() ));
+			hipGetErrorString( (hipError_t) up_err.load() ));
 		rc = AVIRHIP_EHIP;
 	}
 
@@ -1381,6 +1433,24 @@ static int exec_any( avirhip_plan* p, const void* src, int src_mem, void* dst,
 		guard.lock();
 	}
 
+	// hipStreamPerThread is ONE handle that names a different stream in every
+	// thread: such a call records the plan's event itself, when it ends (below).
+	struct PerThreadRecord
+	{
+		avirhip_plan* p;
+		hipStream_t st;
+		bool on;
+		~PerThreadRecord()
+		{
+			if( on && ( p -> last_done == nullptr ||
+				hipEventRecord( p -> last_done, st ) != hipSuccess ))
+			{
+				(void) hipGetLastError();
+				(void) hipStreamSynchronize( st );
+			}
+		}
+	} ptrec = { p, st, false };
+
 	if( !scratch_free )
 	{
 		// The plan's scratch buffers are reused by the next call. Calls on one
@@ -1390,8 +1460,16 @@ static int exec_any( avirhip_plan* p, const void* src, int src_mem, void* dst,
 		// every call: a record between two frames is a barrier packet with a
 		// release fence, 6-8 us of idle GPU per frame (the kernel trace of
 		// 640x480 -> 1024x768: H -> V inside a call 0.6 us apart, V -> the next
-		// call's H 7.7 us).
-		if( p -> last_used && p -> last_stream != (void*) st )
+		// call's H 7.7 us). "The same stream" is the same handle AND, for
+		// hipStreamPerThread, the same thread. (hipStreamGetId would also tell a
+		// destroyed stream's recycled handle value apart, but it is a hip_7.1
+		// symbol: the runtime PyTorch ships is 7.0 and could not load the
+		// library. A caller that destroys a stream with calls of this plan
+		// still in flight has to synchronise it first.)
+		const bool per_thread = ( st == hipStreamPerThread );
+		const std::thread::id tid = std::this_thread::get_id();
+
+		if( p -> last_used )
 		{
 			if( p -> last_done == nullptr )
 			{
@@ -1399,18 +1477,40 @@ static int exec_any( avirhip_plan* p, const void* src, int src_mem, void* dst,
 					hipEventDisableTiming ));
 			}
 
-			if( hipEventRecord( p -> last_done, (hipStream_t) p -> last_stream )
-				!= hipSuccess || hipStreamWaitEvent( st, p -> last_done, 0 ) !=
-				hipSuccess )
+			if( p -> last_recorded )
 			{
-				// (the old stream is gone: everything it held has to be over)
-				(void) hipGetLastError();
-				AVIRHIP_HIPCHECK( hipDeviceSynchronize() );
+				// (the last call was on a per-thread stream and recorded the
+				// event when it ended)
+				if( !( per_thread && p -> last_tid == tid ))
+				{
+					AVIRHIP_HIPCHECK( hipStreamWaitEvent( st, p -> last_done, 0 ));
+				}
 			}
+			else
+			if( p -> last_stream != (void*) st )
+			{
+				if( hipEventRecord( p -> last_done,
+					(hipStream_t) p -> last_stream ) != hipSuccess ||
+					hipStreamWaitEvent( st, p -> last_done, 0 ) != hipSuccess )
+				{
+					// (the old stream is gone: what it held may still run)
+					(void) hipGetLastError();
+					AVIRHIP_HIPCHECK( hipDeviceSynchronize() );
+				}
+			}
+		}
+		else
+		if( per_thread && p -> last_done == nullptr )
+		{
+			AVIRHIP_HIPCHECK( hipEventCreateWithFlags( &p -> last_done,
+				hipEventDisableTiming ));
 		}
 
 		p -> last_stream = (void*) st;
+		p -> last_tid = tid;
+		p -> last_recorded = per_thread;
 		p -> last_used = true;
+		ptrec.on = per_thread;
 	}
 
 	const void* dsrc = src;
@@ -1568,6 +1668,7 @@ static avirhip_plan* new_plan()
 	p -> stage_src_bytes = 0; p -> stage_dst_bytes = 0;
 	p -> shard_band = nullptr; p -> shard_band_bytes = 0; p -> shard_ldev = -1;
 	p -> last_done = nullptr; p -> last_stream = nullptr; p -> last_used = false;
+	p -> last_recorded = false;
 	p -> pipe_in = nullptr; p -> pipe_out = nullptr;
 	p -> shard_src = nullptr; p -> shard_src_bytes = 0;
 	p -> tr_mul = 1.0; p -> pk_out = 0.0;

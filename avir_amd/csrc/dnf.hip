@@ -98,10 +98,12 @@ __device__ __forceinline__ void df_store_elem( const GPOut& O,
 	}
 
 	float t = v;
+	float a = v;
 
 	if( O.use_tr )
 	{
-		t = (float) (int) ( t * O.tr_muli + 0.5f ) * O.tr_mul;
+		a = t * O.tr_muli;
+		t = (float) (int) ( a + 0.5f ) * O.tr_mul;
 	}
 	else
 	{
@@ -109,6 +111,7 @@ __device__ __forceinline__ void df_store_elem( const GPOut& O,
 	}
 
 	t = fminf( fmaxf( t, 0.0f ), O.pk_out );
+	t = avirhip_x86_round_fix( a, t, O.pk_out );
 	const unsigned int q = (unsigned int) t;
 
 	if( O.type == AVIRHIP_U8 )
@@ -752,15 +755,6 @@ int dn_run_hv( void* d, const float* src, long src_ss, float* dst, int row0,
 	static unsigned long long* dclk = nullptr;
 	static int dcalls = 0;
 
-	if( dbg & 16 )
-	{
-		if( dclk == nullptr )
-		{
-			(void) hipMalloc( &dclk, 4096 * 12 * 32 );
-		}
-
-		P.clk = dclk;
-	}
 
 	// one workgroup per compute unit: a chunk's warm-up (NT + 5K source rows)
 	// is paid per work item, so as few, as tall chunks as fill the chip
@@ -770,6 +764,19 @@ int dn_run_hv( void* d, const float* src, long src_ss, float* dst, int row0,
 	P.crows = std::max( 8, ( rows + want - 1 ) / want );
 	P.nchunks = ( rows + P.crows - 1 ) / P.crows;
 	const dim3 grid( P.nstrips * P.nchunks );
+
+	// (debugging aid, single-threaded use: per-wave clocks of up to 4096 work
+	// items; larger launches and a failed allocation run without them)
+	if(( dbg & 16 ) && grid.x <= 4096 )
+	{
+		if( dclk == nullptr && hipMalloc( &dclk, 4096 * 12 * 32 ) != hipSuccess )
+		{
+			(void) hipGetLastError();
+			dclk = nullptr;
+		}
+
+		P.clk = dclk;
+	}
 	const int kk = D -> h.K * 10 + D -> v.K;
 	// K = 3 along y: 9 row waves + 3 column waves (AVIRHIP_DNF_NHW=8: the 8 + 4
 	// split, for A/B timing)
@@ -801,7 +808,7 @@ int dn_run_hv( void* d, const float* src, long src_ss, float* dst, int row0,
 
 #undef DF_LAUNCH
 
-	if(( dbg & 16 ) && ++dcalls == 100 && grid.x <= 4096 )
+	if(( dbg & 16 ) && P.clk != nullptr && ++dcalls == 100 )
 	{
 		// in-kernel clocks of a launch in the middle of a timing loop
 		std::vector< unsigned long long > hc( (size_t) grid.x * 12 * 4 );

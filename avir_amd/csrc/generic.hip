@@ -615,8 +615,8 @@ int launch_pack_gamma( const void* src, int in_type, float* dst, int w, int h,
 // avir::round, avir.h:130-135 (biased, via int cast).
 __host__ __device__ __forceinline__ float avir_round( const float d )
 {
-	return( d < 0.0f ? -(float) (int) ( 0.5f - d ) :
-		(float) (int) ( d + 0.5f ));
+	return( d < 0.0f ? -(float) avirhip_x86_cvtt( 0.5f - d ) :
+		(float) avirhip_x86_cvtt( d + 0.5f ));
 }
 
 // round() of avir_float4_sse.h:303-313 (the ditherer of fpclass_float4):
@@ -870,11 +870,14 @@ __global__ void __launch_bounds__( 256 ) k_epilogue_gamma_thr( const float* res,
 			lo += ( v >= t[ lo + s ] ? s : 0 );
 		}
 
-		// above the range the thresholds were searched in (16.0: nothing an
+		// outside the range the thresholds were searched in (16.0: nothing an
 		// image holds) the direct expressions decide -- +inf, for one, is NOT
 		// the largest byte: the power approximation turns it into a NaN
-		// (found by the all-floats sweep of tests/test_gpu_parity.py)
-		if( v > 16.0f )
+		// (found by the all-floats sweep of tests/test_gpu_parity.py), and
+		// avir::round leaves the int range at both ends: the x86 build turns
+		// a large positive value into byte 0, a large NEGATIVE one into 255
+		// (plan.h avirhip_x86_cvtt; tools/fuzz_values.py found the second)
+		if( !( fabsf( v ) <= 16.0f ))
 		{
 			float d = ( c == alpha_index ? v * ogm : lin_to_srgb( v ) * ogm );
 			d = ( use_tr ? avir_round( d * tr_muli ) * tr_mul : avir_round( d ));
@@ -1678,10 +1681,17 @@ int launch_errd( const float* res, void* dst, int out_type, int w, int h,
 		getenv( "AVIRHIP_ERRD_PLAIN" ) == nullptr )
 	{
 		static std::atomic< unsigned > calls( 0 );
-		const unsigned epoch = ( ++calls ) & 0xfffu;
+		// (never 0: the flags are zeroed below)
+		const unsigned epoch = ( ++calls ) % 0xfffu + 1;
 		const int npass = ( h + EJ_ROWS - 1 ) / EJ_ROWS;
 		// (launch_errd's caller sized `line` for npass rows of values + flags)
 		unsigned* const flags = (unsigned*) ( line + (size_t) npass * w * 4 );
+		// The flags outlive the launch in the plan's buffer, and the epoch is
+		// 12 bits of a process-wide counter: a plan that runs again a multiple of
+		// the period later (or fresh memory that holds another plan's old flags)
+		// would find "valid" flags. Zeroed in stream order before every frame.
+		AVIRHIP_HIPCHECK( hipMemsetAsync( flags, 0, (size_t) npass *
+			sizeof( unsigned ), st ));
 		// AVIRHIP_ERRD_SERIAL: one launch per pass (stream order instead of
 		// the flags; debugging aid)
 		const bool serial = ( getenv( "AVIRHIP_ERRD_SERIAL" ) != nullptr );

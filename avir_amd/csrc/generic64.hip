@@ -316,7 +316,13 @@ __global__ void __launch_bounds__( 256 ) k_pack64( const Tin* src, double* dst,
 // avir::round< double >, avir.h:130-135
 __device__ __forceinline__ double round64( const double d )
 {
-	return( d < 0.0 ? -(double) (int) ( 0.5 - d ) : (double) (int) ( d + 0.5 ));
+	// (the x86-64 build's cvttsd2si: INT_MIN for what the int cannot hold,
+	// NaN included -- plan.h avirhip_x86_cvtt)
+	const double a = ( d < 0.0 ? 0.5 - d : d + 0.5 );
+	const double r = (double) ( fabs( a ) < 2147483648.0 ? (int) a :
+		( -2147483647 - 1 ));
+
+	return( d < 0.0 ? -r : r );
 }
 
 // applySRGBGamma (avir.h:2982-3068), CImageResizerDithererDefINL< double >::

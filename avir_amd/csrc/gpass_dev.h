@@ -115,7 +115,8 @@ static inline void gp_make_out( const avirhip_plan* p, void* iout, GPOut& O )
 
 __device__ __forceinline__ float gp_round( const float d )
 {
-	return( d < 0.0f ? -(float) (int) ( 0.5f - d ) : (float) (int) ( d + 0.5f ));
+	return( d < 0.0f ? -(float) avirhip_x86_cvtt( 0.5f - d ) :
+		(float) avirhip_x86_cvtt( d + 0.5f ));
 }
 
 // pixel x of row `row` (both relative to O.base)
@@ -142,10 +143,12 @@ __device__ __forceinline__ void gp_store_int( const GPOut& O, const long row,
 		// returns for them is <= 0 and the clamp that follows makes it 0 --
 		// as does the truncation of d + 0.5 (<= 0 for every d < 0)
 		float t = v[ c ];
+		float a = t;
 
 		if( O.use_tr )
 		{
-			t = (float) (int) ( t * O.tr_muli + 0.5f ) * O.tr_mul;
+			a = t * O.tr_muli;
+			t = (float) (int) ( a + 0.5f ) * O.tr_mul;
 		}
 		else
 		{
@@ -153,6 +156,7 @@ __device__ __forceinline__ void gp_store_int( const GPOut& O, const long row,
 		}
 
 		t = fminf( fmaxf( t, 0.0f ), O.pk_out );
+		t = avirhip_x86_round_fix( a, t, O.pk_out );
 		q[ c ] = (unsigned int) t;
 	}
 

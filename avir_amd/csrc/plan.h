@@ -20,7 +20,31 @@
 #include <string>
 #include <vector>
 #include <mutex>
+#include <thread>
 #include "../../include/avirhip.h"
+
+// The (int) cast of the reference's x86-64 build (cvttss2si), which avir::round
+// (avir.h:130-135) is made of: a value the 32-bit integer cannot hold -- NaN
+// included -- converts to INT_MIN, the "integer indefinite" (C++ leaves it
+// undefined; the parity target is that build). gfx950's v_cvt_i32_f32
+// saturates instead, so float images with HDR-sized or non-finite samples would
+// give other integer pixels: +1e10 -> 0 and -1e10 -> the maximum in the
+// reference (round() returns -2^31 / +2^31, then the clamp).
+__host__ __device__ __forceinline__ int avirhip_x86_cvtt( const float f )
+{
+	return( fabsf( f ) < 2147483648.0f ? (int) f : ( -2147483647 - 1 ));
+}
+
+// ... for the output stages that drop avir::round's negative branch (whatever it
+// returns for -2^31 < d < 0 the clamp turns into 0): `t` is the clamped result
+// computed with the saturating cast from round()'s argument `a`; beyond the
+// int range the reference's round() is -2^31 for positive and +2^31 for
+// negative arguments, i.e. 0 and the maximum after the clamp.
+__device__ __forceinline__ float avirhip_x86_round_fix( const float a,
+	const float t, const float pk_out )
+{
+	return( fabsf( a ) >= 2147483648.0f ? ( a < 0.0f ? pk_out : 0.0f ) : t );
+}
 
 // internal: an inner plan was run without a float result buffer and its path
 // would have written one (exec_device allocates it and runs again)
@@ -173,6 +197,8 @@ struct avirhip_plan
 	hipEvent_t last_done;
 	void* last_stream; // stream of the last call that used the scratch buffers
 	bool last_used;    // (there was one)
+	std::thread::id last_tid; // its thread (hipStreamPerThread: one handle, a stream per thread)
+	bool last_recorded; // last_done was recorded when that call ended (per-thread streams)
 	// host-pointer calls: copy streams and events of the band pipeline
 	void* pipe_in; void* pipe_out;
 	std::vector< hipEvent_t > pipe_ev;

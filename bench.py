@@ -316,13 +316,30 @@ def main():
                    args.settle_ms)
         return
 
+    # --gpus N is the number of ranks, one per GPU. Launched bare (no
+    # torchrun environment) with N > 1, this process becomes the launcher: it
+    # starts N ranks of itself under torch.distributed.run and passes their
+    # exit code on. Launched by torchrun, WORLD_SIZE must agree with --gpus:
+    # a line that says n_gpus: 1 for a --gpus 8 request is a lie.
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(self_launch(args.gpus))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        sys.exit("bench.py: --gpus %d but WORLD_SIZE=%d: launch one rank per "
+                 "GPU (python bench.py --gpus N starts them itself)"
+                 % (args.gpus, world))
+
     import numpy as np
     import torch
     import torch.distributed as dist
     import avir_amd
     from avir_amd import abi, synth
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    ndev = torch.cuda.device_count()
+    if args.backend == "nccl" and ndev < world:
+        sys.exit("bench.py: --gpus %d on the RCCL backend needs %d devices, "
+                 "this node shows %d (--backend gloo shares devices for a dry "
+                 "run of the rank logic)" % (world, world, ndev))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     # one rank per GPU; a dry run of the multi-rank path on a box with fewer
@@ -352,6 +369,17 @@ def main():
         # would ramp down right before the measurement)
         dist.barrier()
         torch.cuda.synchronize(dev)
+
+    if dist.is_initialized():
+        ranks_seen, devices = rank_census(dist, torch, dev, world, rank)
+        if ranks_seen != world:
+            sys.exit("bench.py: %d ranks answered, %d expected"
+                     % (ranks_seen, world))
+        uu = [d["uuid"] for d in devices if d["uuid"]]
+        if args.backend == "nccl" and len(set(uu)) != len(uu):
+            sys.exit("bench.py: two ranks share a GPU: %r" % (devices,))
+    else:
+        ranks_seen, devices = 1, [dict(device_identity(torch, dev), rank=0)]
 
     lib = abi.load()
     assert lib.avirhip_device_count() >= 1, "no gfx950 device"
@@ -467,7 +495,8 @@ def main():
     out = {
         "metric": "Mpixels/sec (output) for 4K->8K RGBA resize",
         "value": round(value, 1), "unit": "Mpixels/s",
-        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "n_gpus": world, "ranks_seen": ranks_seen, "devices": devices,
+        "steps": args.steps, "warmup": args.warmup,
         "settle_ms": args.settle_ms,
         "ms_per_step": round(t / args.steps * 1e3, 4),
         "higher_is_better": True,
@@ -547,10 +576,20 @@ def main():
         # a sustained figure: the default timed region is a few ms; >= 5 s
         # of back-to-back frames is also what a 1 Hz utilisation sampler sees
         n = max(args.steps, int(5.0 / max(t / args.steps, 1e-6)))
+        import threading
+        tele = {}
+        th = threading.Thread(target=sample_telemetry, args=(local, 2.0, tele))
+        th.start()
         ts, _ = timed(full_frame, n)
+        th.join()
         out["sustained"] = {"steps": n, "seconds": round(ts, 3),
                             "ms_per_step": round(ts / n * 1e3, 4),
                             "value": round(n * mpix / ts, 1)}
+        # clock / power of this box while the sustained leg ran (one sample)
+        out["telemetry"] = dict(tele, sampled="rocm-smi, 2 s into the "
+                                "sustained leg")
+        out["sclk_mhz"] = tele.get("sclk_mhz")
+        out["power_w"] = tele.get("power_w")
 
     if rank == 0 and world == 1 and not args.no_cpu:
         # the drop-in call as a host program makes it: host pointers in and
@@ -580,6 +619,77 @@ def main():
     if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
+
+
+def sample_telemetry(device_index, delay_s, out):
+    """One rocm-smi reading (shader clock, package power) `delay_s` into the
+    sustained leg, from a side thread: the power-capped headline kernel runs at
+    whatever clock the box's cap allows, and the pool's boxes differ by ~10 %
+    -- the reading makes that visible beside the number. Best effort."""
+    import re
+    import subprocess
+    time.sleep(delay_s)
+    try:
+        r = subprocess.run(["rocm-smi", "-d", str(device_index), "--showpower",
+                            "--showclocks", "--showmaxpower", "--json"],
+                           capture_output=True, text=True, timeout=20)
+        card = next(iter(json.loads(r.stdout).values()))
+        for k, v in card.items():
+            kl = k.lower()
+            if "sclk clock level" in kl:
+                m = re.search(r"\((\d+)\s*mhz\)", v.lower())
+                if m:
+                    out["sclk_mhz"] = int(m.group(1))
+            elif "mclk clock level" in kl:
+                m = re.search(r"\((\d+)\s*mhz\)", v.lower())
+                if m:
+                    out["mclk_mhz"] = int(m.group(1))
+            elif "max graphics package power" in kl:
+                out["power_cap_w"] = float(v)
+            elif "power (w)" in kl and "max" not in kl:
+                out["power_w"] = float(v)
+    except Exception as e:  # noqa: BLE001 -- telemetry never fails the bench
+        out["error"] = "%s: %s" % (type(e).__name__, e)
+
+
+def self_launch(n):
+    """`python bench.py --gpus N` without a torchrun environment: start N
+    ranks of this script (one per GPU, rendezvous on 127.0.0.1, a free port)
+    and return their exit code. Rank 0's JSON line goes to our stdout."""
+    import socket
+    import subprocess
+    port = os.environ.get("MASTER_PORT")
+    if not port:
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            port = str(s.getsockname()[1])
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
+           "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", port, os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "1")
+    return subprocess.call(cmd, env=env)
+
+
+def rank_census(dist, torch, dev, world, rank):
+    """Who actually took part: the number of ranks that answer an all-reduce
+    of 1, and every rank's device (index, name, UUID) gathered on all ranks."""
+    on = "cpu" if dist.get_backend() == "gloo" else dev
+    one = torch.ones(1, dtype=torch.int64, device=on)
+    dist.all_reduce(one)
+    mine = device_identity(torch, dev)
+    mine["rank"] = rank
+    every = [None] * world
+    dist.all_gather_object(every, mine)
+    return int(one.item()), every
+
+
+def device_identity(torch, dev):
+    p = torch.cuda.get_device_properties(dev)
+    uuid = getattr(p, "uuid", None)
+    return {"device": dev.index, "name": p.name,
+            "uuid": str(uuid) if uuid is not None else None}
 
 
 def sharded_extras(lib, plan, src, dst, dev, world, rank, dist, torch, pipe,

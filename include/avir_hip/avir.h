@@ -21,8 +21,12 @@
  * Differences by design: there is NO CPU execution path -- if the library
  * cannot run the call (no gfx950 device, or a request outside the built
  * scope) resizeImage() throws std::runtime_error instead of silently computing
- * elsewhere. UseSRGBGamma / AlphaIndex are honoured (bit-exact gamma stages). Only the float pipeline is provided
- * (fpclass_def<float>, the reference's default).
+ * elsewhere. UseSRGBGamma / AlphaIndex are honoured (bit-exact gamma stages).
+ * Pipelines provided: fpclass_def<float> (the reference's default, every fast
+ * kernel), fpclass_def<double> (avir.h:4553-4560: tables and arithmetic in
+ * double, bit-identical to the reference's double class) and, through
+ * avir_float4_sse.h, fpclass_float4; each with the default or the
+ * error-diffusion ditherer as the third template parameter.
  */
 #ifndef AVIR_HIP_AVIR_H
 #define AVIR_HIP_AVIR_H

@@ -10,7 +10,7 @@ import sys
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-pytestmark = pytest.mark.gpu
+gpu = pytest.mark.gpu
 
 
 def _last_json(out):
@@ -19,6 +19,7 @@ def _last_json(out):
     return json.loads(lines[-1])
 
 
+@gpu
 def test_bench_single_gpu_line():
     r = subprocess.run([sys.executable, "bench.py", "--steps", "5", "--warmup",
                         "2", "--settle-ms", "50", "--no-cpu"], cwd=ROOT,
@@ -31,6 +32,7 @@ def test_bench_single_gpu_line():
     assert d["config"]["exec_path"].startswith("exact-2x")
 
 
+@gpu
 def test_bench_two_ranks_band_pipeline_gloo_dry_run():
     port = 29700 + os.getpid() % 200
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
@@ -53,6 +55,7 @@ def test_bench_two_ranks_band_pipeline_gloo_dry_run():
     assert d["value_independent_frames"] == s["independent_frames"]["value"]
 
 
+@gpu
 def test_bench_one_rank_process_group_on_rccl():
     """The N > 1 code path (process group on the nccl backend = RCCL, barriers,
     the max-over-ranks all-reduce, the band pipeline and the sharded extras)
@@ -70,3 +73,52 @@ def test_bench_one_rank_process_group_on_rccl():
         d["config"]["sharding"].startswith("one GPU"), d["config"]
     assert "error" not in d["sharded"], d["sharded"]
     assert d["sharded"]["gather_only"]["stitched_ok"]
+
+
+@gpu
+def test_bench_gpus_2_starts_two_ranks_by_itself():
+    """`python bench.py --gpus 2` with no torchrun around it (how the driver
+    runs the N = 1 line): the script must start the two ranks itself and the
+    line must say so -- ranks_seen counted by an all-reduce, one device record
+    per rank."""
+    env = {k: v for k, v in os.environ.items()
+           if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--steps",
+                        "3", "--warmup", "1", "--settle-ms", "0", "--backend",
+                        "gloo", "--no-cpu"], cwd=ROOT, env=env,
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-3000:])
+    d = _last_json(r.stdout)
+    assert d["n_gpus"] == 2 and d["ranks_seen"] == 2, d
+    assert [x["rank"] for x in d["devices"]] == [0, 1], d["devices"]
+    assert d["parity"]["ok"], d["parity"]
+
+
+def test_bench_refuses_a_world_size_that_disagrees_with_gpus():
+    """WORLD_SIZE from the launcher and --gpus must agree; the check runs
+    before anything touches a device, so it is a CPU test."""
+    env = dict(os.environ, WORLD_SIZE="4", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--steps",
+                        "1", "--warmup", "0"], cwd=ROOT, env=env,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0
+    assert "WORLD_SIZE=4" in r.stderr, r.stderr[-500:]
+    env = {k: v for k, v in os.environ.items() if k != "WORLD_SIZE"}
+    # bare --gpus 1 with WORLD_SIZE=1 from a launcher is fine up to the device
+    # check; --gpus 3 under WORLD_SIZE=1 is not
+    env["WORLD_SIZE"] = "1"
+    r = subprocess.run([sys.executable, "bench.py", "--gpus", "3", "--steps",
+                        "1", "--warmup", "0"], cwd=ROOT, env=env,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "--gpus 3" in r.stderr
+
+
+def test_bench_nccl_refuses_more_ranks_than_devices():
+    """On the RCCL backend N ranks need N devices (this container has none;
+    the GPU box has one): the run ends with a message, not with n_gpus: 1."""
+    env = dict(os.environ, WORLD_SIZE="16", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, "bench.py", "--gpus", "16", "--steps",
+                        "1", "--warmup", "0"], cwd=ROOT, env=env,
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode != 0
+    assert "needs 16 devices" in r.stderr, r.stderr[-500:]

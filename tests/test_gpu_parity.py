@@ -854,6 +854,67 @@ def test_concurrent_calls_on_one_object():
     assert not errs, errs[0]
 
 
+def test_per_thread_default_stream_calls_share_a_plan():
+    """hipStreamPerThread is ONE handle value that names a different stream in
+    every thread: two threads passing it to device-to-device calls on the same
+    plan must still be ordered on the plan's scratch buffers (packed source,
+    FltBuf, float result) -- the library may not take "same handle" for "same
+    stream". Each thread resizes its own image many times; any overlap on the
+    scratch shows as a wrong frame."""
+    import ctypes as C
+    import threading
+    import torch
+    lib = abi.load()
+    r = avir_amd.CImageResizer(8)
+    sw, sh, nw, nh = 1201, 903, 700, 517
+    plan = r.plan(sw, sh, nw, nh, 3, 0.0, None, abi.U8, abi.U8)
+    per_thread = C.c_void_p(2)  # hipStreamPerThread
+    nthr, iters = 4, 25
+    srcs = [rb.lcg_u8((sh, sw, 3), seed=50 + i) for i in range(nthr)]
+    wants = [_checker_avir(a, nw, nh, resbits=8) for a in srcs]
+    errs = []
+
+    def worker(i):
+        try:
+            torch.cuda.set_device(0)
+            d = torch.from_numpy(srcs[i]).to("cuda:0")
+            o = torch.zeros((nh, nw, 3), dtype=torch.uint8, device="cuda:0")
+            torch.cuda.synchronize()
+            for it in range(iters):
+                abi.check(lib.avirhip_resize(plan, d.data_ptr(), abi.MEM_DEVICE,
+                                             o.data_ptr(), abi.MEM_DEVICE,
+                                             per_thread), "resize")
+                if it % 5 == 4:
+                    torch.cuda.synchronize()
+                    _assert_same(o.cpu().numpy(), wants[i],
+                                 "thread %d iteration %d" % (i, it))
+        except Exception as e:  # noqa: BLE001
+            errs.append(e)
+
+    ts = [threading.Thread(target=worker, args=(i,)) for i in range(nthr)]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    assert not errs, errs[0]
+
+
+def test_special_float_values_on_every_path():
+    """tools/fuzz_values.py: float32 / float64 sources with planted +-Inf, NaN,
+    -0.0, denormals, FLT_MAX-sized, tiny and beyond-int-range values (elements,
+    pixels, clusters, rows, columns, corners, zero / minus-zero regions,
+    denormal and HDR-scaled images) through every execution path and kernel
+    variant, row bands, LANCIR and the double pipeline, against the reference:
+    raw words, a NaN only has to be a NaN (payloads are properties of the x86
+    build, see the tool's header)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools",
+                                                     "fuzz_values.py"),
+                        "500", "11"], capture_output=True, text=True,
+                       timeout=900)
+    assert r.returncode == 0, r.stdout[-4000:] + r.stderr[-2000:]
+
+
 def test_zero_sized_and_errors():
     r = avir_amd.CImageResizer(8)
     dst = np.full((4, 5, 3), 7, np.uint8)
