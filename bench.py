@@ -58,7 +58,16 @@ OTHER = {"cfg1": ("avir", 640, 480, 1024, 768, 3, "u8", 8),
          "dn192": ("avir", 3840, 2160, 2000, 1125, 4, "f32", 16),
          # the one timing the reference's README publishes (README.md:157-162:
          # 245 ms on 1 thread, 74 ms on 8 threads of an i7-7700K)
-         "readme": ("avir", 5184, 3456, 1920, 1280, 3, "u8", 8)}
+         "readme": ("avir", 5184, 3456, 1920, 1280, 3, "u8", 8),
+         # the same photo as float RGBA / float RGB (the float-source kernels)
+         "readme_f32": ("avir", 5184, 3456, 1920, 1280, 4, "f32", 16),
+         "readme_rgbf": ("avir", 5184, 3456, 1920, 1280, 3, "f32", 16),
+         # avir::CImageResizer< fpclass_def< double > > (avir.h:4553-4560):
+         # float images through the double pipeline ("avir64")
+         "cfg2_dbl": ("avir64", 1920, 1080, 3840, 2160, 4, "f32", 16),
+         "cfg3_dbl": ("avir64", 3840, 2160, 7680, 4320, 4, "f32", 16),
+         "cfg4_dbl": ("avir64", 3840, 2160, 1280, 720, 4, "f32", 16),
+         "nonint_dbl": ("avir64", 1920, 1080, 2500, 1400, 4, "f32", 16)}
 
 
 XGMI_LINK_GBS = 153.0  # per link, both directions (7 links per GPU)
@@ -85,8 +94,9 @@ def time_other(name, steps, warmup, path, settle_ms=300.0, quiet=False):
     dst = torch.empty((nh, nw, ch), dtype=src.dtype, device=dev)
     tcode = abi.U8 if dt == "u8" else abi.F32
     esz = 1 if dt == "u8" else 4
-    if api == "avir":
-        obj = avir_amd.CImageResizer(bits)
+    if api in ("avir", "avir64"):
+        obj = avir_amd.CImageResizer(
+            bits, aFpPack=abi.FPCLASS_DOUBLE if api == "avir64" else 1)
         plan = obj.plan(sw, sh, nw, nh, ch, 0.0, None, tcode, tcode)
     else:
         obj = avir_amd.CLancIR()
@@ -175,6 +185,22 @@ def report(steps, warmup, settle_ms):
             g["roofline_frac"] * 100, g["path"], ulp))
 
 
+def host_cores():
+    """Physical cores of this host: logical CPUs over SMT siblings per core."""
+    n = os.cpu_count() or 1
+    try:
+        with open("/sys/devices/system/cpu/cpu0/topology/"
+                  "thread_siblings_list") as f:
+            sib = f.read().strip()
+        per = 0
+        for part in sib.split(","):
+            a, _, b = part.partition("-")
+            per += (int(b) - int(a) + 1) if b else 1
+        return max(1, n // max(1, per))
+    except (OSError, ValueError):
+        return n
+
+
 def cpu_baseline(src_np, threads):
     """Reference CPU path on the host cores (bounded: a few frames per
     variant). Timed: the parity build (fpclass_def<float>, -O2
@@ -209,8 +235,9 @@ def cpu_baseline(src_np, threads):
     for vi, (name, fn) in enumerate(variants):
         best = {}
         # the parity build gets the full sweep, the speed builds a short one
-        counts = sweep if vi == 0 else sorted(set([1, min(32, threads),
-                                                   threads]))
+        # (8 threads is the reference's own published point, README.md:161)
+        counts = sweep if vi == 0 else sorted(set([1, min(8, threads),
+                                                   min(32, threads), threads]))
         for t in counts:
             ts = []
             budget = time.perf_counter() + 1.5
@@ -233,7 +260,8 @@ def cpu_baseline(src_np, threads):
     top = min(rows, key=lambda r: r["ms_per_frame"])
     mpix = NEW_W * NEW_H / 1e6
     return {"value": round(mpix / (top["ms_per_frame"] * 1e-3), 2),
-            "unit": "Mpixels/s", "cores": top.get("threads", threads),
+            "unit": "Mpixels/s", "cores": host_cores(),
+            "threads": top.get("threads", threads),
             "host_threads": threads, "kind": kind,
             "sample": "1-3 frames of cfg3 (3840x2160->7680x4320 RGBA f32) per "
                       "build and thread count (sweep 1..all host threads, "
@@ -719,6 +747,23 @@ def sharded_extras(lib, plan, src, dst, dev, world, rank, dist, torch, pipe,
         "frac_of_links": round(gbs / (max(1, world - 1) * XGMI_LINK_GBS), 4),
         "note": "xGMI is point-to-point: the root receives over world-1 of its "
                 "7 links; 153 GB/s is a link's two-way peak (one way: half)"}
+    # what the arithmetic predicts for `value` (ONE frame stitched on the root),
+    # so that a measured N > 1 line can be judged: every peer sends its band
+    # over its own link to the root (one direction of a 153 GB/s link), all
+    # links at once; the kernels of a band take 1/N of a whole frame's time
+    one_way = XGMI_LINK_GBS / 2.0
+    pred_gather_ms = res["bytes_per_rank"] / (one_way * 1e9) * 1e3
+    res["predicted"] = {
+        "gather_ms_per_frame": round(pred_gather_ms, 4),
+        "compute_ms_per_frame": res["compute_only"]["ms_per_frame"],
+        "stitched_value": round(mpix / (max(
+            pred_gather_ms, res["compute_only"]["ms_per_frame"]) * 1e-3), 1),
+        "note": "`value` is link-bound by construction for N > 1 (north_star's "
+                "configuration: the stitched frame lands on ONE GPU): "
+                "bytes_per_rank over one direction of one xGMI link (%.1f GB/s)"
+                ", all peers' links in parallel; `value_distributed` (bands "
+                "left where they were computed) is the compute-bound reading"
+                % one_way}
     if rank == 0:
         res["gather_only"]["stitched_ok"] = (
             __import__("avir_amd").synth.fnv(full.cpu().numpy())

@@ -787,6 +787,51 @@ def test_sharded_resize_with_a_mocked_device_table(staged, monkeypatch):
             _assert_same(dst, want, "mocked devices %r, host" % (devs,))
 
 
+@pytest.mark.parametrize("staged", [False, True])
+def test_sharded_resize_on_real_peer_devices(staged, monkeypatch):
+    """The same call on REAL peers: runs wherever the node shows two or more
+    GPUs (skipped on the 1-GPU box) -- plan replicas on every device, the
+    source copied to each, bands stored straight into the destination on
+    device 0 over xGMI after hipDeviceEnablePeerAccess (or, staged, through
+    band buffers + hipMemcpyPeerAsync), from device and from host memory."""
+    import ctypes as C
+    import torch
+    lib = abi.load()
+    ndev = lib.avirhip_device_count()
+    if ndev < 2:
+        pytest.skip("one GPU: the peer branches run on a multi-GPU node")
+    monkeypatch.delenv("AVIRHIP_SHARDED_DEVMAP", raising=False)
+    if staged:
+        monkeypatch.setenv("AVIRHIP_SHARDED_STAGED", "1")
+    for (sw, sh, nw, nh, ch, dt) in [(300, 200, 600, 400, 4, np.float32),
+                                     (301, 203, 100, 67, 3, np.uint8),
+                                     (1920, 1080, 3840, 2160, 4, np.float32)]:
+        src = (rb.lcg_u8((sh, sw, ch), seed=18) if dt == np.uint8 else
+               rb.lcg_f32((sh, sw, ch), seed=18))
+        r = avir_amd.CImageResizer(16)
+        want = r.resize(src, nw, nh)
+        code = rb._DT[np.dtype(dt)]
+        p = r.plan(sw, sh, nw, nh, ch, 0.0, None, code, code)
+        sets = [tuple(range(min(ndev, 2))), tuple(range(ndev)),
+                tuple(reversed(range(ndev)))]
+        for devs in sets:
+            n = len(devs)
+            cd = (C.c_int * n)(*devs)
+            dsrc = torch.from_numpy(src).to("cuda:0")
+            ddst = torch.zeros((nh, nw, ch), dtype=dsrc.dtype, device="cuda:0")
+            abi.check(lib.avirhip_resize_sharded(
+                p, n, cd, dsrc.data_ptr(), ddst.data_ptr(), 0, None, None),
+                "sharded device")
+            for d in range(ndev):
+                torch.cuda.synchronize(d)
+            _assert_same(ddst.cpu().numpy(), want, "devices %r" % (devs,))
+            dst = np.zeros((nh, nw, ch), dt)
+            abi.check(lib.avirhip_resize_sharded(
+                p, n, cd, src.ctypes.data, dst.ctypes.data, 0, None, None),
+                "sharded host")
+            _assert_same(dst, want, "devices %r, host" % (devs,))
+
+
 def test_in_place_device_resize():
     """NewBuf may alias SrcBuf when the result is not larger
     (avir.h:4650-4652); with device buffers the library copies the
