@@ -143,6 +143,8 @@ PROTOTYPES = {
     "avirhip_plan_get_path": (_I, [_VP]),
     "avirhip_resize": (_I, [_VP, _VP, _I, _VP, _I, _VP]),
     "avirhip_resize_band": (_I, [_VP, _VP, _I, _VP, _I, _I, _I, _VP]),
+    "avirhip_band_source_rows": (_I, [_VP, _I, _I, C.POINTER(C.c_int),
+                                      C.POINTER(C.c_int)]),
     "avirhip_resize_sharded": (_I, [_VP, _I, C.POINTER(C.c_int), _VP, _VP, _I,
                                  C.POINTER(_D), C.POINTER(_D)]),
     "avirhip_time_resize": (_I, [_VP, _VP, _VP, _I, _VP, C.POINTER(_D)]),

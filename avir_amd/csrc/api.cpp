@@ -633,6 +633,9 @@ static int run_generic( avirhip_plan* p, const float* src, long src_stride,
 	return( AVIRHIP_OK );
 }
 
+static void band_src_rows( const avirhip_plan* p, int row0, int row1,
+	int* first, int* last );
+
 static int exec_device( avirhip_plan* p, const void* src, void* dst,
 	int row0, int row1, hipStream_t st )
 {
@@ -823,15 +826,29 @@ static int exec_device( avirhip_plan* p, const void* src, void* dst,
 
 		packed_done = true;
 
+		// a band converts the source rows its windows read, nothing else (the
+		// pipelined host-pointer call is 16 bands: 16 whole-frame packs otherwise)
+		int pa, pb;
+		band_src_rows( p, row0, row1, &pa, &pb );
+
+		if( pb < pa )
+		{
+			return( AVIRHIP_OK );
+		}
+
+		const char* const ps = (const char*) src + (size_t) pa *
+			p -> src_stride * dtype_size( p -> in_type );
+		float* const pd = p -> packed + (size_t) pa * p -> src_w * p -> ch;
+
 		if( p -> gamma )
 		{
-			return( launch_pack_gamma( src, p -> in_type, p -> packed,
-				p -> src_w, p -> src_h, p -> io_ch, p -> ch, p -> src_stride,
+			return( launch_pack_gamma( ps, p -> in_type, pd, p -> src_w,
+				pb - pa + 1, p -> io_ch, p -> ch, p -> src_stride,
 				p -> alpha_index, p -> d_srgb_tbl, st ));
 		}
 
-		return( launch_pack( src, p -> in_type, p -> packed, p -> src_w,
-			p -> src_h, p -> io_ch, p -> ch, p -> src_stride, st ));
+		return( launch_pack( ps, p -> in_type, pd, p -> src_w, pb - pa + 1,
+			p -> io_ch, p -> ch, p -> src_stride, st ));
 	};
 
 	const bool need_pack = ( p -> gamma || p -> in_type != AVIRHIP_F32 ||
@@ -1020,15 +1037,28 @@ namespace avirhip {
 
 static int clone_plan( const avirhip_plan* s, int device, avirhip_plan** out );
 
-// The last source row the output rows [row0, row1) read (inclusive): the
-// vertical axis' op chain walked backwards (AVIR), the vertical filter
-// positions (LANCIR).
-static int band_last_src_row( const avirhip_plan* p, int row0, int row1 )
+// The source rows [*first, *last] (inclusive) the output rows [row0, row1)
+// read: the vertical axis' op chain walked backwards (AVIR), the vertical
+// filter positions (LANCIR). Rows outside the range are never touched by a band
+// call -- not even by a tap that multiplies them by zero (a stale or foreign
+// NaN there must not reach the result; tools/fuzz_values.py poisons them).
+static void band_src_rows( const avirhip_plan* p, int row0, int row1,
+	int* first, int* last )
 {
+	if( row1 <= row0 )
+	{
+		*first = 0;
+		*last = -1;
+		return;
+	}
+
 	if( p -> is_lancir )
 	{
-		return( std::max( 0, std::min( p -> lv.h_start[ row1 - 1 ] +
-			p -> lv.kernel_len - 1, p -> src_h - 1 )));
+		*first = std::max( 0, std::min( p -> lv.h_start[ row0 ],
+			p -> src_h - 1 ));
+		*last = std::max( 0, std::min( p -> lv.h_start[ row1 - 1 ] +
+			p -> lv.kernel_len - 1, p -> src_h - 1 ));
+		return;
 	}
 
 	int a = row0, b = row1 - 1;
@@ -1043,7 +1073,15 @@ static int band_last_src_row( const avirhip_plan* p, int row0, int row1 )
 		b = ib;
 	}
 
-	return( std::max( 0, std::min( b, p -> src_h - 1 )));
+	*first = std::max( 0, std::min( a, p -> src_h - 1 ));
+	*last = std::max( 0, std::min( b, p -> src_h - 1 ));
+}
+
+static int band_last_src_row( const avirhip_plan* p, int row0, int row1 )
+{
+	int a, b;
+	band_src_rows( p, row0, row1, &a, &b );
+	return( b );
 }
 
 // Host-pointer call, pipelined (the call every existing caller of the
@@ -1067,11 +1105,11 @@ static int exec_host_pipelined( avirhip_plan* p, const void* src, void* dst,
 
 	// Every band is one exec_device call. Stages that are not limited to the
 	// band's rows would be repeated NB times: the double pipeline and the
-	// generic kernels run whole axes through a filtered upsample, and the
-	// gamma pack pass converts the whole source -- such calls stay serial.
+	// generic kernels run whole axes through a filtered upsample -- such calls
+	// stay serial. (The pack pass converts only the rows a band reads.)
 	const int xp = ( p -> path != 0 ? p -> path : p -> auto_path );
 
-	if( p -> f64 || ( !p -> is_lancir && ( p -> gamma || xp == 1 )))
+	if( p -> f64 || ( !p -> is_lancir && xp == 1 ))
 	{
 		return( 1 );
 	}
@@ -2512,6 +2550,20 @@ int avirhip_plan_set_variant( avirhip_plan* p, int variant )
 		}
 	}
 
+	return( AVIRHIP_OK );
+}
+
+int avirhip_band_source_rows( const avirhip_plan* p, int row0, int row1,
+	int* first, int* last )
+{
+	if( p == nullptr || first == nullptr || last == nullptr || row0 < 0 ||
+		row1 > p -> new_h || row1 <= row0 )
+	{
+		set_error( "band_source_rows: bad arguments" );
+		return( AVIRHIP_EINVAL );
+	}
+
+	band_src_rows( p, row0, row1, first, last );
 	return( AVIRHIP_OK );
 }
 

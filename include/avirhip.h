@@ -269,6 +269,15 @@ int avirhip_resize(avirhip_plan* plan, const void* src, int src_mem,
 int avirhip_resize_band(avirhip_plan* plan, const void* src, int src_mem,
 	void* dst_band, int dst_mem, int row0, int row1, void* stream);
 
+/* The source rows [*first, *last] (inclusive) that output rows [row0, row1)
+ * read -- the reference's vertical windows with their replicated edges folded
+ * in (avir.h:6560-6619 resizeScanlineV over FltBuf columns; lancir.h:560-640).
+ * A band call touches no other row of `src`: a caller that streams the source
+ * (row bands of a frame arriving over a link, tiles of a larger image) only
+ * has to have these rows in place. */
+int avirhip_band_source_rows(const avirhip_plan* plan, int row0, int row1,
+	int* first, int* last);
+
 /* One frame sharded over several devices of THIS process:
  * the destination rows are split into `n_gpus` contiguous bands, band g is
  * computed on device `devices[g]` (a replica of the plan is created there on

@@ -1605,7 +1605,12 @@ def test_avir_whole_ratio_kernels_read_and_store_integer_images(sw, sh, k, ch,
     ("avir", 2000, 1500, 3000, 2250, 3, np.uint8, np.uint8),
     ("avir", 1920, 1080, 2500, 1400, 4, np.float32, np.uint16),
     ("lancir", 1500, 1000, 2200, 1500, 4, np.float32, np.float32),
-    ("lancir", 2400, 1600, 1200, 800, 3, np.uint8, np.uint8)])
+    ("lancir", 2400, 1600, 1200, 800, 3, np.uint8, np.uint8),
+    # gamma: the pack pass converts only the rows a band reads
+    ("avir-gamma", 2000, 1500, 1100, 830, 3, np.uint8, np.uint8),
+    ("avir-gamma", 1200, 900, 2500, 1900, 4, np.float32, np.uint16),
+    # the double pipeline keeps the serial path
+    ("avir-f64", 1500, 1000, 2100, 1400, 4, np.float32, np.float32)])
 def test_host_pointer_calls_run_the_band_pipeline(case):
     """A host-pointer call of a large frame is pipelined inside the library
     (api.cpp::exec_host_pipelined: source rows up, band kernels, result rows
@@ -1617,15 +1622,26 @@ def test_host_pointer_calls_run_the_band_pipeline(case):
         src = rb.lcg_u8((sh, sw, ch), seed=sw)
     else:
         src = rb.lcg_f32((sh, sw, ch), seed=sw)
-    obj = avir_amd.CImageResizer(16 if tout == np.uint16 else 8) \
-        if api == "avir" else avir_amd.CLancIR()
+    obj = avir_amd.CImageResizer(
+        16 if tout == np.uint16 else 8,
+        aFpPack=abi.FPCLASS_DOUBLE if api == "avir-f64" else 1) \
+        if api.startswith("avir") else avir_amd.CLancIR()
     dsrc = torch.from_numpy(src).to("cuda:0")
-    if api == "avir":
+    v = None
+    if api == "avir-gamma":
+        v = avir_amd.CImageResizerVars()
+        v.UseSRGBGamma = 1
+        v.AlphaIndex = 3 if ch == 4 else -1
+    if api.startswith("avir"):
         want = obj.resize(dsrc, nw, nh, out_dtype={
             np.float32: torch.float32, np.uint8: torch.uint8,
-            np.uint16: torch.uint16}[tout]).cpu().numpy()
-        got = obj.resize(src, nw, nh, out_dtype=tout)
-        again = obj.resize(src, nw, nh, out_dtype=tout)
+            np.uint16: torch.uint16}[tout], aVars=v).cpu().numpy()
+        got = obj.resize(src, nw, nh, out_dtype=tout, aVars=v)
+        again = obj.resize(src, nw, nh, out_dtype=tout, aVars=v)
+        if api == "avir-gamma" and rb.have_ref():
+            _assert_same(want, rb.ref_avir(
+                src, nw, nh, out_dtype=tout, gamma=True, alpha=v.AlphaIndex,
+                resbits=16 if tout == np.uint16 else 8), "gamma vs reference")
     else:
         want = obj.resize(dsrc, nw, nh).cpu().numpy()
         got = obj.resize(src, nw, nh)

@@ -17,6 +17,7 @@ match bit for bit.
 
 usage: fuzz_values.py [cases] [seed] [class]   (class: one of CLASSES, or all)
 exit code 1 if any case differs."""
+import ctypes as C
 import os
 import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -240,7 +241,8 @@ for it in range(N):
         content["cases_nan_partial"] += int(wn.any() and not wn.all())
     tcode_in = avir_amd._NP2T[np.dtype(tin)]
     tcode_out = avir_amd._NP2T[np.dtype(tout)]
-    runs = [(0, 0), (1, 0), (2, 0), (3, 0), (4, 0), (5, 0), ("bands", 0)]
+    runs = [(0, 0), (1, 0), (2, 0), (3, 0), (4, 0), (5, 0), ("bands", 0),
+            ("bands", int(rng.randint(1, 6)))]  # (bands: `variant` = the path)
     if cls in ("dnint", "rand"):
         runs.append((2, 2))  # k_dnh + k_dnv instead of k_dnf
     if cls == "up2":
@@ -263,12 +265,21 @@ for it in range(N):
             if path == "bands":
                 if nh < 2:
                     continue
+                if lib.avirhip_plan_set_path(p, variant) != 0:
+                    continue
                 got = np.zeros((nh, nw, ch), tout)
                 cuts = sorted(set([0, nh] + [int(rng.randint(1, nh))
                                             for _ in range(rng.randint(1, 3))]))
                 for a_, b_ in zip(cuts[:-1], cuts[1:]):
+                    # a band may touch only the source rows its windows read
+                    # (avirhip_band_source_rows): every other row is poisoned
+                    fa, fb = C.c_int(), C.c_int()
+                    abi.check(lib.avirhip_band_source_rows(
+                        p, a_, b_, C.byref(fa), C.byref(fb)), "rows")
+                    bsrc = np.full_like(src, np.nan)
+                    bsrc[fa.value:fb.value + 1] = src[fa.value:fb.value + 1]
                     abi.check(lib.avirhip_resize_band(
-                        p, src.ctypes.data, abi.MEM_HOST,
+                        p, bsrc.ctypes.data, abi.MEM_HOST,
                         got[a_:b_].ctypes.data, abi.MEM_HOST, a_, b_, None),
                         "band")
             else:
@@ -283,7 +294,7 @@ for it in range(N):
                 else:
                     got = rz.resize(src, nw, nh, out_dtype=tout, aVars=v)
         except avir_amd.AvirHipError as e:
-            if path in (0, 1, "bands"):
+            if path in (0, 1) or (path == "bands" and variant < 2):
                 print("ERROR", it, cls, (sw, sh, nw, nh, ch), path, e)
                 nbad += 1
             continue
