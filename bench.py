@@ -664,18 +664,20 @@ def sample_telemetry(device_index, delay_s, out):
         card = next(iter(json.loads(r.stdout).values()))
         for k, v in card.items():
             kl = k.lower()
-            if "sclk clock level" in kl:
-                m = re.search(r"\((\d+)\s*mhz\)", v.lower())
+            if "sclk" in kl or "mclk" in kl:
+                m = re.search(r"(\d+)\s*mhz", str(v).lower())
                 if m:
-                    out["sclk_mhz"] = int(m.group(1))
-            elif "mclk clock level" in kl:
-                m = re.search(r"\((\d+)\s*mhz\)", v.lower())
-                if m:
-                    out["mclk_mhz"] = int(m.group(1))
+                    out["sclk_mhz" if "sclk" in kl else "mclk_mhz"] = \
+                        int(m.group(1))
+                else:
+                    out.setdefault("raw", {})[k] = v
             elif "max graphics package power" in kl:
                 out["power_cap_w"] = float(v)
             elif "power (w)" in kl and "max" not in kl:
                 out["power_w"] = float(v)
+        if "sclk_mhz" not in out:
+            # (no clock line in this rocm-smi's JSON: keep what it did print)
+            out["keys"] = sorted(card.keys())[:24]
     except Exception as e:  # noqa: BLE001 -- telemetry never fails the bench
         out["error"] = "%s: %s" % (type(e).__name__, e)
 
