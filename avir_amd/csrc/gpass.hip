@@ -367,7 +367,9 @@ int sacc_run_axis( const SAData* D, bool rows, const void* src, int src_type,
 	int src_ch, int live_ch, long s_lane, long s_step, float* dst, long d_lane,
 	long d_step, int lane_lo, int lane_hi, int out_lo, int out_hi,
 	hipStream_t st, const GPOut* out = nullptr, bool finite = false,
-	bool ladder = false );
+	bool ladder = false, bool must_two = false,
+	unsigned int* flag_set = nullptr, const unsigned int* guard = nullptr );
+bool sacc_has_two( const SAData* D );
 
 struct GPData
 {
@@ -380,6 +382,7 @@ struct GPData
 	int v_blk, v_rs, v_rc;
 	float* mid;          // intermediate image between the passes
 	size_t mid_bytes;
+	unsigned int* nf_flag; // float sources on the branch-free kernels: the alarm
 	std::vector< void* > allocs;
 };
 
@@ -534,6 +537,7 @@ int gpass_prepare( avirhip_plan* p )
 
 	GPData* D = new GPData();
 	D -> mid = nullptr; D -> mid_bytes = 0; D -> d_hseg = nullptr;
+	D -> nf_flag = nullptr;
 	D -> sa_h = nullptr; D -> sa_v = nullptr;
 	D -> h_geom = false; D -> v_geom = false;
 
@@ -1152,6 +1156,78 @@ int gpass_run( avirhip_plan* p, const float* src, long src_stride, float* dst,
 	const bool int_src = ( raw != nullptr && ( raw_type == AVIRHIP_U8 ||
 		raw_type == AVIRHIP_U16 ));
 	const bool ladder = (( p -> variant & AVIRHIP_VARIANT_SACC_LADDER ) != 0 );
+
+	// Float sources, both axes streaming: OPTIMISTIC execution. The branch-free
+	// kernels are exact for finite samples only; they run first, the last pass
+	// raises the plan's alarm word when it emits a NaN or Inf (any non-finite
+	// sample inside the call's windows ends up in one: c * Inf and 0 * Inf are
+	// never finite; so does an overflow), and the exact kernels follow in the
+	// stream behind the alarm -- empty launches for finite images, a complete
+	// recomputation of both passes otherwise. (5184x3456 -> 1920x1280 float RGBA:
+	// 0.265 ms on the tiles, 0.15 ms this way.)
+	static const bool no_opt = ( getenv( "AVIRHIP_NO_SACC_OPT" ) != nullptr );
+	const bool fsrc = ( raw != nullptr ? raw_type == AVIRHIP_F32 : true );
+
+	if( !int_src && fsrc && !ladder && !no_opt && sacc_has_two( D -> sa_h ) &&
+		sacc_has_two( D -> sa_v ))
+	{
+		if( D -> nf_flag == nullptr )
+		{
+			void* q = nullptr;
+			AVIRHIP_HIPCHECK( hipMalloc( &q, 64 ));
+			D -> allocs.push_back( q );
+			D -> nf_flag = (unsigned int*) q;
+		}
+
+		// (the first optimistic pass lowers the alarm, the second may raise it)
+
+		auto h_pass = [&]( const bool fast ) -> int
+		{
+			if( raw != nullptr )
+			{
+				return( sacc_run_axis( D -> sa_h, true, raw, raw_type, raw_ch,
+					raw_ch, raw_stride * 4, raw_ch * 4, D -> mid, mid_ss, 4, a,
+					b + 1, 0, p -> new_w, st, nullptr, fast, false, fast,
+					fast ? D -> nf_flag : nullptr, fast ? nullptr : D -> nf_flag ));
+			}
+
+			return( sacc_run_axis( D -> sa_h, true, src, AVIRHIP_F32, 4,
+				p -> io_ch, src_stride * 4, 16, D -> mid, mid_ss, 4, a, b + 1, 0,
+				p -> new_w, st, nullptr, fast, false, fast,
+				fast ? D -> nf_flag : nullptr, fast ? nullptr : D -> nf_flag ));
+		};
+
+		auto v_pass = [&]( const bool fast ) -> int
+		{
+			return( sacc_run_axis( D -> sa_v, false, D -> mid, AVIRHIP_F32, 4,
+				p -> io_ch, 16, mid_ss * 4, dst - (long) row0 * dst_ss, 4, dst_ss,
+				0, p -> new_w, row0, row1, st, out, fast, false, fast,
+				fast ? D -> nf_flag : nullptr, fast ? nullptr : D -> nf_flag ));
+		};
+
+		rc = h_pass( true );
+
+		if( rc == 0 )
+		{
+			rc = v_pass( true );
+
+			if( rc == 0 )
+			{
+				// (the exact kernels behind the alarm)
+				rc = h_pass( false );
+				if( rc == 0 ) rc = v_pass( false );
+				return( rc );
+			}
+		}
+
+		if( rc != 1 )
+		{
+			return( rc );
+		}
+		// (a pass cannot take the branch-free form: the exact kernels below)
+	}
+
+	rc = 1;
 
 	if( D -> sa_h != nullptr )
 	{

@@ -76,6 +76,17 @@ struct SAParams
 	int nstrips, chunk;
 	GPOut out;       // on != 0 (column lanes): integer output stage
 	SAAxis ax;
+	// Float sources on the branch-free kernels (k_sacc2 / k_sacc2v) run
+	// OPTIMISTICALLY: those kernels are only exact for finite samples, so the
+	// last pass raises *flag_set when any value it emits is not finite -- a
+	// non-finite sample inside the call's window always reaches an output as
+	// NaN or Inf (c * Inf and 0 * Inf are never finite) -- and the exact kernels
+	// (k_sacc) follow in the stream behind `guard`: they return at once while
+	// *guard == 0 and recompute both passes otherwise.
+	unsigned int* flag_set;
+	unsigned int* flag_clear; // (the first optimistic pass lowers the alarm)
+	const unsigned int* guard;
+	int nitems;      // work items (k_sacc: walked by gridDim.x workgroups)
 };
 
 typedef unsigned int sa_u32u __attribute__(( aligned( 1 )));
@@ -195,9 +206,21 @@ __global__ void __launch_bounds__( 64 ) k_sacc( const SAParams P )
 	f4* const fifo = (f4*) smem;
 	float* const tfifo = (float*) ( smem + DQ_BYTES ); // [SA_TQ][4][16] + pad
 
+	if( P.guard != nullptr &&
+		*(const __attribute__(( address_space( 4 ))) unsigned int*)
+		(unsigned long) P.guard == 0 )
+	{
+		return; // (the optimistic passes' results stand)
+	}
+
+	// (a launch behind a guard is a small grid of workgroups that walk the work
+	// items: 130,000 workgroups that return at once still cost 5 us to
+	// dispatch; every other launch has one item per workgroup)
+	for( int item = blockIdx.x; item < P.nitems; item += gridDim.x )
+	{
 	const int lane = threadIdx.x;
-	const int strip = blockIdx.x % P.nstrips;
-	const int chunk = blockIdx.x / P.nstrips;
+	const int strip = item % P.nstrips;
+	const int chunk = item / P.nstrips;
 	const int l0 = P.lane_lo + strip * 64;
 	const int li = l0 + lane;
 	const bool lok = ( li < P.lane_hi );
@@ -208,7 +231,7 @@ __global__ void __launch_bounds__( 64 ) k_sacc( const SAParams P )
 
 	if( n0 >= n1 )
 	{
-		return;
+		continue;
 	}
 
 	gp_cint* const a_start = (gp_cint*) (unsigned long) A.start;
@@ -706,7 +729,8 @@ __global__ void __launch_bounds__( 64 ) k_sacc( const SAParams P )
 		}
 	}
 
-	GP_WAIT_VM( 0 ); // no LDS-DMA may outlive the workgroup's LDS
+	GP_WAIT_VM( 0 ); // no LDS-DMA may outlive the workgroup's LDS (or the item)
+	}
 }
 
 // ---------------------------------------------------------------------
@@ -898,6 +922,7 @@ struct SA2State
 	bool lok;
 	float f0, f1, f2, f3;
 	float* dp;  // column lanes: the next output's pixel; row lanes: the lane's row
+	unsigned long long bad; // lanes that emitted a NaN / Inf (column lanes)
 };
 
 // Output T.g leaves slot S (compile-time): through the correction FIR's
@@ -990,6 +1015,22 @@ __device__ __forceinline__ void sa2_emit( SA2Acc< NC >& R, SAV< NC > ( &w )[ 8 ]
 		}
 	}
 	else
+	{
+		// NaN or Inf in what leaves (v_cmp_class: signalling / quiet NaN, -inf,
+		// +inf): the optimistic float path's alarm (SAParams::flag_set)
+		const f4 r4 = r.to4();
+		const bool nf = ( __builtin_amdgcn_classf( r4.x, 0x207 ) ||
+			__builtin_amdgcn_classf( r4.y, 0x207 ) ||
+			__builtin_amdgcn_classf( r4.z, 0x207 ) ||
+			__builtin_amdgcn_classf( r4.w, 0x207 ));
+
+		T.bad |= __builtin_amdgcn_ballot_w64( nf );
+	}
+
+	if( ROWS )
+	{
+	}
+	else
 	if( P.out.on != 0 )
 	{
 		if( T.lok )
@@ -1063,8 +1104,9 @@ __global__ void __launch_bounds__( 64 ) k_sacc2( const SAParams P )
 	// (vector-typed so that a half group is one register tuple from the load
 	// on: with single dwords the loop-carried copies of the group in flight
 	// were made right after its load went out -- at full memory latency)
-	constexpr int NV = ( NDW > 4 ? 2 : 1 );
+	constexpr int NV = ( NDW + 3 ) / 4; // (float RGBA: 16 dwords = 4 x dwordx4)
 	constexpr int VW = NDW / NV;
+	static_assert( NV * VW == NDW, "a half group is NV equal register tuples" );
 	typedef typename SA2Vec< VW > :: T HV;
 	struct Half { HV v[ NV ]; };
 	Half curA, curB, nxtA, nxtB; // cur: A = the block up next; nxt: in flight
@@ -1078,20 +1120,32 @@ __global__ void __launch_bounds__( 64 ) k_sacc2( const SAParams P )
 		sa2_gload< VW, 0 >( nxtA.v[ 0 ], gp );
 		sa2_gload< VW, NDW * 4 >( nxtB.v[ 0 ], gp );
 
-		if constexpr( NV == 2 )
+		if constexpr( NV >= 2 )
 		{
-			sa2_gload< VW, VW * 4 >( nxtA.v[ NV - 1 ], gp );
-			sa2_gload< VW, ( NDW + VW ) * 4 >( nxtB.v[ NV - 1 ], gp );
+			sa2_gload< VW, VW * 4 >( nxtA.v[ NV >= 2 ? 1 : 0 ], gp );
+			sa2_gload< VW, ( NDW + VW ) * 4 >( nxtB.v[ NV >= 2 ? 1 : 0 ], gp );
+		}
+
+		if constexpr( NV >= 3 )
+		{
+			sa2_gload< VW, 2 * VW * 4 >( nxtA.v[ NV >= 3 ? 2 : 0 ], gp );
+			sa2_gload< VW, ( NDW + 2 * VW ) * 4 >( nxtB.v[ NV >= 3 ? 2 : 0 ], gp );
+		}
+
+		if constexpr( NV >= 4 )
+		{
+			sa2_gload< VW, 3 * VW * 4 >( nxtA.v[ NV >= 4 ? 3 : 0 ], gp );
+			sa2_gload< VW, ( NDW + 3 * VW ) * 4 >( nxtB.v[ NV >= 4 ? 3 : 0 ], gp );
 		}
 	};
 
 	auto g_take = [&]() // the group in flight becomes the current one
 	{
 		sa2_landed( nxtA.v[ 0 ], nxtB.v[ 0 ]);
-
-		if constexpr( NV == 2 )
+#pragma unroll
+		for( int i = 1; i < NV; i++ )
 		{
-			sa2_landed( nxtA.v[ NV - 1 ], nxtB.v[ NV - 1 ]);
+			sa2_landed( nxtA.v[ i ], nxtB.v[ i ]);
 		}
 
 		curA = nxtA;
@@ -1136,7 +1190,14 @@ __global__ void __launch_bounds__( 64 ) k_sacc2( const SAParams P )
 			for( int c = 0; c < CH; c++ )
 			{
 				const int ei = ( j & 3 ) * CH + c;
-				const unsigned int v = ( u >= u_a ? (unsigned int) px[ c ] : 0u );
+				unsigned int v = 0u; // (floats travel as their bit patterns)
+
+				if( u >= u_a )
+				{
+					if constexpr( SRC == 3 ) v = __builtin_bit_cast( unsigned int,
+						px[ c ]);
+					else v = (unsigned int) px[ c ];
+				}
 
 				if( j < 4 ) h_or( curA, ei / EPD, v << (( ei % EPD ) * ( 32 / EPD )));
 				else h_or( curB, ei / EPD, v << (( ei % EPD ) * ( 32 / EPD )));
@@ -1151,8 +1212,16 @@ __global__ void __launch_bounds__( 64 ) k_sacc2( const SAParams P )
 		for( int c = 0; c < CH; c++ )
 		{
 			const int ei = j * CH + c;
-			v[ c ] = (float) (( h_get( curA, ei / EPD ) >> (( ei % EPD ) *
-				( 32 / EPD ))) & ( SRC == 1 ? 0xffu : 0xffffu ));
+
+			if constexpr( SRC == 3 )
+			{
+				v[ c ] = __builtin_bit_cast( float, h_get( curA, ei ));
+			}
+			else
+			{
+				v[ c ] = (float) (( h_get( curA, ei / EPD ) >> (( ei % EPD ) *
+					( 32 / EPD ))) & ( SRC == 1 ? 0xffu : 0xffffu ));
+			}
 		}
 
 		f4 o; o.x = v[ 0 ]; o.y = v[ 1 ]; o.z = v[ 2 ]; o.w = v[ 3 ];
@@ -1186,6 +1255,7 @@ __global__ void __launch_bounds__( 64 ) k_sacc2( const SAParams P )
 	T.n_out = n0; T.ga = ga; T.gb = gb; T.n0 = n0; T.n1 = n1; T.e = A.e;
 	T.li = li; T.lok = lok; T.dp = P.dst + (long) li * P.d_lane;
 	T.f0 = A.f[ 0 ]; T.f1 = A.f[ 1 ]; T.f2 = A.f[ 2 ]; T.f3 = A.f[ 3 ];
+	T.bad = 0;
 	int endg = a_start[ T.g ] + nt - 1; // the last sample of output T.g
 
 	// the first group: loaded, fixed up, the block of u_a at the bottom
@@ -1367,13 +1437,28 @@ __global__ void __launch_bounds__( 64 ) k_sacc2( const SAParams P )
 #define SA2V_RING ( SA2V_RB * 4 ) // rows in the ring
 #define SA2V_WAIT() GP_WAIT_VM( 8 ) // ( SA2V_PF - 1 ) * 4 younger operations
 
-template< int NC >
+// HCH > 0: the FIRST pass of a plan with a FLOAT source of HCH channels (run
+// optimistically, SAParams::flag_set): lanes are image ROWS, a sample is a
+// pixel of the lane's row. A block of four samples is 16 * HCH contiguous
+// bytes of each row = HCH 16-byte pieces: one LDS-DMA instruction fetches them
+// for 16 rows (lane l: row l / HCH, piece l % HCH -- whole 64-byte runs of a
+// row, not 16 bytes of 64 rows each), four instructions a block; a lane reads
+// its HCH pieces back (4-way bank conflicts on 1 % of the block's time).
+// Blocks that reach beyond the row are re-read sample by sample (the view's
+// replicated edge). Outputs leave as in k_sacc2: four at a time, 64 bytes.
+template< int NC, int HCH >
 __global__ void __launch_bounds__( 64 ) k_sacc2v( const SAParams P )
 {
 	typedef SAV< NC > PV;
+	constexpr bool HOR = ( HCH > 0 );
 	extern __shared__ __attribute__(( aligned( 16 ))) char smem[];
 	const f4* const ring = (const f4*) smem;
 	const SAAxis& A = P.ax;
+
+	if( P.flag_clear != nullptr && blockIdx.x == 0 && threadIdx.x == 0 )
+	{
+		*P.flag_clear = 0u; // (set, if at all, by the pass after this one)
+	}
 
 	const int lane = threadIdx.x;
 	const int strip = blockIdx.x % P.nstrips;
@@ -1410,8 +1495,34 @@ __global__ void __launch_bounds__( 64 ) k_sacc2v( const SAParams P )
 	const int voff = lc * (int) P.s_lane;
 	const unsigned sstep = (unsigned) P.s_step;
 
+	// row lanes: this lane's (row, piece) of the four DMA instructions
+	constexpr int HC = ( HOR ? HCH : 1 );
+	const int hrow = min( lane / HC, 15 );
+	const int hpiece = lane - ( lane / HC ) * HC;
+	int hvoff[ 4 ];
+#pragma unroll
+	for( int i = 0; i < 4; i++ )
+	{
+		hvoff[ i ] = min( l0 + 16 * i + hrow, P.lane_hi - 1 ) * (int) P.s_lane +
+			hpiece * 16;
+	}
+
 	auto d_issue = [&]( const int qb ) // the four rows of block qb
 	{
+		if( HOR )
+		{
+			// the block's first sample, inside the row (blocks that reach
+			// beyond it are fixed up when they are read)
+			const int us = min( max( qb * 4, 0 ), slast - 3 );
+#pragma unroll
+			for( int i = 0; i < 4; i++ )
+			{
+				df_dma( rsrc, lds0 + (unsigned) ((( qb & ( SA2V_RB - 1 )) * 4 + i ) *
+					1024 ), hvoff[ i ], (unsigned) ( us * HC * 4 ));
+			}
+
+			return;
+		}
 #pragma unroll
 		for( int j = 0; j < 4; j++ )
 		{
@@ -1424,11 +1535,56 @@ __global__ void __launch_bounds__( 64 ) k_sacc2v( const SAParams P )
 	PV x[ 4 ];
 	auto x_read = [&]( const int qb )
 	{
+		if( HOR )
+		{
+			// HC pieces = 4 * HC floats = four pixels of HC channels
+			float fl[ 4 * HC ];
+			const f4* const rp = ring + (( qb & ( SA2V_RB - 1 )) * 4 +
+				( lane >> 4 )) * 64 + ( lane & 15 ) * HC;
+#pragma unroll
+			for( int k = 0; k < HC; k++ )
+			{
+				const f4 t = rp[ k ];
+				fl[ 4 * k ] = t.x; fl[ 4 * k + 1 ] = t.y;
+				fl[ 4 * k + 2 ] = t.z; fl[ 4 * k + 3 ] = t.w;
+			}
+
+			if( qb * 4 < 0 || qb * 4 + 3 > slast )
+			{
+				// (the view repeats the edge pixels beyond the row: rare)
+				const float* const row = (const float*) ( (const char*) P.src +
+					(long) lc * P.s_lane );
+#pragma unroll
+				for( int j = 0; j < 4; j++ )
+				{
+					const float* const px = row + (long) gp_clamp( qb * 4 + j,
+						slast ) * HC;
+#pragma unroll
+					for( int c = 0; c < HC; c++ )
+					{
+						fl[ j * HC + c ] = px[ c ];
+					}
+				}
+			}
+#pragma unroll
+			for( int j = 0; j < 4; j++ )
+			{
+				f4 o;
+				o.x = fl[ j * HC ];
+				o.y = ( HC > 1 ? fl[ j * HC + ( HC > 1 ? 1 : 0 )] : 0.0f );
+				o.z = ( HC > 2 ? fl[ j * HC + ( HC > 2 ? 2 : 0 )] : 0.0f );
+				o.w = ( HC > 3 ? fl[ j * HC + ( HC > 3 ? 3 : 0 )] : 0.0f );
+				x[ j ] = PV::from( o );
+			}
+		}
+		else
+		{
 #pragma unroll
 		for( int j = 0; j < 4; j++ )
 		{
 			x[ j ] = PV::from( ring[ (( qb & ( SA2V_RB - 1 )) * 4 + j ) * 64 +
 				lane ]);
+		}
 		}
 
 		if( qb == q_a )
@@ -1461,13 +1617,20 @@ __global__ void __launch_bounds__( 64 ) k_sacc2v( const SAParams P )
 	}
 
 	f4 pend[ 4 ]; // (row lanes only)
+#pragma unroll
+	for( int i = 0; i < 4; i++ )
+	{
+		pend[ i ] = (f4) 0.0f;
+	}
 
 	SA2State T;
 	T.g = a_first[ u_a - A.u_min ]; // (<= ga)
 	T.n_out = n0; T.ga = ga; T.gb = gb; T.n0 = n0; T.n1 = n1; T.e = A.e;
 	T.li = li; T.lok = lok;
-	T.dp = P.dst + (long) li * P.d_lane + (long) n0 * P.d_step;
+	T.dp = ( HOR ? P.dst + (long) li * P.d_lane :
+		P.dst + (long) li * P.d_lane + (long) n0 * P.d_step );
 	T.f0 = A.f[ 0 ]; T.f1 = A.f[ 1 ]; T.f2 = A.f[ 2 ]; T.f3 = A.f[ 3 ];
+	T.bad = 0;
 	int endg = a_start[ T.g ] + nt - 1; // the last sample of output T.g
 
 #pragma unroll
@@ -1576,7 +1739,7 @@ __global__ void __launch_bounds__( 64 ) k_sacc2v( const SAParams P )
 			x_read( qn );
 		}
 
-		sa2_emit< NC, S, false >( R, w, pend, T, P );
+		sa2_emit< NC, S, HOR >( R, w, pend, T, P );
 		T.g++;
 
 		if( T.g <= gb )
@@ -1605,6 +1768,11 @@ __global__ void __launch_bounds__( 64 ) k_sacc2v( const SAParams P )
 		if( body( std::integral_constant< int, 13 >() )) break;
 		if( body( std::integral_constant< int, 14 >() )) break;
 		if( body( std::integral_constant< int, 15 >() )) break;
+	}
+
+	if( P.flag_set != nullptr && T.bad != 0 && lane == 0 )
+	{
+		atomicOr( P.flag_set, 1u );
 	}
 
 	GP_WAIT_VM( 0 ); // no LDS-DMA may outlive the workgroup's LDS
@@ -1824,6 +1992,12 @@ void sacc_release_axis( SAData* D )
 	delete D;
 }
 
+// whether the axis has the per-slot table of the branch-free kernels
+bool sacc_has_two( const SAData* D )
+{
+	return( D != nullptr && D -> a.tab2 != nullptr );
+}
+
 template< int SRC, int CH, int NC >
 static void sa2_launch( const SAParams& P, int items, hipStream_t st )
 {
@@ -1874,7 +2048,8 @@ static void sa_launch1( const SAParams& P, int ch, int items, size_t lds,
 int sacc_run_axis( const SAData* D, bool rows, const void* src, int src_type,
 	int src_ch, int live_ch, long s_lane, long s_step, float* dst, long d_lane,
 	long d_step, int lane_lo, int lane_hi, int out_lo, int out_hi,
-	hipStream_t st, const GPOut* out, bool finite, bool ladder )
+	hipStream_t st, const GPOut* out, bool finite, bool ladder,
+	bool must_two, unsigned int* flag_set, const unsigned int* guard )
 {
 	if( lane_hi <= lane_lo || out_hi <= out_lo )
 	{
@@ -1921,13 +2096,28 @@ int sacc_run_axis( const SAData* D, bool rows, const void* src, int src_type,
 	// ALU-bound: whole rounds of the 1024 SIMDs, two or more waves on each.
 	// k_sacc2: sources known to be finite -- the caller's integer image (row
 	// lanes) or the FltBuf made from one (column lanes)
+	// (float sources come here optimistically, see SAParams::flag_set: row
+	// lanes read pixels of src_ch floats as they lie, s_step == src_ch * 4)
 	const bool two = ( finite && !ladder && D -> a.tab2 != nullptr &&
-		P.ax.in_len >= 8 && (( rows && !dma && out == nullptr &&
-		( src_type == AVIRHIP_U8 || src_type == AVIRHIP_U16 )) ||
+		P.ax.in_len >= 8 && (( rows && out == nullptr &&
+		(( !dma && ( src_type == AVIRHIP_U8 || src_type == AVIRHIP_U16 )) ||
+		( src_type == AVIRHIP_F32 && s_step == (long) src_ch * 4 &&
+		( (uintptr_t) src & 3 ) == 0 && ( s_lane & 3 ) == 0 &&
+		(double) s_lane * lane_hi < 2147483648.0 ))) ||
 		( !rows && dma && s_lane == 16 &&
 		(double) s_step * P.ax.in_len < 2147483648.0 )));
 
-	const size_t lds = ( two ? ( rows ? 0 : SA2V_RING * 1024 ) :
+	if( must_two && !two )
+	{
+		return( 1 );
+	}
+
+	P.flag_set = ( two && !rows ? flag_set : nullptr );
+	P.flag_clear = ( two && rows ? flag_set : nullptr );
+	P.guard = ( two ? nullptr : guard );
+
+	const size_t lds = ( two ? ( rows && src_type != AVIRHIP_F32 ? 0 :
+		SA2V_RING * 1024 ) :
 		(size_t) ( dma ? 3 * 4096 : 8 * 1024 ) + SA_TQ * 256 + 64 +
 		( rows ? 4096 : 0 ));
 
@@ -1979,7 +2169,11 @@ int sacc_run_axis( const SAData* D, bool rows, const void* src, int src_type,
 		P.chunk = std::max( 1, atoi( getenv( "AVIRHIP_SA_CHUNK_V" )));
 	}
 
-	const int items = P.nstrips * (( nout + P.chunk - 1 ) / P.chunk );
+	int items = P.nstrips * (( nout + P.chunk - 1 ) / P.chunk );
+	P.nitems = items;
+	// the branch-free kernel of float row lanes (k_sacc2v< NC, CH >)
+	const bool two_hf = ( two && rows && src_type == AVIRHIP_F32 );
+
 	if( !dma && ( !rows || P.ax.in_len < 4 ))
 	{
 		return( 1 );
@@ -1991,14 +2185,29 @@ int sacc_run_axis( const SAData* D, bool rows, const void* src, int src_type,
 		{
 			if( live_ch == 3 )
 			{
-				hipLaunchKernelGGL(( k_sacc2v< 3 > ), dim3( items ), dim3( 64 ),
+				hipLaunchKernelGGL(( k_sacc2v< 3, 0 > ), dim3( items ), dim3( 64 ),
 					lds, st, P );
 			}
 			else
 			{
-				hipLaunchKernelGGL(( k_sacc2v< 4 > ), dim3( items ), dim3( 64 ),
+				hipLaunchKernelGGL(( k_sacc2v< 4, 0 > ), dim3( items ), dim3( 64 ),
 					lds, st, P );
 			}
+		}
+		else
+		if( two_hf )
+		{
+			// float pixels of src_ch channels, lanes = image rows
+#define SA2H( NC, CH ) hipLaunchKernelGGL(( k_sacc2v< NC, CH > ), dim3( items ), \
+				dim3( 64 ), lds, st, P )
+			switch( src_ch )
+			{
+				case 1: SA2H( 1, 1 ); break;
+				case 2: SA2H( 2, 2 ); break;
+				case 3: SA2H( 3, 3 ); break;
+				default: if( live_ch == 3 ) SA2H( 3, 4 ); else SA2H( 4, 4 ); break;
+			}
+#undef SA2H
 		}
 		else
 		if( src_type == AVIRHIP_U8 )
@@ -2012,6 +2221,11 @@ int sacc_run_axis( const SAData* D, bool rows, const void* src, int src_type,
 
 		AVIRHIP_HIPCHECK( hipGetLastError() );
 		return( AVIRHIP_OK );
+	}
+
+	if( P.guard != nullptr )
+	{
+		items = std::min( items, 2048 ); // (workgroups: they walk P.nitems)
 	}
 
 	if( dma )

@@ -62,6 +62,10 @@ OTHER = {"cfg1": ("avir", 640, 480, 1024, 768, 3, "u8", 8),
          # the same photo as float RGBA / float RGB (the float-source kernels)
          "readme_f32": ("avir", 5184, 3456, 1920, 1280, 4, "f32", 16),
          "readme_rgbf": ("avir", 5184, 3456, 1920, 1280, 3, "f32", 16),
+         # float RGBA, both axes k >= 2 and not a whole number, smaller frames
+         "dnk_4k": ("avir", 3840, 2160, 1500, 844, 4, "f32", 16),
+         "dnk_1080": ("avir", 1920, 1080, 700, 394, 4, "f32", 16),
+         "dnk_720": ("avir", 1280, 720, 500, 281, 4, "f32", 16),
          # avir::CImageResizer< fpclass_def< double > > (avir.h:4553-4560):
          # float images through the double pipeline ("avir64")
          "cfg2_dbl": ("avir64", 1920, 1080, 3840, 2160, 4, "f32", 16),
