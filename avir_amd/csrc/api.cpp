@@ -1700,7 +1700,7 @@ static avirhip_plan* new_plan()
 {
 	avirhip_plan* p = new avirhip_plan();
 	p -> is_lancir = 0; p -> device = 0; p -> alloc_bytes = 0;
-	p -> path = 0; p -> variant = 0; p -> fused_ok = 0; p -> auto_path = 1; p -> fused = nullptr; p -> up2 = nullptr; p -> lanc2 = nullptr; p -> gpass = nullptr;
+	p -> path = 0; p -> variant = 0; p -> fused_ok = 0; p -> auto_path = 1; p -> fused = nullptr; p -> tile64 = nullptr; p -> up2 = nullptr; p -> lanc2 = nullptr; p -> gpass = nullptr;
 	p -> packed = nullptr; p -> resbuf = nullptr; p -> lres = nullptr;
 	p -> stage_src = nullptr; p -> stage_dst = nullptr;
 	p -> stage_src_bytes = 0; p -> stage_dst_bytes = 0;
@@ -1888,9 +1888,12 @@ int finalize_avir_plan( avirhip_plan* p )
 
 	if( rc == 0 && p -> f64 )
 	{
-		// the double pipeline: the generic kernels in double (generic64.hip),
-		// no fast paths
-		p -> auto_path = 1;
+		// the double pipeline: LDS-tiled two-pass kernels in double (tile64.hip;
+		// reported as path 2), or -- plans with a filtered upsample, and path 1
+		// on request -- one launch per op (generic64.hip)
+		rc = tile64_prepare( p );
+		p -> auto_path = ( rc == 0 && tile64_ok( p ) ? 2 : 1 );
+		p -> fused_ok = ( rc == 0 && tile64_ok( p ) ? 1 : 0 );
 		return( rc );
 	}
 
@@ -1942,6 +1945,7 @@ int finalize_avir_plan( avirhip_plan* p )
 	{
 		// no fast path for this plan: run the generic kernels unpadded
 		fused_release( p );
+		tile64_release( p );
 		up2_release( p );
 		gpass_release( p );
 		p -> ch = p -> io_ch;
@@ -2454,6 +2458,7 @@ void avirhip_plan_destroy( avirhip_plan* p )
 	avirhip_plan_destroy( p -> inner );
 	p -> inner = nullptr;
 	fused_release( p );
+	tile64_release( p );
 	up2_release( p );
 	lanc2_release( p );
 	gpass_release( p );

@@ -397,8 +397,16 @@ int exec_f64( avirhip_plan* p, const void* src, void* dst, int row0, int row1,
 	const int ch = p -> ch; // (== io_ch: no RGBA padding here)
 	const int nv = (int) p -> v.ops.size();
 	const int nh = (int) p -> h.ops.size();
-	const bool need_pack = ( p -> gamma || p -> in_type != AVIRHIP_F64 );
-	const bool direct = ( p -> out_type == AVIRHIP_F64 );
+	// the tiled two-pass kernels (tile64.hip) run every plan without a filtered
+	// upsample unless path 1 is forced: their H pass reads the caller's image
+	// itself and their V pass stores through the output stage, so without gamma
+	// neither the double copy of the source nor the double result exists
+	const int xpath = ( p -> path != 0 ? p -> path : p -> auto_path );
+	const bool tiled = ( xpath != 1 && tile64_ok( p ));
+	const bool need_pack = ( tiled ? p -> gamma != 0 :
+		( p -> gamma || p -> in_type != AVIRHIP_F64 ));
+	const bool direct = ( p -> out_type == AVIRHIP_F64 ||
+		( tiled && !p -> gamma ));
 
 	if( need_pack && p -> packed64 == nullptr &&
 		( rc = dalloc( p, (size_t) p -> src_w * p -> src_h * ch *
@@ -408,7 +416,7 @@ int exec_f64( avirhip_plan* p, const void* src, void* dst, int row0, int row1,
 		( rc = dalloc( p, (size_t) p -> new_w * p -> new_h * ch *
 		sizeof( double ), &p -> resbuf64 )) != 0 ) return( rc );
 
-	if( p -> hbuf64.empty() )
+	if( !tiled && p -> hbuf64.empty() )
 	{
 		for( int i = 0; i < nh; i++ )
 		{
@@ -488,11 +496,26 @@ int exec_f64( avirhip_plan* p, const void* src, void* dst, int row0, int row1,
 		sstride = re;
 	}
 
+	if( tiled )
+	{
+		void* const tdst = ( direct ? dst : (void*) p -> resbuf64 );
+
+		rc = tile64_run( p, fsrc, ( need_pack ? AVIRHIP_F64 : p -> in_type ),
+			sstride, tdst, ( p -> gamma && p -> out_type != AVIRHIP_F64 ?
+			AVIRHIP_F64 : p -> out_type ), (long) p -> new_w * ch, row0, row1,
+			ya, yb, st );
+
+		if( rc != 0 || direct )
+		{
+			return( rc );
+		}
+	}
+
 	Surf64 in;
 	in.base = (double*) fsrc; in.scan_stride = sstride; in.idx_stride = ch;
 	in.prefix = 0;
 
-	for( int i = 0; i < nh; i++ )
+	for( int i = 0; !tiled && i < nh; i++ )
 	{
 		const LOp& op = p -> h.ops[ i ];
 		Surf64 out;
@@ -509,12 +532,12 @@ int exec_f64( avirhip_plan* p, const void* src, void* dst, int row0, int row1,
 
 	// vertical pass: scanlines are the NewWidth columns of FltBuf
 	double* const fdst = ( direct ? (double*) dst : p -> resbuf64 );
-	in.base = p -> hbuf64[ nh - 1 ];
+	in.base = ( tiled ? nullptr : p -> hbuf64[ nh - 1 ]);
 	in.scan_stride = ch;
 	in.idx_stride = (long) p -> new_w * ch;
 	in.prefix = 0;
 
-	for( int i = 0; i < nv; i++ )
+	for( int i = 0; !tiled && i < nv; i++ )
 	{
 		const LOp& op = p -> v.ops[ i ];
 		Surf64 out;

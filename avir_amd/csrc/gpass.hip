@@ -803,6 +803,19 @@ bool gpass_preferred( const avirhip_plan* p )
 		return( true );
 	}
 
+	// ... and float sources (any channel count) of large frames: the same
+	// kernels run optimistically (gpass_run), 3840x2160 -> 1500x844 RGBA 0.103
+	// against 0.125 ms on the tiles, 5184x3456 -> 1920x1280 0.19 against 0.265;
+	// at 1920x1080 -> 700x394 the four launches lose (0.065 against 0.045).
+	// Whole-number ratios keep their own kernels (dnf.hip: cfg4 0.046 ms).
+	if( D -> sa_h != nullptr && D -> sa_v != nullptr && !p -> gamma &&
+		p -> in_type == AVIRHIP_F32 && sacc_has_two( D -> sa_h ) &&
+		sacc_has_two( D -> sa_v ) && !fused_dn_both( p ) &&
+		(long) p -> src_w * p -> src_h >= 6000000L )
+	{
+		return( true );
+	}
+
 	// both axes upsize: float RGBA sources always; sources that need the pack
 	// pass (integer, 1-3 channels, gamma) once the frame is large enough for
 	// two more launches not to matter -- 1920x1080 -> 2500x1400 RGB u8: 0.068

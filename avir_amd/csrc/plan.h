@@ -169,6 +169,7 @@ struct avirhip_plan
 	void* up2;      // exact-2x marching kernel private data (fused_ok bit 2)
 	void* lanc2;    // LANCIR exact-2x kernel private data (fused_ok bit 2)
 	void* gpass;    // general-ratio pass kernels, path 5 (fused_ok bit 3)
+	void* tile64;   // double pipeline: LDS-tiled two-pass executor (tile64.hip)
 
 	// scratch (device), lazily sized
 	std::vector< void* > allocs;
@@ -243,6 +244,15 @@ void need_range( const LOp& op, int a, int b, int& ia, int& ib );
 
 // generic64.hip: the double pipeline (plan -> f64), output rows [row0, row1)
 int exec_f64( avirhip_plan* p, const void* src, void* dst, int row0, int row1,
+	hipStream_t st );
+
+// tile64.hip: the double pipeline's tiled two-pass executor. tile64_run
+// returns 1 when the plan has none (filtered upsamples: generic64.hip runs it).
+int tile64_prepare( avirhip_plan* p );
+void tile64_release( avirhip_plan* p );
+bool tile64_ok( const avirhip_plan* p );
+int tile64_run( avirhip_plan* p, const void* src, int src_type, long src_ss,
+	void* dst, int dst_type, long dst_ss, int row0, int row1, int ya, int yb,
 	hipStream_t st );
 
 int launch_errd( const float* res, void* dst, int out_type, int w, int h,

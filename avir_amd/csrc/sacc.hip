@@ -1639,7 +1639,21 @@ __global__ void __launch_bounds__( 64 ) k_sacc2v( const SAParams P )
 		d_issue( q_a + i );
 	}
 
-	SA2V_WAIT(); // loads retire in order: block q_a has landed
+	// Row lanes fetch blocks in PAIRS -- an even block and the odd one after it
+	// are the two halves of a 128-byte line of every row, requested back to
+	// back instead of a block's worth of arithmetic apart (as single blocks the
+	// pass fetched 1.57 x the source): at an even block q the blocks q + 2 and
+	// q + 3 go out, so blocks up to q + 3 (even q) / q + 2 (odd q) are issued.
+	if( HOR && ( q_a & 1 ) == 0 )
+	{
+		d_issue( q_a + 3 );
+		GP_WAIT_VM( 12 );
+	}
+	else
+	{
+		SA2V_WAIT(); // loads retire in order: block q_a has landed
+	}
+
 	x_read( q_a );
 
 	// ---- the table feed (see k_sacc2)
@@ -1734,8 +1748,25 @@ __global__ void __launch_bounds__( 64 ) k_sacc2v( const SAParams P )
 			// the next block goes out into slots read long ago; with only
 			// the operations of the SA2V_PF - 1 blocks after qn (or fewer:
 			// stores) outstanding, block qn has landed
-			d_issue( qn + SA2V_PF - 1 );
-			SA2V_WAIT();
+			if( HOR )
+			{
+				if(( qn & 1 ) == 0 )
+				{
+					d_issue( qn + 2 );
+					d_issue( qn + 3 );
+					GP_WAIT_VM( 12 ); // blocks qn + 1 .. qn + 3 may be in flight
+				}
+				else
+				{
+					SA2V_WAIT();      // blocks qn + 1, qn + 2
+				}
+			}
+			else
+			{
+				d_issue( qn + SA2V_PF - 1 );
+				SA2V_WAIT();
+			}
+
 			x_read( qn );
 		}
 

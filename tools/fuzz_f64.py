@@ -21,6 +21,7 @@ PRESETS = [None,
            (1.0, 5.55209, 1.69326, 0.52508, 18, 7.28790, 7.54, 0.79285)]
 bad = 0
 ran = 0
+tiled = 0
 for it in range(N):
     hi = 400 if rng.rand() < 0.2 else 160
     sw, sh, nw, nh = [int(rng.randint(1, hi)) for _ in range(4)]
@@ -64,16 +65,40 @@ for it in range(N):
             setattr(P, n, x)
     r = avir_amd.CImageResizer(bits, 0, P, aFpPack=abi.FPCLASS_DOUBLE) if P is not None \
         else avir_amd.CImageResizer(bits, aFpPack=abi.FPCLASS_DOUBLE)
-    try:
-        got = r.resize(src, nw, nh, k, tout, v)
-    except avir_amd.AvirHipError as e:
-        print("ERROR", (sw, sh, nw, nh, ch, tin.__name__, tout.__name__, bits, mode), e)
-        bad += 1
-        continue
-    ran += 1
-    if not np.array_equal(got.view(np.uint8), want.view(np.uint8)):
-        bad += 1
-        print("MISMATCH", (sw, sh, nw, nh, ch, tin.__name__, tout.__name__, bits,
-                           gamma, alpha, mode, k, ox, oy, params is not None))
-print("fuzz_f64:", N, "cases,", ran, "compared,", bad, "problems")
+    # the automatic path (tile64.hip's tiled two-pass kernels where the plan
+    # has them, reported as path 2), the per-op kernels (generic64.hip, path
+    # 1), and row bands of the automatic path
+    p = r.plan(sw, sh, nw, nh, ch, k, v, avir_amd._NP2T[np.dtype(tin)],
+               avir_amd._NP2T[np.dtype(tout)])
+    tiled += int(lib.avirhip_plan_get_path(p) == 2)
+    for what in ("auto", "generic", "bands"):
+        try:
+            abi.check(lib.avirhip_plan_set_path(p, 1 if what == "generic" else 0),
+                      "set_path")
+            if what == "bands":
+                if nh < 2:
+                    continue
+                got = np.zeros((nh, nw, ch), tout)
+                cut = int(rng.randint(1, nh))
+                for a_, b_ in ((0, cut), (cut, nh)):
+                    abi.check(lib.avirhip_resize_band(
+                        p, src.ctypes.data, abi.MEM_HOST, got[a_:b_].ctypes.data,
+                        abi.MEM_HOST, a_, b_, None), "band")
+            else:
+                got = r.resize(src, nw, nh, k, tout, v)
+        except avir_amd.AvirHipError as e:
+            print("ERROR", what, (sw, sh, nw, nh, ch, tin.__name__, tout.__name__,
+                                  bits, mode), e)
+            bad += 1
+            continue
+        ran += 1
+        if not np.array_equal(got.view(np.uint8), want.view(np.uint8)):
+            bad += 1
+            print("MISMATCH", what, (sw, sh, nw, nh, ch, tin.__name__,
+                                     tout.__name__, bits, gamma, alpha, mode, k,
+                                     ox, oy, params is not None),
+                  int((got != want).sum()), "of", got.size)
+    abi.check(lib.avirhip_plan_set_path(p, 0), "set_path")
+print("fuzz_f64:", N, "cases (%d on the tiled kernels)," % tiled, ran,
+      "comparisons,", bad, "problems")
 sys.exit(1 if bad else 0)

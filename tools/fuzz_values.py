@@ -250,7 +250,9 @@ for it in range(N):
     if cls in ("dnk", "dnint", "rand"):
         runs.append((5, 4))  # k_sacc (ladder) where k_sacc2 would run
     if dbl:
-        runs = [(0, 0), ("bands", 0)]
+        # the double pipeline: tiled two-pass kernels (tile64.hip) on the
+        # automatic path, one launch per op (generic64.hip) as path 1
+        runs = [(0, 0), (1, 0), ("bands", 0), ("bands", 1)]
     for path, variant in runs:
         key = (cls, "f64pipe" if dbl else np.dtype(tin).name,
                np.dtype(tout).name, path, variant)
