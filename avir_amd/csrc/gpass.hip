@@ -208,7 +208,12 @@ __global__ void __launch_bounds__( 64 ) k_gh( const GHParams P )
 				issue_row( r + GH_NB - 1, ( buf + GH_NB - 1 ) & ( GH_NB - 1 ));
 			}
 
-			gp_wait_vm( min( GH_NB - 1, r1 - 1 - r ) * P.nseg );
+			// (... and the rows stored since row r's pieces went out, one store
+			// at least each: stores count on vmcnt too and retire in issue
+			// order with the loads -- without them the wait also drains the
+			// stores of the last rows and the three-row lead shrinks to one)
+			gp_wait_vm( min( GH_NB - 1, r1 - 1 - r ) * P.nseg +
+				( P.stw ? min( GH_NB - 1, r - r0 ) : 0 ));
 		}
 
 		if( MODE != GP_PRE && slo + scnt - 1 > A.view_mmax )
@@ -930,6 +935,9 @@ static int run_h( const GPData* D, const float* src, long src_ss, int src_w,
 		P.lout = *lout;
 	}
 
+	static const int stw = ( getenv( "AVIRHIP_GH_STW" ) != nullptr ?
+		atoi( getenv( "AVIRHIP_GH_STW" )) : 1 );
+	P.stw = stw;
 	P.raw = raw; P.raw_ss = raw_stride; P.raw_ch = raw_ch;
 	const int src_kind = ( raw == nullptr ? 0 : ( raw_type == AVIRHIP_U8 ? 1 :
 		( raw_type == AVIRHIP_U16 ? 2 : 3 )));
@@ -1089,7 +1097,27 @@ int gpass_run( avirhip_plan* p, const float* src, long src_stride, float* dst,
 		return( AVIRHIP_OK );
 	}
 
-	if( D -> mid == nullptr )
+	// Large upsizing plans of float RGBA sources run both passes in one launch
+	// (gfuse.hip): no intermediate image. "Large": a fused chunk repeats the
+	// horizontal arithmetic of its 18-row vertical run-in, which the saved
+	// FltBuf round trip only pays for once the frame is memory-heavy -- measured
+	// (tools/gf_sweep.py, fused / two-pass): 1920x1080 x1.3 1.12, x2.3 1.01,
+	// x2.7 0.94, x3.0 0.88; 3840x2160 x1.3 0.89, x1.6 0.80; 1280x720 never
+	// (x3.6: 1.06) -- the crossing is at about 12 Mpixels of output.
+	// AVIRHIP_GF_MINPIX moves it (0: always), AVIRHIP_VARIANT_UPG_TWO_PASS
+	// keeps the two pass kernels.
+	static const long gf_minpix = ( getenv( "AVIRHIP_GF_MINPIX" ) != nullptr ?
+		atol( getenv( "AVIRHIP_GF_MINPIX" )) : 12000000L );
+	// (a forced variant bit 4 = "fused whatever the size": tests)
+	const bool use_gf = ( !p -> is_lancir && D -> h.a.mode == GP_PRE &&
+		D -> v.a.mode == GP_PRE && D -> h.a.nt == 12 && D -> v.a.nt == 12 &&
+		D -> h_geom && raw == nullptr &&
+		( p -> variant & AVIRHIP_VARIANT_UPG_TWO_PASS ) == 0 &&
+		((long) p -> new_w * p -> new_h >= gf_minpix ||
+		( p -> variant & AVIRHIP_VARIANT_UPG_FUSED ) != 0 ) &&
+		getenv( "AVIRHIP_NO_GFUSE" ) == nullptr );
+
+	if( D -> mid == nullptr && !use_gf )
 	{
 		void* q = nullptr;
 		AVIRHIP_HIPCHECK( hipMalloc( &q, D -> mid_bytes ));
@@ -1155,6 +1183,29 @@ int gpass_run( avirhip_plan* p, const float* src, long src_stride, float* dst,
 
 		return( run_h( D, D -> mid, mid_ss, p -> src_w, dst, dst_ss, row0,
 			p -> new_w, row0, row1, st ));
+	}
+
+	// Upsizing on both axes from a float RGBA source: ONE launch runs both
+	// passes (gfuse.hip), FltBuf never exists. AVIRHIP_VARIANT_UPG_TWO_PASS
+	// keeps the two pass kernels (tests, A/B timing).
+	if( use_gf )
+	{
+		GFParams G;
+		memset( &G, 0, sizeof( G ));
+		G.src = src; G.src_ss = src_stride;
+		G.dst = dst; G.dst_ss = dst_ss; G.dst_row0 = row0;
+		G.hx = D -> h.a; G.vx = D -> v.a;
+		G.row_lo = row0; G.row_hi = row1;
+		G.nstrips = D -> h_nstrips; G.ow = D -> h_ow;
+		G.seg = D -> d_hseg; G.nseg = D -> h_nseg;
+		G.sbuf = D -> h_sbuf; G.mbuf = D -> h_mbuf;
+
+		if( out != nullptr )
+		{
+			G.out = *out;
+		}
+
+		return( gfuse_launch( G, (double) p -> src_h / p -> new_h, st ));
 	}
 
 	// AVIR: horizontal first into mid = FltBuf [src_h][new_w], only the source

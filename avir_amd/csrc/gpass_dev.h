@@ -303,7 +303,24 @@ struct GHParams
 	int raw_ch;
 	long raw_elems;      // elements of that image (the loader's bound)
 	GPLOut lout;         // on != 0: LANCIR's output stage in the store
+	int stw;             // the row wait allows for the stores since (A/B switch)
 };
+
+// gfuse.hip: both passes of an upsizing plan in one launch (k_gf)
+struct GFParams
+{
+	const float* src; long src_ss;  // float RGBA source, floats per row
+	float* dst; long dst_ss; int dst_row0;
+	GPAxis hx, vx;       // both GP_PRE, 12 taps
+	int row_lo, row_hi;  // output rows to produce
+	int nstrips, ow, chunk; // k_gh's strips; output rows per work item
+	const int* seg;      // [nstrips][4]: source lo, count; FIR output lo, count
+	int nseg;            // DMA instructions per source row
+	int sbuf, mbuf;      // LDS pixels per source row buffer / FIR row
+	GPOut out;           // on != 0: integer output stage in the store
+};
+
+int gfuse_launch( GFParams& P, double k_v, hipStream_t st );
 
 // One gather output: tap t reads ld( t ); cf4( b ) returns the coefficients
 // of taps 4b .. 4b + 3 (rows are padded to a multiple of four; padded taps are

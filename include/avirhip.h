@@ -246,6 +246,12 @@ int avirhip_plan_get_path(const avirhip_plan* plan);
 #define AVIRHIP_VARIANT_UP2_PLAIN_V 1
 #define AVIRHIP_VARIANT_DN_TWO_PASS 2
 #define AVIRHIP_VARIANT_SACC_LADDER 4
+/* upsizing on both axes (path 5): the horizontal and the vertical pass kernel
+ * through FltBuf instead of the single fused launch of gfuse.hip */
+#define AVIRHIP_VARIANT_UPG_TWO_PASS 8
+/* ... and the fused launch whatever the frame size (automatically: frames of
+ * 12 Mpixels of output and more) */
+#define AVIRHIP_VARIANT_UPG_FUSED 16
 int avirhip_plan_set_variant(avirhip_plan* plan, int variant);
 
 /* Device memory the plan holds right now, in bytes: tables, scratch buffers

@@ -65,7 +65,15 @@ for it in range(N):
         if rng.rand() < 0.2:
             v.ox, v.oy = float(rng.uniform(-1, 1)), float(rng.uniform(-1, 1))
     kstep = float(rng.choice([0.0, 0.0, 0.0, 1.7, 0.6])) if not lanc else 0.0
-    for path in (1, 0, 5, 2, 3, 4):
+    # (path 58: the pass kernels of path 5 with AVIRHIP_VARIANT_UPG_TWO_PASS --
+    # upsizing plans through FltBuf instead of the fused launch)
+    # ... path 516: AVIRHIP_VARIANT_UPG_FUSED, the fused launch at any size)
+    for path in (1, 0, 5, 58, 516, 2, 3, 4):
+        variant = 0
+        if path in (58, 516):
+            if lanc or not (nw >= sw and nh >= sh):
+                continue
+            variant = 8 if path == 58 else 16
         try:
             if lanc:
                 r = avir_amd.CLancIR()
@@ -76,8 +84,9 @@ for it in range(N):
                 p = r.plan(sw, sh, nw, nh, ch, kstep, v,
                            avir_amd._NP2T[np.dtype(tin)],
                            avir_amd._NP2T[np.dtype(tout)])
-            if lib.avirhip_plan_set_path(p, path) != 0:
+            if lib.avirhip_plan_set_path(p, path if path < 50 else 5) != 0:
                 continue
+            abi.check(lib.avirhip_plan_set_variant(p, variant), "set_variant")
             if lanc:
                 res[path] = r.resize(src, nw, nh, out_dtype=tout, aParams=lp)
             else:

@@ -249,6 +249,9 @@ for it in range(N):
         runs.append((4, 1))  # the 13-row-window form of k_up2
     if cls in ("dnk", "dnint", "rand"):
         runs.append((5, 4))  # k_sacc (ladder) where k_sacc2 would run
+    if cls in ("up", "up2", "rand"):
+        runs.append((5, 8))   # k_gh + k_gv through FltBuf ...
+        runs.append((5, 16))  # ... and k_gf, the fused launch, at any size
     if dbl:
         # the double pipeline: tiled two-pass kernels (tile64.hip) on the
         # automatic path, one launch per op (generic64.hip) as path 1
