@@ -1455,6 +1455,74 @@ def test_avir_pass_kernels_store_integer_images_themselves(ch, tin, tout, bits):
         _assert_same(out, want, "fused out bands")
 
 
+@pytest.mark.parametrize("tout,bits", [(np.float32, 16), (np.float32, 8),
+                                       (np.uint8, 8), (np.uint16, 10)])
+def test_avir_fused_upsizing_kernel(tout, bits):
+    """gfuse.hip (k_gf): both passes of an upsizing plan in one launch, no
+    FltBuf -- against the reference and against the two pass kernels
+    (AVIRHIP_VARIANT_UPG_TWO_PASS), whole frames and row bands, float and
+    integer results, shapes of one strip / one chunk up to several of both,
+    non-zero offsets and a forced build mode."""
+    lib = abi.load()
+    for (sw, sh, nw, nh, ox, oy, mode) in [
+            (64, 48, 100, 77, 0, 0, -1), (129, 67, 513, 259, 0, 0, -1),
+            (90, 300, 200, 720, 0, 0, -1), (300, 40, 1001, 47, 0.3, -0.4, -1),
+            (17, 9, 60, 31, 0, 0, -1), (1, 50, 3, 120, 0, 0, -1),
+            (400, 300, 1300, 1000, 0, 0, 1), (257, 255, 300, 700, -0.7, 0.2, -1)]:
+        src = rb.lcg_f32((sh, sw, 4), seed=sw * 3 + nh) * 1.2 - 0.1
+        if np.dtype(tout).kind == "u":
+            src = src * float(np.iinfo(tout).max)
+        want = _checker_avir(src, nw, nh, resbits=bits, out_dtype=tout, ox=ox,
+                             oy=oy, build_mode=mode)
+        ran = 0
+        for variant in (abi.VARIANT_UPG_FUSED, abi.VARIANT_UPG_TWO_PASS):
+            try:
+                got = _run_avir(src, nw, nh, resbits=bits, out_dtype=tout,
+                                path=abi.PATH_GPASS, variant=variant, ox=ox,
+                                oy=oy, build_mode=mode)
+            except avir_amd.AvirHipError as e:
+                assert "cannot run this plan" in str(e)
+                continue
+            ran += 1
+            _assert_same(got, want, "variant %d %r" % (variant,
+                                                      (sw, sh, nw, nh)))
+        if not ran or nh < 4:
+            continue
+        r = avir_amd.CImageResizer(bits)
+        v = avir_amd.CImageResizerVars()
+        v.ox, v.oy, v.BuildMode = ox, oy, mode
+        p = r.plan(sw, sh, nw, nh, 4, 0.0, v, abi.F32, rb._DT[np.dtype(tout)])
+        abi.check(lib.avirhip_plan_set_path(p, abi.PATH_GPASS), "set_path")
+        abi.check(lib.avirhip_plan_set_variant(p, abi.VARIANT_UPG_FUSED),
+                  "set_variant")
+        out = np.zeros((nh, nw, 4), tout)
+        for a_, b_ in [(0, nh // 3), (nh // 3, nh // 3 + 1), (nh // 3 + 1, nh)]:
+            abi.check(lib.avirhip_resize_band(
+                p, src.ctypes.data, abi.MEM_HOST, out[a_:b_].ctypes.data,
+                abi.MEM_HOST, a_, b_, None), "band")
+        _assert_same(out, want, "fused bands %r" % ((sw, sh, nw, nh),))
+
+
+def test_avir_fused_upsizing_is_the_default_for_large_frames():
+    """1920x1080 -> 5760x3240 (18.7 Mpixels of output) takes k_gf by itself:
+    the hash of the reference's result (tests/golden/make_golden.py wrote it
+    from the reference; here recomputed when oracle/_ref is present)."""
+    import torch
+    from avir_amd import synth
+    src = rb.lcg_f32((1080, 1920, 4))
+    r = avir_amd.CImageResizer(16)
+    got = r.resize(torch.from_numpy(src).to("cuda:0"), 5760, 3240).cpu().numpy()
+    lib = abi.load()
+    p = r.plan(1920, 1080, 5760, 3240, 4)
+    assert lib.avirhip_plan_get_path(p) == abi.PATH_GPASS
+    abi.check(lib.avirhip_plan_set_variant(p, abi.VARIANT_UPG_TWO_PASS), "v")
+    two = r.resize(torch.from_numpy(src).to("cuda:0"), 5760, 3240).cpu().numpy()
+    _assert_same(got, two, "fused vs two-pass, 1080p x3")
+    if rb.have_ref():
+        _assert_same(got, rb.ref_avir(src, 5760, 3240, resbits=16, threads=8),
+                     "fused vs reference, 1080p x3")
+
+
 def test_avir_pass_kernels_are_the_default_for_general_ratios():
     lib = abi.load()
     r = avir_amd.CImageResizer(16)
