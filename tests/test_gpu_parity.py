@@ -1523,6 +1523,78 @@ def test_avir_fused_upsizing_is_the_default_for_large_frames():
                      "fused vs reference, 1080p x3")
 
 
+def _same_but_nan_payloads(got, want, what):
+    """Raw words equal, except that a NaN only has to be a NaN (payloads are
+    properties of the reference's x86 build, tools/fuzz_values.py)."""
+    assert got.shape == want.shape and got.dtype == want.dtype
+    gn, wn = np.isnan(got), np.isnan(want)
+    assert np.array_equal(gn, wn), "%s: NaNs in other places (%d vs %d)" % (
+        what, int(gn.sum()), int(wn.sum()))
+    g = np.where(gn, 0, got).astype(got.dtype)
+    w = np.where(wn, 0, want).astype(want.dtype)
+    _assert_same(g, w, what)
+
+
+@pytest.mark.parametrize("ch", [4, 3, 1])
+def test_float_sources_on_the_branch_free_accumulation_kernels(ch):
+    """Downsizing by k >= 2 on both axes from a FLOAT source (path 5): the
+    branch-free kernels (k_sacc2v row lanes / column lanes) are exact for
+    finite samples only and run optimistically -- the last pass raises an
+    alarm when it emits NaN / Inf and the exact kernels (k_sacc) recompute
+    behind it. Finite images, images with planted Inf / NaN / huge values, the
+    same plan alternating between them (the alarm must clear), row bands, and
+    AVIRHIP_VARIANT_SACC_LADDER (the exact kernels alone) all equal the
+    reference."""
+    lib = abi.load()
+    for (sw, sh, nw, nh) in [(700, 500, 260, 190), (1000, 333, 187, 150),
+                             (2600, 900, 1000, 347)]:
+        clean = rb.lcg_f32((sh, sw, ch), seed=sw + ch)
+        dirty = clean.copy()
+        dirty[sh // 3, sw // 2, 0] = np.inf
+        dirty[sh // 2, sw // 3, ch - 1] = np.nan
+        dirty[5, 7, 0] = -np.inf
+        dirty[sh - 2, sw - 3, :] = 3e38
+        dirty[sh // 4, :, 0] = -0.0
+        r = avir_amd.CImageResizer(16)
+        p = r.plan(sw, sh, nw, nh, ch)
+        if lib.avirhip_plan_set_path(p, abi.PATH_GPASS) != 0:
+            pytest.fail("path 5 refused %r" % ((sw, sh, nw, nh, ch),))
+        wants = {id(a): _checker_avir(a, nw, nh, resbits=16)
+                 for a in (clean, dirty)}
+        for variant in (0, abi.VARIANT_SACC_LADDER):
+            abi.check(lib.avirhip_plan_set_variant(p, variant), "variant")
+            for a in (clean, dirty, clean, dirty, dirty, clean):
+                got = r.resize(a, nw, nh)
+                _same_but_nan_payloads(got, wants[id(a)], "variant %d %r %s" % (
+                    variant, (sw, sh, nw, nh, ch),
+                    "clean" if a is clean else "dirty"))
+        abi.check(lib.avirhip_plan_set_variant(p, 0), "variant")
+        for a in (dirty, clean):
+            out = np.zeros((nh, nw, ch), np.float32)
+            for a_, b_ in [(0, nh // 2), (nh // 2, nh)]:
+                abi.check(lib.avirhip_resize_band(
+                    p, a.ctypes.data, abi.MEM_HOST, out[a_:b_].ctypes.data,
+                    abi.MEM_HOST, a_, b_, None), "band")
+            _same_but_nan_payloads(out, wants[id(a)], "bands")
+
+
+def test_double_pipeline_on_the_tiled_kernels():
+    """tools/fuzz_f64.py: the double pipeline (fpclass_def<double>) on the
+    LDS-tiled two-pass kernels (tile64.hip), on the per-op kernels
+    (generic64.hip, path 1) and in row bands against the reference's own
+    double class -- random geometries, channel counts, element types, bit
+    depths, build modes, steps, offsets, presets, gamma."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools",
+                                                     "fuzz_f64.py"),
+                        "300", "17"], capture_output=True, text=True,
+                       timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert "on the tiled kernels" in r.stdout
+
+
 def test_avir_pass_kernels_are_the_default_for_general_ratios():
     lib = abi.load()
     r = avir_amd.CImageResizer(16)
