@@ -149,103 +149,122 @@ __device__ __forceinline__ void run_op64( const T64Op& op, const double* in,
 
 	__syncthreads();
 
-	// x runs over lanes (image x: contiguous stores), y over thread rows
-	const int nx = ( ALONG_X ? on : n_o );
+	// A thread computes ONE double at a time: channel k of one output pixel.
+	// Lanes run over the flat elements of an image row (x * CH + k), so
+	// neighbouring lanes read neighbouring doubles of LDS (conflict-free
+	// ds_read_b64; a lane per whole pixel strode 32 bytes: 4-way conflicts,
+	// k_v64 took 349 us for cfg2) and store contiguous runs; the four waves of
+	// the workgroup take rows, TWO rows each per trip (y and y + 4): two
+	// independent accumulation chains per thread hide the LDS latency that two
+	// workgroups per CU cannot. LDS offsets are 32-bit.
+	const int nx = ( ALONG_X ? on : n_o ) * CH;
 	const int ny = ( ALONG_X ? n_o : on );
-	const int istep = ( ALONG_X ? 1 : ipitch ) * CH;
-	const int tx = tid & 31, ty = tid >> 5;
+	const int istep = ( ALONG_X ? CH : ipitch * CH );
+	const int tx = tid & 63, ty = tid >> 6;
+
+	auto put = [&]( const int n, const int o, const int k, const int xe,
+		const double acc )
+	{
+		const int g = olo + n;
+
+		if( STORE == 1 )
+		{
+			// H pass -> FltBuf (double), row = o (source row), column = g
+			((double*) P.dst )[ (long) ( g_o_lo + o ) * P.dst_ss +
+				(long) g * CH + k ] = acc;
+		}
+		else
+		if( STORE == 2 )
+		{
+			// V pass -> the caller's image: row = g, columns from g_o_lo on
+			if( g >= P.a_lo && g < P.a_hi )
+			{
+				((Tout*) P.dst )[ (long) ( g - P.dst_row0 ) * P.dst_ss +
+					(long) g_o_lo * CH + xe ] = out_stage< Tout >( P, acc );
+			}
+		}
+		else
+		{
+			out[ ( ALONG_X ? o * opitch + n : n * opitch + o ) * CH + k ] =
+				( g > op.zero_above ? 0.0 : acc );
+		}
+	};
 
 	for( int y = ty; y < ny; y += 8 )
 	{
-		for( int x = tx; x < nx; x += 32 )
+		const int y2 = y + 4;
+		const bool two = ( y2 < ny );
+
+		for( int xe = tx; xe < nx; xe += 64 )
 		{
-			const int n = ( ALONG_X ? x : y );
-			const int o = ( ALONG_X ? y : x );
-			const int g = olo + n;
-			const double* base = in + ( ALONG_X ? (long) o * ipitch : o ) * CH;
-			double acc[ CH ];
+			const int xp = xe / CH;       // pixel along x
+			const int k = xe - xp * CH;   // its channel
+			const int n0 = ( ALONG_X ? xp : y ), n1 = ( ALONG_X ? xp : y2 );
+			const int o0 = ( ALONG_X ? y : xp ), o1 = ( ALONG_X ? y2 : xp );
+			const double* const b0 = in + ( ALONG_X ? o0 * ipitch * CH + k : xe );
+			const double* const b1 = in + ( ALONG_X ? o1 * ipitch * CH + k : xe );
+			double a0, a1 = 0.0;
 
 			if( op.type == OP_FIR )
 			{
-				const int cp = op.rf * ( cl( g, olast ) - op.e ) - ilo;
-				const double* c = base + (long) cp * istep;
-#pragma unroll
-				for( int k = 0; k < CH; k++ )
+				const double* c0 = b0 + ( op.rf * ( cl( olo + n0, olast ) -
+					op.e ) - ilo ) * istep;
+				const double* c1 = b1 + ( op.rf * ( cl( olo + ( two ? n1 : n0 ),
+					olast ) - op.e ) - ilo ) * istep;
+
+				if( !two )
 				{
-					acc[ k ] = cfl[ 0 ] * c[ k ];
+					c1 = c0;
 				}
+
+				a0 = cfl[ 0 ] * c0[ 0 ];
+				a1 = cfl[ 0 ] * c1[ 0 ];
 
 				for( int i = 1; i <= op.lat; i++ )
 				{
 					const double f = cfl[ i ];
-#pragma unroll
-					for( int k = 0; k < CH; k++ )
-					{
-						acc[ k ] = acc[ k ] + f * ( c[ (long) i * istep + k ] +
-							c[ (long) -i * istep + k ]);
-					}
+					a0 = a0 + f * ( c0[ i * istep ] + c0[ -i * istep ]);
+					a1 = a1 + f * ( c1[ i * istep ] + c1[ -i * istep ]);
 				}
 			}
 			else
 			{
-				const double* c = base + (long) sti[ n * 2 ] * istep;
-				const int nt = sti[ n * 2 + 1 ];
-				const double* cf = cfl + n * mt;
-#pragma unroll
-				for( int k = 0; k < CH; k++ )
+				const int m1 = ( two ? n1 : n0 );
+				const double* c0 = b0 + sti[ n0 * 2 ] * istep;
+				const double* c1 = ( two ? b1 : b0 ) + sti[ m1 * 2 ] * istep;
+				const int nt0 = sti[ n0 * 2 + 1 ], nt1 = sti[ m1 * 2 + 1 ];
+				const double* cf0 = cfl + n0 * mt;
+				const double* cf1 = cfl + m1 * mt;
+				const int ntc = min( nt0, nt1 );
+				a0 = 0.0;
+				int t = 0;
+
+				for( ; t < ntc; t++ )
 				{
-					acc[ k ] = 0.0;
+					a0 = a0 + cf0[ t ] * c0[ 0 ];
+					a1 = a1 + cf1[ t ] * c1[ 0 ];
+					c0 += istep;
+					c1 += istep;
 				}
 
-				for( int t = 0; t < nt; t++ )
+				for( int u = t; u < nt0; u++ )
 				{
-					const double f = cf[ t ];
-#pragma unroll
-					for( int k = 0; k < CH; k++ )
-					{
-						acc[ k ] = acc[ k ] + f * c[ k ];
-					}
+					a0 = a0 + cf0[ u ] * c0[ 0 ];
+					c0 += istep;
+				}
 
-					c += istep;
+				for( int u = t; u < nt1; u++ )
+				{
+					a1 = a1 + cf1[ u ] * c1[ 0 ];
+					c1 += istep;
 				}
 			}
 
-			if( STORE == 1 )
+			put( n0, o0, k, xe, a0 );
+
+			if( two )
 			{
-				// H pass -> FltBuf (double), row = o (source row), column = g
-				double* const q = (double*) P.dst + (long) ( g_o_lo + o ) *
-					P.dst_ss + (long) g * CH;
-#pragma unroll
-				for( int k = 0; k < CH; k++ )
-				{
-					q[ k ] = acc[ k ];
-				}
-			}
-			else
-			if( STORE == 2 )
-			{
-				// V pass -> the caller's image: row = g, column = g_o_lo + o
-				if( g >= P.a_lo && g < P.a_hi )
-				{
-					Tout* const q = (Tout*) P.dst + (long) ( g - P.dst_row0 ) *
-						P.dst_ss + (long) ( g_o_lo + o ) * CH;
-#pragma unroll
-					for( int k = 0; k < CH; k++ )
-					{
-						q[ k ] = out_stage< Tout >( P, acc[ k ]);
-					}
-				}
-			}
-			else
-			{
-				double* const q = out + ( ALONG_X ? (long) o * opitch + n :
-					(long) n * opitch + o ) * CH;
-				const bool z = ( g > op.zero_above );
-#pragma unroll
-				for( int k = 0; k < CH; k++ )
-				{
-					q[ k ] = ( z ? 0.0 : acc[ k ]);
-				}
+				put( n1, o1, k, xe, a1 );
 			}
 		}
 	}
@@ -595,11 +614,11 @@ int tile64_prepare( avirhip_plan* p )
 	// (tile along the chain's axis, tile along the other one)
 	static const int ch_[][ 2 ] = { { 64, 8 }, { 128, 4 }, { 64, 4 }, { 32, 4 },
 		{ 32, 2 }, { 16, 2 }, { 8, 1 } };
-	static const int cv_[][ 2 ] = { { 32, 32 }, { 16, 32 }, { 32, 16 }, { 16, 16 },
-		{ 8, 16 }, { 8, 8 }, { 4, 8 }, { 2, 8 } };
+	static const int cv_[][ 2 ] = { { 64, 16 }, { 48, 16 }, { 32, 32 }, { 32, 16 },
+		{ 16, 32 }, { 16, 16 }, { 8, 16 }, { 8, 8 }, { 4, 8 }, { 2, 8 } };
 	const size_t cap = 64 * 1024;
 	int rc = geom64( D, p -> h, p -> new_w, p -> ch, ch_, 7, cap, D -> h, true );
-	if( rc == 0 ) rc = geom64( D, p -> v, p -> new_h, p -> ch, cv_, 8, cap,
+	if( rc == 0 ) rc = geom64( D, p -> v, p -> new_h, p -> ch, cv_, 10, cap,
 		D -> v, false );
 
 	if( rc != 0 || !D -> h.ok || !D -> v.ok )
