@@ -1495,34 +1495,46 @@ __global__ void __launch_bounds__( 64 ) k_sacc2v( const SAParams P )
 	const int voff = lc * (int) P.s_lane;
 	const unsigned sstep = (unsigned) P.s_step;
 
-	// row lanes: this lane's (row, piece) of the four DMA instructions
+	// Row lanes fetch SUPERBLOCKS of eight samples: 32 * HC contiguous bytes of
+	// each row = PPR 16-byte pieces, one DMA instruction for RPI rows (lane l:
+	// row l / PPR, piece l % PPR) -- whole 128-byte lines of a row per request
+	// (float RGBA); as blocks of four samples (64 bytes of 16 rows) the pass ran
+	// at 2.1 TB/s with 45 % of its wave-cycles in s_waitcnt. Two superblocks
+	// in the ring: the one being multiplied in and the next one in flight.
 	constexpr int HC = ( HOR ? HCH : 1 );
-	const int hrow = min( lane / HC, 15 );
-	const int hpiece = lane - ( lane / HC ) * HC;
-	int hvoff[ 4 ];
-#pragma unroll
-	for( int i = 0; i < 4; i++ )
+	constexpr int PPR = 2 * HC;         // pieces per row and superblock
+	constexpr int RPI = 64 / PPR;       // rows per instruction
+	constexpr int NI = ( 64 + RPI - 1 ) / RPI; // instructions per superblock
+	static_assert( !HOR || 2 * NI <= SA2V_RING, "two superblocks fit the ring" );
+	int hvoff[ HOR ? NI : 1 ];
+
+	if( HOR )
 	{
-		hvoff[ i ] = min( l0 + 16 * i + hrow, P.lane_hi - 1 ) * (int) P.s_lane +
-			hpiece * 16;
+		const int hr = min( lane / PPR, RPI - 1 );
+		const int hp = lane - ( lane / PPR ) * PPR;
+#pragma unroll
+		for( int i = 0; i < ( HOR ? NI : 1 ); i++ )
+		{
+			hvoff[ i ] = min( l0 + RPI * i + hr, P.lane_hi - 1 ) * (int) P.s_lane +
+				hp * 16;
+		}
 	}
 
-	auto d_issue = [&]( const int qb ) // the four rows of block qb
+	auto d_issue_sb = [&]( const int sb ) // the eight samples of superblock sb
 	{
-		if( HOR )
-		{
-			// the block's first sample, inside the row (blocks that reach
-			// beyond it are fixed up when they are read)
-			const int us = min( max( qb * 4, 0 ), slast - 3 );
+		// its first sample, inside the row (a superblock that reaches beyond
+		// the row is re-read pixel by pixel when it is used)
+		const int us = min( max( sb * 8, 0 ), slast - 7 );
 #pragma unroll
-			for( int i = 0; i < 4; i++ )
-			{
-				df_dma( rsrc, lds0 + (unsigned) ((( qb & ( SA2V_RB - 1 )) * 4 + i ) *
-					1024 ), hvoff[ i ], (unsigned) ( us * HC * 4 ));
-			}
-
-			return;
+		for( int i = 0; i < ( HOR ? NI : 1 ); i++ )
+		{
+			df_dma( rsrc, lds0 + (unsigned) ((( sb & 1 ) * NI + i ) * 1024 ),
+				hvoff[ i ], (unsigned) ( us * HC * 4 ));
 		}
+	};
+
+	auto d_issue = [&]( const int qb ) // column lanes: the four rows of block qb
+	{
 #pragma unroll
 		for( int j = 0; j < 4; j++ )
 		{
@@ -1539,8 +1551,9 @@ __global__ void __launch_bounds__( 64 ) k_sacc2v( const SAParams P )
 		{
 			// HC pieces = 4 * HC floats = four pixels of HC channels
 			float fl[ 4 * HC ];
-			const f4* const rp = ring + (( qb & ( SA2V_RB - 1 )) * 4 +
-				( lane >> 4 )) * 64 + ( lane & 15 ) * HC;
+			const int sb = qb >> 1;
+			const f4* const rp = ring + (( sb & 1 ) * NI + lane / RPI ) * 64 +
+				( lane - ( lane / RPI ) * RPI ) * PPR + ( qb & 1 ) * HC;
 #pragma unroll
 			for( int k = 0; k < HC; k++ )
 			{
@@ -1549,9 +1562,10 @@ __global__ void __launch_bounds__( 64 ) k_sacc2v( const SAParams P )
 				fl[ 4 * k + 2 ] = t.z; fl[ 4 * k + 3 ] = t.w;
 			}
 
-			if( qb * 4 < 0 || qb * 4 + 3 > slast )
+			if( sb * 8 < 0 || sb * 8 + 7 > slast )
 			{
-				// (the view repeats the edge pixels beyond the row: rare)
+				// (the view repeats the edge pixels beyond the row; the
+				// superblock was fetched from a shifted position: rare)
 				const float* const row = (const float*) ( (const char*) P.src +
 					(long) lc * P.s_lane );
 #pragma unroll
@@ -1633,28 +1647,28 @@ __global__ void __launch_bounds__( 64 ) k_sacc2v( const SAParams P )
 	T.bad = 0;
 	int endg = a_start[ T.g ] + nt - 1; // the last sample of output T.g
 
-#pragma unroll
-	for( int i = 0; i < SA2V_PF; i++ )
+	if( HOR )
 	{
-		d_issue( q_a + i );
-	}
-
-	// Row lanes fetch blocks in PAIRS -- an even block and the odd one after it
-	// are the two halves of a 128-byte line of every row, requested back to
-	// back instead of a block's worth of arithmetic apart (as single blocks the
-	// pass fetched 1.57 x the source): at an even block q the blocks q + 2 and
-	// q + 3 go out, so blocks up to q + 3 (even q) / q + 2 (odd q) are issued.
-	if( HOR && ( q_a & 1 ) == 0 )
-	{
-		d_issue( q_a + 3 );
-		GP_WAIT_VM( 12 );
+		d_issue_sb( q_a >> 1 );
+		GP_WAIT_VM( 0 );
 	}
 	else
 	{
+#pragma unroll
+		for( int i = 0; i < SA2V_PF; i++ )
+		{
+			d_issue( q_a + i );
+		}
+
 		SA2V_WAIT(); // loads retire in order: block q_a has landed
 	}
 
 	x_read( q_a );
+
+	if( HOR )
+	{
+		d_issue_sb(( q_a >> 1 ) + 1 ); // (into the other half of the ring)
+	}
 
 	// ---- the table feed (see k_sacc2)
 	gp_cfloat* const tabu = (gp_cfloat*) (unsigned long) A.tab2;
@@ -1752,22 +1766,24 @@ __global__ void __launch_bounds__( 64 ) k_sacc2v( const SAParams P )
 			{
 				if(( qn & 1 ) == 0 )
 				{
-					d_issue( qn + 2 );
-					d_issue( qn + 3 );
-					GP_WAIT_VM( 12 ); // blocks qn + 1 .. qn + 3 may be in flight
+					// a new superblock: its pieces went out two blocks ago, its
+					// half of the ring was read out before that; the one after
+					// it goes out into the half just used up
+					GP_WAIT_VM( 0 );
+					x_read( qn );
+					d_issue_sb(( qn >> 1 ) + 1 );
 				}
 				else
 				{
-					SA2V_WAIT();      // blocks qn + 1, qn + 2
+					x_read( qn );
 				}
 			}
 			else
 			{
 				d_issue( qn + SA2V_PF - 1 );
 				SA2V_WAIT();
+				x_read( qn );
 			}
-
-			x_read( qn );
 		}
 
 		sa2_emit< NC, S, HOR >( R, w, pend, T, P );
