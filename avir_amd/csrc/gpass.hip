@@ -375,6 +375,20 @@ int sacc_run_axis( const SAData* D, bool rows, const void* src, int src_type,
 	bool ladder = false, bool must_two = false,
 	unsigned int* flag_set = nullptr, const unsigned int* guard = nullptr );
 bool sacc_has_two( const SAData* D );
+bool sacc_is_zs( const SAData* D );
+double sacc_k( const SAData* D );
+
+// Whether a pass takes the accumulation kernel where the axis has one. Axes
+// that downsize by 1 < k < 2 (13 .. 25 taps over the zero-stuffed view) have had
+// one since round 4; measured against the gather kernels on one box
+// (3840x2160 sources): RGB uint8 k = 1.5 0.109 vs 0.151 ms, k = 1.92 0.099 vs
+// 0.141 -- integer sources always; float RGBA k = 1.5 0.139 vs 0.126 (slower),
+// k = 1.75 0.113 vs 0.115, k = 1.92 0.111 vs 0.118 -- float sources from 1.7 on.
+static bool sa_wanted( const SAData* sa, const bool int_src )
+{
+	return( sa != nullptr && ( int_src || !sacc_is_zs( sa ) ||
+		sacc_k( sa ) >= 1.7 ));
+}
 
 struct GPData
 {
@@ -801,9 +815,14 @@ bool gpass_preferred( const avirhip_plan* p )
 	// (measured, profiles/r02_sacc: it wins where its first pass replaces the
 	// pack pass or a long-tap tile loader -- integer or narrower sources; for
 	// float RGBA the gather / whole-ratio kernels stay ahead)
+	// (1 < k < 2, round 4: large frames only -- 1920x1080 -> 1280x720 RGB uint8
+	// ties with the tiles at 0.061 ms, 1280x720 -> 854x480 loses 0.048 vs 0.037)
+	const bool zs_axes = ( sacc_is_zs( D -> sa_h ) || sacc_is_zs( D -> sa_v ));
+
 	if( D -> sa_h != nullptr && D -> sa_v != nullptr && !p -> gamma &&
 		( p -> in_type == AVIRHIP_U8 || p -> in_type == AVIRHIP_U16 ||
-		( p -> in_type == AVIRHIP_F32 && p -> io_ch != 4 )))
+		( p -> in_type == AVIRHIP_F32 && p -> io_ch != 4 && !zs_axes )) &&
+		( !zs_axes || (long) p -> new_w * p -> new_h >= 2000000L ))
 	{
 		return( true );
 	}
@@ -816,6 +835,7 @@ bool gpass_preferred( const avirhip_plan* p )
 	if( D -> sa_h != nullptr && D -> sa_v != nullptr && !p -> gamma &&
 		p -> in_type == AVIRHIP_F32 && sacc_has_two( D -> sa_h ) &&
 		sacc_has_two( D -> sa_v ) && !fused_dn_both( p ) &&
+		sa_wanted( D -> sa_h, false ) && sa_wanted( D -> sa_v, false ) &&
 		(long) p -> src_w * p -> src_h >= 6000000L )
 	{
 		return( true );
@@ -830,7 +850,7 @@ bool gpass_preferred( const avirhip_plan* p )
 	// the correction FIR): ahead of the tiles on large frames (3840x2160 ->
 	// 2560x1440 RGBA float 0.137 against 0.179 ms), even with them at 1080p
 	if( D -> h.a.mode == GP_POST && D -> v.a.mode == GP_POST &&
-		D -> sa_h == nullptr && D -> sa_v == nullptr )
+		(( D -> sa_h == nullptr && D -> sa_v == nullptr ) || zs_axes ))
 	{
 		return( (long) p -> new_w * p -> new_h >= 2000000L );
 	}
@@ -1049,7 +1069,11 @@ bool gpass_lancir_takes_raw( const avirhip_plan* p )
 bool gpass_takes_raw( const avirhip_plan* p )
 {
 	const GPData* D = (const GPData*) p -> gpass;
-	return( D != nullptr && !p -> is_lancir && ( D -> sa_h != nullptr ||
+	const bool int_src = ( p -> in_type == AVIRHIP_U8 ||
+		p -> in_type == AVIRHIP_U16 );
+
+	return( D != nullptr && !p -> is_lancir &&
+		( sa_wanted( D -> sa_h, int_src ) ||
 		( D -> h_geom && D -> h_nseg <= 4 )));
 }
 
@@ -1232,8 +1256,11 @@ int gpass_run( avirhip_plan* p, const float* src, long src_stride, float* dst,
 	static const bool no_opt = ( getenv( "AVIRHIP_NO_SACC_OPT" ) != nullptr );
 	const bool fsrc = ( raw != nullptr ? raw_type == AVIRHIP_F32 : true );
 
-	if( !int_src && fsrc && !ladder && !no_opt && sacc_has_two( D -> sa_h ) &&
-		sacc_has_two( D -> sa_v ))
+	const bool use_sa_h = sa_wanted( D -> sa_h, int_src );
+	const bool use_sa_v = sa_wanted( D -> sa_v, int_src );
+
+	if( !int_src && fsrc && !ladder && !no_opt && use_sa_h && use_sa_v &&
+		sacc_has_two( D -> sa_h ) && sacc_has_two( D -> sa_v ))
 	{
 		if( D -> nf_flag == nullptr )
 		{
@@ -1293,7 +1320,7 @@ int gpass_run( avirhip_plan* p, const float* src, long src_stride, float* dst,
 
 	rc = 1;
 
-	if( D -> sa_h != nullptr )
+	if( use_sa_h )
 	{
 		if( raw != nullptr )
 		{
@@ -1327,7 +1354,7 @@ int gpass_run( avirhip_plan* p, const float* src, long src_stride, float* dst,
 
 	rc = 1;
 
-	if( D -> sa_v != nullptr )
+	if( use_sa_v )
 	{
 		rc = sacc_run_axis( D -> sa_v, false, D -> mid, AVIRHIP_F32, 4,
 			p -> io_ch, 16, mid_ss * 4, dst - (long) row0 * dst_ss, 4, dst_ss,

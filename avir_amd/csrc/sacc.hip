@@ -53,6 +53,8 @@ struct SAAxis
 {
 	int nt, in_len, g_len, out_len, e, lanc;
 	float f[ 4 ];
+	int mmax;           // zero-stuffed view (the 2x upsample before a 1 < k < 2
+	                    // resize, folded into the gather): samples above read 0
 	int u_min;          // view index of table row 0
 	const int* start;   // [g_len] first input of each output (unclamped)
 	const int* first;   // [rows] first output alive at the sample
@@ -431,12 +433,12 @@ __global__ void __launch_bounds__( 64 ) k_sacc( const SAParams P )
 
 	auto x_read = [&]( const int u ) -> f4
 	{
-		if( SRC == 0 )
-		{
-			return( d_read( u ));
-		}
+		// (d_read counts the samples: called for every u)
+		const f4 v = ( SRC == 0 ? d_read( u ) :
+			fifo[ (( u - ub0 ) & 7 ) * 64 + lane ]);
 
-		return( fifo[ (( u - ub0 ) & 7 ) * 64 + lane ]);
+		// a zero-stuffed view reads 0 above its last replicated sample
+		return( u > A.mmax ? (f4) 0.0f : v );
 	};
 
 	// ---- prologue: the first output's samples may be alive for outputs before
@@ -1192,7 +1194,7 @@ __global__ void __launch_bounds__( 64 ) k_sacc2( const SAParams P )
 				const int ei = ( j & 3 ) * CH + c;
 				unsigned int v = 0u; // (floats travel as their bit patterns)
 
-				if( u >= u_a )
+				if( u >= u_a && u <= A.mmax ) // (zero-stuffed view: 0 above)
 				{
 					if constexpr( SRC == 3 ) v = __builtin_bit_cast( unsigned int,
 						px[ c ]);
@@ -1576,7 +1578,7 @@ __global__ void __launch_bounds__( 64 ) k_sacc2v( const SAParams P )
 #pragma unroll
 					for( int c = 0; c < HC; c++ )
 					{
-						fl[ j * HC + c ] = px[ c ];
+						fl[ j * HC + c ] = ( qb * 4 + j > A.mmax ? 0.0f : px[ c ]);
 					}
 				}
 			}
@@ -1609,6 +1611,20 @@ __global__ void __launch_bounds__( 64 ) k_sacc2v( const SAParams P )
 			for( int j = 0; j < 3; j++ )
 			{
 				if( qb * 4 + j < u_a )
+				{
+					x[ j ] = PV::zero();
+				}
+			}
+		}
+
+		if( !HOR && qb * 4 + 3 > A.mmax )
+		{
+			// (column lanes: a zero-stuffed view reads 0 above its last
+			// replicated row; row lanes did it in their re-read above)
+#pragma unroll
+			for( int j = 0; j < 4; j++ )
+			{
+				if( qb * 4 + j > A.mmax )
 				{
 					x[ j ] = PV::zero();
 				}
@@ -1855,8 +1871,9 @@ int sacc_prepare_axis( const GPAxisHost& H, std::vector< void* >& allocs,
 	*out = nullptr;
 	const GPAxis& A = H.a;
 
-	if( !H.ok || A.mode != GP_POST || A.lanc || A.view_mmax != 0x7fffffff ||
-		A.g_len < 1 || getenv( "AVIRHIP_NO_SACC" ) != nullptr )
+	if( !H.ok || A.mode != GP_POST || A.lanc || A.g_len < 1 ||
+		A.view_mmax < A.in_len - 1 || getenv( "AVIRHIP_NO_SACC" ) != nullptr ||
+		( A.view_mmax != 0x7fffffff && getenv( "AVIRHIP_NO_SACC_ZS" ) != nullptr ))
 	{
 		return( AVIRHIP_OK );
 	}
@@ -1914,6 +1931,7 @@ int sacc_prepare_axis( const GPAxisHost& H, std::vector< void* >& allocs,
 	D -> a.out_len = A.out_len; D -> a.e = A.e; D -> a.lanc = 0;
 	memcpy( D -> a.f, A.f, sizeof( A.f ));
 	D -> a.u_min = u_min;
+	D -> a.mmax = A.view_mmax;
 	D -> a.start = A.start;
 	D -> k = (double) rows / A.g_len;
 
@@ -2043,6 +2061,18 @@ void sacc_release_axis( SAData* D )
 bool sacc_has_two( const SAData* D )
 {
 	return( D != nullptr && D -> a.tab2 != nullptr );
+}
+
+// the axis reads a zero-stuffed view (1 < k < 2: a 2x upsample folded into
+// the resize); its average input advance per output
+bool sacc_is_zs( const SAData* D )
+{
+	return( D != nullptr && D -> a.mmax != 0x7fffffff );
+}
+
+double sacc_k( const SAData* D )
+{
+	return( D != nullptr ? D -> k : 0.0 );
 }
 
 template< int SRC, int CH, int NC >

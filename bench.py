@@ -56,6 +56,11 @@ OTHER = {"cfg1": ("avir", 640, 480, 1024, 768, 3, "u8", 8),
          "half_u8": ("avir", 3840, 2160, 1920, 1080, 3, "u8", 8),
          "dn15": ("avir", 3840, 2160, 2560, 1440, 4, "f32", 16),
          "dn192": ("avir", 3840, 2160, 2000, 1125, 4, "f32", 16),
+         "dn15_u8": ("avir", 3840, 2160, 2560, 1440, 3, "u8", 8),
+         "dn192_u8": ("avir", 3840, 2160, 2000, 1125, 3, "u8", 8),
+         "dn15_1080_u8": ("avir", 1920, 1080, 1280, 720, 3, "u8", 8),
+         "dn15_720_u8": ("avir", 1280, 720, 854, 480, 3, "u8", 8),
+         "dn17": ("avir", 3840, 2160, 2200, 1238, 4, "f32", 16),
          # the one timing the reference's README publishes (README.md:157-162:
          # 245 ms on 1 thread, 74 ms on 8 threads of an i7-7700K)
          "readme": ("avir", 5184, 3456, 1920, 1280, 3, "u8", 8),
