@@ -1015,11 +1015,15 @@ __device__ __forceinline__ void sa2_emit( SA2Acc< NC >& R, SAV< NC > ( &w )[ 8 ]
 				}
 			}
 		}
+		T.n_out++;
+		return;
 	}
-	else
+
+	// column lanes -- the plan's last pass. NaN or Inf in what leaves
+	// (v_cmp_class: signalling / quiet NaN, -inf, +inf) raises the optimistic
+	// float path's alarm (SAParams::flag_set; gathered per wave, see the
+	// kernel's end)
 	{
-		// NaN or Inf in what leaves (v_cmp_class: signalling / quiet NaN, -inf,
-		// +inf): the optimistic float path's alarm (SAParams::flag_set)
 		const f4 r4 = r.to4();
 		const bool nf = ( __builtin_amdgcn_classf( r4.x, 0x207 ) ||
 			__builtin_amdgcn_classf( r4.y, 0x207 ) ||
@@ -1029,10 +1033,6 @@ __device__ __forceinline__ void sa2_emit( SA2Acc< NC >& R, SAV< NC > ( &w )[ 8 ]
 		T.bad |= __builtin_amdgcn_ballot_w64( nf );
 	}
 
-	if( ROWS )
-	{
-	}
-	else
 	if( P.out.on != 0 )
 	{
 		if( T.lok )
@@ -1106,7 +1106,7 @@ __global__ void __launch_bounds__( 64 ) k_sacc2( const SAParams P )
 	// (vector-typed so that a half group is one register tuple from the load
 	// on: with single dwords the loop-carried copies of the group in flight
 	// were made right after its load went out -- at full memory latency)
-	constexpr int NV = ( NDW + 3 ) / 4; // (float RGBA: 16 dwords = 4 x dwordx4)
+	constexpr int NV = ( NDW + 3 ) / 4;
 	constexpr int VW = NDW / NV;
 	static_assert( NV * VW == NDW, "a half group is NV equal register tuples" );
 	typedef typename SA2Vec< VW > :: T HV;
@@ -1192,13 +1192,11 @@ __global__ void __launch_bounds__( 64 ) k_sacc2( const SAParams P )
 			for( int c = 0; c < CH; c++ )
 			{
 				const int ei = ( j & 3 ) * CH + c;
-				unsigned int v = 0u; // (floats travel as their bit patterns)
+				unsigned int v = 0u;
 
 				if( u >= u_a && u <= A.mmax ) // (zero-stuffed view: 0 above)
 				{
-					if constexpr( SRC == 3 ) v = __builtin_bit_cast( unsigned int,
-						px[ c ]);
-					else v = (unsigned int) px[ c ];
+					v = (unsigned int) px[ c ];
 				}
 
 				if( j < 4 ) h_or( curA, ei / EPD, v << (( ei % EPD ) * ( 32 / EPD )));
@@ -1215,15 +1213,8 @@ __global__ void __launch_bounds__( 64 ) k_sacc2( const SAParams P )
 		{
 			const int ei = j * CH + c;
 
-			if constexpr( SRC == 3 )
-			{
-				v[ c ] = __builtin_bit_cast( float, h_get( curA, ei ));
-			}
-			else
-			{
-				v[ c ] = (float) (( h_get( curA, ei / EPD ) >> (( ei % EPD ) *
-					( 32 / EPD ))) & ( SRC == 1 ? 0xffu : 0xffffu ));
-			}
+			v[ c ] = (float) (( h_get( curA, ei / EPD ) >> (( ei % EPD ) *
+				( 32 / EPD ))) & ( SRC == 1 ? 0xffu : 0xffffu ));
 		}
 
 		f4 o; o.x = v[ 0 ]; o.y = v[ 1 ]; o.z = v[ 2 ]; o.w = v[ 3 ];

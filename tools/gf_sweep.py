@@ -28,15 +28,19 @@ def bench(plan, src, dst, n=60):
     return e0.elapsed_time(e1) / n
 
 
+U8 = len(sys.argv) > 1 and sys.argv[1] == "u8"   # RGB uint8 images in and out
+CH = 3 if U8 else 4
 for (sw, sh) in ((1280, 720), (1920, 1080), (3840, 2160)):
-    src = torch.from_numpy(synth.lcg_f32((sh, sw, 4))).to(dev)
+    src = torch.from_numpy(synth.lcg_u8((sh, sw, CH)) if U8 else
+                           synth.lcg_f32((sh, sw, CH))).to(dev)
     for ratio in (1.15, 1.3, 1.6, 1.9, 2.3, 2.7, 3.0, 3.6):
         nw, nh = int(sw * ratio), int(sh * ratio)
         if nw * nh > 40e6:
             continue
-        dst = torch.empty((nh, nw, 4), dtype=torch.float32, device=dev)
-        r = avir_amd.CImageResizer(16)
-        p = r.plan(sw, sh, nw, nh, 4)
+        dst = torch.empty((nh, nw, CH), dtype=src.dtype, device=dev)
+        r = avir_amd.CImageResizer(8 if U8 else 16)
+        tc = abi.U8 if U8 else abi.F32
+        p = r.plan(sw, sh, nw, nh, CH, 0.0, None, tc, tc)
         if lib.avirhip_plan_set_path(p, 5) != 0:
             print("%dx%d x%.2f: path 5 refused" % (sw, sh, ratio))
             continue
