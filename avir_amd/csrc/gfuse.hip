@@ -140,10 +140,7 @@ __global__ void __launch_bounds__( 64 ) k_gf( const GFParams P )
 
 		if( P.out.on != 0 )
 		{
-			if( jok )
-			{
-				gp_store_int( P.out, orow, j, o );
-			}
+			gp_store_int_row( P.out, orow, j, o, jok );
 
 			orow++;
 			return;

@@ -176,13 +176,12 @@ __global__ void __launch_bounds__( 64 ) k_gv( const GVParams P )
 #endif
 		if( WP == 2 && P.out.on != 0 )
 		{
-			if( xok )
 			{
 				f4 o4;
 				o4.x = o.x; o4.y = o.y;
 				o4.z = ( WP == 2 ? o[ WP == 2 ? 2 : 0 ] : 0.0f );
 				o4.w = ( WP == 2 ? o[ WP == 2 ? 3 : 0 ] : 0.0f );
-				gp_store_int( P.out, orow, hx, o4 );
+				gp_store_int_row( P.out, orow, hx, o4, xok );
 			}
 
 			orow++;

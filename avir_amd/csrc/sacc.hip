@@ -535,11 +535,7 @@ __global__ void __launch_bounds__( 64 ) k_sacc( const SAParams P )
 		{
 			if( P.out.on != 0 )
 			{
-				if( lok )
-				{
-					gp_store_int( P.out, n_out - P.out_lo, li, o.to4() );
-				}
-
+				gp_store_int_row( P.out, n_out - P.out_lo, li, o.to4(), lok );
 				n_out++;
 				return;
 			}
@@ -1035,15 +1031,12 @@ __device__ __forceinline__ void sa2_emit( SA2Acc< NC >& R, SAV< NC > ( &w )[ 8 ]
 
 	if( P.out.on != 0 )
 	{
-		if( T.lok )
-		{
-			GPOut O;
-			O.on = 1; O.type = P.out.type; O.ch = P.out.ch;
-			O.use_tr = P.out.use_tr; O.tr_mul = P.out.tr_mul;
-			O.tr_muli = P.out.tr_muli; O.pk_out = P.out.pk_out;
-			O.base = P.out.base; O.stride = P.out.stride;
-			gp_store_int( O, T.n_out - P.out_lo, T.li, r.to4() );
-		}
+		GPOut O;
+		O.on = 1; O.type = P.out.type; O.ch = P.out.ch;
+		O.use_tr = P.out.use_tr; O.tr_mul = P.out.tr_mul;
+		O.tr_muli = P.out.tr_muli; O.pk_out = P.out.pk_out;
+		O.base = P.out.base; O.stride = P.out.stride;
+		gp_store_int_row( O, T.n_out - P.out_lo, T.li, r.to4(), T.lok );
 	}
 	else
 	{
