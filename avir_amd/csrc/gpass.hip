@@ -402,6 +402,10 @@ struct GPData
 	float* mid;          // intermediate image between the passes
 	size_t mid_bytes;
 	unsigned int* nf_flag; // float sources on the branch-free kernels: the alarm
+	// LANCIR upsizing in one launch (lfuse.hip): strips whose source segment is
+	// at most 64 pixels
+	int lf_ow, lf_nstrips;
+	int* d_lfseg;
 	std::vector< void* > allocs;
 };
 
@@ -557,6 +561,7 @@ int gpass_prepare( avirhip_plan* p )
 	GPData* D = new GPData();
 	D -> mid = nullptr; D -> mid_bytes = 0; D -> d_hseg = nullptr;
 	D -> nf_flag = nullptr;
+	D -> lf_ow = 0; D -> lf_nstrips = 0; D -> d_lfseg = nullptr;
 	D -> sa_h = nullptr; D -> sa_v = nullptr;
 	D -> h_geom = false; D -> v_geom = false;
 
@@ -747,6 +752,43 @@ int gpass_prepare( avirhip_plan* p )
 		}
 
 		D -> v_blk = 1; D -> v_rs = rs; D -> v_rc = rc;
+	}
+
+	// ---- LANCIR upsizing, both kernels 6 taps, RGBA order: the fused launch's
+	// strips -- the widest whose source segments fit one 64-pixel piece
+	if( p -> is_lancir && D -> h.a.lanc == 4 && D -> v.a.lanc == 4 &&
+		D -> h.a.nt == 6 && D -> v.a.nt == 6 &&
+		getenv( "AVIRHIP_NO_LFUSE" ) == nullptr )
+	{
+		const GPAxis& A = D -> h.a;
+		const std::vector< int >& st = D -> h.start;
+
+		for( int cw = 64; cw >= 16 && D -> lf_ow == 0; cw-- )
+		{
+			const int cn = ( A.out_len + cw - 1 ) / cw;
+			std::vector< int > seg( (size_t) cn * 2, 0 );
+			bool fits = true;
+
+			for( int s = 0; s < cn && fits; s++ )
+			{
+				const int ja = s * cw;
+				const int jb = std::min( A.out_len, ja + cw ) - 1;
+				const int sa = st[ ja ], sb = st[ jb ] + A.nt - 1;
+				seg[ s * 2 ] = sa; seg[ s * 2 + 1 ] = sb - sa + 1;
+				fits = ( sb - sa + 1 <= 64 );
+			}
+
+			if( fits )
+			{
+				void* q = nullptr;
+				AVIRHIP_HIPCHECK( hipMalloc( &q, seg.size() * sizeof( int )));
+				D -> allocs.push_back( q );
+				AVIRHIP_HIPCHECK( hipMemcpy( q, seg.data(), seg.size() *
+					sizeof( int ), hipMemcpyHostToDevice ));
+				D -> d_lfseg = (int*) q;
+				D -> lf_ow = cw; D -> lf_nstrips = cn;
+			}
+		}
 	}
 
 	// row offsets travel as 32-bit byte offsets
@@ -1141,7 +1183,11 @@ int gpass_run( avirhip_plan* p, const float* src, long src_stride, float* dst,
 		( p -> variant & AVIRHIP_VARIANT_UPG_FUSED ) != 0 ) &&
 		getenv( "AVIRHIP_NO_GFUSE" ) == nullptr );
 
-	if( D -> mid == nullptr && !use_gf )
+	// ... and so do LANCIR's upsizing plans of float RGBA pixels (lfuse.hip)
+	const bool use_lf = ( p -> is_lancir && D -> lf_ow != 0 && !p -> lraw.on &&
+		( p -> variant & AVIRHIP_VARIANT_UPG_TWO_PASS ) == 0 );
+
+	if( D -> mid == nullptr && !use_gf && !use_lf )
 	{
 		void* q = nullptr;
 		AVIRHIP_HIPCHECK( hipMalloc( &q, D -> mid_bytes ));
@@ -1163,6 +1209,35 @@ int gpass_run( avirhip_plan* p, const float* src, long src_stride, float* dst,
 		if( dst == nullptr && !p -> lfuse.on )
 		{
 			return( AVIRHIP_NEED_DST );
+		}
+
+		// Upsizing from float RGBA pixels: both passes in ONE launch
+		// (lfuse.hip) -- LANCIR's vertical-first order makes the fusion free of
+		// recomputation. AVIRHIP_VARIANT_UPG_TWO_PASS keeps the two kernels.
+		if( use_lf )
+		{
+			LFParams G;
+			memset( &G, 0, sizeof( G ));
+			G.src = src; G.src_ss = src_stride;
+			G.dst = dst; G.dst_ss = dst_ss; G.dst_row0 = row0;
+			G.hx = D -> h.a; G.vx = D -> v.a;
+			G.row_lo = row0; G.row_hi = row1;
+			G.nstrips = D -> lf_nstrips; G.ow = D -> lf_ow;
+			G.seg = D -> d_lfseg;
+
+			if( p -> lfuse.on )
+			{
+				G.lout.on = 1; G.lout.type = p -> lfuse.type;
+				G.lout.ch = p -> lfuse.ch; G.lout.unity = p -> lfuse.unity;
+				G.lout.out_mul = p -> lfuse.out_mul;
+				G.lout.clampv = p -> lfuse.clampv;
+				G.lout.l4 = ( p -> new_w * p -> lfuse.ch ) & ~3;
+				G.lout.base = p -> lfuse.dst; G.lout.stride = p -> lfuse.stride;
+			}
+
+			rc = lfuse_launch( G, st );
+			p -> lfuse.done = ( rc == 0 && p -> lfuse.on );
+			return( rc );
 		}
 
 		// vertical first (lancir.h:601-646): mid = [new_h][src_w], only the

@@ -397,6 +397,20 @@ struct GFParams
 
 int gfuse_launch( GFParams& P, double k_v, hipStream_t st );
 
+// lfuse.hip: both passes of a LANCIR upsizing plan in one launch (k_lf)
+struct LFParams
+{
+	const float* src; long src_ss;  // float RGBA source, floats per row
+	float* dst; long dst_ss; int dst_row0;
+	GPAxis hx, vx;       // both LANCIR (lanc == 4), 6 taps
+	int row_lo, row_hi;  // output rows to produce
+	int nstrips, ow, chunk; // strips of `ow` outputs (segment <= 64 source px)
+	const int* seg;      // [nstrips][2]: first source column, count
+	GPLOut lout;         // on != 0: the owner's output stage in the store
+};
+
+int lfuse_launch( LFParams& P, hipStream_t st );
+
 // One gather output: tap t reads ld( t ); cf4( b ) returns the coefficients
 // of taps 4b .. 4b + 3 (rows are padded to a multiple of four; padded taps are
 // never multiplied: x * 0 is not a no-op for non-finite x). NTC > 0: the tap

@@ -1,0 +1,305 @@
+// lfuse.hip -- k_lf: BOTH passes of a general-ratio LANCIR upsizing plan in one
+// launch (CLancIR::resizeImage, lancir.h:386-713: the vertical pass first --
+// copyScanline*v + resize* down the columns, lancir.h:601-646 -- then the
+// horizontal one -- padScanline*h + resize* along the rows, lancir.h:648-710).
+//
+// LANCIR runs its passes the other way round than AVIR, and that makes its
+// fusion free of recomputation: the vertical window of an output row holds RAW
+// source rows (a chunk's run-in is six row loads, no arithmetic), and the
+// horizontal taps of an output pixel read the vertically resized row of that
+// very output row -- nothing a neighbouring chunk or strip computes is needed
+// twice. (AVIR's fused kernel, gfuse.hip, repeats the horizontal arithmetic of
+// its 18-row vertical run-in and only pays from 12 Mpixels on.)
+//
+//   one wavefront per (strip of `ow` output columns whose source segment is at
+//   most 64 pixels) x (chunk of output rows), marching down the source rows:
+//     a source row's segment arrives by LDS-DMA (three rows ahead); each lane
+//     reads ITS source column's pixel into the 6-row window it keeps in
+//     registers (compile-time slots: the step loop is unrolled 8 times);
+//     for every output row whose last source row this was:
+//       V  lane = source column: the 6-tap Lanczos dot product down its window,
+//          x86 even / odd summation order (lancir.h:2482-2515), wave-uniform
+//          coefficient row of the row's fractional phase -> LDS;
+//       H  lane = output column: its 6 taps from LDS, its coefficient row in
+//          registers -> the pixel, stored (or through the owner's output stage:
+//          gain, clamps, integer rounding -- gp_store_lancir).
+//
+// The intermediate image [new_h][src_w] never exists, one launch instead of two.
+// Same expressions in the same order as k_gv< NONE, LANC > + k_gh< NONE, LANC >
+// => the same bits.
+
+#include "gpass_dev.h"
+#include <algorithm>
+#include <type_traits>
+
+namespace avirhip {
+
+#define LF_NB 4   // source row buffers: rows u .. u + 3 are in LDS or in flight
+#define LF_TE 24  // table staging: 6 KiB of vertical coefficient rows per chunk
+
+__global__ void __launch_bounds__( 64 ) k_lf( const LFParams P )
+{
+	constexpr int NT = 6;   // taps of both kernels (la = 3, upsizing)
+	constexpr int NTP = 8;  // ... padded to whole f4 rows
+	constexpr int RW = 8;   // vertical window (ring slots, >= NT)
+	extern __shared__ __attribute__(( aligned( 16 ))) char smem[];
+	const GPAxis& HA = P.hx;
+	const GPAxis& VA = P.vx;
+	f4* const sbuf = (f4*) smem;           // [LF_NB][64 px]
+	f4* const mbuf = sbuf + LF_NB * 64;    // [64 px]: the vertically resized row
+	float* const ctab = (float*) ( mbuf + 64 ); // [chunk rows][NTP]
+	const unsigned sbuf_lds = (unsigned) (unsigned long) (lds_char*) smem;
+
+	const int lane = threadIdx.x;
+	const int strip = blockIdx.x % P.nstrips;
+	const int chunk = blockIdx.x / P.nstrips;
+	const int y0 = P.row_lo + chunk * P.chunk;
+	const int y1 = min( y0 + P.chunk, P.row_hi );
+
+	if( y0 >= y1 )
+	{
+		return;
+	}
+
+	// ---- horizontal side: this lane's output column
+	const int slo = P.seg[ strip * 2 ]; // first source column of the segment
+	const int j = strip * P.ow + lane;
+	const bool jok = ( lane < P.ow && j < HA.out_len );
+	const int gh = gp_clamp( j, HA.g_len - 1 );
+	const int gs = HA.start[ gh ] - slo;
+	const int hslast = HA.in_len - 1;
+	float cf[ NTP ];
+	{
+		const float* const cr = HA.coef + (long) HA.fidx[ gh ] * NT;
+#pragma unroll
+		for( int t = 0; t < NTP; t++ )
+		{
+			cf[ t ] = ( t < NT ? cr[ t < NT ? t : 0 ] : 0.0f );
+		}
+	}
+
+	// ---- vertical side: this lane's source column (clamped: the padded view)
+	gp_cint* const a_start = (gp_cint*) (unsigned long) VA.start;
+	const int vslast = VA.in_len - 1;
+	const int ga = y0, gb = y1 - 1;
+	const int u_a = a_start[ ga ];
+	const int u_b = a_start[ gb ] + NT - 1;
+
+	int* const stab = (int*) ( ctab + ( gb - ga + 1 ) * NTP );
+	{
+		const int total = ( gb - ga + 1 ) * NTP;
+		float tmp[ LF_TE ];
+#pragma unroll
+		for( int k = 0; k < LF_TE; k++ )
+		{
+			const int i = lane + 64 * k;
+			tmp[ k ] = 0.0f;
+
+			if( i < total )
+			{
+				const int gi = i / NTP;
+				const int t = i - gi * NTP;
+
+				if( t < NT )
+				{
+					tmp[ k ] = VA.coef[ (long) VA.fidx[ ga + gi ] * NT + t ];
+				}
+			}
+		}
+#pragma unroll
+		for( int k = 0; k < LF_TE; k++ )
+		{
+			const int i = lane + 64 * k;
+
+			if( i < total )
+			{
+				ctab[ i ] = tmp[ k ];
+			}
+		}
+
+		for( int i = lane; i <= gb - ga; i += 64 )
+		{
+			stab[ i ] = VA.start[ ga + i ] + NT - 1;
+		}
+	}
+
+	int g = ga;                          // next output row
+	int g_need = a_start[ g ] + NT - 1;  // its last source row
+	float* dp = P.dst + (long) ( y0 - P.dst_row0 ) * P.dst_ss + (long) j * 4;
+	long orow = y0 - P.dst_row0;
+
+	// rows stored per step: the wait for a source row allows for them (stores
+	// count on vmcnt and retire in issue order with the loads, gfuse.hip)
+	int nst[ 4 ] = { 0, 0, 0, 0 };
+	int nst_cur = 0;
+
+	f4 cpre[ 2 ];
+	int need1_v;
+
+	auto prefetch_tabs = [&]()
+	{
+		const int gi = min( g + 1, gb ) - ga;
+		need1_v = ( g + 1 <= gb ? stab[ gi ] : 0x7fffffff );
+		const float* const cr = ctab + ( min( g, gb ) - ga ) * NTP;
+		cpre[ 0 ] = *(const f4*) cr;
+		cpre[ 1 ] = *(const f4*) ( cr + 4 );
+	};
+
+	f4 win[ RW ];
+#pragma unroll
+	for( int i = 0; i < RW; i++ )
+	{
+		win[ i ] = (f4) 0.0f;
+	}
+
+	auto drain = [&]( const int u, auto IC )
+	{
+		constexpr int I = decltype( IC )::value;
+
+		while( g <= gb && g_need <= u )
+		{
+			// V: this lane's source column, the last NT rows
+			const f4 c = gp_dot< true, f4, NT >( NT,
+				[&]( const int t ) { return( win[ ( I - ( NT - 1 ) + t + 4 * RW ) &
+					( RW - 1 )]); },
+				[&]( const int b ) { return( cpre[ b ]); });
+
+			mbuf[ lane ] = c;
+
+			// H: this lane's output column
+			f4 o = (f4) 0.0f;
+
+			if( jok )
+			{
+				const f4* const in = mbuf + gs;
+				f4 w[ NT ];
+#pragma unroll
+				for( int t = 0; t < NT; t++ )
+				{
+					w[ t ] = in[ t ];
+				}
+
+				o = gp_dot< true, f4, NT >( NT,
+					[&]( const int t ) { return( w[ t % NT ]); },
+					[&]( const int b ) -> f4
+					{
+						f4 q;
+						q.x = cf[ ( 4 * b ) % NTP ]; q.y = cf[ ( 4 * b + 1 ) % NTP ];
+						q.z = cf[ ( 4 * b + 2 ) % NTP ]; q.w = cf[ ( 4 * b + 3 ) % NTP ];
+						return( q );
+					});
+			}
+
+			nst_cur++;
+
+			if( P.lout.on != 0 )
+			{
+				if( jok )
+				{
+					gp_store_lancir( P.lout, orow, j, o );
+				}
+
+				orow++;
+			}
+			else
+			{
+				if( jok )
+				{
+					*(f4*) dp = o;
+				}
+
+				dp += P.dst_ss;
+			}
+
+			g++;
+			g_need = __builtin_amdgcn_readfirstlane( need1_v );
+			prefetch_tabs();
+		}
+	};
+
+	prefetch_tabs();
+
+	// ---- the feed: source row clamp( u ) of step u, 64 pixels from slo on
+	const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+		(void*) P.src, 0, 0x7fffffff, 0x00020000 );
+	const int srow_b = (int) P.src_ss * 4;
+	const int xoff = gp_clamp( slo + lane, hslast ) * 16;
+
+	auto issue_row = [&]( const int u, const int buf )
+	{
+		gp_dma( rsrc, sbuf_lds + ( buf * 64 ) * 16, gp_clamp( u, vslast ) *
+			srow_b + xoff );
+	};
+
+	for( int k = 0; k < LF_NB - 1 && u_a + k <= u_b; k++ )
+	{
+		issue_row( u_a + k, k );
+	}
+
+	auto step = [&]( const int u, auto IC )
+	{
+		constexpr int i = decltype( IC )::value;
+
+		if( u > u_b )
+		{
+			return;
+		}
+
+		const int buf = i & ( LF_NB - 1 );
+
+		if( u + LF_NB - 1 <= u_b )
+		{
+			issue_row( u + LF_NB - 1, ( buf + LF_NB - 1 ) & ( LF_NB - 1 ));
+		}
+
+		gp_wait_vm( min( LF_NB - 1, u_b - u ) + nst[ ( i - 1 ) & 3 ] +
+			nst[ ( i - 2 ) & 3 ] + nst[ ( i - 3 ) & 3 ]);
+
+		win[ i & ( RW - 1 )] = sbuf[ buf * 64 + lane ];
+		drain( u, IC );
+		nst[ i & 3 ] = nst_cur;
+		nst_cur = 0;
+	};
+
+	for( int ub = u_a; ub <= u_b; ub += 8 )
+	{
+		step( ub + 0, std::integral_constant< int, 0 >() );
+		step( ub + 1, std::integral_constant< int, 1 >() );
+		step( ub + 2, std::integral_constant< int, 2 >() );
+		step( ub + 3, std::integral_constant< int, 3 >() );
+		step( ub + 4, std::integral_constant< int, 4 >() );
+		step( ub + 5, std::integral_constant< int, 5 >() );
+		step( ub + 6, std::integral_constant< int, 6 >() );
+		step( ub + 7, std::integral_constant< int, 7 >() );
+	}
+
+	GP_WAIT_VM( 0 ); // no LDS-DMA may outlive the workgroup's LDS
+}
+
+// Output rows [row_lo, row_hi); P comes filled in by gpass.hip but for the
+// launch geometry.
+int lfuse_launch( LFParams& P, hipStream_t st )
+{
+	const int rows = P.row_hi - P.row_lo;
+	const size_t lds_fix = (size_t) ( LF_NB * 64 + 64 ) * 16;
+	const int max_chunk = ( LF_TE * 64 ) / 8; // 6 KiB of table: 192 rows
+	const size_t lds_max = lds_fix + (size_t) max_chunk * ( 8 + 1 ) * 4 + 64;
+	const int wpc = std::max( 1, std::min( 16, (int) ( 160 * 1024 /
+		( lds_max + 512 ))));
+
+	// (a chunk's run-in: six row loads and the table staging, about three
+	// output rows' worth)
+	static const int force = ( getenv( "AVIRHIP_LF_CHUNK" ) != nullptr ?
+		atoi( getenv( "AVIRHIP_LF_CHUNK" )) : 0 );
+
+	P.chunk = ( force > 0 ? std::min( force, max_chunk ) :
+		balanced_chunk( rows, P.nstrips, 4, max_chunk, 3, wpc, true ));
+
+	const int nch = ( rows + P.chunk - 1 ) / P.chunk;
+	const size_t lds = lds_fix + (size_t) P.chunk * ( 8 + 1 ) * 4 + 64;
+	hipLaunchKernelGGL( k_lf, dim3( P.nstrips * nch ), dim3( 64 ), lds, st, P );
+	AVIRHIP_HIPCHECK( hipGetLastError() );
+	return( AVIRHIP_OK );
+}
+
+} // namespace avirhip
