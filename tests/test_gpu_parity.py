@@ -1503,6 +1503,46 @@ def test_avir_fused_upsizing_kernel(tout, bits):
         _assert_same(out, want, "fused bands %r" % ((sw, sh, nw, nh),))
 
 
+def test_lancir_fused_upsizing_kernel():
+    """lfuse.hip (k_lf): both passes of a LANCIR upsizing plan of float RGBA
+    pixels in one launch -- against the reference and against the two pass
+    kernels (AVIRHIP_VARIANT_UPG_TWO_PASS), frames and row bands, default and
+    non-default parameters (offsets, la), integer results through the owner's
+    output stage."""
+    lib = abi.load()
+    ref_l = rb.ref_lancir if rb.have_ref() else rb.orc_lancir
+    for (sw, sh, nw, nh, kw) in [
+            (64, 48, 100, 77, {}), (129, 67, 513, 259, {}),
+            (90, 300, 200, 720, {}), (300, 40, 1001, 47, {"ox": 0.4, "oy": -0.2}),
+            (17, 9, 60, 31, {}), (1, 50, 3, 120, {}), (640, 480, 1024, 768, {}),
+            (257, 255, 300, 700, {"kx": 0.0, "ky": 0.0, "la": 3.0})]:
+        src = rb.lcg_f32((sh, sw, 4), seed=sw * 7 + nh)
+        want = ref_l(src, nw, nh, **kw)
+        lp = None
+        if kw:
+            lp = avir_amd.CLancIRParams(0, 0, kw.get("kx", 0.0), kw.get("ky", 0.0),
+                                        kw.get("ox", 0.0), kw.get("oy", 0.0))
+            lp.la = kw.get("la", 3.0)
+        r = avir_amd.CLancIR()
+        p = r.plan(sw, sh, nw, nh, 4, lp)
+        for variant in (0, abi.VARIANT_UPG_TWO_PASS):
+            if lib.avirhip_plan_set_path(p, abi.PATH_GPASS) != 0:
+                break
+            abi.check(lib.avirhip_plan_set_variant(p, variant), "variant")
+            got = r.resize(src, nw, nh, aParams=lp)
+            _assert_same(got, want, "lancir variant %d %r" % (variant,
+                                                             (sw, sh, nw, nh)))
+        else:
+            abi.check(lib.avirhip_plan_set_variant(p, 0), "variant")
+            if nh >= 4:
+                out = np.zeros((nh, nw, 4), np.float32)
+                for a_, b_ in [(0, nh // 3), (nh // 3, nh)]:
+                    abi.check(lib.avirhip_resize_band(
+                        p, src.ctypes.data, abi.MEM_HOST, out[a_:b_].ctypes.data,
+                        abi.MEM_HOST, a_, b_, None), "band")
+                _assert_same(out, want, "lancir fused bands")
+
+
 def test_avir_fused_upsizing_is_the_default_for_large_frames():
     """1920x1080 -> 5760x3240 (18.7 Mpixels of output) takes k_gf by itself:
     the hash of the reference's result (tests/golden/make_golden.py wrote it

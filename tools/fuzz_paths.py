@@ -71,7 +71,9 @@ for it in range(N):
     for path in (1, 0, 5, 58, 516, 2, 3, 4):
         variant = 0
         if path in (58, 516):
-            if lanc or not (nw >= sw and nh >= sh):
+            # (LANCIR: its fused launch is the automatic form at every size;
+            # 58 = its two pass kernels)
+            if not (nw >= sw and nh >= sh) or (lanc and path == 516):
                 continue
             variant = 8 if path == 58 else 16
         try:

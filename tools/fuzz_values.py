@@ -249,6 +249,8 @@ for it in range(N):
         runs.append((4, 1))  # the 13-row-window form of k_up2
     if cls in ("dnk", "dnint", "rand"):
         runs.append((5, 4))  # k_sacc (ladder) where k_sacc2 would run
+    if cls in ("lanc", "lanc2"):
+        runs.append((5, 8))   # LANCIR: k_gv + k_gh instead of the fused k_lf
     if cls in ("up", "up2", "rand"):
         runs.append((5, 8))   # k_gh + k_gv through FltBuf ...
         runs.append((5, 16))  # ... and k_gf, the fused launch, at any size
