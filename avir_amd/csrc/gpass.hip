@@ -406,6 +406,7 @@ struct GPData
 	// at most 64 pixels
 	int lf_ow, lf_nstrips;
 	int* d_lfseg;
+	float* d_lfvtab;     // [v.g_len][8]: vertical coefficient rows per output
 	std::vector< void* > allocs;
 };
 
@@ -562,6 +563,7 @@ int gpass_prepare( avirhip_plan* p )
 	D -> mid = nullptr; D -> mid_bytes = 0; D -> d_hseg = nullptr;
 	D -> nf_flag = nullptr;
 	D -> lf_ow = 0; D -> lf_nstrips = 0; D -> d_lfseg = nullptr;
+	D -> d_lfvtab = nullptr;
 	D -> sa_h = nullptr; D -> sa_v = nullptr;
 	D -> h_geom = false; D -> v_geom = false;
 
@@ -786,6 +788,22 @@ int gpass_prepare( avirhip_plan* p )
 				AVIRHIP_HIPCHECK( hipMemcpy( q, seg.data(), seg.size() *
 					sizeof( int ), hipMemcpyHostToDevice ));
 				D -> d_lfseg = (int*) q;
+
+				// the vertical axis' coefficient rows, one per OUTPUT row
+				const GPAxis& V = D -> v.a;
+				std::vector< float > vt( (size_t) V.g_len * 8, 0.0f );
+
+				for( int g = 0; g < V.g_len; g++ )
+				{
+					memcpy( &vt[ (size_t) g * 8 ], D -> v.h_coef +
+						(size_t) D -> v.h_fidx[ g ] * V.nt, V.nt * sizeof( float ));
+				}
+
+				AVIRHIP_HIPCHECK( hipMalloc( &q, vt.size() * sizeof( float )));
+				D -> allocs.push_back( q );
+				AVIRHIP_HIPCHECK( hipMemcpy( q, vt.data(), vt.size() *
+					sizeof( float ), hipMemcpyHostToDevice ));
+				D -> d_lfvtab = (float*) q;
 				D -> lf_ow = cw; D -> lf_nstrips = cn;
 			}
 		}
@@ -1223,7 +1241,7 @@ int gpass_run( avirhip_plan* p, const float* src, long src_stride, float* dst,
 			G.hx = D -> h.a; G.vx = D -> v.a;
 			G.row_lo = row0; G.row_hi = row1;
 			G.nstrips = D -> lf_nstrips; G.ow = D -> lf_ow;
-			G.seg = D -> d_lfseg;
+			G.seg = D -> d_lfseg; G.vtab = D -> d_lfvtab;
 
 			if( p -> lfuse.on )
 			{

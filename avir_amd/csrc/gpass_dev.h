@@ -81,7 +81,19 @@ __device__ __forceinline__ void gp_wait_vm( const int n )
 		case 10: GP_WAIT_VM( 10 ); break;
 		case 11: GP_WAIT_VM( 11 ); break;
 		case 12: GP_WAIT_VM( 12 ); break;
-		default: GP_WAIT_VM( 12 ); break;
+		case 13: GP_WAIT_VM( 13 ); break;
+		case 14: GP_WAIT_VM( 14 ); break;
+		case 15: GP_WAIT_VM( 15 ); break;
+		case 16: GP_WAIT_VM( 16 ); break;
+		case 17: GP_WAIT_VM( 17 ); break;
+		case 18: GP_WAIT_VM( 18 ); break;
+		case 19: GP_WAIT_VM( 19 ); break;
+		case 20: GP_WAIT_VM( 20 ); break;
+		case 21: GP_WAIT_VM( 21 ); break;
+		case 22: GP_WAIT_VM( 22 ); break;
+		case 23: GP_WAIT_VM( 23 ); break;
+		case 24: GP_WAIT_VM( 24 ); break;
+		default: GP_WAIT_VM( 24 ); break;
 	}
 }
 
@@ -406,6 +418,8 @@ struct LFParams
 	int row_lo, row_hi;  // output rows to produce
 	int nstrips, ow, chunk; // strips of `ow` outputs (segment <= 64 source px)
 	const int* seg;      // [nstrips][2]: first source column, count
+	const float* vtab;   // [vx.g_len][8]: the vertical coefficient row of every
+	                     // output row (its phase's, zero padded)
 	GPLOut lout;         // on != 0: the owner's output stage in the store
 };
 

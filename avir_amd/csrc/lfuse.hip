@@ -35,7 +35,7 @@
 namespace avirhip {
 
 #define LF_NB 4   // source row buffers: rows u .. u + 3 are in LDS or in flight
-#define LF_TE 24  // table staging: 6 KiB of vertical coefficient rows per chunk
+#define LF_TE 24  // 6 KiB of vertical coefficient rows per chunk at most
 
 __global__ void __launch_bounds__( 64 ) k_lf( const LFParams P )
 {
@@ -85,35 +85,34 @@ __global__ void __launch_bounds__( 64 ) k_lf( const LFParams P )
 	const int u_a = a_start[ ga ];
 	const int u_b = a_start[ gb ] + NT - 1;
 
+	// This chunk's coefficient rows -> LDS. P.vtab is the vertical axis' table
+	// expanded per output row on the host ([g_len][NTP], zero padded): one
+	// contiguous run, fetched four independent loads at a time with clamped
+	// (always valid) addresses. Through the per-phase table and its index the
+	// same staging compiled to 24 dependent load pairs, each behind its own
+	// branch and vmcnt(0) -- half of a 24-us launch.
 	int* const stab = (int*) ( ctab + ( gb - ga + 1 ) * NTP );
 	{
 		const int total = ( gb - ga + 1 ) * NTP;
-		float tmp[ LF_TE ];
-#pragma unroll
-		for( int k = 0; k < LF_TE; k++ )
+		const float* const vt = P.vtab + (long) ga * NTP;
+
+		for( int k0 = 0; k0 * 64 < total; k0 += 4 )
 		{
-			const int i = lane + 64 * k;
-			tmp[ k ] = 0.0f;
-
-			if( i < total )
+			float t4[ 4 ];
+#pragma unroll
+			for( int q = 0; q < 4; q++ )
 			{
-				const int gi = i / NTP;
-				const int t = i - gi * NTP;
-
-				if( t < NT )
-				{
-					tmp[ k ] = VA.coef[ (long) VA.fidx[ ga + gi ] * NT + t ];
-				}
+				t4[ q ] = vt[ min(( k0 + q ) * 64 + lane, total - 1 )];
 			}
-		}
 #pragma unroll
-		for( int k = 0; k < LF_TE; k++ )
-		{
-			const int i = lane + 64 * k;
-
-			if( i < total )
+			for( int q = 0; q < 4; q++ )
 			{
-				ctab[ i ] = tmp[ k ];
+				const int i = ( k0 + q ) * 64 + lane;
+
+				if( i < total )
+				{
+					ctab[ i ] = t4[ q ];
+				}
 			}
 		}
 

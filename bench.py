@@ -48,6 +48,8 @@ OTHER = {"cfg1": ("avir", 640, 480, 1024, 768, 3, "u8", 8),
          "cfg4": ("avir", 3840, 2160, 1280, 720, 4, "f32", 16),
          "cfg5": ("lancir", 3840, 2160, 7680, 4320, 4, "f32", 16),
          "nonint": ("avir", 1920, 1080, 2500, 1400, 4, "f32", 16),
+         "lanc_nonint": ("lancir", 1920, 1080, 2500, 1400, 4, "f32", 16),
+         "lanc_dn3": ("lancir", 3840, 2160, 1280, 720, 4, "f32", 16),
          "half": ("avir", 3840, 2160, 1920, 1080, 4, "f32", 16),
          "triple": ("avir", 1920, 1080, 5760, 3240, 4, "f32", 16),
          "nonint_u8": ("avir", 1920, 1080, 2500, 1400, 3, "u8", 8),
