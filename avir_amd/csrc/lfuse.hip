@@ -85,6 +85,24 @@ __global__ void __launch_bounds__( 64 ) k_lf( const LFParams P )
 	const int u_a = a_start[ ga ];
 	const int u_b = a_start[ gb ] + NT - 1;
 
+	// ---- the feed: source row clamp( u ) of step u, 64 pixels from slo on
+	const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+		(void*) P.src, 0, 0x7fffffff, 0x00020000 );
+	const int srow_b = (int) P.src_ss * 4;
+	const int xoff = gp_clamp( slo + lane, hslast ) * 16;
+
+	auto issue_row = [&]( const int u, const int buf )
+	{
+		gp_dma( rsrc, sbuf_lds + ( buf * 64 ) * 16, gp_clamp( u, vslast ) *
+			srow_b + xoff );
+	};
+
+	for( int k = 0; k < LF_NB - 1 && u_a + k <= u_b; k++ )
+	{
+		issue_row( u_a + k, k );
+	}
+
+	// (the first rows are on their way: the tables are fetched under them)
 	// This chunk's coefficient rows -> LDS. P.vtab is the vertical axis' table
 	// expanded per output row on the host ([g_len][NTP], zero padded): one
 	// contiguous run, fetched four independent loads at a time with clamped
@@ -121,6 +139,7 @@ __global__ void __launch_bounds__( 64 ) k_lf( const LFParams P )
 			stab[ i ] = VA.start[ ga + i ] + NT - 1;
 		}
 	}
+
 
 	int g = ga;                          // next output row
 	int g_need = a_start[ g ] + NT - 1;  // its last source row
@@ -217,23 +236,6 @@ __global__ void __launch_bounds__( 64 ) k_lf( const LFParams P )
 	};
 
 	prefetch_tabs();
-
-	// ---- the feed: source row clamp( u ) of step u, 64 pixels from slo on
-	const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
-		(void*) P.src, 0, 0x7fffffff, 0x00020000 );
-	const int srow_b = (int) P.src_ss * 4;
-	const int xoff = gp_clamp( slo + lane, hslast ) * 16;
-
-	auto issue_row = [&]( const int u, const int buf )
-	{
-		gp_dma( rsrc, sbuf_lds + ( buf * 64 ) * 16, gp_clamp( u, vslast ) *
-			srow_b + xoff );
-	};
-
-	for( int k = 0; k < LF_NB - 1 && u_a + k <= u_b; k++ )
-	{
-		issue_row( u_a + k, k );
-	}
 
 	auto step = [&]( const int u, auto IC )
 	{
