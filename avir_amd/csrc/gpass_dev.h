@@ -421,6 +421,7 @@ struct LFParams
 	const float* vtab;   // [vx.g_len][8]: the vertical coefficient row of every
 	                     // output row (its phase's, zero padded)
 	GPLOut lout;         // on != 0: the owner's output stage in the store
+	int dbg;
 };
 
 int lfuse_launch( LFParams& P, hipStream_t st );

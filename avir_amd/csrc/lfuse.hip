@@ -34,7 +34,7 @@
 
 namespace avirhip {
 
-#define LF_NB 4   // source row buffers: rows u .. u + 3 are in LDS or in flight
+#define LF_NB 8   // source row buffers: rows u .. u + 7 are in LDS or in flight
 #define LF_TE 24  // 6 KiB of vertical coefficient rows per chunk at most
 
 __global__ void __launch_bounds__( 64 ) k_lf( const LFParams P )
@@ -148,7 +148,6 @@ __global__ void __launch_bounds__( 64 ) k_lf( const LFParams P )
 
 	// rows stored per step: the wait for a source row allows for them (stores
 	// count on vmcnt and retire in issue order with the loads, gfuse.hip)
-	int nst[ 4 ] = { 0, 0, 0, 0 };
 	int nst_cur = 0;
 
 	f4 cpre[ 2 ];
@@ -177,17 +176,21 @@ __global__ void __launch_bounds__( 64 ) k_lf( const LFParams P )
 		while( g <= gb && g_need <= u )
 		{
 			// V: this lane's source column, the last NT rows
-			const f4 c = gp_dot< true, f4, NT >( NT,
+			f4 c = win[ I & ( RW - 1 )];
+
+			if( !( P.dbg & 4 ))
+			c = gp_dot< true, f4, NT >( NT,
 				[&]( const int t ) { return( win[ ( I - ( NT - 1 ) + t + 4 * RW ) &
 					( RW - 1 )]); },
 				[&]( const int b ) { return( cpre[ b ]); });
 
+			if( !( P.dbg & 2 ))
 			mbuf[ lane ] = c;
 
 			// H: this lane's output column
-			f4 o = (f4) 0.0f;
+			f4 o = c;
 
-			if( jok )
+			if( jok && !( P.dbg & 2 ))
 			{
 				const f4* const in = mbuf + gs;
 				f4 w[ NT ];
@@ -221,7 +224,7 @@ __global__ void __launch_bounds__( 64 ) k_lf( const LFParams P )
 			}
 			else
 			{
-				if( jok )
+				if( jok && ( !( P.dbg & 1 ) || o.x == 1234.5f ))
 				{
 					*(f4*) dp = o;
 				}
@@ -248,22 +251,34 @@ __global__ void __launch_bounds__( 64 ) k_lf( const LFParams P )
 
 		const int buf = i & ( LF_NB - 1 );
 
-		if( u + LF_NB - 1 <= u_b )
+		if( u + LF_NB - 1 <= u_b && !( P.dbg & 8 ))
 		{
 			issue_row( u + LF_NB - 1, ( buf + LF_NB - 1 ) & ( LF_NB - 1 ));
 		}
 
-		gp_wait_vm( min( LF_NB - 1, u_b - u ) + nst[ ( i - 1 ) & 3 ] +
-			nst[ ( i - 2 ) & 3 ] + nst[ ( i - 3 ) & 3 ]);
+		// Row u has landed when at most the LF_NB - 1 rows after it are
+		// outstanding. The stores in between count on vmcnt too, so the fixed
+		// count also waits for some of them and for rows nearer than u + 7 --
+		// which the deep queue can afford; an exact count (rows + stores since)
+		// needs a 24-way branch ladder per step, which measured slower than
+		// what it saves.
+		if( u_b - u >= LF_NB - 1 )
+		{
+			GP_WAIT_VM( 7 );
+		}
+		else
+		{
+			gp_wait_vm( u_b - u );
+		}
 
 		win[ i & ( RW - 1 )] = sbuf[ buf * 64 + lane ];
 		drain( u, IC );
-		nst[ i & 3 ] = nst_cur;
-		nst_cur = 0;
 	};
 
+	if( P.dbg & 16 ) { GP_WAIT_VM( 0 ); return; }
 	for( int ub = u_a; ub <= u_b; ub += 8 )
 	{
+		if( P.dbg & 32 ) { if( lane == 0 && ub == u_a ) mbuf[ 0 ] = win[ 0 ]; continue; }
 		step( ub + 0, std::integral_constant< int, 0 >() );
 		step( ub + 1, std::integral_constant< int, 1 >() );
 		step( ub + 2, std::integral_constant< int, 2 >() );
@@ -298,6 +313,9 @@ int lfuse_launch( LFParams& P, hipStream_t st )
 
 	const int nch = ( rows + P.chunk - 1 ) / P.chunk;
 	const size_t lds = lds_fix + (size_t) P.chunk * ( 8 + 1 ) * 4 + 64;
+	static const int dbg = ( getenv( "AVIRHIP_LF_DBG" ) != nullptr ?
+		atoi( getenv( "AVIRHIP_LF_DBG" )) : 0 );
+	P.dbg = dbg;
 	hipLaunchKernelGGL( k_lf, dim3( P.nstrips * nch ), dim3( 64 ), lds, st, P );
 	AVIRHIP_HIPCHECK( hipGetLastError() );
 	return( AVIRHIP_OK );
