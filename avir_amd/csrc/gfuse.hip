@@ -36,7 +36,7 @@
 
 namespace avirhip {
 
-#define GF_NB 4   // source row buffers: rows u .. u + 3 are in LDS or in flight
+#define GF_NB 8   // source row buffers: rows u .. u + 7 are in LDS or in flight
 #define GF_TE 32  // table staging: 8 KiB of vertical coefficient rows per chunk
 
 __global__ void __launch_bounds__( 64 ) k_gf( const GFParams P )
@@ -128,16 +128,8 @@ __global__ void __launch_bounds__( 64 ) k_gf( const GFParams P )
 	float* dp = P.dst + (long) ( y0 - P.dst_row0 ) * P.dst_ss + (long) j * 4;
 	long orow = y0 - P.dst_row0;
 
-	// rows stored per step (a compile-time slot per step of the unrolled loop):
-	// stores count on vmcnt and retire in issue order with the loads, so the
-	// wait for a source row allows for the rows stored since its DMA went out
-	int nst[ 4 ] = { 0, 0, 0, 0 };
-	int nst_cur = 0;
-
 	auto store_row = [&]( const f4 o )
 	{
-		nst_cur++; // (lane 0 is always inside the image: one store at least)
-
 		if( P.out.on != 0 )
 		{
 			gp_store_int_row( P.out, orow, j, o, jok );
@@ -242,10 +234,20 @@ __global__ void __launch_bounds__( 64 ) k_gf( const GFParams P )
 			issue_row( u + GF_NB - 1, ( buf + GF_NB - 1 ) & ( GF_NB - 1 ));
 		}
 
-		// row u's pieces have landed when only the pieces of the rows after it
-		// and the stores since its DMA went out (steps u - 3 .. u - 1) are left
-		gp_wait_vm( min( GF_NB - 1, u_b - u ) * P.nseg + nst[ ( i - 1 ) & 3 ] +
-			nst[ ( i - 2 ) & 3 ] + nst[ ( i - 3 ) & 3 ]);
+		// Row u's pieces have landed when at most the pieces of the GF_NB - 1
+		// rows after it are outstanding. The stores in between count on vmcnt
+		// too: the fixed count also waits for some of them and for rows nearer
+		// than u + 7, which the deep queue can afford -- an exact count (pieces +
+		// rows stored since) is a branch ladder per step that cost more than it
+		// saved (lfuse.hip: 16.5 -> 12.1 us of skeleton).
+		if( P.nseg == 1 && u_b - u >= GF_NB - 1 )
+		{
+			GP_WAIT_VM( 7 );
+		}
+		else
+		{
+			gp_wait_vm( min( GF_NB - 1, u_b - u ) * P.nseg );
+		}
 
 		// H: FIR7 along x of the segment (clamped source view; C above the
 		// zero-stuffed view's end is zero) ...
@@ -304,8 +306,6 @@ __global__ void __launch_bounds__( 64 ) k_gf( const GFParams P )
 			drain( u, IC );
 		}
 
-		nst[ i & 3 ] = nst_cur;
-		nst_cur = 0;
 	};
 
 	for( int ub = u_a; ub <= u_b; ub += 16 )
