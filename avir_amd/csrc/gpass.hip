@@ -1185,13 +1185,14 @@ int gpass_run( avirhip_plan* p, const float* src, long src_stride, float* dst,
 	// (gfuse.hip): no intermediate image. "Large": a fused chunk repeats the
 	// horizontal arithmetic of its 18-row vertical run-in, which the saved
 	// FltBuf round trip only pays for once the frame is memory-heavy -- measured
-	// (tools/gf_sweep.py, fused / two-pass): 1920x1080 x1.3 1.12, x2.3 1.01,
-	// x2.7 0.94, x3.0 0.88; 3840x2160 x1.3 0.89, x1.6 0.80; 1280x720 never
-	// (x3.6: 1.06) -- the crossing is at about 12 Mpixels of output.
+	// (tools/gf_sweep.py, fused / two-pass, profiles/r04_upg/gf_sweep.txt):
+	// 1920x1080 x1.3 1.06, x1.6 0.99, x1.9 0.94, x2.3 0.90, x3.0 0.78;
+	// 3840x2160 x1.15 0.92, x1.6 0.71; 1280x720 x2.3 1.01, x3.0 0.97 -- the
+	// crossing is at about 7 Mpixels of output.
 	// AVIRHIP_GF_MINPIX moves it (0: always), AVIRHIP_VARIANT_UPG_TWO_PASS
 	// keeps the two pass kernels.
 	static const long gf_minpix = ( getenv( "AVIRHIP_GF_MINPIX" ) != nullptr ?
-		atol( getenv( "AVIRHIP_GF_MINPIX" )) : 12000000L );
+		atol( getenv( "AVIRHIP_GF_MINPIX" )) : 7000000L );
 	// (a forced variant bit 4 = "fused whatever the size": tests)
 	const bool use_gf = ( !p -> is_lancir && D -> h.a.mode == GP_PRE &&
 		D -> v.a.mode == GP_PRE && D -> h.a.nt == 12 && D -> v.a.nt == 12 &&

@@ -250,7 +250,7 @@ int avirhip_plan_get_path(const avirhip_plan* plan);
  * through FltBuf instead of the single fused launch of gfuse.hip */
 #define AVIRHIP_VARIANT_UPG_TWO_PASS 8
 /* ... and the fused launch whatever the frame size (automatically: frames of
- * 12 Mpixels of output and more) */
+ * 7 Mpixels of output and more) */
 #define AVIRHIP_VARIANT_UPG_FUSED 16
 int avirhip_plan_set_variant(avirhip_plan* plan, int variant);
 
