@@ -37,6 +37,14 @@ namespace avirhip {
 #define LF_NB 8   // source row buffers: rows u .. u + 7 are in LDS or in flight
 #define LF_TE 24  // 6 KiB of vertical coefficient rows per chunk at most
 
+// timing ablations (make gpdbg; AVIRHIP_LF_DBG bits: 1 no stores, 2 no
+// horizontal stage, 4 no vertical dot product, 8 no DMA, 16 no row loop at all)
+#ifdef GP_DBG
+#define LF_ON( bit ) ( !( P.dbg & ( bit )))
+#else
+#define LF_ON( bit ) true
+#endif
+
 __global__ void __launch_bounds__( 64 ) k_lf( const LFParams P )
 {
 	constexpr int NT = 6;   // taps of both kernels (la = 3, upsizing)
@@ -178,19 +186,19 @@ __global__ void __launch_bounds__( 64 ) k_lf( const LFParams P )
 			// V: this lane's source column, the last NT rows
 			f4 c = win[ I & ( RW - 1 )];
 
-			if( !( P.dbg & 4 ))
+			if( LF_ON( 4 ))
 			c = gp_dot< true, f4, NT >( NT,
 				[&]( const int t ) { return( win[ ( I - ( NT - 1 ) + t + 4 * RW ) &
 					( RW - 1 )]); },
 				[&]( const int b ) { return( cpre[ b ]); });
 
-			if( !( P.dbg & 2 ))
+			if( LF_ON( 2 ))
 			mbuf[ lane ] = c;
 
 			// H: this lane's output column
 			f4 o = c;
 
-			if( jok && !( P.dbg & 2 ))
+			if( jok && LF_ON( 2 ))
 			{
 				const f4* const in = mbuf + gs;
 				f4 w[ NT ];
@@ -224,7 +232,7 @@ __global__ void __launch_bounds__( 64 ) k_lf( const LFParams P )
 			}
 			else
 			{
-				if( jok && ( !( P.dbg & 1 ) || o.x == 1234.5f ))
+				if( jok && ( LF_ON( 1 ) || o.x == 1234.5f ))
 				{
 					*(f4*) dp = o;
 				}
@@ -251,7 +259,7 @@ __global__ void __launch_bounds__( 64 ) k_lf( const LFParams P )
 
 		const int buf = i & ( LF_NB - 1 );
 
-		if( u + LF_NB - 1 <= u_b && !( P.dbg & 8 ))
+		if( u + LF_NB - 1 <= u_b && LF_ON( 8 ))
 		{
 			issue_row( u + LF_NB - 1, ( buf + LF_NB - 1 ) & ( LF_NB - 1 ));
 		}
@@ -275,10 +283,9 @@ __global__ void __launch_bounds__( 64 ) k_lf( const LFParams P )
 		drain( u, IC );
 	};
 
-	if( P.dbg & 16 ) { GP_WAIT_VM( 0 ); return; }
+	if( !LF_ON( 16 )) { GP_WAIT_VM( 0 ); return; }
 	for( int ub = u_a; ub <= u_b; ub += 8 )
 	{
-		if( P.dbg & 32 ) { if( lane == 0 && ub == u_a ) mbuf[ 0 ] = win[ 0 ]; continue; }
 		step( ub + 0, std::integral_constant< int, 0 >() );
 		step( ub + 1, std::integral_constant< int, 1 >() );
 		step( ub + 2, std::integral_constant< int, 2 >() );
