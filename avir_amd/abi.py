@@ -22,6 +22,7 @@ PATH_AUTO, PATH_GENERIC, PATH_TILED, PATH_FUSED, PATH_UP2 = 0, 1, 2, 3, 4
 PATH_GPASS = 5
 VARIANT_UP2_PLAIN_V, VARIANT_DN_TWO_PASS, VARIANT_SACC_LADDER = 1, 2, 4
 VARIANT_UPG_TWO_PASS, VARIANT_UPG_FUSED = 8, 16
+VARIANT_SACC_OPTIMISTIC = 32
 FPCLASS_DOUBLE = 64  # avirhip_resizer_set_fpclass: fpclass_def<double>
 
 _fp = C.POINTER(C.c_float)

@@ -2522,7 +2522,7 @@ unsigned long long avirhip_plan_device_bytes( avirhip_plan* p )
 
 int avirhip_plan_set_variant( avirhip_plan* p, int variant )
 {
-	if( p == nullptr || variant < 0 || variant > 31 )
+	if( p == nullptr || variant < 0 || variant > 63 )
 	{
 		set_error( "bad variant" );
 		return( AVIRHIP_EINVAL );

@@ -382,12 +382,18 @@ double sacc_k( const SAData* D );
 // that downsize by 1 < k < 2 (13 .. 25 taps over the zero-stuffed view) have had
 // one since round 4; measured against the gather kernels on one box
 // (3840x2160 sources): RGB uint8 k = 1.5 0.109 vs 0.151 ms, k = 1.92 0.099 vs
-// 0.141 -- integer sources always; float RGBA k = 1.5 0.139 vs 0.126 (slower),
-// k = 1.75 0.113 vs 0.115, k = 1.92 0.111 vs 0.118 -- float sources from 1.7 on.
-static bool sa_wanted( const SAData* sa, const bool int_src )
+// 0.141; float RGBA on the EXACT kernels k = 1.5 0.118 vs 0.122, k = 1.75 0.109
+// vs 0.113, k = 1.92 0.111 vs 0.116 -- `always`: integer and float RGBA
+// sources. Float pixels of 1-3 channels run optimistically (gpass_run: two
+// more launches) and take it from k = 1.7 on (RGBA, optimistic: k = 1.5 0.139
+// vs 0.126, k = 1.75 0.113 vs 0.115, k = 1.92 0.111 vs 0.118).
+static bool sa_wanted( const SAData* sa, const bool always )
 {
-	return( sa != nullptr && ( int_src || !sacc_is_zs( sa ) ||
-		sacc_k( sa ) >= 1.7 ));
+	static const double kmin = ( getenv( "AVIRHIP_SA_ZS_KMIN" ) != nullptr ?
+		atof( getenv( "AVIRHIP_SA_ZS_KMIN" )) : 1.7 ); // (tuning aid)
+
+	return( sa != nullptr && ( always || !sacc_is_zs( sa ) ||
+		sacc_k( sa ) >= kmin ));
 }
 
 struct GPData
@@ -895,7 +901,8 @@ bool gpass_preferred( const avirhip_plan* p )
 	if( D -> sa_h != nullptr && D -> sa_v != nullptr && !p -> gamma &&
 		p -> in_type == AVIRHIP_F32 && sacc_has_two( D -> sa_h ) &&
 		sacc_has_two( D -> sa_v ) && !fused_dn_both( p ) &&
-		sa_wanted( D -> sa_h, false ) && sa_wanted( D -> sa_v, false ) &&
+		sa_wanted( D -> sa_h, p -> io_ch == 4 ) &&
+		sa_wanted( D -> sa_v, p -> io_ch == 4 ) &&
 		(long) p -> src_w * p -> src_h >= 6000000L )
 	{
 		return( true );
@@ -1133,7 +1140,8 @@ bool gpass_takes_raw( const avirhip_plan* p )
 		p -> in_type == AVIRHIP_U16 );
 
 	return( D != nullptr && !p -> is_lancir &&
-		( sa_wanted( D -> sa_h, int_src ) ||
+		( sa_wanted( D -> sa_h, int_src || ( p -> in_type == AVIRHIP_F32 &&
+		p -> io_ch == 4 )) ||
 		( D -> h_geom && D -> h_nseg <= 4 )));
 }
 
@@ -1347,13 +1355,25 @@ int gpass_run( avirhip_plan* p, const float* src, long src_stride, float* dst,
 	// stream behind the alarm -- empty launches for finite images, a complete
 	// recomputation of both passes otherwise. (5184x3456 -> 1920x1280 float RGBA:
 	// 0.265 ms on the tiles, 0.15 ms this way.)
+	// Float RGBA sources (raw == nullptr: they travel by LDS-DMA) do NOT run
+	// optimistically unless asked to (AVIRHIP_VARIANT_SACC_OPTIMISTIC): their
+	// exact kernels are as fast as the branch-free ones (5184x3456 -> 1920x1280:
+	// 127 + 59 us against 131 + 59, profiles/r04_sacc/exact_vs_optimistic.txt)
+	// and the two launches behind the alarm cost 9 us a frame. Float pixels of
+	// 1-3 channels gain: 0.273 -> 0.198 ms for the same frame as float RGB.
 	static const bool no_opt = ( getenv( "AVIRHIP_NO_SACC_OPT" ) != nullptr );
 	const bool fsrc = ( raw != nullptr ? raw_type == AVIRHIP_F32 : true );
+	const bool opt_wanted = ( raw != nullptr ||
+		( p -> variant & AVIRHIP_VARIANT_SACC_OPTIMISTIC ) != 0 );
 
-	const bool use_sa_h = sa_wanted( D -> sa_h, int_src );
-	const bool use_sa_v = sa_wanted( D -> sa_v, int_src );
+	// (raw == nullptr: float RGBA -- the exact kernels unless the variant asks)
+	const bool sa_always = ( int_src || ( raw == nullptr &&
+		( p -> variant & AVIRHIP_VARIANT_SACC_OPTIMISTIC ) == 0 ));
+	const bool use_sa_h = sa_wanted( D -> sa_h, sa_always );
+	const bool use_sa_v = sa_wanted( D -> sa_v, sa_always );
 
-	if( !int_src && fsrc && !ladder && !no_opt && use_sa_h && use_sa_v &&
+	if( !int_src && fsrc && !ladder && !no_opt && opt_wanted && use_sa_h &&
+		use_sa_v &&
 		sacc_has_two( D -> sa_h ) && sacc_has_two( D -> sa_v ))
 	{
 		if( D -> nf_flag == nullptr )

@@ -252,6 +252,11 @@ int avirhip_plan_get_path(const avirhip_plan* plan);
 /* ... and the fused launch whatever the frame size (automatically: frames of
  * 7 Mpixels of output and more) */
 #define AVIRHIP_VARIANT_UPG_FUSED 16
+/* float RGBA sources on downsizing axes: the branch-free accumulation kernels
+ * run optimistically (exact kernels behind an alarm) as they do for float
+ * pixels of 1-3 channels; automatically such sources take the exact kernels
+ * alone, which are as fast there and need no alarm launches */
+#define AVIRHIP_VARIANT_SACC_OPTIMISTIC 32
 int avirhip_plan_set_variant(avirhip_plan* plan, int variant);
 
 /* Device memory the plan holds right now, in bytes: tables, scratch buffers

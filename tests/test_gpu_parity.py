@@ -1603,7 +1603,10 @@ def test_float_sources_on_the_branch_free_accumulation_kernels(ch):
         ran += 1
         wants = {id(a): _checker_avir(a, nw, nh, resbits=16)
                  for a in (clean, dirty)}
-        for variant in (0, abi.VARIANT_SACC_LADDER):
+        # (float RGBA: the exact kernels by default -- as fast there, no alarm
+        # launches --, the optimistic ones under VARIANT_SACC_OPTIMISTIC)
+        for variant in (0, abi.VARIANT_SACC_LADDER,
+                        abi.VARIANT_SACC_OPTIMISTIC):
             abi.check(lib.avirhip_plan_set_variant(p, variant), "variant")
             for a in (clean, dirty, clean, dirty, dirty, clean):
                 got = r.resize(a, nw, nh)

@@ -249,6 +249,7 @@ for it in range(N):
         runs.append((4, 1))  # the 13-row-window form of k_up2
     if cls in ("dnk", "dnint", "rand"):
         runs.append((5, 4))  # k_sacc (ladder) where k_sacc2 would run
+        runs.append((5, 32))  # float RGBA on the optimistic branch-free kernels
     if cls in ("lanc", "lanc2"):
         runs.append((5, 8))   # LANCIR: k_gv + k_gh instead of the fused k_lf
     if cls in ("up", "up2", "rand"):
