@@ -1363,11 +1363,13 @@ int gpass_run( avirhip_plan* p, const float* src, long src_stride, float* dst,
 	// 1-3 channels gain: 0.273 -> 0.198 ms for the same frame as float RGB.
 	static const bool no_opt = ( getenv( "AVIRHIP_NO_SACC_OPT" ) != nullptr );
 	const bool fsrc = ( raw != nullptr ? raw_type == AVIRHIP_F32 : true );
-	const bool opt_wanted = ( raw != nullptr ||
+	static const bool opt_rgba = ( getenv( "AVIRHIP_SACC_OPT_RGBA" ) != nullptr &&
+		atoi( getenv( "AVIRHIP_SACC_OPT_RGBA" )) != 0 ); // (tuning aid)
+	const bool opt_wanted = ( raw != nullptr || opt_rgba ||
 		( p -> variant & AVIRHIP_VARIANT_SACC_OPTIMISTIC ) != 0 );
 
 	// (raw == nullptr: float RGBA -- the exact kernels unless the variant asks)
-	const bool sa_always = ( int_src || ( raw == nullptr &&
+	const bool sa_always = ( int_src || ( raw == nullptr && !opt_rgba &&
 		( p -> variant & AVIRHIP_VARIANT_SACC_OPTIMISTIC ) == 0 ));
 	const bool use_sa_h = sa_wanted( D -> sa_h, sa_always );
 	const bool use_sa_v = sa_wanted( D -> sa_v, sa_always );
