@@ -208,12 +208,15 @@ __global__ void __launch_bounds__( 64 ) k_gh( const GHParams P )
 				issue_row( r + GH_NB - 1, ( buf + GH_NB - 1 ) & ( GH_NB - 1 ));
 			}
 
-			// (... and the rows stored since row r's pieces went out, one store
-			// at least each: stores count on vmcnt too and retire in issue
-			// order with the loads -- without them the wait also drains the
-			// stores of the last rows and the three-row lead shrinks to one)
-			gp_wait_vm( min( GH_NB - 1, r1 - 1 - r ) * P.nseg +
-				( P.stw ? min( GH_NB - 1, r - r0 ) : 0 ));
+			// (the count stands for LOADS only. The stores of the rows that left
+			// meanwhile count on vmcnt too, but they do not retire in order with
+			// the loads -- a store's acknowledgement can overtake an older load
+			// (measured in sacc.hip's feed at the end of round 4: a count that
+			// included "the stores since" let a group be used before it landed)
+			// -- so they may only make this wait longer, never shorter. Rounds
+			// 3-4 added them to the count here; no mismatch was ever seen, but
+			// it was a race.)
+			gp_wait_vm( min( GH_NB - 1, r1 - 1 - r ) * P.nseg );
 		}
 
 		if( MODE != GP_PRE && slo + scnt - 1 > A.view_mmax )
@@ -1022,9 +1025,6 @@ static int run_h( const GPData* D, const float* src, long src_ss, int src_w,
 		P.lout = *lout;
 	}
 
-	static const int stw = ( getenv( "AVIRHIP_GH_STW" ) != nullptr ?
-		atoi( getenv( "AVIRHIP_GH_STW" )) : 1 );
-	P.stw = stw;
 	P.raw = raw; P.raw_ss = raw_stride; P.raw_ch = raw_ch;
 	const int src_kind = ( raw == nullptr ? 0 : ( raw_type == AVIRHIP_U8 ? 1 :
 		( raw_type == AVIRHIP_U16 ? 2 : 3 )));

@@ -390,7 +390,6 @@ struct GHParams
 	int raw_ch;
 	long raw_elems;      // elements of that image (the loader's bound)
 	GPLOut lout;         // on != 0: LANCIR's output stage in the store
-	int stw;             // the row wait allows for the stores since (A/B switch)
 };
 
 // gfuse.hip: both passes of an upsizing plan in one launch (k_gf)

@@ -154,10 +154,6 @@ __global__ void __launch_bounds__( 64 ) k_lf( const LFParams P )
 	float* dp = P.dst + (long) ( y0 - P.dst_row0 ) * P.dst_ss + (long) j * 4;
 	long orow = y0 - P.dst_row0;
 
-	// rows stored per step: the wait for a source row allows for them (stores
-	// count on vmcnt and retire in issue order with the loads, gfuse.hip)
-	int nst_cur = 0;
-
 	f4 cpre[ 2 ];
 	int need1_v;
 
@@ -218,8 +214,6 @@ __global__ void __launch_bounds__( 64 ) k_lf( const LFParams P )
 						return( q );
 					});
 			}
-
-			nst_cur++;
 
 			if( P.lout.on != 0 )
 			{
