@@ -2023,3 +2023,18 @@ def test_avir_fpclass_def_double(tin, tout, bits, gamma, alpha):
                         p, src.ctypes.data, abi.MEM_HOST, out[a_:b_].ctypes.data,
                         abi.MEM_HOST, a_, b_, None), "band")
             _assert_same(out, want, "f64 bands")
+
+def test_fast_paths_under_concurrent_memory_traffic():
+    """tools/stress_race.py: the kernels prove "the row has landed" by counting
+    outstanding vector-memory operations; a count that proves too little is a
+    race that an idle GPU hides. Frames of every fast path while another stream
+    saturates HBM and a second resizer runs beside them equal the quiet
+    result bit for bit."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools",
+                                                     "stress_race.py"), "40"],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert "0 mismatching frames" in r.stdout
