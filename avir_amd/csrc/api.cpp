@@ -925,7 +925,30 @@ static int exec_device( avirhip_plan* p, const void* src, void* dst,
 		else
 		if( path == 4 )
 		{
-			rc = up2_run( p, fsrc, sstride, fdst, row0, row1, st );
+			// integer / narrow output: the marching kernel's vertical phase
+			// converts and stores into the caller's image itself
+			void* iout4 = ( !direct && !p -> gamma &&
+				(( p -> dither == AVIRHIP_DITHER_DEF &&
+				( p -> out_type == AVIRHIP_U8 || p -> out_type == AVIRHIP_U16 )) ||
+				p -> out_type == AVIRHIP_F32 ) &&
+				getenv( "AVIRHIP_NO_FUSED_OUT" ) == nullptr ? dst : nullptr );
+
+			rc = 1;
+
+			if( iout4 != nullptr )
+			{
+				rc = up2_run( p, fsrc, sstride, nullptr, row0, row1, st, iout4 );
+
+				if( rc == 0 )
+				{
+					return( AVIRHIP_OK ); // (no epilogue)
+				}
+			}
+
+			if( rc == 1 )
+			{
+				rc = up2_run( p, fsrc, sstride, fdst, row0, row1, st );
+			}
 		}
 		else
 		{
@@ -1931,8 +1954,17 @@ int finalize_avir_plan( avirhip_plan* p )
 		// RGB float 0.071 against 0.101 ms, RGB u8 -> float 0.070 / 0.102,
 		// RGBA float -> u8 0.082 / 0.087); RGBA float output keeps it (a
 		// uint8 RGBA source costs it one pack pass: 0.064 against 0.068)
+		// Round 4: the marching kernel's vertical phase stores uint8 / uint16
+		// / narrow float pixels itself (up2_stores_io): no epilogue, and from
+		// 1080p sources on it is ahead of the pass kernels again (tools/
+		// up2_io_sweep.py: 1920x1080 RGB u8 0.071 against 0.080 ms, u16 0.072 /
+		// 0.103, RGBA float -> u8 0.051 / 0.083; 3840x2160 RGB u8 0.174 / 0.321;
+		// 1280x720 RGB u8 0.051 / 0.045: the pass kernels keep small frames)
+		const bool up2_io = ( p -> auto_path == 4 && up2_stores_io( p ) &&
+			(long) p -> src_w * p -> src_h >= 1500000L );
+
 		if( p -> auto_path == 4 && gpass_preferred( p ) && !p -> gamma &&
-			p -> dither == AVIRHIP_DITHER_DEF &&
+			!up2_io && p -> dither == AVIRHIP_DITHER_DEF &&
 			!( p -> out_type == AVIRHIP_F32 && p -> io_ch == 4 ) &&
 			( p -> out_type == AVIRHIP_U8 || p -> out_type == AVIRHIP_U16 ||
 			p -> out_type == AVIRHIP_F32 ))

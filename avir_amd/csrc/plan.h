@@ -312,7 +312,8 @@ bool fused_dn_both( const avirhip_plan* p );
 int up2_prepare( avirhip_plan* p );
 void up2_release( avirhip_plan* p );
 int up2_run( avirhip_plan* p, const float* src, long src_stride, float* dst,
-	int row0, int row1, hipStream_t st );
+	int row0, int row1, hipStream_t st, void* iout = nullptr );
+bool up2_stores_io( const avirhip_plan* p );
 
 // lanc2.hip: LANCIR exact-2x RGBA float kernel (path 4 of LANCIR plans)
 int lanc2_prepare( avirhip_plan* p );

@@ -66,6 +66,10 @@ struct Up2Params
 	float* dst; long dst_ss; int dst_row0; int nw, nh;
 	int srow_lo, srow_hi;
 	int nstrips, chunk0, nchunks, cq; // cq: source rows (output row pairs) per chunk
+	// IO != 0: the caller's image instead of dst -- uint8 / uint16 (the output
+	// stage of dither(), avir.h:4392-4419, without bit-depth truncation) or
+	// float pixels of 1-3 channels; ibase = the band's first row
+	void* ibase; int istride_b; int ich;
 #ifdef U2_DBG
 	int dbg; // timing ablations (debug build only)
 	unsigned long long* clk; // [items][4]: shader cycles, start, end (100 MHz ticks), hw id
@@ -210,10 +214,16 @@ __device__ __forceinline__ int clampi( int i, int hi )
 // sums per thread instead of a 13-row window: each new C2 row costs 12
 // multiplies + 24 adds instead of 24 + 24, every sum still receives its
 // products in ascending tap order from a +0 start => same bits.
-template< bool VT >
+// IO (VT only): 0 the float RGBA result; 1 uint8, 2 uint16, 3 float pixels of
+// P.ich channels stored by the vertical phase itself (a lane holds two
+// channels of a pixel: one store per channel, lanes without one carry an
+// out-of-range offset) -- no float result, no epilogue pass over it.
+template< bool VT, int IO = 0 >
 __global__ void __launch_bounds__( U2_NT )
 __attribute__(( amdgpu_waves_per_eu( 4, 4 ))) k_up2( const Up2Params P )
 {
+	static_assert( IO == 0 || VT, "the fused output stage lives in the VT form" );
+	constexpr int ESZ = ( IO == 1 ? 1 : ( IO == 2 ? 2 : 4 ));
 	// LDS tiles, whole pixels (16 B). The horizontal phases work on whole
 	// pixels so that every LDS access is a conflict-free 128-bit one; the
 	// vertical phase reads half pixels (8 B) of T.
@@ -259,7 +269,8 @@ __attribute__(( amdgpu_waves_per_eu( 4, 4 ))) k_up2( const Up2Params P )
 	const bool xok = ( xo < P.nw );
 	const bool strip_full = ( qx0 * 2 + U2_TW <= P.nw );
 	const int dlane_b = ( xo * 4 + hf * 2 ) * 4; // byte offset within a row
-	const int drow_b = (int) P.dst_ss * 4;   // bytes per destination row
+	const int drow_b = ( IO != 0 ? P.istride_b :
+		(int) P.dst_ss * 4 );                // bytes per destination row
 	const int srow_b = (int) P.src_ss * 4;   // bytes per source row
 
 	// Buffer addressing (uniform 128-bit resource + 32-bit lane offset + scalar
@@ -301,6 +312,7 @@ __attribute__(( amdgpu_waves_per_eu( 4, 4 ))) k_up2( const Up2Params P )
 	unsigned t16 = 0; // thread index * 16 (flat pixel slot in sC / sT)
 	int pvoff = -1;   // source byte offset of this lane's DMA pixel (< 0: none)
 	int dlv = 0;      // destination byte offset within a row
+	int dlv2 = 0;     // IO != 0: ... of the lane's second channel
 
 	if constexpr( VT )
 	{
@@ -314,7 +326,18 @@ __attribute__(( amdgpu_waves_per_eu( 4, 4 ))) k_up2( const Up2Params P )
 			pvoff = ( tid < RPI0 * U2_SW ? r * srow_b + sx * 16 : -1 );
 		}
 
-		dlv = ( xo < P.nw ? ( xo * 4 + hf * 2 ) * 4 : (int) 0x80000000u );
+		if constexpr( IO != 0 )
+		{
+			dlv = ( xo < P.nw && hf * 2 < P.ich ?
+				( xo * P.ich + hf * 2 ) * ESZ : (int) 0x80000000u );
+			dlv2 = ( xo < P.nw && hf * 2 + 1 < P.ich ?
+				( xo * P.ich + hf * 2 + 1 ) * ESZ : (int) 0x80000000u );
+		}
+		else
+		{
+			dlv = ( xo < P.nw ? ( xo * 4 + hf * 2 ) * 4 : (int) 0x80000000u );
+		}
+
 		t16 = (unsigned) tid * 16;
 		pkA = la( &sC[ ( tid / ( U2_TW / 2 )) * U2_CW +
 			( tid & ( U2_TW / 2 - 1 ))]) |
@@ -335,6 +358,11 @@ __attribute__(( amdgpu_waves_per_eu( 4, 4 ))) k_up2( const Up2Params P )
 		pkC = ha[ 2 ] | ( hd << 16 );
 		asm volatile( "" : "+v"( pkA ), "+v"( pkB ), "+v"( pkC ), "+v"( t16 ),
 			"+v"( pvoff ), "+v"( dlv ));
+
+		if constexpr( IO != 0 )
+		{
+			asm volatile( "" : "+v"( dlv2 ));
+		}
 	}
 
 	typedef const __attribute__(( address_space( 3 ))) f4* lds_cf4;
@@ -771,8 +799,51 @@ __attribute__(( amdgpu_waves_per_eu( 4, 4 ))) k_up2( const Up2Params P )
 		// test, and lanes right of the image carry an out-of-range buffer
 		// offset (the hardware drops their stores).
 		static_assert( !VT || U2_RB == 8, "VT marching period is 3 x 8 rows" );
-		void* const dbase = (void*) ( P.dst +
-			(long) ( qy0 * 2 - P.dst_row0 ) * P.dst_ss );
+		void* const dbase = ( IO != 0 ? (void*) ( (char*) P.ibase +
+			(long) ( qy0 * 2 - P.dst_row0 ) * P.istride_b ) :
+			(void*) ( P.dst + (long) ( qy0 * 2 - P.dst_row0 ) * P.dst_ss ));
+
+		// IO != 0: a lane's two channels through the output stage (round
+		// half up by truncation, clamp; the x86 build's cast beyond the int
+		// range: plan.h) into the caller's image
+		auto store_io = [&]( const f2 v, const __amdgpu_buffer_rsrc_t rs,
+			const int soff )
+		{
+			if constexpr( IO == 3 )
+			{
+				// (element by element: __builtin_bit_cast of `v.y` stored v.x)
+				const float v0 = v.x, v1 = v.y;
+				__builtin_amdgcn_raw_buffer_store_b32( __float_as_uint( v0 ), rs,
+					dlv, soff, U2_STAUX );
+				__builtin_amdgcn_raw_buffer_store_b32( __float_as_uint( v1 ), rs,
+					dlv2, soff, U2_STAUX );
+			}
+			else
+			{
+				constexpr float PK = ( IO == 1 ? 255.0f : 65535.0f );
+				float t0 = (float) (int) ( v.x + 0.5f );
+				float t1 = (float) (int) ( v.y + 0.5f );
+				t0 = fminf( fmaxf( t0, 0.0f ), PK );
+				t1 = fminf( fmaxf( t1, 0.0f ), PK );
+				t0 = avirhip_x86_round_fix( v.x, t0, PK );
+				t1 = avirhip_x86_round_fix( v.y, t1, PK );
+
+				if constexpr( IO == 1 )
+				{
+					__builtin_amdgcn_raw_buffer_store_b8(
+						(unsigned char) (unsigned) t0, rs, dlv, soff, U2_STAUX );
+					__builtin_amdgcn_raw_buffer_store_b8(
+						(unsigned char) (unsigned) t1, rs, dlv2, soff, U2_STAUX );
+				}
+				else
+				{
+					__builtin_amdgcn_raw_buffer_store_b16(
+						(unsigned short) (unsigned) t0, rs, dlv, soff, U2_STAUX );
+					__builtin_amdgcn_raw_buffer_store_b16(
+						(unsigned short) (unsigned) t1, rs, dlv2, soff, U2_STAUX );
+				}
+			}
+		};
 
 		auto vstep_t = [&]( auto R0C, auto MODEC, const int ub,
 			const bool more )
@@ -890,6 +961,17 @@ __attribute__(( amdgpu_waves_per_eu( 4, 4 ))) k_up2( const Up2Params P )
 						// accumulation chains into them): an unwanted row goes
 						// through a zero-length view of the destination, whose
 						// range check drops the store.
+						if constexpr( IO != 0 )
+						{
+							store_io( od, __builtin_amdgcn_make_buffer_rsrc(
+								dbase, 0, ( rmask & ( 1u << ( 2 * rr )) ?
+								0x7fffffff : 0 ), 0x00020000 ), so + drow_b );
+							store_io( ed, __builtin_amdgcn_make_buffer_rsrc(
+								dbase, 0, ( rmask & ( 2u << ( 2 * rr )) ?
+								0x7fffffff : 0 ), 0x00020000 ), so + 2 * drow_b );
+						}
+						else
+						{
 						if( U2_ON( 1 ) || od.x == 1234.5f )
 						{
 							__builtin_amdgcn_raw_buffer_store_b64(
@@ -906,6 +988,7 @@ __attribute__(( amdgpu_waves_per_eu( 4, 4 ))) k_up2( const Up2Params P )
 								__builtin_amdgcn_make_buffer_rsrc( dbase, 0,
 								( rmask & ( 2u << ( 2 * rr )) ? 0x7fffffff : 0 ),
 								0x00020000 ), dlane_v, so + 2 * drow_b, U2_STAUX );
+						}
 						}
 					}
 				}
@@ -1142,15 +1225,60 @@ void up2_release( avirhip_plan* p )
 	p -> up2 = nullptr;
 }
 
-int up2_run( avirhip_plan* p, const float* src, long src_stride, float* dst,
-	int row0, int row1, hipStream_t st )
+// Whether the plan's marching kernel can store the caller's pixels itself
+// (up2_run's `iout`): the transposed vertical phase, default ditherer, no
+// gamma, and uint8 / uint16 without bit-depth truncation or float pixels of
+// 1-3 channels.
+bool up2_stores_io( const avirhip_plan* p )
 {
 	const Up2Data* D = (const Up2Data*) p -> up2;
+	static const bool novt = ( getenv( "AVIRHIP_UP2_NOVT" ) != nullptr );
+
+	return( D != nullptr && U2_RB == 8 && D -> vsym && !novt &&
+		!( p -> variant & AVIRHIP_VARIANT_UP2_PLAIN_V ) && !p -> gamma &&
+		p -> dither == AVIRHIP_DITHER_DEF &&
+		(( p -> out_type == AVIRHIP_U8 && p -> tr_mul == 1.0 &&
+		p -> pk_out == 255.0 ) ||
+		( p -> out_type == AVIRHIP_U16 && p -> tr_mul == 1.0 &&
+		p -> pk_out == 65535.0 ) ||
+		( p -> out_type == AVIRHIP_F32 && p -> io_ch < 4 )));
+}
+
+// `iout` != nullptr: the caller's image (the band's first row) -- uint8 /
+// uint16 without bit-depth truncation, or float pixels of 1-3 channels: the
+// vertical phase converts and stores there (no float result, no epilogue
+// pass); returns 1 if this plan's form of the kernel cannot (the caller then
+// runs with a float result).
+int up2_run( avirhip_plan* p, const float* src, long src_stride, float* dst,
+	int row0, int row1, hipStream_t st, void* iout )
+{
+	const Up2Data* D = (const Up2Data*) p -> up2;
+	static const bool novt = ( getenv( "AVIRHIP_UP2_NOVT" ) != nullptr );
+	int io = 0;
+
+	if( iout != nullptr )
+	{
+		const bool vt = ( D != nullptr && U2_RB == 8 && D -> vsym && !novt &&
+			!( p -> variant & AVIRHIP_VARIANT_UP2_PLAIN_V ));
+
+		io = ( p -> out_type == AVIRHIP_U8 && p -> tr_mul == 1.0 &&
+			p -> pk_out == 255.0 ? 1 :
+			( p -> out_type == AVIRHIP_U16 && p -> tr_mul == 1.0 &&
+			p -> pk_out == 65535.0 && ( (uintptr_t) iout & 1 ) == 0 ? 2 :
+			( p -> out_type == AVIRHIP_F32 && p -> io_ch < 4 &&
+			( (uintptr_t) iout & 3 ) == 0 ? 3 : 0 )));
+
+		if( !vt || io == 0 || p -> dither != AVIRHIP_DITHER_DEF || p -> gamma )
+		{
+			return( 1 );
+		}
+
+	}
 
 	// source pixels travel as 16-byte LDS-DMA pieces, destination half-pixels
 	// as 8-byte stores
-	if( D == nullptr || ( (uintptr_t) src & 15 ) || ( (uintptr_t) dst & 7 ) ||
-		( src_stride & 3 ))
+	if( D == nullptr || ( (uintptr_t) src & 15 ) ||
+		( io == 0 && ( (uintptr_t) dst & 7 )) || ( src_stride & 3 ))
 	{
 		return( 1 );
 	}
@@ -1173,6 +1301,8 @@ int up2_run( avirhip_plan* p, const float* src, long src_stride, float* dst,
 	P.nw = p -> new_w; P.nh = p -> new_h;
 	P.srow_lo = row0; P.srow_hi = row1;
 	P.nstrips = ( p -> new_w + U2_TW - 1 ) / U2_TW;
+	P.ibase = iout; P.ich = p -> io_ch;
+	P.istride_b = p -> new_w * p -> io_ch * ( io == 1 ? 1 : ( io == 2 ? 2 : 4 ));
 
 	// Chunk height. A chunk of cq source rows costs (cq + 18) / U2_RB marching
 	// steps (6 rows of preload + 12 of warm-up), so cq = U2_RB*k - 18 wastes
@@ -1249,24 +1379,35 @@ int up2_run( avirhip_plan* p, const float* src, long src_stride, float* dst,
 	{
 		int nb = -1;
 		(void) hipOccupancyMaxActiveBlocksPerMultiprocessor( &nb,
-			(const void*) k_up2< false >, U2_NT, 0 );
+			(const void*) k_up2< false, 0 >, U2_NT, 0 );
 		fprintf( stderr, "k_up2: %d items (strips %d, cq %d), occupancy API "
 			"%d workgroups/CU\n", items, P.nstrips, P.cq, nb );
 	}
 
 	const char* pad = getenv( "AVIRHIP_UP2_LDSPAD" ); // residency experiments
 	const int ldspad = ( pad != nullptr ? atoi( pad ) : 0 );
-	static const bool novt = ( getenv( "AVIRHIP_UP2_NOVT" ) != nullptr );
-
+	if( io != 0 )
+	{
+		switch( io )
+		{
+			case 1: hipLaunchKernelGGL(( k_up2< U2_RB == 8, U2_RB == 8 ? 1 : 0 > ),
+				dim3( items ), dim3( U2_NT ), ldspad, st, P ); break;
+			case 2: hipLaunchKernelGGL(( k_up2< U2_RB == 8, U2_RB == 8 ? 2 : 0 > ),
+				dim3( items ), dim3( U2_NT ), ldspad, st, P ); break;
+			default: hipLaunchKernelGGL(( k_up2< U2_RB == 8, U2_RB == 8 ? 3 : 0 > ),
+				dim3( items ), dim3( U2_NT ), ldspad, st, P ); break;
+		}
+	}
+	else
 	if( U2_RB == 8 && D -> vsym && !novt &&
 		!( p -> variant & AVIRHIP_VARIANT_UP2_PLAIN_V ))
 	{
-		hipLaunchKernelGGL( k_up2< U2_RB == 8 >, dim3( items ), dim3( U2_NT ),
+		hipLaunchKernelGGL(( k_up2< U2_RB == 8, 0 > ), dim3( items ), dim3( U2_NT ),
 			ldspad, st, P );
 	}
 	else
 	{
-		hipLaunchKernelGGL( k_up2< false >, dim3( items ), dim3( U2_NT ),
+		hipLaunchKernelGGL(( k_up2< false, 0 > ), dim3( items ), dim3( U2_NT ),
 			ldspad, st, P );
 	}
 	AVIRHIP_HIPCHECK( hipGetLastError() );

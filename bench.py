@@ -54,6 +54,8 @@ OTHER = {"cfg1": ("avir", 640, 480, 1024, 768, 3, "u8", 8),
          "triple": ("avir", 1920, 1080, 5760, 3240, 4, "f32", 16),
          "nonint_u8": ("avir", 1920, 1080, 2500, 1400, 3, "u8", 8),
          "up2_u8": ("avir", 1920, 1080, 3840, 2160, 3, "u8", 8),
+         "up2_rgba8": ("avir", 1920, 1080, 3840, 2160, 4, "u8", 8),
+         "up2_4k_u8": ("avir", 3840, 2160, 7680, 4320, 3, "u8", 8),
          "cfg4_u8": ("avir", 3840, 2160, 1280, 720, 3, "u8", 8),
          "half_u8": ("avir", 3840, 2160, 1920, 1080, 3, "u8", 8),
          "dn15": ("avir", 3840, 2160, 2560, 1440, 4, "f32", 16),

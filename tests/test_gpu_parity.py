@@ -2038,3 +2038,61 @@ def test_fast_paths_under_concurrent_memory_traffic():
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     assert "0 mismatching frames" in r.stdout
+
+
+@pytest.mark.parametrize("ch,tin,tout,bits", [
+    (3, np.uint8, np.uint8, 8), (4, np.uint8, np.uint8, 8),
+    (1, np.uint8, np.uint8, 8), (2, np.uint16, np.uint16, 16),
+    (3, np.float32, np.float32, 16), (2, np.float32, np.float32, 16),
+    (4, np.float32, np.uint8, 8), (3, np.uint8, np.float32, 8),
+    (3, np.uint8, np.uint8, 6)])
+def test_exact_2x_marching_kernel_stores_the_callers_pixels(ch, tin, tout, bits):
+    """k_up2< true, IO >: exact 2x plans whose output is uint8 / uint16 (no
+    bit-depth truncation) or float pixels of 1-3 channels -- the vertical phase
+    runs the output stage (dither(), avir.h:4392-4419, the x86 cast included)
+    and stores into the caller's image: no float result, no epilogue pass.
+    Forced path 4 (fused), path 4 with AVIRHIP_VARIANT_UP2_PLAIN_V (the form
+    without the fused stage: float result + epilogue), bands, odd widths, values
+    beyond the int range; 6-bit results take the unfused form (truncation)."""
+    lib = abi.load()
+    ran = 0
+    for (sw, sh) in [(97, 61), (640, 360), (33, 200), (1000, 300)]:
+        if tin == np.float32:
+            src = rb.lcg_f32((sh, sw, ch), seed=sw + ch) * 1.2 - 0.1
+            src[3, 5, 0] = 3e10
+            src[7, 2, ch - 1] = -3e10
+            src[sh // 2, sw // 2, 0] = np.inf
+        elif tin == np.uint16:
+            src = (rb.lcg_u8((sh, sw, ch), seed=sw).astype(np.uint16) * 257)
+        else:
+            src = rb.lcg_u8((sh, sw, ch), seed=sw + ch)
+        nw, nh = sw * 2, sh * 2
+        want = _checker_avir(src, nw, nh, resbits=bits, out_dtype=tout)
+        r = avir_amd.CImageResizer(bits)
+        p = r.plan(sw, sh, nw, nh, ch, 0.0, None, avir_amd._NP2T[np.dtype(tin)],
+                   avir_amd._NP2T[np.dtype(tout)])
+        if lib.avirhip_plan_set_path(p, abi.PATH_UP2) != 0:
+            continue  # (narrow plans of small frames keep the unpadded kernels)
+        ran += 1
+        for variant in (0, abi.VARIANT_UP2_PLAIN_V):
+            abi.check(lib.avirhip_plan_set_variant(p, variant), "variant")
+            got = r.resize(src, nw, nh, out_dtype=tout)
+            _same_but_nan_payloads(got, want, "variant %d %r" % (
+                variant, (sw, sh, ch, tin, tout)))
+        abi.check(lib.avirhip_plan_set_variant(p, 0), "variant")
+        out = np.zeros((nh, nw, ch), tout)
+        for a_, b_ in [(0, nh // 3), (nh // 3, nh - 5), (nh - 5, nh)]:
+            abi.check(lib.avirhip_resize_band(
+                p, src.ctypes.data, abi.MEM_HOST, out[a_:b_].ctypes.data,
+                abi.MEM_HOST, a_, b_, None), "band")
+        _same_but_nan_payloads(out, want, "bands %r" % ((sw, sh, ch),))
+    assert ran >= 2, "path 4 took %d of the shapes" % ran
+
+
+def test_exact_2x_integer_frames_take_the_marching_kernel_from_1080p_on():
+    lib = abi.load()
+    r8 = avir_amd.CImageResizer(8)
+    for (sw, sh, want) in [(1920, 1080, abi.PATH_UP2), (3840, 2160, abi.PATH_UP2),
+                           (1280, 720, abi.PATH_GPASS), (640, 480, abi.PATH_GPASS)]:
+        p = r8.plan(sw, sh, sw * 2, sh * 2, 3, 0.0, None, abi.U8, abi.U8)
+        assert lib.avirhip_plan_get_path(p) == want, (sw, sh)
