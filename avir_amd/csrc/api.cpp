@@ -1957,9 +1957,9 @@ int finalize_avir_plan( avirhip_plan* p )
 		// Round 4: the marching kernel's vertical phase stores uint8 / uint16
 		// / narrow float pixels itself (up2_stores_io): no epilogue, and from
 		// 1080p sources on it is ahead of the pass kernels again (tools/
-		// up2_io_sweep.py: 1920x1080 RGB u8 0.071 against 0.080 ms, u16 0.072 /
-		// 0.103, RGBA float -> u8 0.051 / 0.083; 3840x2160 RGB u8 0.174 / 0.321;
-		// 1280x720 RGB u8 0.051 / 0.045: the pass kernels keep small frames)
+		// up2_io_sweep.py: 1920x1080 RGB u8 0.063 against 0.080 ms, u16 0.062 /
+		// 0.102, RGBA float -> u8 0.053 / 0.084; 3840x2160 RGB u8 0.154 / 0.314;
+		// 1280x720 RGB u8 0.046 / 0.044: the pass kernels keep small frames)
 		const bool up2_io = ( p -> auto_path == 4 && up2_stores_io( p ) &&
 			(long) p -> src_w * p -> src_h >= 1500000L );
 

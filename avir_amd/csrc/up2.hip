@@ -223,7 +223,9 @@ __global__ void __launch_bounds__( U2_NT )
 __attribute__(( amdgpu_waves_per_eu( 4, 4 ))) k_up2( const Up2Params P )
 {
 	static_assert( IO == 0 || VT, "the fused output stage lives in the VT form" );
-	constexpr int ESZ = ( IO == 1 ? 1 : ( IO == 2 ? 2 : 4 ));
+	// (IO 4 / 5: uint8 / uint16 results of an INTEGER source -- finite and far
+	// inside the int range, so the stage is add, convert, integer clamp)
+	constexpr int ESZ = ( IO == 1 || IO == 4 ? 1 : ( IO == 2 || IO == 5 ? 2 : 4 ));
 	// LDS tiles, whole pixels (16 B). The horizontal phases work on whole
 	// pixels so that every LDS access is a conflict-free 128-bit one; the
 	// vertical phase reads half pixels (8 B) of T.
@@ -819,6 +821,32 @@ __attribute__(( amdgpu_waves_per_eu( 4, 4 ))) k_up2( const Up2Params P )
 					dlv2, soff, U2_STAUX );
 			}
 			else
+			if constexpr( IO == 4 || IO == 5 )
+			{
+				// (float) (int) ( v + 0.5f ), clamped to [0, PK], cast: the same
+				// number as the integer ( v + 0.5f ) truncates to, clamped --
+				// for every |v| < 2^31, and an integer image's results are
+				// within a few hundred of [0, PK]
+				constexpr int PKI = ( IO == 4 ? 255 : 65535 );
+				const int q0 = min( max( (int) ( v.x + 0.5f ), 0 ), PKI );
+				const int q1 = min( max( (int) ( v.y + 0.5f ), 0 ), PKI );
+
+				if constexpr( IO == 4 )
+				{
+					__builtin_amdgcn_raw_buffer_store_b8( (unsigned char) q0, rs,
+						dlv, soff, U2_STAUX );
+					__builtin_amdgcn_raw_buffer_store_b8( (unsigned char) q1, rs,
+						dlv2, soff, U2_STAUX );
+				}
+				else
+				{
+					__builtin_amdgcn_raw_buffer_store_b16( (unsigned short) q0, rs,
+						dlv, soff, U2_STAUX );
+					__builtin_amdgcn_raw_buffer_store_b16( (unsigned short) q1, rs,
+						dlv2, soff, U2_STAUX );
+				}
+			}
+			else
 			{
 				constexpr float PK = ( IO == 1 ? 255.0f : 65535.0f );
 				float t0 = (float) (int) ( v.x + 0.5f );
@@ -1273,6 +1301,14 @@ int up2_run( avirhip_plan* p, const float* src, long src_stride, float* dst,
 			return( 1 );
 		}
 
+		// an integer image in (the pack pass' float copy of it): every sum
+		// is finite and small
+		if(( io == 1 || io == 2 ) && ( p -> in_type == AVIRHIP_U8 ||
+			p -> in_type == AVIRHIP_U16 ))
+		{
+			io += 3;
+		}
+
 	}
 
 	// source pixels travel as 16-byte LDS-DMA pieces, destination half-pixels
@@ -1302,7 +1338,8 @@ int up2_run( avirhip_plan* p, const float* src, long src_stride, float* dst,
 	P.srow_lo = row0; P.srow_hi = row1;
 	P.nstrips = ( p -> new_w + U2_TW - 1 ) / U2_TW;
 	P.ibase = iout; P.ich = p -> io_ch;
-	P.istride_b = p -> new_w * p -> io_ch * ( io == 1 ? 1 : ( io == 2 ? 2 : 4 ));
+	P.istride_b = p -> new_w * p -> io_ch * ( io == 1 || io == 4 ? 1 :
+		( io == 2 || io == 5 ? 2 : 4 ));
 
 	// Chunk height. A chunk of cq source rows costs (cq + 18) / U2_RB marching
 	// steps (6 rows of preload + 12 of warm-up), so cq = U2_RB*k - 18 wastes
@@ -1394,7 +1431,11 @@ int up2_run( avirhip_plan* p, const float* src, long src_stride, float* dst,
 				dim3( items ), dim3( U2_NT ), ldspad, st, P ); break;
 			case 2: hipLaunchKernelGGL(( k_up2< U2_RB == 8, U2_RB == 8 ? 2 : 0 > ),
 				dim3( items ), dim3( U2_NT ), ldspad, st, P ); break;
-			default: hipLaunchKernelGGL(( k_up2< U2_RB == 8, U2_RB == 8 ? 3 : 0 > ),
+			case 3: hipLaunchKernelGGL(( k_up2< U2_RB == 8, U2_RB == 8 ? 3 : 0 > ),
+				dim3( items ), dim3( U2_NT ), ldspad, st, P ); break;
+			case 4: hipLaunchKernelGGL(( k_up2< U2_RB == 8, U2_RB == 8 ? 4 : 0 > ),
+				dim3( items ), dim3( U2_NT ), ldspad, st, P ); break;
+			default: hipLaunchKernelGGL(( k_up2< U2_RB == 8, U2_RB == 8 ? 5 : 0 > ),
 				dim3( items ), dim3( U2_NT ), ldspad, st, P ); break;
 		}
 	}
