@@ -754,7 +754,7 @@ static int exec_device( avirhip_plan* p, const void* src, void* dst,
 	{
 		const int lpath = ( p -> path != 0 ? p -> path : p -> auto_path );
 
-		if( lpath == 4 && dst == nullptr )
+		if( lpath == 4 && dst == nullptr && !p -> lfuse.on )
 		{
 			return( AVIRHIP_NEED_DST );
 		}

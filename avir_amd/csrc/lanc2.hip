@@ -46,6 +46,12 @@ struct Lanc2Params
 	int srow_lo, srow_hi;
 	int nstrips, chunk0, cq;
 	const float* coef; // device: [va 6 | vb 6 | pad 4 | ha 6 | hb 6 | pad 4]
+	// IO != 0: the OWNER plan's output stage (outputScanline, lancir.h:
+	// 1772-2056: gain, clamps, rounding by the element's position in its
+	// scanline) run by the horizontal phase, into the caller's image
+	void* ibase; long istride; // the band's first row; elements per row
+	int ich, l4, unity;        // channels; elements rounded to nearest even
+	float out_mul, clampv;
 };
 
 struct Taps12
@@ -71,6 +77,9 @@ __device__ __forceinline__ Taps12 load_taps12( const float* p )
 	((( F( 0 ) * ( p0 ) + F( 2 ) * ( p2 )) + F( 4 ) * ( p4 )) + \
 	(( F( 1 ) * ( p1 ) + F( 3 ) * ( p3 )) + F( 5 ) * ( p5 )))
 
+// IO: 0 the float RGBA result; 1 uint8, 2 uint16, 3 float (gain and / or
+// fewer than four channels) elements of the owner plan's image.
+template< int IO >
 __global__ void __launch_bounds__( L2_NT ) k_lanc2( const Lanc2Params P )
 {
 	// intermediate rows of this step, half-pixel units: [16][L2_SW * 2]
@@ -195,9 +204,67 @@ __global__ void __launch_bounds__( L2_NT ) k_lanc2( const Lanc2Params P )
 
 				if( xok && y >= ylo && y < yhi )
 				{
-					// streaming store (never re-read): nt, measured -10 %
-					__builtin_nontemporal_store( o, (f2*) ( P.dst +
-						(long) ( y - P.dst_row0 ) * P.dst_ss + dlane ));
+					if constexpr( IO == 0 )
+					{
+						// streaming store (never re-read): nt, measured -10 %
+						__builtin_nontemporal_store( o, (f2*) ( P.dst +
+							(long) ( y - P.dst_row0 ) * P.dst_ss + dlane ));
+					}
+					else
+					{
+						// this lane's two channels: elements e0, e0 + 1 of the
+						// scanline (as gp_store_lancir of gpass_dev.h spells the
+						// stage out: the SSE2 form rounds whole groups of four
+						// to nearest even, the 1-3 element tail by + 0.5)
+						const int e0 = xo * P.ich + hf * 2;
+						const long ro = (long) ( y - P.dst_row0 ) * P.istride;
+						const float vv[ 2 ] = { o.x, o.y };
+#pragma unroll
+						for( int c = 0; c < 2; c++ )
+						{
+							if( hf * 2 + c < P.ich )
+							{
+								float v = vv[ c ];
+
+								if( !P.unity )
+								{
+									v = v * P.out_mul;
+								}
+
+								if constexpr( IO == 3 )
+								{
+									((float*) P.ibase )[ ro + e0 + c ] = v;
+								}
+								else
+								{
+									unsigned int q;
+
+									if( e0 + c < P.l4 )
+									{
+										v = ( v < P.clampv ? v : P.clampv );
+										v = ( v > 0.0f ? v : 0.0f );
+										q = (unsigned int) (int) rintf( v );
+									}
+									else
+									{
+										q = (unsigned int) (int) (( v > P.clampv ?
+											P.clampv : ( v < 0.0f ? 0.0f : v )) + 0.5f );
+									}
+
+									if constexpr( IO == 1 )
+									{
+										((unsigned char*) P.ibase )[ ro + e0 + c ] =
+											(unsigned char) q;
+									}
+									else
+									{
+										((unsigned short*) P.ibase )[ ro + e0 + c ] =
+											(unsigned short) q;
+									}
+								}
+							}
+						}
+					}
 				}
 			}
 #undef HA
@@ -286,12 +353,27 @@ void lanc2_release( avirhip_plan* p )
 	p -> lanc2 = nullptr;
 }
 
+// p -> lfuse.on (an inner plan, set by its owner around the call): the
+// horizontal phase runs the owner's output stage and stores into its image;
+// dst is not used then. Sets p -> lfuse.done.
 int lanc2_run( avirhip_plan* p, const float* src, float* dst, int row0,
 	int row1, hipStream_t st )
 {
 	const Lanc2Data* D = (const Lanc2Data*) p -> lanc2;
+	const int io = ( !p -> lfuse.on ? 0 :
+		( p -> lfuse.type == AVIRHIP_U8 ? 1 :
+		( p -> lfuse.type == AVIRHIP_U16 ? 2 :
+		( p -> lfuse.type == AVIRHIP_F32 ? 3 : -1 ))));
 
-	if( D == nullptr || ( (uintptr_t) src & 7 ) || ( (uintptr_t) dst & 7 ) ||
+	if( io < 0 || ( io == 0 && dst == nullptr ))
+	{
+		return( 1 );
+	}
+
+	if( D == nullptr || ( (uintptr_t) src & 7 ) ||
+		( io == 0 && ( (uintptr_t) dst & 7 )) ||
+		( io == 2 && ( (uintptr_t) p -> lfuse.dst & 1 )) ||
+		( io == 3 && ( (uintptr_t) p -> lfuse.dst & 3 )) ||
 		( p -> src_stride & 1 ) ||
 		(long) p -> src_h * p -> src_stride >= ( 1L << 31 ) ||
 		(long) p -> new_w * 4 >= ( 1L << 30 ))
@@ -312,6 +394,10 @@ int lanc2_run( avirhip_plan* p, const float* src, float* dst, int row0,
 	P.srow_lo = row0; P.srow_hi = row1;
 	P.nstrips = ( p -> new_w + L2_TW - 1 ) / L2_TW;
 	P.coef = D -> d_coef;
+	P.ibase = p -> lfuse.dst; P.istride = p -> lfuse.stride;
+	P.ich = p -> lfuse.ch; P.l4 = ( p -> new_w * p -> lfuse.ch ) & ~3;
+	P.unity = p -> lfuse.unity; P.out_mul = p -> lfuse.out_mul;
+	P.clampv = p -> lfuse.clampv;
 
 	// chunk = 8k - 6 source rows (6 warm-up rows per chunk); fill whole rounds
 	// of 256 CUs x 8 resident workgroups with chunks of >= 58 rows
@@ -343,8 +429,20 @@ int lanc2_run( avirhip_plan* p, const float* src, float* dst, int row0,
 	const int chunk1 = ( row1 - 1 ) / cr;
 	const int items = P.nstrips * ( chunk1 - P.chunk0 + 1 );
 
-	hipLaunchKernelGGL( k_lanc2, dim3( items ), dim3( L2_NT ), 0, st, P );
+	switch( io )
+	{
+		case 0: hipLaunchKernelGGL( k_lanc2< 0 >, dim3( items ), dim3( L2_NT ),
+			0, st, P ); break;
+		case 1: hipLaunchKernelGGL( k_lanc2< 1 >, dim3( items ), dim3( L2_NT ),
+			0, st, P ); break;
+		case 2: hipLaunchKernelGGL( k_lanc2< 2 >, dim3( items ), dim3( L2_NT ),
+			0, st, P ); break;
+		default: hipLaunchKernelGGL( k_lanc2< 3 >, dim3( items ), dim3( L2_NT ),
+			0, st, P ); break;
+	}
+
 	AVIRHIP_HIPCHECK( hipGetLastError() );
+	p -> lfuse.done = ( io != 0 );
 	return( AVIRHIP_OK );
 }
 

@@ -50,6 +50,8 @@ OTHER = {"cfg1": ("avir", 640, 480, 1024, 768, 3, "u8", 8),
          "nonint": ("avir", 1920, 1080, 2500, 1400, 4, "f32", 16),
          "lanc_nonint": ("lancir", 1920, 1080, 2500, 1400, 4, "f32", 16),
          "lanc_dn3": ("lancir", 3840, 2160, 1280, 720, 4, "f32", 16),
+         "lanc_up2_rgba8": ("lancir", 1920, 1080, 3840, 2160, 4, "u8", 8),
+         "lanc_up2_u8": ("lancir", 1920, 1080, 3840, 2160, 3, "u8", 8),
          "half": ("avir", 3840, 2160, 1920, 1080, 4, "f32", 16),
          "triple": ("avir", 1920, 1080, 5760, 3240, 4, "f32", 16),
          "nonint_u8": ("avir", 1920, 1080, 2500, 1400, 3, "u8", 8),
@@ -113,7 +115,7 @@ def time_other(name, steps, warmup, path, settle_ms=300.0, quiet=False):
         plan = obj.plan(sw, sh, nw, nh, ch, 0.0, None, tcode, tcode)
     else:
         obj = avir_amd.CLancIR()
-        plan = obj.plan(sw, sh, nw, nh, ch)
+        plan = obj.plan(sw, sh, nw, nh, ch, None, tcode, tcode)
     if path:
         abi.check(lib.avirhip_plan_set_path(plan, path), "set_path")
     st = torch.cuda.current_stream(dev).cuda_stream

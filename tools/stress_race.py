@@ -57,7 +57,7 @@ def main():
             plan = obj.plan(sw, sh, nw, nh, ch, 0.0, None, tcode, tcode)
         else:
             obj = avir_amd.CLancIR()
-            plan = obj.plan(sw, sh, nw, nh, ch)
+            plan = obj.plan(sw, sh, nw, nh, ch, None, tcode, tcode)
         quiet = torch.empty((nh, nw, ch), dtype=src.dtype, device=dev)
         torch.cuda.synchronize(dev)
         st = main_s.cuda_stream
