@@ -107,6 +107,12 @@ struct GPOut
 	int type;        // AVIRHIP_U8 / AVIRHIP_U16; AVIRHIP_F32 with 1-3 channels
 	int ch;          // channels of the caller's pixels (1..4)
 	int use_tr;
+	// an INTEGER source without bit-depth truncation: every result is finite
+	// and within a few hundred of [0, pk_out], so the stage is add, convert,
+	// integer clamp -- the same number as (float) (int) ( v + 0.5f ) clamped
+	// in float and cast, for every |v| < 2^31 (three instructions a channel
+	// instead of ten)
+	int fin, pk_i;
 	float tr_mul, tr_muli, pk_out;
 	void* base;      // the caller's rows (row 0 = the band's first row)
 	long stride;     // elements per row
@@ -121,6 +127,9 @@ static inline void gp_make_out( const avirhip_plan* p, void* iout, GPOut& O )
 	O.tr_mul = (float) p -> tr_mul;
 	O.tr_muli = (float) ( 1.0 / p -> tr_mul );
 	O.pk_out = (float) p -> pk_out;
+	O.fin = ( !O.use_tr && !p -> gamma && ( p -> in_type == AVIRHIP_U8 ||
+		p -> in_type == AVIRHIP_U16 ));
+	O.pk_i = (int) p -> pk_out;
 	O.base = iout;
 	O.stride = (long) p -> new_w * p -> io_ch;
 }
@@ -148,6 +157,16 @@ __device__ __forceinline__ void gp_store_int( const GPOut& O, const long row,
 	}
 
 	unsigned int q[ 4 ];
+
+	if( O.fin )
+	{
+#pragma unroll
+		for( int c = 0; c < 4; c++ )
+		{
+			q[ c ] = (unsigned int) min( max( (int) ( v[ c ] + 0.5f ), 0 ), O.pk_i );
+		}
+	}
+	else
 #pragma unroll
 	for( int c = 0; c < 4; c++ )
 	{
@@ -225,6 +244,17 @@ __device__ __forceinline__ void gp_store_int_row( const GPOut& O, const long row
 
 	const float v[ 3 ] = { o.x, o.y, o.z };
 	unsigned int pk = 0;
+
+	if( O.fin )
+	{
+#pragma unroll
+		for( int c = 0; c < 3; c++ )
+		{
+			pk |= (unsigned int) min( max( (int) ( v[ c ] + 0.5f ), 0 ), 255 ) <<
+				( 8 * c );
+		}
+	}
+	else
 #pragma unroll
 	for( int c = 0; c < 3; c++ )
 	{

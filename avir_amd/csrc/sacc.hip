@@ -1034,6 +1034,7 @@ __device__ __forceinline__ void sa2_emit( SA2Acc< NC >& R, SAV< NC > ( &w )[ 8 ]
 		GPOut O;
 		O.on = 1; O.type = P.out.type; O.ch = P.out.ch;
 		O.use_tr = P.out.use_tr; O.tr_mul = P.out.tr_mul;
+		O.fin = P.out.fin; O.pk_i = P.out.pk_i;
 		O.tr_muli = P.out.tr_muli; O.pk_out = P.out.pk_out;
 		O.base = P.out.base; O.stride = P.out.stride;
 		gp_store_int_row( O, T.n_out - P.out_lo, T.li, r.to4(), T.lok );
