@@ -693,7 +693,13 @@ static int exec_device( avirhip_plan* p, const void* src, void* dst,
 		// the inner plan's first pass reads this image itself where it can;
 		// otherwise the pack pass makes its float RGBA copy
 		q -> lraw.on = ( getenv( "AVIRHIP_NO_FUSED_OUT" ) == nullptr &&
-			gpass_lancir_takes_raw( q ));
+			( gpass_lancir_takes_raw( q ) || ( lanc2_takes_raw( q, src,
+			p -> in_type, p -> io_ch, p -> src_stride ) &&
+			// (its integer stage stores a lane's two elements at once)
+			( p -> new_stride & 1 ) == 0 &&
+			( p -> out_type != AVIRHIP_U8 || ( (uintptr_t) dst & 1 ) == 0 ) &&
+			( p -> out_type != AVIRHIP_U16 || ( (uintptr_t) dst & 3 ) == 0 ) &&
+			( p -> out_type != AVIRHIP_F32 || ( (uintptr_t) dst & 3 ) == 0 ))));
 
 		q -> lraw.ptr = src; q -> lraw.type = p -> in_type;
 		q -> lraw.ch = p -> io_ch; q -> lraw.stride = p -> src_stride;

@@ -49,6 +49,9 @@ struct Lanc2Params
 	// IO != 0: the OWNER plan's output stage (outputScanline, lancir.h:
 	// 1772-2056: gain, clamps, rounding by the element's position in its
 	// scanline) run by the horizontal phase, into the caller's image
+	// SRC != 0: the owner's uint8 / uint16 RGBA image read as it is (the
+	// (float) cast of copyScanline*v, lancir.h:1541-1594, in the loader)
+	const void* raw; long raw_ss; // elements per row
 	void* ibase; long istride; // the band's first row; elements per row
 	int ich, l4, unity;        // channels; elements rounded to nearest even
 	float out_mul, clampv;
@@ -79,7 +82,8 @@ __device__ __forceinline__ Taps12 load_taps12( const float* p )
 
 // IO: 0 the float RGBA result; 1 uint8, 2 uint16, 3 float (gain and / or
 // fewer than four channels) elements of the owner plan's image.
-template< int IO >
+// SRC: 0 float RGBA; 1 uint8, 2 uint16 RGBA pixels of the owner's image.
+template< int IO, int SRC >
 __global__ void __launch_bounds__( L2_NT ) k_lanc2( const Lanc2Params P )
 {
 	// intermediate rows of this step, half-pixel units: [16][L2_SW * 2]
@@ -132,8 +136,29 @@ __global__ void __launch_bounds__( L2_NT ) k_lanc2( const Lanc2Params P )
 			for( int r = 0; r < L2_RB; r++ )
 			{
 				const int sy = min( max( ub + r, 0 ), P.sh - 1 );
-				pre[ r ] = *(const f2*) ( P.src + ( (unsigned) sy *
-					(unsigned) P.src_ss + scol ));
+
+				if constexpr( SRC == 1 )
+				{
+					const unsigned short w = *(const unsigned short*) (
+						(const unsigned char*) P.raw + ( (unsigned) sy *
+						(unsigned) P.raw_ss + scol ));
+					pre[ r ].x = (float) ( w & 0xffu );
+					pre[ r ].y = (float) ( w >> 8 );
+				}
+				else
+				if constexpr( SRC == 2 )
+				{
+					const unsigned int w = *(const unsigned int*) (
+						(const unsigned short*) P.raw + ( (unsigned) sy *
+						(unsigned) P.raw_ss + scol ));
+					pre[ r ].x = (float) ( w & 0xffffu );
+					pre[ r ].y = (float) ( w >> 16 );
+				}
+				else
+				{
+					pre[ r ] = *(const f2*) ( P.src + ( (unsigned) sy *
+						(unsigned) P.src_ss + scol ));
+				}
 			}
 		}
 	};
@@ -209,6 +234,40 @@ __global__ void __launch_bounds__( L2_NT ) k_lanc2( const Lanc2Params P )
 						// streaming store (never re-read): nt, measured -10 %
 						__builtin_nontemporal_store( o, (f2*) ( P.dst +
 							(long) ( y - P.dst_row0 ) * P.dst_ss + dlane ));
+					}
+					else
+					if constexpr( SRC != 0 && ( IO == 1 || IO == 2 ))
+					{
+						// An integer RGBA image in, an integer RGBA image out:
+						// every value is finite (either spelling of the clamps
+						// gives the same number), a scanline is whole groups of
+						// four elements (nearest even throughout), and the
+						// lane's two channels are adjacent elements: one store.
+						float v0 = o.x, v1 = o.y;
+
+						if( !P.unity )
+						{
+							v0 = v0 * P.out_mul;
+							v1 = v1 * P.out_mul;
+						}
+
+						const unsigned int q0 = (unsigned int) (int) rintf(
+							fminf( fmaxf( v0, 0.0f ), P.clampv ));
+						const unsigned int q1 = (unsigned int) (int) rintf(
+							fminf( fmaxf( v1, 0.0f ), P.clampv ));
+						const long ei = (long) ( y - P.dst_row0 ) * P.istride +
+							xo * 4 + hf * 2;
+
+						if constexpr( IO == 1 )
+						{
+							*(unsigned short*) ( (unsigned char*) P.ibase + ei ) =
+								(unsigned short) ( q0 | ( q1 << 8 ));
+						}
+						else
+						{
+							*(unsigned int*) ( (unsigned short*) P.ibase + ei ) =
+								q0 | ( q1 << 16 );
+						}
 					}
 					else
 					{
@@ -353,6 +412,20 @@ void lanc2_release( avirhip_plan* p )
 	p -> lanc2 = nullptr;
 }
 
+// Whether the exact-2x kernel of an inner plan reads its owner's image itself
+// (uint8 / uint16 RGBA; the conditions lanc2_run checks again).
+bool lanc2_takes_raw( const avirhip_plan* q, const void* raw, int type, int ch,
+	long stride )
+{
+	const int lpath = ( q -> path != 0 ? q -> path : q -> auto_path );
+
+	return( q -> lanc2 != nullptr && q -> is_lancir && lpath == 4 && ch == 4 &&
+		( type == AVIRHIP_U8 || type == AVIRHIP_U16 ) && ( stride & 1 ) == 0 &&
+		( (uintptr_t) raw & ( type == AVIRHIP_U8 ? 1 : 3 )) == 0 &&
+		(long) q -> src_h * stride < ( 1L << 31 ) &&
+		(long) q -> new_w * 4 < ( 1L << 30 ));
+}
+
 // p -> lfuse.on (an inner plan, set by its owner around the call): the
 // horizontal phase runs the owner's output stage and stores into its image;
 // dst is not used then. Sets p -> lfuse.done.
@@ -370,7 +443,24 @@ int lanc2_run( avirhip_plan* p, const float* src, float* dst, int row0,
 		return( 1 );
 	}
 
-	if( D == nullptr || ( (uintptr_t) src & 7 ) ||
+	// (an inner plan whose owner asked for its image to be read as it is)
+	const int sk = ( !p -> lraw.on ? 0 : ( p -> lraw.type == AVIRHIP_U8 ? 1 :
+		( p -> lraw.type == AVIRHIP_U16 ? 2 : -1 )));
+
+	if( sk < 0 || ( sk != 0 && ( p -> lraw.ch != 4 ||
+		( sk == 1 && ( (uintptr_t) p -> lraw.ptr & 1 )) ||
+		( sk == 1 && ( p -> lraw.stride & 1 )) ||
+		( sk == 2 && ( (uintptr_t) p -> lraw.ptr & 3 )) ||
+		( sk == 2 && ( p -> lraw.stride & 1 )) ||
+		(long) p -> src_h * p -> lraw.stride >= ( 1L << 31 ) ||
+		( io != 0 && ( p -> lfuse.ch != 4 || ( p -> lfuse.stride & 1 ) ||
+		( io == 1 && ( (uintptr_t) p -> lfuse.dst & 1 )) ||
+		( io == 2 && ( (uintptr_t) p -> lfuse.dst & 3 )))))))
+	{
+		return( 1 );
+	}
+
+	if( D == nullptr || ( sk == 0 && ( (uintptr_t) src & 7 )) ||
 		( io == 0 && ( (uintptr_t) dst & 7 )) ||
 		( io == 2 && ( (uintptr_t) p -> lfuse.dst & 1 )) ||
 		( io == 3 && ( (uintptr_t) p -> lfuse.dst & 3 )) ||
@@ -394,6 +484,7 @@ int lanc2_run( avirhip_plan* p, const float* src, float* dst, int row0,
 	P.srow_lo = row0; P.srow_hi = row1;
 	P.nstrips = ( p -> new_w + L2_TW - 1 ) / L2_TW;
 	P.coef = D -> d_coef;
+	P.raw = p -> lraw.ptr; P.raw_ss = p -> lraw.stride;
 	P.ibase = p -> lfuse.dst; P.istride = p -> lfuse.stride;
 	P.ich = p -> lfuse.ch; P.l4 = ( p -> new_w * p -> lfuse.ch ) & ~3;
 	P.unity = p -> lfuse.unity; P.out_mul = p -> lfuse.out_mul;
@@ -429,17 +520,20 @@ int lanc2_run( avirhip_plan* p, const float* src, float* dst, int row0,
 	const int chunk1 = ( row1 - 1 ) / cr;
 	const int items = P.nstrips * ( chunk1 - P.chunk0 + 1 );
 
+#define L2_LAUNCH( IOK, SK ) hipLaunchKernelGGL(( k_lanc2< IOK, SK > ), \
+		dim3( items ), dim3( L2_NT ), 0, st, P )
+#define L2_LAUNCH_S( IOK ) switch( sk ) { case 0: L2_LAUNCH( IOK, 0 ); break; \
+		case 1: L2_LAUNCH( IOK, 1 ); break; default: L2_LAUNCH( IOK, 2 ); break; }
+
 	switch( io )
 	{
-		case 0: hipLaunchKernelGGL( k_lanc2< 0 >, dim3( items ), dim3( L2_NT ),
-			0, st, P ); break;
-		case 1: hipLaunchKernelGGL( k_lanc2< 1 >, dim3( items ), dim3( L2_NT ),
-			0, st, P ); break;
-		case 2: hipLaunchKernelGGL( k_lanc2< 2 >, dim3( items ), dim3( L2_NT ),
-			0, st, P ); break;
-		default: hipLaunchKernelGGL( k_lanc2< 3 >, dim3( items ), dim3( L2_NT ),
-			0, st, P ); break;
+		case 0: L2_LAUNCH_S( 0 ) break;
+		case 1: L2_LAUNCH_S( 1 ) break;
+		case 2: L2_LAUNCH_S( 2 ) break;
+		default: L2_LAUNCH_S( 3 ) break;
 	}
+#undef L2_LAUNCH_S
+#undef L2_LAUNCH
 
 	AVIRHIP_HIPCHECK( hipGetLastError() );
 	p -> lfuse.done = ( io != 0 );

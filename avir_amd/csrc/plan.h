@@ -320,5 +320,7 @@ int lanc2_prepare( avirhip_plan* p );
 void lanc2_release( avirhip_plan* p );
 int lanc2_run( avirhip_plan* p, const float* src, float* dst, int row0,
 	int row1, hipStream_t st );
+bool lanc2_takes_raw( const avirhip_plan* q, const void* raw, int type, int ch,
+	long stride );
 
 } // namespace avirhip
