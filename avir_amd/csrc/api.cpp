@@ -695,10 +695,12 @@ static int exec_device( avirhip_plan* p, const void* src, void* dst,
 		q -> lraw.on = ( getenv( "AVIRHIP_NO_FUSED_OUT" ) == nullptr &&
 			( gpass_lancir_takes_raw( q ) || ( lanc2_takes_raw( q, src,
 			p -> in_type, p -> io_ch, p -> src_stride ) &&
-			// (its integer stage stores a lane's two elements at once)
-			( p -> new_stride & 1 ) == 0 &&
-			( p -> out_type != AVIRHIP_U8 || ( (uintptr_t) dst & 1 ) == 0 ) &&
-			( p -> out_type != AVIRHIP_U16 || ( (uintptr_t) dst & 3 ) == 0 ) &&
+			// (RGBA: its integer stage stores a lane's two elements at once)
+			( p -> io_ch == 3 || ( p -> new_stride & 1 ) == 0 ) &&
+			( p -> out_type != AVIRHIP_U8 || p -> io_ch == 3 ||
+			( (uintptr_t) dst & 1 ) == 0 ) &&
+			( p -> out_type != AVIRHIP_U16 ||
+			( (uintptr_t) dst & ( p -> io_ch == 3 ? 1 : 3 )) == 0 ) &&
 			( p -> out_type != AVIRHIP_F32 || ( (uintptr_t) dst & 3 ) == 0 ))));
 
 		q -> lraw.ptr = src; q -> lraw.type = p -> in_type;
@@ -2014,7 +2016,13 @@ static int finalize_lancir_plan( avirhip_plan* p )
 	{
 		p -> fused_ok |= 8;
 
-		if( p -> auto_path != 4 )
+		// exact 2x: the marching kernel from 1080p sources on; smaller frames
+		// take the pass kernels / the fused k_lf (tools/lanc2_io_sweep.py:
+		// 640x480 float RGBA 0.012 against 0.023 ms, 1280x720 0.022 / 0.027,
+		// 1920x1080 0.042 / 0.035; RGB uint8 0.043 / 0.050 at 720p, 0.072 /
+		// 0.062 at 1080p, 0.255 / 0.140 at 2160p)
+		if( p -> auto_path != 4 ||
+			(long) p -> src_w * p -> src_h < 1500000L )
 		{
 			p -> auto_path = 5;
 		}

@@ -51,7 +51,7 @@ struct Lanc2Params
 	// scanline) run by the horizontal phase, into the caller's image
 	// SRC != 0: the owner's uint8 / uint16 RGBA image read as it is (the
 	// (float) cast of copyScanline*v, lancir.h:1541-1594, in the loader)
-	const void* raw; long raw_ss; // elements per row
+	const void* raw; long raw_ss; int rch; // elements per row; channels (3, 4)
 	void* ibase; long istride; // the band's first row; elements per row
 	int ich, l4, unity;        // channels; elements rounded to nearest even
 	float out_mul, clampv;
@@ -80,12 +80,48 @@ __device__ __forceinline__ Taps12 load_taps12( const float* p )
 	((( F( 0 ) * ( p0 ) + F( 2 ) * ( p2 )) + F( 4 ) * ( p4 )) + \
 	(( F( 1 ) * ( p1 ) + F( 3 ) * ( p3 )) + F( 5 ) * ( p5 )))
 
+// LORD: 4 the order above; 3 RGB images' (resize3, lancir.h:2284-2464, as
+// gp_dot of gpass_dev.h spells it: sums over taps 4g + j, the two tail taps of
+// a 6-tap kernel entering differently in channel 0).
+template< int LORD, class FA >
+__device__ __forceinline__ f2 l2_dot6( FA F, const bool ch0, const f2 p0,
+	const f2 p1, const f2 p2, const f2 p3, const f2 p4, const f2 p5 )
+{
+	if constexpr( LORD == 4 )
+	{
+		return((( F( 0 ) * p0 + F( 2 ) * p2 ) + F( 4 ) * p4 ) +
+			(( F( 1 ) * p1 + F( 3 ) * p3 ) + F( 5 ) * p5 ));
+	}
+	else
+	{
+		f2 a0 = F( 0 ) * p0;
+		const f2 a1 = F( 1 ) * p1, a2 = F( 2 ) * p2, a3 = F( 3 ) * p3;
+		const f2 t0 = F( 4 ) * p4, t1 = F( 5 ) * p5;
+		a0 = a0 + t0;
+		f2 r = (( a0 + a1 ) + ( a2 + a3 )) + t1;
+		const f2 r0 = ( a0 + ( a1 + t1 )) + ( a2 + a3 );
+
+		if( ch0 )
+		{
+			r.x = r0.x;
+		}
+
+		return( r );
+	}
+}
+
 // IO: 0 the float RGBA result; 1 uint8, 2 uint16, 3 float (gain and / or
 // fewer than four channels) elements of the owner plan's image.
-// SRC: 0 float RGBA; 1 uint8, 2 uint16 RGBA pixels of the owner's image.
-template< int IO, int SRC >
+// SRC: 0 float RGBA; 1 uint8, 2 uint16 pixels (RGBA or RGB: P.rch) of the
+// owner's image.
+template< int IO, int SRC, int LORD >
 __global__ void __launch_bounds__( L2_NT ) k_lanc2( const Lanc2Params P )
 {
+	// SRC 1 / 2: uint8 / uint16 RGBA; 3 / 4: uint8 / uint16 RGB (compile-time:
+	// as a run-time channel count the RGBA form lost a third of its speed)
+	constexpr int RCH = ( SRC == 3 || SRC == 4 ? 3 : 4 );
+	constexpr bool S8 = ( SRC == 1 || SRC == 3 );
+	constexpr bool S16 = ( SRC == 2 || SRC == 4 );
 	// intermediate rows of this step, half-pixel units: [16][L2_SW * 2]
 	__shared__ __attribute__(( aligned( 16 ))) f2 sT[ 2 * L2_RB * L2_SW * 2 ];
 
@@ -112,6 +148,7 @@ __global__ void __launch_bounds__( L2_NT ) k_lanc2( const Lanc2Params P )
 	const bool vact = ( tid < L2_SW * 2 );
 	const int sx = min( max( qx0 - 3 + ( tid >> 1 ), 0 ), P.sw - 1 );
 	const unsigned scol = (unsigned) ( sx * 4 + hf * 2 );
+	const unsigned rcol = (unsigned) ( sx * RCH + hf * 2 ); // (SRC != 0)
 
 	// horizontal phase: this thread's output half-column
 	const int xo = qx0 * 2 + ( tid >> 1 );
@@ -137,22 +174,41 @@ __global__ void __launch_bounds__( L2_NT ) k_lanc2( const Lanc2Params P )
 			{
 				const int sy = min( max( ub + r, 0 ), P.sh - 1 );
 
-				if constexpr( SRC == 1 )
+				if constexpr( S8 )
 				{
-					const unsigned short w = *(const unsigned short*) (
-						(const unsigned char*) P.raw + ( (unsigned) sy *
-						(unsigned) P.raw_ss + scol ));
-					pre[ r ].x = (float) ( w & 0xffu );
-					pre[ r ].y = (float) ( w >> 8 );
+					const unsigned char* const q = (const unsigned char*) P.raw +
+						( (unsigned) sy * (unsigned) P.raw_ss + rcol );
+
+					if constexpr( RCH == 4 )
+					{
+						const unsigned short w = *(const unsigned short*) q;
+						pre[ r ].x = (float) ( w & 0xffu );
+						pre[ r ].y = (float) ( w >> 8 );
+					}
+					else
+					{
+						// RGB: channels 0, 1 | channel 2 and the zero padding
+						pre[ r ].x = (float) q[ 0 ];
+						pre[ r ].y = ( hf == 0 ? (float) q[ 1 ] : 0.0f );
+					}
 				}
 				else
-				if constexpr( SRC == 2 )
+				if constexpr( S16 )
 				{
-					const unsigned int w = *(const unsigned int*) (
-						(const unsigned short*) P.raw + ( (unsigned) sy *
-						(unsigned) P.raw_ss + scol ));
-					pre[ r ].x = (float) ( w & 0xffffu );
-					pre[ r ].y = (float) ( w >> 16 );
+					const unsigned short* const q = (const unsigned short*) P.raw +
+						( (unsigned) sy * (unsigned) P.raw_ss + rcol );
+
+					if constexpr( RCH == 4 )
+					{
+						const unsigned int w = *(const unsigned int*) q;
+						pre[ r ].x = (float) ( w & 0xffffu );
+						pre[ r ].y = (float) ( w >> 16 );
+					}
+					else
+					{
+						pre[ r ].x = (float) q[ 0 ];
+						pre[ r ].y = ( hf == 0 ? (float) q[ 1 ] : 0.0f );
+					}
 				}
 				else
 				{
@@ -184,10 +240,12 @@ __global__ void __launch_bounds__( L2_NT ) k_lanc2( const Lanc2Params P )
 				const f2 m4 = ring[ ( rr - 4 ) & 7 ], m3 = ring[ ( rr - 3 ) & 7 ];
 				const f2 m2 = ring[ ( rr - 2 ) & 7 ], m1 = ring[ ( rr - 1 ) & 7 ];
 				const f2 m0 = ring[ rr ];
-				sT[ ( 2 * rr ) * ( L2_SW * 2 ) + tid ] =
-					L2_DOT6( VA, m6, m5, m4, m3, m2, m1 );
-				sT[ ( 2 * rr + 1 ) * ( L2_SW * 2 ) + tid ] =
-					L2_DOT6( VB, m5, m4, m3, m2, m1, m0 );
+				sT[ ( 2 * rr ) * ( L2_SW * 2 ) + tid ] = l2_dot6< LORD >(
+					[&]( const int i ) { return( V.fa( i )); }, hf == 0,
+					m6, m5, m4, m3, m2, m1 );
+				sT[ ( 2 * rr + 1 ) * ( L2_SW * 2 ) + tid ] = l2_dot6< LORD >(
+					[&]( const int i ) { return( V.fb( i )); }, hf == 0,
+					m5, m4, m3, m2, m1, m0 );
 			}
 #undef VA
 #undef VB
@@ -220,11 +278,13 @@ __global__ void __launch_bounds__( L2_NT ) k_lanc2( const Lanc2Params P )
 
 				if( hodd )
 				{
-					o = L2_DOT6( HB, p0, p1, p2, p3, p4, p5 );
+					o = l2_dot6< LORD >( [&]( const int i ) { return( H.fb( i )); },
+						hf == 0, p0, p1, p2, p3, p4, p5 );
 				}
 				else
 				{
-					o = L2_DOT6( HA, p0, p1, p2, p3, p4, p5 );
+					o = l2_dot6< LORD >( [&]( const int i ) { return( H.fa( i )); },
+						hf == 0, p0, p1, p2, p3, p4, p5 );
 				}
 
 				if( xok && y >= ylo && y < yhi )
@@ -237,6 +297,8 @@ __global__ void __launch_bounds__( L2_NT ) k_lanc2( const Lanc2Params P )
 					}
 					else
 					if constexpr( SRC != 0 && ( IO == 1 || IO == 2 ))
+					{
+					if constexpr( RCH == 4 )
 					{
 						// An integer RGBA image in, an integer RGBA image out:
 						// every value is finite (either spelling of the clamps
@@ -268,6 +330,44 @@ __global__ void __launch_bounds__( L2_NT ) k_lanc2( const Lanc2Params P )
 							*(unsigned int*) ( (unsigned short*) P.ibase + ei ) =
 								q0 | ( q1 << 16 );
 						}
+					}
+					else
+					{
+						// RGB: finite values again, but the last 1-3 elements of
+						// a scanline round by + 0.5 and a lane's channels are
+						// stored one by one (channel 3 is padding)
+						const int e0 = xo * 3 + hf * 2;
+						const long ro = (long) ( y - P.dst_row0 ) * P.istride;
+						const float vv[ 2 ] = { o.x, o.y };
+#pragma unroll
+						for( int c = 0; c < 2; c++ )
+						{
+							if( hf * 2 + c < 3 )
+							{
+								float v = vv[ c ];
+
+								if( !P.unity )
+								{
+									v = v * P.out_mul;
+								}
+
+								v = fminf( fmaxf( v, 0.0f ), P.clampv );
+								const unsigned int q = (unsigned int) (int) (
+									e0 + c < P.l4 ? rintf( v ) : v + 0.5f );
+
+								if constexpr( IO == 1 )
+								{
+									((unsigned char*) P.ibase )[ ro + e0 + c ] =
+										(unsigned char) q;
+								}
+								else
+								{
+									((unsigned short*) P.ibase )[ ro + e0 + c ] =
+										(unsigned short) q;
+								}
+							}
+						}
+					}
 					}
 					else
 					{
@@ -378,7 +478,8 @@ int lanc2_prepare( avirhip_plan* p )
 {
 	p -> lanc2 = nullptr;
 
-	if( !p -> is_lancir || p -> ch != 4 || p -> l_order != 4 ||
+	if( !p -> is_lancir || p -> ch != 4 ||
+		( p -> l_order != 4 && p -> l_order != 3 ) ||
 		p -> in_type != AVIRHIP_F32 ||
 		p -> out_type != AVIRHIP_F32 || !p -> l_unity ||
 		p -> new_stride != p -> new_w * 4 )
@@ -419,9 +520,12 @@ bool lanc2_takes_raw( const avirhip_plan* q, const void* raw, int type, int ch,
 {
 	const int lpath = ( q -> path != 0 ? q -> path : q -> auto_path );
 
-	return( q -> lanc2 != nullptr && q -> is_lancir && lpath == 4 && ch == 4 &&
-		( type == AVIRHIP_U8 || type == AVIRHIP_U16 ) && ( stride & 1 ) == 0 &&
-		( (uintptr_t) raw & ( type == AVIRHIP_U8 ? 1 : 3 )) == 0 &&
+	return( q -> lanc2 != nullptr && q -> is_lancir && lpath == 4 &&
+		( ch == 4 || ch == 3 ) && ch == q -> l_order &&
+		( type == AVIRHIP_U8 || type == AVIRHIP_U16 ) &&
+		( ch == 3 || ( stride & 1 ) == 0 ) &&
+		( (uintptr_t) raw & ( ch == 3 ? ( type == AVIRHIP_U8 ? 0 : 1 ) :
+		( type == AVIRHIP_U8 ? 1 : 3 ))) == 0 &&
 		(long) q -> src_h * stride < ( 1L << 31 ) &&
 		(long) q -> new_w * 4 < ( 1L << 30 ));
 }
@@ -447,15 +551,19 @@ int lanc2_run( avirhip_plan* p, const float* src, float* dst, int row0,
 	const int sk = ( !p -> lraw.on ? 0 : ( p -> lraw.type == AVIRHIP_U8 ? 1 :
 		( p -> lraw.type == AVIRHIP_U16 ? 2 : -1 )));
 
-	if( sk < 0 || ( sk != 0 && ( p -> lraw.ch != 4 ||
-		( sk == 1 && ( (uintptr_t) p -> lraw.ptr & 1 )) ||
-		( sk == 1 && ( p -> lraw.stride & 1 )) ||
-		( sk == 2 && ( (uintptr_t) p -> lraw.ptr & 3 )) ||
-		( sk == 2 && ( p -> lraw.stride & 1 )) ||
+	const bool r4 = ( p -> lraw.ch == 4 );
+
+	if( sk < 0 || ( sk != 0 && (( p -> lraw.ch != 4 && p -> lraw.ch != 3 ) ||
+		p -> lraw.ch != p -> l_order ||
+		( r4 && sk == 1 && ( (uintptr_t) p -> lraw.ptr & 1 )) ||
+		( r4 && ( p -> lraw.stride & 1 )) ||
+		( r4 && sk == 2 && ( (uintptr_t) p -> lraw.ptr & 3 )) ||
+		( !r4 && sk == 2 && ( (uintptr_t) p -> lraw.ptr & 1 )) ||
 		(long) p -> src_h * p -> lraw.stride >= ( 1L << 31 ) ||
-		( io != 0 && ( p -> lfuse.ch != 4 || ( p -> lfuse.stride & 1 ) ||
-		( io == 1 && ( (uintptr_t) p -> lfuse.dst & 1 )) ||
-		( io == 2 && ( (uintptr_t) p -> lfuse.dst & 3 )))))))
+		( io != 0 && ( p -> lfuse.ch != p -> lraw.ch ||
+		( r4 && ( p -> lfuse.stride & 1 )) ||
+		( r4 && io == 1 && ( (uintptr_t) p -> lfuse.dst & 1 )) ||
+		( io == 2 && ( (uintptr_t) p -> lfuse.dst & ( r4 ? 3 : 1 ))))))))
 	{
 		return( 1 );
 	}
@@ -484,7 +592,7 @@ int lanc2_run( avirhip_plan* p, const float* src, float* dst, int row0,
 	P.srow_lo = row0; P.srow_hi = row1;
 	P.nstrips = ( p -> new_w + L2_TW - 1 ) / L2_TW;
 	P.coef = D -> d_coef;
-	P.raw = p -> lraw.ptr; P.raw_ss = p -> lraw.stride;
+	P.raw = p -> lraw.ptr; P.raw_ss = p -> lraw.stride; P.rch = p -> lraw.ch;
 	P.ibase = p -> lfuse.dst; P.istride = p -> lfuse.stride;
 	P.ich = p -> lfuse.ch; P.l4 = ( p -> new_w * p -> lfuse.ch ) & ~3;
 	P.unity = p -> lfuse.unity; P.out_mul = p -> lfuse.out_mul;
@@ -520,10 +628,15 @@ int lanc2_run( avirhip_plan* p, const float* src, float* dst, int row0,
 	const int chunk1 = ( row1 - 1 ) / cr;
 	const int items = P.nstrips * ( chunk1 - P.chunk0 + 1 );
 
-#define L2_LAUNCH( IOK, SK ) hipLaunchKernelGGL(( k_lanc2< IOK, SK > ), \
-		dim3( items ), dim3( L2_NT ), 0, st, P )
-#define L2_LAUNCH_S( IOK ) switch( sk ) { case 0: L2_LAUNCH( IOK, 0 ); break; \
-		case 1: L2_LAUNCH( IOK, 1 ); break; default: L2_LAUNCH( IOK, 2 ); break; }
+#define L2_LAUNCH( IOK, SK ) { if( p -> l_order == 3 ) \
+		hipLaunchKernelGGL(( k_lanc2< IOK, SK, 3 > ), dim3( items ), \
+		dim3( L2_NT ), 0, st, P ); else \
+		hipLaunchKernelGGL(( k_lanc2< IOK, SK, 4 > ), dim3( items ), \
+		dim3( L2_NT ), 0, st, P ); }
+#define L2_LAUNCH_S( IOK ) switch( sk == 0 ? 0 : ( r4 ? sk : sk + 2 )) { \
+		case 0: L2_LAUNCH( IOK, 0 ); break; case 1: L2_LAUNCH( IOK, 1 ); break; \
+		case 2: L2_LAUNCH( IOK, 2 ); break; case 3: L2_LAUNCH( IOK, 3 ); break; \
+		default: L2_LAUNCH( IOK, 4 ); break; }
 
 	switch( io )
 	{
