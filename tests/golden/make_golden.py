@@ -68,12 +68,20 @@ for m in (0, 1, 2, 3):
 for t in ("u8", "u16", "f32"):
     for ch in (1, 2, 3, 4):
         AVIR_CASES += [(t, 64, 48, 100, 77, ch, 8, -1), (t, 100, 77, 33, 29, ch, 16, -1)]
+# exact 2x at the size where the marching kernels' integer / narrow-pixel forms
+# are the automatic path (round 4: k_up2< true, IO >, k_lanc2< IO, SRC, LORD >)
+AVIR_CASES += [("u8", 1920, 1080, 3840, 2160, 3, 8, -1),
+               ("u8", 1920, 1080, 3840, 2160, 4, 8, -1),
+               ("u16", 1920, 1080, 3840, 2160, 3, 16, -1),
+               ("f32", 1920, 1080, 3840, 2160, 3, 16, -1)]
 AVIR_CASES += [("f32", 7, 5, 13, 11, 4, 8, -1), ("f32", 1, 50, 3, 20, 4, 8, -1),
                ("f32", 100, 1, 37, 1, 1, 8, -1), ("u8", 16, 9, 5, 7, 2, 6, -1)]
 
 LANCIR_CASES = [("f32", 3840, 2160, 7680, 4320, 4), ("f32", 1920, 1080, 3840, 2160, 4),
                 ("f32", 3840, 2160, 1280, 720, 4), ("f32", 640, 480, 1024, 768, 4),
-                ("u8", 5184, 3456, 1920, 1280, 3)]
+                ("u8", 5184, 3456, 1920, 1280, 3),
+                ("u8", 1920, 1080, 3840, 2160, 4), ("u8", 1920, 1080, 3840, 2160, 3),
+                ("u16", 1920, 1080, 3840, 2160, 4), ("u16", 1920, 1080, 3840, 2160, 3)]
 for t in ("u8", "u16", "f32"):
     for ch in (1, 2, 3, 4):
         LANCIR_CASES += [(t, 64, 48, 100, 77, ch), (t, 300, 200, 100, 67, ch),

@@ -2096,3 +2096,32 @@ def test_exact_2x_integer_frames_take_the_marching_kernel_from_1080p_on():
                            (1280, 720, abi.PATH_GPASS), (640, 480, abi.PATH_GPASS)]:
         p = r8.plan(sw, sh, sw * 2, sh * 2, 3, 0.0, None, abi.U8, abi.U8)
         assert lib.avirhip_plan_get_path(p) == want, (sw, sh)
+
+
+def test_exact_2x_integer_frames_golden_hashes():
+    """1920x1080 -> 3840x2160 with uint8 / uint16 / narrow float pixels on the
+    AUTOMATIC path (the marching kernels' integer-I/O forms from 1.5 Mpixel
+    sources on: k_up2< true, IO >, k_lanc2< IO, SRC, LORD >) against the golden
+    hashes tests/golden/make_golden.py took from the reference itself."""
+    import json
+    from tests.golden.make_golden import src_for, avir_key, lancir_key
+    with open(os.path.join(os.path.dirname(__file__), "golden",
+                           "golden.json")) as f:
+        golden = json.load(f)["cases"]
+    lib = abi.load()
+    for (t, ch, bits) in [("u8", 3, 8), ("u8", 4, 8), ("u16", 3, 16),
+                          ("f32", 3, 16)]:
+        src = src_for(t, 1920, 1080, ch)
+        r = avir_amd.CImageResizer(bits)
+        got = r.resize(src, 3840, 2160)
+        tc = avir_amd._NP2T[src.dtype]
+        p = r.plan(1920, 1080, 3840, 2160, ch, 0.0, None, tc, tc)
+        assert lib.avirhip_plan_get_path(p) == abi.PATH_UP2, (t, ch)
+        assert rb.fnv(got) == golden[avir_key(t, 1920, 1080, 3840, 2160, ch,
+                                              bits, -1)], (t, ch)
+    for (t, ch) in [("u8", 4), ("u8", 3), ("u16", 4), ("u16", 3)]:
+        src = src_for(t, 1920, 1080, ch)
+        l = avir_amd.CLancIR()
+        got = l.resize(src, 3840, 2160)
+        assert rb.fnv(got) == golden[lancir_key(t, 1920, 1080, 3840, 2160,
+                                                ch)], (t, ch)
