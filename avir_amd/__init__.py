@@ -16,13 +16,16 @@ import ctypes as C
 import numpy as np
 
 from . import abi
-from .abi import AvirHipError, U8, U16, F32, F64
+from .abi import AvirHipError, U8, U16, F32, F64, U32
 
 __all__ = ["CImageResizer", "CImageResizerParams", "CImageResizerVars",
            "CLancIR", "CLancIRParams", "AvirHipError", "device_count"]
 
 _NP2T = {np.dtype(np.uint8): U8, np.dtype(np.uint16): U16,
-         np.dtype(np.float32): F32, np.dtype(np.float64): F64}
+         np.dtype(np.float32): F32, np.dtype(np.float64): F64,
+         # CLancIR only ("treated as uint16_t", lancir.h:376-377); CImageResizer
+         # refuses it like the reference's unsupported types
+         np.dtype(np.uint32): U32}
 
 
 def device_count():
@@ -74,6 +77,8 @@ def _buf(x):
         tmap = {torch.uint8: U8, torch.float32: F32, torch.float64: F64}
         if hasattr(torch, "uint16"):
             tmap[torch.uint16] = U16
+        if hasattr(torch, "uint32"):
+            tmap[torch.uint32] = U32
         if not x.is_contiguous():
             raise ValueError("tensor must be contiguous")
         if x.is_cuda:

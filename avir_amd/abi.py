@@ -12,6 +12,8 @@ LIB_PATH = os.environ.get("AVIRHIP_LIB") or os.path.join(
     _HERE, "lib", "libavirhip.so")  # AVIRHIP_LIB: alternate build (experiments)
 
 U8, U16, F32, F64 = 0, 1, 2, 3
+U32 = 4  # CLancIR only: 32-bit elements, uint16 value range (lancir.h:376-377)
+EINVAL, ENODEV, EHIP, EUNSUPPORTED, ENOMEM, EINTERNAL = -1, -2, -3, -4, -5, -6
 MEM_HOST, MEM_DEVICE = 0, 1
 
 STEP_FIR, STEP_UP_ZEROSTUFF, STEP_UP_FILTERED, STEP_RESIZE, STEP_RESIZE2 = range(5)
@@ -141,6 +143,7 @@ PROTOTYPES = {
     "avirhip_plan_set_path": (_I, [_VP, _I]),
     "avirhip_plan_set_variant": (_I, [_VP, _I]),
     "avirhip_plan_device_bytes": (C.c_ulonglong, [_VP]),
+    "avirhip_debug_fail_alloc": (C.c_long, [C.c_long]),
     "avirhip_debug_gamma_u8": (_I, [_VP, C.c_long, C.c_double, _I, _VP, _VP, _VP]),
     "avirhip_plan_get_path": (_I, [_VP]),
     "avirhip_resize": (_I, [_VP, _VP, _I, _VP, _I, _VP]),
@@ -236,6 +239,9 @@ class AvirHipError(RuntimeError):
 
 
 def check(rc, what=""):
+    if rc == ENOMEM:
+        msg = load().avirhip_last_error()
+        raise MemoryError("%s: %s" % (what, msg.decode() if msg else "?"))
     if rc < 0:
         msg = load().avirhip_last_error()
         raise AvirHipError("%s failed (%d): %s" % (

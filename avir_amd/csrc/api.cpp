@@ -14,6 +14,8 @@
 #include <atomic>
 #include <thread>
 #include <system_error>
+#include <new>
+#include <stdexcept>
 
 namespace avirhip {
 
@@ -30,7 +32,95 @@ void set_error( const char* fmt, ... )
 size_t dtype_size( int t )
 {
 	return( t == AVIRHIP_U8 ? 1 : t == AVIRHIP_U16 ? 2 : t == AVIRHIP_F32 ? 4 :
-		8 );
+		t == AVIRHIP_U32 ? 4 : 8 );
+}
+
+int guard_fail( const char* fn ) noexcept
+{
+	// (called from a catch( ... ) handler: rethrow to see what is in flight)
+	try
+	{
+		throw;
+	}
+	catch( const std::bad_alloc& )
+	{
+		set_error( "%s: out of host memory", fn );
+		return( AVIRHIP_ENOMEM );
+	}
+	catch( const std::length_error& e )
+	{
+		// (a container asked for more than max_size(): the same condition)
+		set_error( "%s: out of host memory (%s)", fn, e.what() );
+		return( AVIRHIP_ENOMEM );
+	}
+	catch( const std::exception& e )
+	{
+		set_error( "%s: internal error: %s", fn, e.what() );
+	}
+	catch( ... )
+	{
+		set_error( "%s: internal error (unknown exception)", fn );
+	}
+
+	return( AVIRHIP_EINTERNAL );
+}
+
+bool mul_fits( size_t a, size_t b, size_t c, size_t d, size_t* out )
+{
+	size_t r = 0;
+
+	if( __builtin_mul_overflow( a, b, &r ) || __builtin_mul_overflow( r, c, &r ) ||
+		__builtin_mul_overflow( r, d, &r ))
+	{
+		return( false );
+	}
+
+	if( out != nullptr )
+	{
+		*out = r;
+	}
+
+	return( true );
+}
+
+bool geometry_ok( const char* fn, int src_w, int src_h, long src_stride,
+	int new_w, int new_h, long new_stride, int ch, int in_type, int out_type )
+{
+	if( src_w < 0 || src_h < 0 || new_w < 0 || new_h < 0 || ch < 1 || ch > 4 )
+	{
+		set_error( "%s: bad image geometry", fn );
+		return( false );
+	}
+
+	const long INTMAX = 0x7fffffffL;
+	const long se = (long) src_w * ch, ne = (long) new_w * ch;
+
+	if( src_stride < 1 ) src_stride = se;
+	if( new_stride < 1 ) new_stride = ne;
+
+	// a float copy of either image (16 bytes per RGBA pixel) is the largest
+	// buffer a plan may allocate per pixel
+	if( se > INTMAX || ne > INTMAX || src_stride > INTMAX || new_stride > INTMAX ||
+		!mul_fits( (size_t) src_stride, (size_t) src_h, 16, 1 ) ||
+		!mul_fits( (size_t) new_stride, (size_t) new_h, 16, 1 ) ||
+		!mul_fits( (size_t) src_w, (size_t) new_h, 16 * ch, 1 ) ||
+		!mul_fits( (size_t) new_w, (size_t) src_h, 16 * ch, 1 ) ||
+		dtype_size( in_type ) == 0 || dtype_size( out_type ) == 0 )
+	{
+		set_error( "%s: image of %d x %d x %d -> %d x %d elements does not fit "
+			"int rows / size_t bytes", fn, src_w, src_h, ch, new_w, new_h );
+		return( false );
+	}
+
+	return( true );
+}
+
+PlanHold :: ~PlanHold()
+{
+	if( p != nullptr )
+	{
+		avirhip_plan_destroy( p );
+	}
 }
 
 template< typename T >
@@ -685,14 +775,18 @@ static int exec_device( avirhip_plan* p, const void* src, void* dst,
 			p -> src_h - 1 ));
 		const int sb = std::max( 0, std::min( V.h_start[ row1 - 1 ] +
 			V.kernel_len - 1, p -> src_h - 1 ));
-		const size_t es = ( p -> in_type == AVIRHIP_U8 ? 1 :
-			( p -> in_type == AVIRHIP_U16 ? 2 : 4 ));
+		const size_t es = dtype_size( p -> in_type );
+		// (double and uint32 elements, lancir.h:373-377: the pack pass and the
+		// output stage convert them; the fast kernels' own loaders and fused
+		// stores know uint8, uint16 and float)
+		const bool in_fast = ( p -> in_type <= AVIRHIP_F32 );
+		const bool out_fast = ( p -> out_type <= AVIRHIP_F32 );
 
 		q -> path = p -> path;
 
 		// the inner plan's first pass reads this image itself where it can;
 		// otherwise the pack pass makes its float RGBA copy
-		q -> lraw.on = ( getenv( "AVIRHIP_NO_FUSED_OUT" ) == nullptr &&
+		q -> lraw.on = ( getenv( "AVIRHIP_NO_FUSED_OUT" ) == nullptr && in_fast &&
 			( gpass_lancir_takes_raw( q ) || ( lanc2_takes_raw( q, src,
 			p -> in_type, p -> io_ch, p -> src_stride ) &&
 			// (RGBA: its integer stage stores a lane's two elements at once)
@@ -706,22 +800,27 @@ static int exec_device( avirhip_plan* p, const void* src, void* dst,
 		q -> lraw.ptr = src; q -> lraw.type = p -> in_type;
 		q -> lraw.ch = p -> io_ch; q -> lraw.stride = p -> src_stride;
 
-		if( !q -> lraw.on )
+		auto do_pack = [&]() -> int
 		{
 			if( p -> packed == nullptr )
 			{
-				if(( rc = dev_alloc( p, (size_t) p -> src_w * p -> src_h * 4 *
-					sizeof( float ), &m )) != 0 ) return( rc );
+				const int r = dev_alloc( p, (size_t) p -> src_w * p -> src_h * 4 *
+					sizeof( float ), &m );
+
+				if( r != 0 ) return( r );
 				p -> packed = (float*) m;
 			}
 
-			if(( rc = launch_pack( (const char*) src +
+			return( launch_pack( (const char*) src +
 				(size_t) sa * p -> src_stride * es, p -> in_type, p -> packed +
 				(size_t) sa * p -> src_w * 4, p -> src_w, sb - sa + 1,
-				p -> io_ch, 4, p -> src_stride, st )) != 0 ) return( rc );
-		}
+				p -> io_ch, 4, p -> src_stride, st ));
+		};
 
-		q -> lfuse.on = ( getenv( "AVIRHIP_NO_FUSED_OUT" ) == nullptr );
+		if( !q -> lraw.on && ( rc = do_pack() ) != 0 ) return( rc );
+
+		q -> lfuse.on = ( getenv( "AVIRHIP_NO_FUSED_OUT" ) == nullptr &&
+			out_fast );
 		q -> lfuse.done = 0;
 		q -> lfuse.type = p -> out_type; q -> lfuse.ch = p -> io_ch;
 		q -> lfuse.unity = p -> l_unity; q -> lfuse.out_mul = p -> l_out_mul;
@@ -734,15 +833,32 @@ static int exec_device( avirhip_plan* p, const void* src, void* dst,
 
 		rc = exec_device( q, p -> packed, p -> lres, row0, row1, st );
 
-		if( rc == AVIRHIP_NEED_DST )
+		// (at most one round of each: the kernel that was to read the owner's
+		// image refused the call -> float copy; a pass would have written the
+		// float result -> result buffer)
+		for( int round = 0; round < 2 && ( rc == AVIRHIP_NEED_SRC ||
+			rc == AVIRHIP_NEED_DST ); round++ )
 		{
-			if(( rc = need_lres() ) != 0 ) return( rc );
+			if( rc == AVIRHIP_NEED_SRC )
+			{
+				q -> lraw.on = 0;
+				if(( rc = do_pack() ) != 0 ) break;
+			}
+			else
+			if(( rc = need_lres() ) != 0 ) break;
+
 			q -> lfuse.done = 0;
 			rc = exec_device( q, p -> packed, p -> lres, row0, row1, st );
 		}
 
 		q -> lfuse.on = 0;
 		q -> lraw.on = 0;
+
+		if( rc == AVIRHIP_NEED_SRC || rc == AVIRHIP_NEED_DST )
+		{
+			set_error( "LANCIR: the inner plan kept asking for buffers (%d)", rc );
+			return( AVIRHIP_EINTERNAL );
+		}
 
 		if( rc != 0 || q -> lfuse.done )
 		{
@@ -775,6 +891,12 @@ static int exec_device( avirhip_plan* p, const void* src, void* dst,
 			if( rc != 1 )
 			{
 				return( rc );
+			}
+
+			if( p -> lraw.on )
+			{
+				// (the kernels below would read the float copy the owner skipped)
+				return( AVIRHIP_NEED_SRC );
 			}
 
 			if( p -> path != 0 )
@@ -1281,13 +1403,20 @@ static int exec_host_pipelined( avirhip_plan* p, const void* src, void* dst,
 
 	// (a thread that cannot be started must not throw through extern "C":
 	// the rows then go up from this thread, band after band, before the loop)
-	std::thread uploader;
+	// (... and a throw below -- a host allocation failing inside a band's launch
+	// code -- must not unwind past a joinable thread: that is std::terminate)
+	struct Joiner
+	{
+		std::thread t;
+		~Joiner() { if( t.joinable() ) t.join(); }
+	} up;
+	std::thread& uploader = up.t;
 
 	try
 	{
 		uploader = std::thread( upload_rows );
 	}
-	catch( const std::system_error& )
+	catch( ... )
 	{
 		upload_rows();
 	}
@@ -1491,12 +1620,13 @@ static int exec_any( avirhip_plan* p, const void* src, int src_mem, void* dst,
 
 		if( spare != nullptr )
 		{
-			// (exec_any on the spare: its mutex is held by this thread)
-			const int rc = exec_any( spare, src, src_mem, dst, dst_mem,
-				row0, row1, stream, true );
+			// (exec_any on the spare: its mutex is held by this thread, and
+			// released on every way out -- a throw included)
+			std::unique_lock< std::mutex > sg( spare -> exec_mtx,
+				std::adopt_lock );
 
-			spare -> exec_mtx.unlock();
-			return( rc );
+			return( exec_any( spare, src, src_mem, dst, dst_mem, row0, row1,
+				stream, true ));
 		}
 
 		guard.lock();
@@ -1786,6 +1916,7 @@ int avirhip_device_count( void )
 }
 
 int avirhip_init( int device )
+try
 {
 	if( avirhip_device_count() < 1 )
 	{
@@ -1796,6 +1927,7 @@ int avirhip_init( int device )
 	AVIRHIP_HIPCHECK( hipSetDevice( device ));
 	return( AVIRHIP_OK );
 }
+AVIRHIP_CATCH( avirhip_init )
 
 const char* avirhip_last_error( void )
 {
@@ -1808,6 +1940,7 @@ const char* avirhip_version( void )
 }
 
 int avirhip_plan_create( const avirhip_plan_desc* d, avirhip_plan** out )
+try
 {
 	if( d == nullptr || out == nullptr )
 	{
@@ -1825,7 +1958,15 @@ int avirhip_plan_create( const avirhip_plan_desc* d, avirhip_plan** out )
 		return( AVIRHIP_EINVAL );
 	}
 
-	avirhip_plan* p = new_plan();
+	if( !geometry_ok( "plan_create", d -> src_w, d -> src_h,
+		d -> src_stride_elems, d -> new_w, d -> new_h, 0, d -> channels,
+		d -> in_type, d -> out_type ))
+	{
+		return( AVIRHIP_EINVAL );
+	}
+
+	PlanHold hold( new_plan() );
+	avirhip_plan* const p = hold.p;
 	p -> src_w = d -> src_w; p -> src_h = d -> src_h;
 	p -> src_stride = ( d -> src_stride_elems < 1 ?
 		d -> src_w * d -> channels : d -> src_stride_elems );
@@ -1846,7 +1987,6 @@ int avirhip_plan_create( const avirhip_plan_desc* d, avirhip_plan** out )
 		d -> dither != AVIRHIP_DITHER_DEF_RNE )
 	{
 		set_error( "unknown ditherer %d", d -> dither );
-		avirhip_plan_destroy( p );
 		return( AVIRHIP_EINVAL );
 	}
 
@@ -1861,7 +2001,6 @@ int avirhip_plan_create( const avirhip_plan_desc* d, avirhip_plan** out )
 	if( p -> f64 && ( p -> dither != AVIRHIP_DITHER_DEF || p -> fp4 ))
 	{
 		set_error( "the double pipeline runs the default ditherer only" );
-		avirhip_plan_destroy( p );
 		return( AVIRHIP_EUNSUPPORTED );
 	}
 
@@ -1874,13 +2013,13 @@ int avirhip_plan_create( const avirhip_plan_desc* d, avirhip_plan** out )
 
 	if( rc != 0 )
 	{
-		avirhip_plan_destroy( p );
 		return( rc );
 	}
 
-	*out = p;
+	*out = hold.release();
 	return( AVIRHIP_OK );
 }
+AVIRHIP_CATCH( avirhip_plan_create )
 
 } // extern "C"
 
@@ -2037,7 +2176,8 @@ static int finalize_lancir_plan( avirhip_plan* p )
 		p -> out_type == AVIRHIP_F32 && p -> l_unity ) &&
 		getenv( "AVIRHIP_NO_INNER" ) == nullptr )
 	{
-		avirhip_plan* q = new_plan();
+		PlanHold qhold( new_plan() );
+		avirhip_plan* const q = qhold.p;
 		q -> device = p -> device;
 		q -> is_lancir = 1;
 		q -> src_w = p -> src_w; q -> src_h = p -> src_h;
@@ -2053,13 +2193,9 @@ static int finalize_lancir_plan( avirhip_plan* p )
 
 		if( rc == 0 && q -> auto_path != 1 )
 		{
-			p -> inner = q;
+			p -> inner = qhold.release();
 			p -> auto_path = q -> auto_path;
 			p -> fused_ok |= ( q -> fused_ok & ( 4 | 8 ));
-		}
-		else
-		{
-			avirhip_plan_destroy( q );
 		}
 	}
 
@@ -2071,7 +2207,8 @@ static int finalize_lancir_plan( avirhip_plan* p )
 static int clone_plan( const avirhip_plan* s, int device, avirhip_plan** out )
 {
 	AVIRHIP_HIPCHECK( hipSetDevice( device ));
-	avirhip_plan* q = new_plan();
+	PlanHold hold( new_plan() );
+	avirhip_plan* const q = hold.p;
 	q -> is_lancir = s -> is_lancir;
 	q -> src_w = s -> src_w; q -> src_h = s -> src_h;
 	q -> src_stride = s -> src_stride;
@@ -2097,11 +2234,10 @@ static int clone_plan( const avirhip_plan* s, int device, avirhip_plan** out )
 
 	if( rc != 0 )
 	{
-		avirhip_plan_destroy( q );
 		return( rc );
 	}
 
-	*out = q;
+	*out = hold.release();
 	return( AVIRHIP_OK );
 }
 
@@ -2129,6 +2265,7 @@ extern "C" {
 int avirhip_resize_sharded( avirhip_plan* p, int n_gpus, const int* devices,
 	const void* src, void* dst, int gather_root, double* t_compute_ms,
 	double* t_gather_ms )
+try
 {
 	if( p == nullptr || n_gpus < 1 || src == nullptr || dst == nullptr ||
 		( devices == nullptr && n_gpus > 1 ) || gather_root < 0 ||
@@ -2373,6 +2510,7 @@ int avirhip_resize_sharded( avirhip_plan* p, int n_gpus, const int* devices,
 
 	return( rc );
 }
+AVIRHIP_CATCH( avirhip_resize_sharded )
 
 static int lower_lancir_axis( avirhip_plan* p, const avirhip_lancir_axis& a,
 	LancirAxisDev& L )
@@ -2411,6 +2549,7 @@ static int lower_lancir_axis( avirhip_plan* p, const avirhip_lancir_axis& a,
 
 int avirhip_lancir_plan_create( const avirhip_lancir_desc* d,
 	avirhip_plan** out )
+try
 {
 	if( d == nullptr || out == nullptr )
 	{
@@ -2427,14 +2566,23 @@ int avirhip_lancir_plan_create( const avirhip_lancir_desc* d,
 		return( AVIRHIP_EINVAL );
 	}
 
-	if( d -> in_type < 0 || d -> in_type > AVIRHIP_F32 || d -> out_type < 0 ||
-		d -> out_type > AVIRHIP_F32 )
+	if( d -> in_type < 0 || d -> in_type > AVIRHIP_U32 || d -> out_type < 0 ||
+		d -> out_type > AVIRHIP_U32 )
 	{
-		set_error( "LANCIR: element types are uint8, uint16 or float" );
-		return( AVIRHIP_EUNSUPPORTED );
+		set_error( "LANCIR: element types are uint8, uint16, uint32 (as "
+			"uint16), float or double (lancir.h:373-381)" );
+		return( AVIRHIP_EINVAL );
 	}
 
-	avirhip_plan* p = new_plan();
+	if( !geometry_ok( "lancir_plan_create", d -> src_w, d -> src_h,
+		d -> src_stride_elems, d -> new_w, d -> new_h, d -> new_stride_elems,
+		d -> channels, d -> in_type, d -> out_type ))
+	{
+		return( AVIRHIP_EINVAL );
+	}
+
+	PlanHold hold( new_plan() );
+	avirhip_plan* const p = hold.p;
 	p -> is_lancir = 1;
 	p -> src_w = d -> src_w; p -> src_h = d -> src_h;
 	p -> src_stride = ( d -> src_stride_elems < 1 ?
@@ -2454,13 +2602,13 @@ int avirhip_lancir_plan_create( const avirhip_lancir_desc* d,
 
 	if( rc != 0 )
 	{
-		avirhip_plan_destroy( p );
 		return( rc );
 	}
 
-	*out = p;
+	*out = hold.release();
 	return( AVIRHIP_OK );
 }
+AVIRHIP_CATCH( avirhip_lancir_plan_create )
 
 void avirhip_plan_destroy( avirhip_plan* p )
 {
@@ -2518,6 +2666,7 @@ void avirhip_plan_destroy( avirhip_plan* p )
 }
 
 int avirhip_plan_set_path( avirhip_plan* p, int path )
+try
 {
 	if( p == nullptr || path < 0 || path > 5 )
 	{
@@ -2560,6 +2709,7 @@ int avirhip_plan_set_path( avirhip_plan* p, int path )
 
 	return( AVIRHIP_OK );
 }
+AVIRHIP_CATCH( avirhip_plan_set_path )
 
 unsigned long long avirhip_plan_device_bytes( avirhip_plan* p )
 {
@@ -2567,6 +2717,7 @@ unsigned long long avirhip_plan_device_bytes( avirhip_plan* p )
 }
 
 int avirhip_plan_set_variant( avirhip_plan* p, int variant )
+try
 {
 	if( p == nullptr || variant < 0 || variant > 63 )
 	{
@@ -2603,9 +2754,11 @@ int avirhip_plan_set_variant( avirhip_plan* p, int variant )
 
 	return( AVIRHIP_OK );
 }
+AVIRHIP_CATCH( avirhip_plan_set_variant )
 
 int avirhip_band_source_rows( const avirhip_plan* p, int row0, int row1,
 	int* first, int* last )
+try
 {
 	if( p == nullptr || first == nullptr || last == nullptr || row0 < 0 ||
 		row1 > p -> new_h || row1 <= row0 )
@@ -2617,8 +2770,10 @@ int avirhip_band_source_rows( const avirhip_plan* p, int row0, int row1,
 	band_src_rows( p, row0, row1, first, last );
 	return( AVIRHIP_OK );
 }
+AVIRHIP_CATCH( avirhip_band_source_rows )
 
 int avirhip_plan_get_path( const avirhip_plan* p )
+try
 {
 	if( p == nullptr )
 	{
@@ -2627,9 +2782,11 @@ int avirhip_plan_get_path( const avirhip_plan* p )
 
 	return( p -> path != 0 ? p -> path : p -> auto_path );
 }
+AVIRHIP_CATCH( avirhip_plan_get_path )
 
 int avirhip_resize( avirhip_plan* p, const void* src, int src_mem, void* dst,
 	int dst_mem, void* stream )
+try
 {
 	if( p == nullptr )
 	{
@@ -2639,16 +2796,20 @@ int avirhip_resize( avirhip_plan* p, const void* src, int src_mem, void* dst,
 
 	return( exec_any( p, src, src_mem, dst, dst_mem, 0, p -> new_h, stream ));
 }
+AVIRHIP_CATCH( avirhip_resize )
 
 int avirhip_resize_band( avirhip_plan* p, const void* src, int src_mem,
 	void* dst_band, int dst_mem, int row0, int row1, void* stream )
+try
 {
 	return( exec_any( p, src, src_mem, dst_band, dst_mem, row0, row1,
 		stream ));
 }
+AVIRHIP_CATCH( avirhip_resize_band )
 
 int avirhip_time_resize( avirhip_plan* p, const void* src, void* dst,
 	int iters, void* stream, double* avg_ms )
+try
 {
 	if( p == nullptr || iters < 1 || avg_ms == nullptr )
 	{
@@ -2682,5 +2843,6 @@ int avirhip_time_resize( avirhip_plan* p, const void* src, void* dst,
 	*avg_ms = (double) ms / iters;
 	return( AVIRHIP_OK );
 }
+AVIRHIP_CATCH( avirhip_time_resize )
 
 } // extern "C"

@@ -10,6 +10,7 @@
 #include <stdlib.h>
 #include <algorithm>
 #include <map>
+#include <memory>
 #include <mutex>
 #include <tuple>
 
@@ -219,6 +220,7 @@ void avirhip_vars_default( avirhip_vars* v )
 
 int avirhip_resizer_create( int res_bit_depth, int src_bit_depth,
 	const avirhip_params* params, avirhip_resizer** out )
+try
 {
 	if( out == nullptr || res_bit_depth < 1 || res_bit_depth > 16 ||
 		src_bit_depth < 0 || src_bit_depth > 16 )
@@ -238,16 +240,20 @@ int avirhip_resizer_create( int res_bit_depth, int src_bit_depth,
 		P = *params;
 	}
 
+	std::unique_ptr< AvirPlanner > pl( new AvirPlanner( res_bit_depth,
+		src_bit_depth, P ));
 	avirhip_resizer* r = new avirhip_resizer();
-	r -> planner = new AvirPlanner( res_bit_depth, src_bit_depth, P );
+	r -> planner = pl.release();
 	r -> dither = AVIRHIP_DITHER_DEF;
 	r -> fppack = 1;
 	r -> f64 = 0;
 	*out = r;
 	return( AVIRHIP_OK );
 }
+AVIRHIP_CATCH( avirhip_resizer_create )
 
 int avirhip_resizer_set_ditherer( avirhip_resizer* r, int dither )
+try
 {
 	if( r == nullptr || ( dither != AVIRHIP_DITHER_DEF &&
 		dither != AVIRHIP_DITHER_ERRD ))
@@ -260,8 +266,10 @@ int avirhip_resizer_set_ditherer( avirhip_resizer* r, int dither )
 	r -> dither = dither;
 	return( AVIRHIP_OK );
 }
+AVIRHIP_CATCH( avirhip_resizer_set_ditherer )
 
 int avirhip_resizer_set_fpclass( avirhip_resizer* r, int fppack )
+try
 {
 	if( r == nullptr || ( fppack != 1 && fppack != 4 &&
 		fppack != AVIRHIP_FPCLASS_DOUBLE ))
@@ -276,6 +284,7 @@ int avirhip_resizer_set_fpclass( avirhip_resizer* r, int fppack )
 	r -> fppack = ( r -> f64 ? 1 : fppack );
 	return( AVIRHIP_OK );
 }
+AVIRHIP_CATCH( avirhip_resizer_set_fpclass )
 
 void avirhip_resizer_destroy( avirhip_resizer* r )
 {
@@ -293,10 +302,17 @@ int avirhip_resizer_build_desc( avirhip_resizer* r, int src_w, int src_h,
 	int src_scanline_size, int new_w, int new_h, int el_count_io, double k,
 	const avirhip_vars* vars, int in_type, int out_type,
 	avirhip_plan_desc** out )
+try
 {
 	if( r == nullptr || out == nullptr )
 	{
 		set_error( "build_desc: null argument" );
+		return( AVIRHIP_EINVAL );
+	}
+
+	if( !geometry_ok( "build_desc", src_w, src_h, src_scanline_size, new_w,
+		new_h, 0, el_count_io, in_type, out_type ))
+	{
 		return( AVIRHIP_EINVAL );
 	}
 
@@ -323,6 +339,7 @@ int avirhip_resizer_build_desc( avirhip_resizer* r, int src_w, int src_h,
 	*out = &S -> d;
 	return( AVIRHIP_OK );
 }
+AVIRHIP_CATCH( avirhip_resizer_build_desc )
 
 void avirhip_plan_desc_free( avirhip_plan_desc* d )
 {
@@ -378,7 +395,9 @@ static int resizer_acquire( avirhip_resizer* r, int src_w, int src_h,
 			return( rc );
 		}
 
+		PlanHold hold( p ); // (the cache's map node may fail to allocate)
 		e = r -> cache.insert( key, p );
+		hold.release();
 	}
 
 	if( pin )
@@ -412,6 +431,7 @@ static void resizer_release( avirhip_resizer* r, avirhip_plan* p )
 int avirhip_resizer_get_plan( avirhip_resizer* r, int src_w, int src_h,
 	int src_scanline_size, int new_w, int new_h, int el_count_io, double k,
 	const avirhip_vars* vars, int in_type, int out_type, avirhip_plan** out )
+try
 {
 	if( r == nullptr || out == nullptr )
 	{
@@ -422,6 +442,7 @@ int avirhip_resizer_get_plan( avirhip_resizer* r, int src_w, int src_h,
 	return( resizer_acquire( r, src_w, src_h, src_scanline_size, new_w, new_h,
 		el_count_io, k, vars, in_type, out_type, true, out ));
 }
+AVIRHIP_CATCH( avirhip_resizer_get_plan )
 
 // CImageResizerVarsBase after resizeImage() (avir.h:2473-2506), from the
 // vertical axis of the plan description. The coordinate pair (k, o) walks the
@@ -528,6 +549,7 @@ int avirhip_resizer_vars_base( avirhip_resizer* r, int src_w, int src_h,
 	int src_scanline_size, int new_w, int new_h, int el_count_io, double k,
 	const avirhip_vars* vars, int in_type, int out_type,
 	avirhip_vars_base* out )
+try
 {
 	if( r == nullptr || out == nullptr )
 	{
@@ -601,11 +623,13 @@ int avirhip_resizer_vars_base( avirhip_resizer* r, int src_w, int src_h,
 	r -> vbcache[ key ] = *out;
 	return( AVIRHIP_OK );
 }
+AVIRHIP_CATCH( avirhip_resizer_vars_base )
 
 int avirhip_resizer_resize( avirhip_resizer* r, const void* src, int src_mem,
 	int src_w, int src_h, int src_scanline_size, void* dst, int dst_mem,
 	int new_w, int new_h, int el_count_io, double k, const avirhip_vars* vars,
 	int in_type, int out_type, void* stream )
+try
 {
 	if( r == nullptr || out_type < 0 || out_type > 3 )
 	{
@@ -659,6 +683,7 @@ int avirhip_resizer_resize( avirhip_resizer* r, const void* src, int src_mem,
 	resizer_release( r, p );
 	return( rc );
 }
+AVIRHIP_CATCH( avirhip_resizer_resize )
 
 void avirhip_lancir_params_default( avirhip_lancir_params* p )
 {
@@ -671,6 +696,7 @@ void avirhip_lancir_params_default( avirhip_lancir_params* p )
 }
 
 int avirhip_lancir_create( avirhip_lancir** out )
+try
 {
 	if( out == nullptr )
 	{
@@ -681,6 +707,7 @@ int avirhip_lancir_create( avirhip_lancir** out )
 	*out = new avirhip_lancir();
 	return( AVIRHIP_OK );
 }
+AVIRHIP_CATCH( avirhip_lancir_create )
 
 void avirhip_lancir_destroy( avirhip_lancir* l )
 {
@@ -696,6 +723,7 @@ void avirhip_lancir_destroy( avirhip_lancir* l )
 int avirhip_lancir_build_desc( avirhip_lancir* l, int src_w, int src_h,
 	int new_w, int new_h, int el_count, const avirhip_lancir_params* params,
 	int in_type, int out_type, avirhip_lancir_desc** out )
+try
 {
 	if( out == nullptr )
 	{
@@ -714,6 +742,12 @@ int avirhip_lancir_build_desc( avirhip_lancir* l, int src_w, int src_h,
 		P = *params;
 	}
 
+	if( !geometry_ok( "lancir_build_desc", src_w, src_h, P.SrcSSize, new_w,
+		new_h, P.NewSSize, el_count, in_type, out_type ))
+	{
+		return( AVIRHIP_EINVAL );
+	}
+
 	DescStore* S = lancir_build( src_w, src_h, new_w, new_h, el_count, P,
 		in_type, out_type );
 
@@ -725,6 +759,7 @@ int avirhip_lancir_build_desc( avirhip_lancir* l, int src_w, int src_h,
 	*out = &S -> ld;
 	return( AVIRHIP_OK );
 }
+AVIRHIP_CATCH( avirhip_lancir_build_desc )
 
 void avirhip_lancir_desc_free( avirhip_lancir_desc* d )
 {
@@ -779,7 +814,9 @@ static int lancir_acquire( avirhip_lancir* l, int src_w, int src_h,
 			return( rc );
 		}
 
+		PlanHold hold( p );
 		e = l -> cache.insert( key, p );
+		hold.release();
 	}
 
 	if( pin )
@@ -813,6 +850,7 @@ static void lancir_release( avirhip_lancir* l, avirhip_plan* p )
 int avirhip_lancir_get_plan( avirhip_lancir* l, int src_w, int src_h,
 	int new_w, int new_h, int el_count, const avirhip_lancir_params* params,
 	int in_type, int out_type, avirhip_plan** out )
+try
 {
 	if( l == nullptr || out == nullptr )
 	{
@@ -823,11 +861,13 @@ int avirhip_lancir_get_plan( avirhip_lancir* l, int src_w, int src_h,
 	return( lancir_acquire( l, src_w, src_h, new_w, new_h, el_count, params,
 		in_type, out_type, true, out ));
 }
+AVIRHIP_CATCH( avirhip_lancir_get_plan )
 
 int avirhip_lancir_resize( avirhip_lancir* l, const void* src, int src_mem,
 	int src_w, int src_h, void* dst, int dst_mem, int new_w, int new_h,
 	int el_count, const avirhip_lancir_params* params, int in_type,
 	int out_type, void* stream )
+try
 {
 	// Parameter errors return 0, lancir.h:392-407.
 	if( l == nullptr || src_w < 0 || src_h < 0 || new_w <= 0 || new_h <= 0 ||
@@ -877,5 +917,6 @@ int avirhip_lancir_resize( avirhip_lancir* l, const void* src, int src_mem,
 	lancir_release( l, p );
 	return( rc != 0 ? rc : new_h );
 }
+AVIRHIP_CATCH( avirhip_lancir_resize )
 
 } // extern "C"

@@ -352,6 +352,8 @@ int launch_pack( const void* src, int in_type, float* dst, int w, int h,
 			launch_pack_px< uint16_t >( src, dst, w, h, ch, src_stride, st );
 		else if( in_type == AVIRHIP_F64 )
 			launch_pack_px< double >( src, dst, w, h, ch, src_stride, st );
+		else if( in_type == AVIRHIP_U32 )
+			launch_pack_px< uint32_t >( src, dst, w, h, ch, src_stride, st );
 		else
 			launch_pack_px< float >( src, dst, w, h, ch, src_stride, st );
 
@@ -372,6 +374,9 @@ int launch_pack( const void* src, int in_type, float* dst, int w, int h,
 	else if( in_type == AVIRHIP_F64 )
 		hipLaunchKernelGGL( k_pack< double >, grd, dim3( 256 ), 0, st,
 			(const double*) src, dst, re, h, src_stride, ch, ech );
+	else if( in_type == AVIRHIP_U32 )
+		hipLaunchKernelGGL( k_pack< uint32_t >, grd, dim3( 256 ), 0, st,
+			(const uint32_t*) src, dst, re, h, src_stride, ch, ech );
 	else
 		hipLaunchKernelGGL( k_pack< float >, grd, dim3( 256 ), 0, st,
 			(const float*) src, dst, re, h, src_stride, ch, ech );
@@ -2049,6 +2054,10 @@ int launch_lancir_generic( const avirhip_plan* p, const void* src, void* dst,
 		launch_lancir_v< uint8_t >( p, src, tmp, row0, nrows, st );
 	else if( p -> in_type == AVIRHIP_U16 )
 		launch_lancir_v< uint16_t >( p, src, tmp, row0, nrows, st );
+	else if( p -> in_type == AVIRHIP_F64 )
+		launch_lancir_v< double >( p, src, tmp, row0, nrows, st ); // (float) ip[ c ]
+	else if( p -> in_type == AVIRHIP_U32 )
+		launch_lancir_v< uint32_t >( p, src, tmp, row0, nrows, st );
 	else
 		launch_lancir_v< float >( p, src, tmp, row0, nrows, st );
 
@@ -2214,6 +2223,10 @@ int launch_lancir_out_pad( const avirhip_plan* p, const float* res, void* dst,
 		launch_out_pad< uint8_t >( p, res, dst, nrows, 0, st );
 	else if( p -> out_type == AVIRHIP_U16 )
 		launch_out_pad< uint16_t >( p, res, dst, nrows, 0, st );
+	else if( p -> out_type == AVIRHIP_U32 )
+		launch_out_pad< uint32_t >( p, res, dst, nrows, 0, st );
+	else if( p -> out_type == AVIRHIP_F64 )
+		launch_out_pad< double >( p, res, dst, nrows, 1, st );
 	else
 		launch_out_pad< float >( p, res, dst, nrows, 1, st );
 
@@ -2228,7 +2241,8 @@ int launch_lancir_out( const avirhip_plan* p, const float* res, long rstride,
 {
 	const size_t oes = ( p -> out_type == AVIRHIP_U8 ? 1 : 2 );
 
-	if( p -> ch == 4 && p -> out_type != AVIRHIP_F32 && ( rstride & 3 ) == 0 &&
+	if( p -> ch == 4 && ( p -> out_type == AVIRHIP_U8 ||
+		p -> out_type == AVIRHIP_U16 ) && ( rstride & 3 ) == 0 &&
 		( (uintptr_t) res & 15 ) == 0 && ( (uintptr_t) dst & ( 4 * oes - 1 )) == 0 &&
 		( p -> new_stride & 3 ) == 0 )
 	{
@@ -2262,6 +2276,11 @@ int launch_lancir_out( const avirhip_plan* p, const float* res, long rstride,
 
 	if( p -> out_type == AVIRHIP_U8 ) { LO( uint8_t, 0 ); }
 	else if( p -> out_type == AVIRHIP_U16 ) { LO( uint16_t, 0 ); }
+	// (uint32_t: the 4-byte integer stores of lancir.h:1869-1887, range 65535)
+	else if( p -> out_type == AVIRHIP_U32 ) { LO( uint32_t, 0 ); }
+	// (double: (T) ip[ i ] or (T) ( ip[ i ] * OutMul ), the product in float,
+	// lancir.h:1786-1856)
+	else if( p -> out_type == AVIRHIP_F64 ) { LO( double, 1 ); }
 	else { LO( float, 1 ); }
 
 #undef LO
@@ -2277,6 +2296,7 @@ int launch_lancir_out( const avirhip_plan* p, const float* res, long rstride,
 extern "C" int avirhip_debug_gamma_u8( const float* dev_rgba, long npx,
 	double tr_mul, int alpha_index, unsigned char* dev_out_table,
 	unsigned char* dev_out_direct, void* stream )
+try
 {
 	using namespace avirhip;
 
@@ -2331,3 +2351,4 @@ extern "C" int avirhip_debug_gamma_u8( const float* dev_rgba, long npx,
 
 	return( AVIRHIP_OK );
 }
+AVIRHIP_CATCH( avirhip_debug_gamma_u8 )

@@ -572,8 +572,11 @@ int lanc2_run( avirhip_plan* p, const float* src, float* dst, int row0,
 		( io == 0 && ( (uintptr_t) dst & 7 )) ||
 		( io == 2 && ( (uintptr_t) p -> lfuse.dst & 1 )) ||
 		( io == 3 && ( (uintptr_t) p -> lfuse.dst & 3 )) ||
-		( p -> src_stride & 1 ) ||
-		(long) p -> src_h * p -> src_stride >= ( 1L << 31 ) ||
+		// (the float image's pitch only matters when it is the one read: an
+		// inner plan reading its owner's integer image was checked on that
+		// image's pitch above, as lanc2_takes_raw() did)
+		( sk == 0 && (( p -> src_stride & 1 ) ||
+		(long) p -> src_h * p -> src_stride >= ( 1L << 31 ))) ||
 		(long) p -> new_w * 4 >= ( 1L << 30 ))
 	{
 		return( 1 );

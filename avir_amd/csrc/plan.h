@@ -49,6 +49,10 @@ __device__ __forceinline__ float avirhip_x86_round_fix( const float a,
 // internal: an inner plan was run without a float result buffer and its path
 // would have written one (exec_device allocates it and runs again)
 #define AVIRHIP_NEED_DST 1001
+// internal: an inner plan was told to read its owner's image as it is
+// (lraw.on) and the kernel that would have done so refused the call: the owner
+// runs the pack pass and calls again with the float copy
+#define AVIRHIP_NEED_SRC 1002
 
 namespace avirhip {
 
@@ -214,7 +218,36 @@ void set_error( const char* fmt, ... );
 #define AVIRHIP_HIPCHECK( expr ) do { hipError_t e_ = ( expr ); \
 	if( e_ != hipSuccess ) { avirhip::set_error( "%s: %s (%s:%d)", #expr, \
 		hipGetErrorString( e_ ), __FILE__, __LINE__ ); \
-		return( AVIRHIP_EHIP ); } } while( 0 )
+		return( e_ == hipErrorOutOfMemory ? AVIRHIP_ENOMEM : AVIRHIP_EHIP ); } } \
+	while( 0 )
+
+// The boundary is exception-tight (include/avirhip.h, "Conventions"): every
+// `extern "C"` entry point is a function-try-block that ends in AVIRHIP_CATCH.
+// guard_fail() runs inside the handler, classifies the exception in flight
+// (std::bad_alloc -> AVIRHIP_ENOMEM, anything else -> AVIRHIP_EINTERNAL) and
+// leaves the message for avirhip_last_error(). The reference's own contract is
+// "no exceptions besides bad_alloc" (avir.h:564-827 CBuffer::alloc); the C++
+// front end (include/avir_hip) turns AVIRHIP_ENOMEM back into std::bad_alloc.
+int guard_fail( const char* fn ) noexcept;
+#define AVIRHIP_CATCH( fn ) catch( ... ) { return( avirhip::guard_fail( #fn )); }
+
+// a * b * c * d without wrapping; false when the product does not fit size_t
+bool mul_fits( size_t a, size_t b, size_t c, size_t d, size_t* out = nullptr );
+// Geometry every entry point checks before it allocates: row lengths in
+// elements fit `int` (the reference computes them in int, avir.h:4786-4794,
+// lancir.h:409-411), image sizes in bytes fit size_t. Sets the error string.
+bool geometry_ok( const char* fn, int src_w, int src_h, long src_stride,
+	int new_w, int new_h, long new_stride, int ch, int in_type, int out_type );
+
+// An owning handle for a plan under construction: a throw between new_plan()
+// and the hand-over destroys it (device tables included).
+struct PlanHold
+{
+	avirhip_plan* p;
+	explicit PlanHold( avirhip_plan* q ) : p( q ) {}
+	~PlanHold();
+	avirhip_plan* release() { avirhip_plan* q = p; p = nullptr; return( q ); }
+};
 
 size_t dtype_size( int t );
 int finalize_avir_plan( avirhip_plan* p ); // api.cpp

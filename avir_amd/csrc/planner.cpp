@@ -414,15 +414,19 @@ namespace avirhip {
 AvirPlanner::AvirPlanner( int res_bit_depth, int src_bit_depth,
 	const avirhip_params& params )
 {
-	impl = new pl32::AvirPlannerImpl();
+	// (built aside: a throw half-way must not leave the object with a
+	// half-built bank)
+	std::unique_ptr< pl32::AvirPlannerImpl > q( new pl32::AvirPlannerImpl() );
+	impl = nullptr;
 	impl64 = nullptr;
-	impl -> P = params;
-	impl -> resBits = res_bit_depth;
-	impl -> srcBits = ( src_bit_depth == 0 ? res_bit_depth : src_bit_depth );
+	q -> P = params;
+	q -> resBits = res_bit_depth;
+	q -> srcBits = ( src_bit_depth == 0 ? res_bit_depth : src_bit_depth );
 
 	// FixedFilterBank, avir.h:4637-4638.
-	impl -> setupBank( impl -> fixedBank, 1.0, false, FirDesign() );
-	impl -> fixedBank.buildAll();
+	q -> setupBank( q -> fixedBank, 1.0, false, FirDesign() );
+	q -> fixedBank.buildAll();
+	impl = q.release();
 }
 
 AvirPlanner::~AvirPlanner()
@@ -439,12 +443,14 @@ DescStore* AvirPlanner::build( int sw, int sh, int sstride, int nw, int nh,
 	{
 		if( impl64 == nullptr )
 		{
-			impl64 = new pl64::AvirPlannerImpl();
-			impl64 -> P = impl -> P;
-			impl64 -> resBits = impl -> resBits;
-			impl64 -> srcBits = impl -> srcBits;
-			impl64 -> setupBank( impl64 -> fixedBank, 1.0, false, FirDesign() );
-			impl64 -> fixedBank.buildAll();
+			std::unique_ptr< pl64::AvirPlannerImpl > q(
+				new pl64::AvirPlannerImpl() );
+			q -> P = impl -> P;
+			q -> resBits = impl -> resBits;
+			q -> srcBits = impl -> srcBits;
+			q -> setupBank( q -> fixedBank, 1.0, false, FirDesign() );
+			q -> fixedBank.buildAll();
+			impl64 = q.release();
 		}
 
 		return( pl64::build_impl( *impl64, sw, sh, sstride, nw, nh, ch, k, vars,
@@ -658,8 +664,8 @@ DescStore* lancir_build( int sw, int sh, int nw, int nh, int ch,
 	const avirhip_lancir_params& P, int in_type, int out_type )
 {
 	if( sw < 1 || sh < 1 || nw < 1 || nh < 1 || ch < 1 || ch > 4 ||
-		P.la < 2.0 || in_type < 0 || in_type > 2 || out_type < 0 ||
-		out_type > 2 )
+		P.la < 2.0 || in_type < 0 || in_type > AVIRHIP_U32 || out_type < 0 ||
+		out_type > AVIRHIP_U32 )
 	{
 		set_error( "lancir planner: bad arguments" );
 		return( nullptr );
@@ -714,10 +720,15 @@ DescStore* lancir_build( int sw, int sh, int nw, int nh, int ch,
 	d.in_type = in_type; d.out_type = out_type;
 
 	// Output constants, lancir.h:526-533.
-	const bool inFloat = ( in_type >= AVIRHIP_F32 );
-	const bool outFloat = ( out_type >= AVIRHIP_F32 );
-	const int szin = ( in_type == AVIRHIP_U8 ? 1 : in_type == AVIRHIP_U16 ? 2 : 4 );
-	const int szout = ( out_type == AVIRHIP_U8 ? 1 : out_type == AVIRHIP_U16 ? 2 : 4 );
+	// Tin / Tout: uint8_t, uint16_t, float, double, and uint32_t "treated as
+	// uint16_t" (lancir.h:373-381) -- what the reference derives from the types
+	// is IsInFloat / IsOutFloat and sizeof() (a uint32_t is a non-float of size
+	// 4: range 65535, but never "the same size" as a uint16_t)
+	const bool inFloat = ( in_type == AVIRHIP_F32 || in_type == AVIRHIP_F64 );
+	const bool outFloat = ( out_type == AVIRHIP_F32 || out_type == AVIRHIP_F64 );
+	static const int tsz[ 5 ] = { 1, 2, 4, 8, 4 };
+	const int szin = tsz[ in_type ];
+	const int szout = tsz[ out_type ];
 	d.is_unity_mul = (( inFloat && outFloat ) ||
 		( inFloat == outFloat && szin == szout )) ? 1 : 0;
 	d.clamp = ( szout == 1 ? 255.0f : 65535.0f );

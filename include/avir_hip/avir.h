@@ -32,6 +32,7 @@
 #define AVIR_HIP_AVIR_H
 
 #include <stdint.h>
+#include <new>
 #include <stdexcept>
 #include <string>
 #include "../avirhip.h"
@@ -200,8 +201,16 @@ template<> struct dtype_of< uint16_t > { static const int v = AVIRHIP_U16; };
 template<> struct dtype_of< float > { static const int v = AVIRHIP_F32; };
 template<> struct dtype_of< double > { static const int v = AVIRHIP_F64; };
 
+/* Memory exhaustion comes back from the library as a code (no exception
+ * crosses its C boundary) and leaves here as what the reference itself throws,
+ * std::bad_alloc (avir.h:564-827 CBuffer :: alloc). */
 inline void check( const int rc, const char* const what )
 {
+	if( rc == AVIRHIP_ENOMEM )
+	{
+		throw std::bad_alloc();
+	}
+
 	if( rc < 0 )
 	{
 		throw std::runtime_error( std::string( what ) + ": " +

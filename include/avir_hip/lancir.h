@@ -12,12 +12,16 @@
  * as HIP kernels on gfx950 with the x86 SSE2/AVX summation order of the
  * reference (bit-identical results). Device or host pointers are accepted.
  * There is no CPU execution path: a request the device library cannot run
- * throws std::runtime_error.
+ * throws std::runtime_error. Memory exhaustion (AVIRHIP_ENOMEM from the
+ * library, which itself lets no exception out) is rethrown here as
+ * std::bad_alloc -- what the reference's own `new[]` would have thrown
+ * (lancir.h:769-815 reallocBuf).
  */
 #ifndef AVIR_HIP_LANCIR_H
 #define AVIR_HIP_LANCIR_H
 
 #include <stdint.h>
+#include <new>
 #include <stdexcept>
 #include <string>
 #include "../avirhip.h"
@@ -64,7 +68,14 @@ public:
 	CLancIR()
 		: h( nullptr )
 	{
-		if( avirhip_lancir_create( &h ) < 0 )
+		const int rc = avirhip_lancir_create( &h );
+
+		if( rc == AVIRHIP_ENOMEM )
+		{
+			throw std::bad_alloc();
+		}
+
+		if( rc < 0 )
 		{
 			throw std::runtime_error( avirhip_last_error() );
 		}
@@ -97,6 +108,11 @@ public:
 			SrcWidth, SrcHeight, NewBuf, AVIRHIP_MEM_AUTO, NewWidth,
 			NewHeight, ElCount, &p, dt< Tin > :: v, dt< Tout > :: v, nullptr );
 
+		if( rc == AVIRHIP_ENOMEM )
+		{
+			throw std::bad_alloc();
+		}
+
 		if( rc < 0 )
 		{
 			throw std::runtime_error( std::string(
@@ -127,6 +143,10 @@ private:
 template<> struct CLancIR :: dt< uint8_t > { static const int v = AVIRHIP_U8; };
 template<> struct CLancIR :: dt< uint16_t > { static const int v = AVIRHIP_U16; };
 template<> struct CLancIR :: dt< float > { static const int v = AVIRHIP_F32; };
+template<> struct CLancIR :: dt< double > { static const int v = AVIRHIP_F64; };
+/* "`uint32_t` type is treated as `uint16_t`" (lancir.h:376-377): 32-bit
+ * elements, 0..65535 value range. */
+template<> struct CLancIR :: dt< uint32_t > { static const int v = AVIRHIP_U32; };
 
 } // namespace avir
 

@@ -11,11 +11,17 @@
  * host, and hands the immutable plan + the two image buffers across this ABI.
  * See INTEGRATION.md for the reference-side stub.
  *
- * Conventions: plain C, plain pointers and sizes, no C++ exceptions cross the
- * boundary. Every function returning `int` returns 0 on success and a negative
- * AVIRHIP_E* code on error; avirhip_last_error() returns a thread-local
- * message. The library copies every table it is given; the caller keeps
- * ownership of its arrays.
+ * Conventions: plain C, plain pointers and sizes. Every function returning
+ * `int` returns 0 on success and a negative AVIRHIP_E* code on error;
+ * avirhip_last_error() returns a thread-local message. No C++ exception
+ * crosses the boundary: every entry point is a function-try-block, a failed
+ * host allocation comes back as AVIRHIP_ENOMEM (a failed device allocation as
+ * AVIRHIP_EHIP / AVIRHIP_ENOMEM), anything else as AVIRHIP_EINTERNAL, and the
+ * object the call worked on stays usable. Image geometries whose element or
+ * byte counts do not fit the reference's own `int` / `size_t` arithmetic
+ * (avir.h:4786-4794, lancir.h:409-430) are refused with AVIRHIP_EINVAL before
+ * anything is allocated. The library copies every table it is given; the
+ * caller keeps ownership of its arrays.
  */
 #ifndef AVIRHIP_H
 #define AVIRHIP_H
@@ -32,7 +38,9 @@ extern "C" {
 #define AVIRHIP_ENODEV (-2)      /* no usable gfx950 device */
 #define AVIRHIP_EHIP (-3)        /* HIP runtime error (see last_error) */
 #define AVIRHIP_EUNSUPPORTED (-4)/* valid request outside the built scope */
-#define AVIRHIP_ENOMEM (-5)
+#define AVIRHIP_ENOMEM (-5)       /* host or device memory exhausted */
+#define AVIRHIP_EINTERNAL (-6)    /* an unexpected C++ exception was caught at the
+                                     boundary (never crosses it; see last_error) */
 
 /* Element types of the source / destination image (Tin/Tout of
  * resizeImage<Tin,Tout>, avir.h:4670-4677; lancir.h:373-381). */
@@ -40,7 +48,11 @@ typedef enum avirhip_dtype {
 	AVIRHIP_U8 = 0,
 	AVIRHIP_U16 = 1,
 	AVIRHIP_F32 = 2,
-	AVIRHIP_F64 = 3
+	AVIRHIP_F64 = 3,
+	/* CLancIR only: 32-bit unsigned elements whose value range is treated as
+	 * uint16_t's, 0..65535 (lancir.h:373-377; Clamp / OutMul derive from
+	 * sizeof() == 1 or not, lancir.h:531-533). */
+	AVIRHIP_U32 = 4
 } avirhip_dtype;
 
 /* Where a buffer passed to an execute call lives. */
@@ -460,6 +472,14 @@ int avirhip_lancir_resize(avirhip_lancir* l, const void* src, int src_mem,
 int avirhip_lancir_get_plan(avirhip_lancir* l, int src_w, int src_h,
 	int new_w, int new_h, int el_count, const avirhip_lancir_params* params,
 	int in_type, int out_type, avirhip_plan** out);
+
+/* Test hook: the `nth` host allocation (operator new) the CALLING THREAD makes
+ * inside the library from now on throws std::bad_alloc (1 = the next one;
+ * 0 = off). tests/test_abi.py sweeps it over every allocation of the planning
+ * and plan-creation entry points: each must return AVIRHIP_ENOMEM with a
+ * message -- never abort the process. Returns the allocations counted on this
+ * thread since the previous call. */
+long avirhip_debug_fail_alloc(long nth);
 
 /* Test hook: the uint8 sRGB-gamma output stage (applySRGBGamma + default
  * ditherer + unpackScanline, avir.h:2982-3068, 4392-4419, 3155-3215) applied to

@@ -24,6 +24,22 @@ def test_reference_style_program_compiles_and_links():
     assert os.path.exists(EXE)
 
 
+def test_memory_exhaustion_surfaces_as_bad_alloc(tmp_path):
+    """AVIRHIP_ENOMEM from the C ABI becomes std::bad_alloc in the C++ front
+    end, as in the reference (no GPU needed: the planner fails first)."""
+    lib = os.path.join(ROOT, "avir_amd", "lib")
+    exe = str(tmp_path / "bad_alloc")
+    subprocess.run(["g++", "-O1", "-std=c++11",
+                    "-I" + os.path.join(ROOT, "include", "avir_hip"),
+                    os.path.join(ROOT, "tests", "cpp", "bad_alloc.cpp"),
+                    "-L" + lib, "-lavirhip", "-Wl,-rpath," + lib,
+                    "-Wl,-rpath-link,/opt/rocm/lib", "-o", exe], check=True)
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0 and out.stdout.strip().endswith("OK"), \
+        out.stdout + out.stderr
+    assert out.stdout.count("bad_alloc") >= 8
+
+
 @pytest.mark.gpu
 def test_reference_style_program_matches_reference():
     _build()
