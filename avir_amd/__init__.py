@@ -176,6 +176,21 @@ class CImageResizer(object):
             C.byref(p)), "avirhip_resizer_get_plan")
         return p
 
+    def band_source_rows(self, SrcWidth, SrcHeight, NewWidth, NewHeight,
+                         ElCountIO, row0, row1, k=0.0, aVars=None,
+                         in_type=F32, out_type=F32, SrcScanlineSize=0):
+        """The source rows (first, last), inclusive, that output rows
+        [row0, row1) read -- from the host planner alone, no GPU needed
+        (avirhip_resizer_band_source_rows; SURVEY.md 8e: what a sharded frame's
+        rank has to receive)."""
+        a, b = C.c_int(), C.c_int()
+        abi.check(self._lib.avirhip_resizer_band_source_rows(
+            self._h, SrcWidth, SrcHeight, SrcScanlineSize, NewWidth, NewHeight,
+            ElCountIO, float(k), C.byref(aVars) if aVars is not None else None,
+            in_type, out_type, row0, row1, C.byref(a), C.byref(b)),
+            "avirhip_resizer_band_source_rows")
+        return a.value, b.value
+
     # Convenience (not part of the reference API).
     def resize(self, src, NewWidth, NewHeight, k=0.0, out_dtype=None,
                aVars=None):
@@ -247,6 +262,18 @@ class CLancIR(object):
             C.byref(aParams) if aParams is not None else None, in_type,
             out_type, C.byref(p)), "avirhip_lancir_get_plan")
         return p
+
+    def band_source_rows(self, SrcWidth, SrcHeight, NewWidth, NewHeight,
+                         ElCount, row0, row1, aParams=None, in_type=F32,
+                         out_type=F32):
+        """(first, last) source rows of output rows [row0, row1); host only."""
+        a, b = C.c_int(), C.c_int()
+        abi.check(self._lib.avirhip_lancir_band_source_rows(
+            self._h, SrcWidth, SrcHeight, NewWidth, NewHeight, ElCount,
+            C.byref(aParams) if aParams is not None else None, in_type,
+            out_type, row0, row1, C.byref(a), C.byref(b)),
+            "avirhip_lancir_band_source_rows")
+        return a.value, b.value
 
     def resize(self, src, NewWidth, NewHeight, out_dtype=None, aParams=None):
         h, w, ch = src.shape

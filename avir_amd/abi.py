@@ -150,6 +150,7 @@ PROTOTYPES = {
     "avirhip_resize_band": (_I, [_VP, _VP, _I, _VP, _I, _I, _I, _VP]),
     "avirhip_band_source_rows": (_I, [_VP, _I, _I, C.POINTER(C.c_int),
                                       C.POINTER(C.c_int)]),
+    "avirhip_resize_window": (_I, [_VP, _VP, _I, _I, _I, _VP, _I, _I, _I, _VP]),
     "avirhip_resize_sharded": (_I, [_VP, _I, C.POINTER(C.c_int), _VP, _VP, _I,
                                  C.POINTER(_D), C.POINTER(_D)]),
     "avirhip_time_resize": (_I, [_VP, _VP, _VP, _I, _VP, C.POINTER(_D)]),
@@ -171,6 +172,14 @@ PROTOTYPES = {
     "avirhip_resizer_vars_base": (_I, [_VP, _I, _I, _I, _I, _I, _I, _D,
                                        C.POINTER(Vars), _I, _I,
                                        C.POINTER(VarsBase)]),
+    "avirhip_resizer_band_source_rows": (_I, [_VP, _I, _I, _I, _I, _I, _I, _D,
+                                              C.POINTER(Vars), _I, _I, _I, _I,
+                                              C.POINTER(C.c_int),
+                                              C.POINTER(C.c_int)]),
+    "avirhip_lancir_band_source_rows": (_I, [_VP, _I, _I, _I, _I, _I,
+                                             C.POINTER(LancirParams), _I, _I,
+                                             _I, _I, C.POINTER(C.c_int),
+                                             C.POINTER(C.c_int)]),
     "avirhip_resizer_get_plan": (_I, [_VP, _I, _I, _I, _I, _I, _I, _D,
                                       C.POINTER(Vars), _I, _I, C.POINTER(_VP)]),
     "avirhip_lancir_params_default": (None, [C.POINTER(LancirParams)]),

@@ -1195,6 +1195,43 @@ static int clone_plan( const avirhip_plan* s, int device, avirhip_plan** out );
 // filter positions (LANCIR). Rows outside the range are never touched by a band
 // call -- not even by a tap that multiplies them by zero (a stale or foreign
 // NaN there must not reach the result; tools/fuzz_values.py poisons them).
+void axis_src_range( const LAxis& ax, int row0, int row1, int src_len,
+	int* first, int* last )
+{
+	int a = row0, b = row1 - 1;
+
+	for( int i = (int) ax.ops.size() - 1; i >= 0; i-- )
+	{
+		int ia, ib;
+		const LOp& op = ax.ops[ i ];
+		need_range( op, std::max( 0, std::min( a, op.out_len - 1 )),
+			std::max( 0, std::min( b, op.out_len - 1 )), ia, ib );
+		a = ia;
+		b = ib;
+	}
+
+	*first = std::max( 0, std::min( a, src_len - 1 ));
+	*last = std::max( 0, std::min( b, src_len - 1 ));
+}
+
+// (host only: the planner front end answers avirhip_*_band_source_rows for a
+// geometry without creating a device plan)
+int desc_band_src_rows( const avirhip_plan_desc* d, int row0, int row1,
+	int* first, int* last )
+{
+	LAxis v;
+	const int rc = lower_axis( d -> v, d -> src_h, d -> new_h, v,
+		d -> work_f64 != 0 );
+
+	if( rc != 0 )
+	{
+		return( rc );
+	}
+
+	axis_src_range( v, row0, row1, d -> src_h, first, last );
+	return( AVIRHIP_OK );
+}
+
 static void band_src_rows( const avirhip_plan* p, int row0, int row1,
 	int* first, int* last )
 {
@@ -1214,20 +1251,7 @@ static void band_src_rows( const avirhip_plan* p, int row0, int row1,
 		return;
 	}
 
-	int a = row0, b = row1 - 1;
-
-	for( int i = (int) p -> v.ops.size() - 1; i >= 0; i-- )
-	{
-		int ia, ib;
-		const LOp& op = p -> v.ops[ i ];
-		need_range( op, std::max( 0, std::min( a, op.out_len - 1 )),
-			std::max( 0, std::min( b, op.out_len - 1 )), ia, ib );
-		a = ia;
-		b = ib;
-	}
-
-	*first = std::max( 0, std::min( a, p -> src_h - 1 ));
-	*last = std::max( 0, std::min( b, p -> src_h - 1 ));
+	axis_src_range( p -> v, row0, row1, p -> src_h, first, last );
 }
 
 static int band_last_src_row( const avirhip_plan* p, int row0, int row1 )
@@ -1505,8 +1529,11 @@ static int exec_host_pipelined( avirhip_plan* p, const void* src, void* dst,
 }
 
 
+// `win_rows` > 0: `src` holds only the source rows [win_first, win_first +
+// win_rows) of the frame (avirhip_resize_window); otherwise the whole frame.
 static int exec_any( avirhip_plan* p, const void* src, int src_mem, void* dst,
-	int dst_mem, int row0, int row1, void* stream, bool have_lock = false )
+	int dst_mem, int row0, int row1, void* stream, bool have_lock = false,
+	int win_first = 0, int win_rows = 0 )
 {
 	src_mem = avirhip_resolve_mem( src, src_mem );
 	dst_mem = avirhip_resolve_mem( dst, dst_mem );
@@ -1516,6 +1543,24 @@ static int exec_any( avirhip_plan* p, const void* src, int src_mem, void* dst,
 	{
 		set_error( "bad execute arguments" );
 		return( AVIRHIP_EINVAL );
+	}
+
+	const bool windowed = ( win_rows > 0 );
+
+	if( windowed )
+	{
+		int need_a = 0, need_b = -1;
+		band_src_rows( p, row0, row1, &need_a, &need_b );
+
+		if( win_first < 0 || win_first + win_rows > p -> src_h ||
+			( need_b >= need_a && ( need_a < win_first ||
+			need_b >= win_first + win_rows )))
+		{
+			set_error( "resize_window: output rows [%d, %d) read source rows "
+				"[%d, %d], the window holds [%d, %d)", row0, row1, need_a,
+				need_b, win_first, win_first + win_rows );
+			return( AVIRHIP_EINVAL );
+		}
 	}
 
 	if( !p -> is_lancir && p -> dither == AVIRHIP_DITHER_ERRD &&
@@ -1551,12 +1596,16 @@ static int exec_any( avirhip_plan* p, const void* src, int src_mem, void* dst,
 	// single-launch 2x kernels, skips this.
 	const size_t src_bytes = ( (size_t) ( p -> src_h - 1 ) * p -> src_stride +
 		(size_t) p -> src_w * p -> io_ch ) * dtype_size( p -> in_type );
+	// (what `src` addresses: the frame, or the rows of a window)
+	const size_t win_bytes = ( !windowed ? src_bytes :
+		( (size_t) ( win_rows - 1 ) * p -> src_stride +
+		(size_t) p -> src_w * p -> io_ch ) * dtype_size( p -> in_type ));
 	const size_t row_bytes = (size_t) p -> new_stride *
 		dtype_size( p -> out_type );
 	const size_t dst_bytes = ( row1 > row0 ?
 		(size_t) ( row1 - row0 - 1 ) * row_bytes + (size_t) p -> new_w *
 		p -> io_ch * dtype_size( p -> out_type ) : 0 );
-	const bool overlap = ( src_mem == AVIRHIP_MEM_DEVICE &&
+	const bool overlap = ( !windowed && src_mem == AVIRHIP_MEM_DEVICE &&
 		dst_mem == AVIRHIP_MEM_DEVICE &&
 		(const char*) src < (const char*) dst + dst_bytes &&
 		(const char*) dst < (const char*) src + src_bytes );
@@ -1564,7 +1613,8 @@ static int exec_any( avirhip_plan* p, const void* src, int src_mem, void* dst,
 	const int xpath = ( p -> path != 0 ? p -> path : p -> auto_path );
 	// (CLancIR is not thread-safe in the reference either, lancir.h:319-349:
 	// its plans always take the lock, and may allocate scratch under it)
-	const bool scratch_free = ( !p -> is_lancir && !overlap && xpath == 4 &&
+	const bool scratch_free = ( !p -> is_lancir && !overlap && !windowed &&
+		xpath == 4 &&
 		p -> in_type == AVIRHIP_F32 &&
 		p -> out_type == AVIRHIP_F32 && p -> ch == p -> io_ch &&
 		!p -> gamma && src_mem == AVIRHIP_MEM_DEVICE &&
@@ -1626,7 +1676,7 @@ static int exec_any( avirhip_plan* p, const void* src, int src_mem, void* dst,
 				std::adopt_lock );
 
 			return( exec_any( spare, src, src_mem, dst, dst_mem, row0, row1,
-				stream, true ));
+				stream, true, win_first, win_rows ));
 		}
 
 		guard.lock();
@@ -1715,7 +1765,7 @@ static int exec_any( avirhip_plan* p, const void* src, int src_mem, void* dst,
 	const void* dsrc = src;
 	void* ddst = dst;
 
-	if( src_mem == AVIRHIP_MEM_HOST )
+	if( src_mem == AVIRHIP_MEM_HOST || windowed )
 	{
 		if( p -> stage_src_bytes < src_bytes )
 		{
@@ -1727,6 +1777,19 @@ static int exec_any( avirhip_plan* p, const void* src, int src_mem, void* dst,
 		}
 
 		dsrc = p -> stage_src;
+	}
+
+	// A window's rows go to their place in the plan's frame-sized staging
+	// buffer -- the only source bytes that move ("GPU g receives
+	// source rows [r0 - halo, r1 + halo]"); the kernels then run as on a whole
+	// frame, and whatever they load outside the window never reaches a result
+	// (avirhip_band_source_rows).
+	if( windowed )
+	{
+		AVIRHIP_HIPCHECK( hipMemcpyAsync( (char*) p -> stage_src +
+			(size_t) win_first * p -> src_stride * dtype_size( p -> in_type ),
+			src, win_bytes, ( src_mem == AVIRHIP_MEM_HOST ?
+			hipMemcpyHostToDevice : hipMemcpyDeviceToDevice ), st ));
 	}
 
 	// NewBuf may alias SrcBuf (avir.h:4650-4652: allowed when the result is
@@ -1772,7 +1835,7 @@ static int exec_any( avirhip_plan* p, const void* src, int src_mem, void* dst,
 		(const char*) dst < (const char*) src + src_bytes );
 
 	if( src_mem == AVIRHIP_MEM_HOST && dst_mem == AVIRHIP_MEM_HOST &&
-		!host_alias && row0 == 0 && row1 == p -> new_h &&
+		!windowed && !host_alias && row0 == 0 && row1 == p -> new_h &&
 		(size_t) p -> new_w * p -> io_ch * dtype_size( p -> out_type ) ==
 		row_bytes )
 	{
@@ -1785,7 +1848,7 @@ static int exec_any( avirhip_plan* p, const void* src, int src_mem, void* dst,
 		}
 	}
 
-	if( src_mem == AVIRHIP_MEM_HOST )
+	if( src_mem == AVIRHIP_MEM_HOST && !windowed )
 	{
 		AVIRHIP_HIPCHECK( hipMemcpyAsync( p -> stage_src, src, src_bytes,
 			hipMemcpyHostToDevice, st ));
@@ -2806,6 +2869,22 @@ try
 		stream ));
 }
 AVIRHIP_CATCH( avirhip_resize_band )
+
+int avirhip_resize_window( avirhip_plan* p, const void* src_rows, int src_mem,
+	int first_row, int n_rows, void* dst_band, int dst_mem, int row0, int row1,
+	void* stream )
+try
+{
+	if( p == nullptr || n_rows < 1 )
+	{
+		set_error( "resize_window: bad arguments" );
+		return( AVIRHIP_EINVAL );
+	}
+
+	return( exec_any( p, src_rows, src_mem, dst_band, dst_mem, row0, row1,
+		stream, false, first_row, n_rows ));
+}
+AVIRHIP_CATCH( avirhip_resize_window )
 
 int avirhip_time_resize( avirhip_plan* p, const void* src, void* dst,
 	int iters, void* stream, double* avg_ms )

@@ -349,6 +349,35 @@ void avirhip_plan_desc_free( avirhip_plan_desc* d )
 	}
 }
 
+int avirhip_resizer_band_source_rows( avirhip_resizer* r, int src_w, int src_h,
+	int src_scanline_size, int new_w, int new_h, int el_count_io, double k,
+	const avirhip_vars* vars, int in_type, int out_type, int row0, int row1,
+	int* first, int* last )
+try
+{
+	if( r == nullptr || first == nullptr || last == nullptr || row0 < 0 ||
+		row1 > new_h || row1 <= row0 )
+	{
+		set_error( "resizer_band_source_rows: bad arguments" );
+		return( AVIRHIP_EINVAL );
+	}
+
+	avirhip_plan_desc* d = nullptr;
+	int rc = avirhip_resizer_build_desc( r, src_w, src_h, src_scanline_size,
+		new_w, new_h, el_count_io, k, vars, in_type, out_type, &d );
+
+	if( rc != 0 )
+	{
+		return( rc );
+	}
+
+	struct Free { avirhip_plan_desc* d; ~Free() { avirhip_plan_desc_free( d ); } }
+		fr = { d };
+
+	return( desc_band_src_rows( d, row0, row1, first, last ));
+}
+AVIRHIP_CATCH( avirhip_resizer_band_source_rows )
+
 // Finds or builds the plan of a call. `pin`: the handle leaves the library
 // (never evicted); otherwise the entry is marked busy until release().
 static int resizer_acquire( avirhip_resizer* r, int src_w, int src_h,
@@ -768,6 +797,39 @@ void avirhip_lancir_desc_free( avirhip_lancir_desc* d )
 		delete (DescStore*) ( (char*) d - offsetof( DescStore, ld ));
 	}
 }
+
+int avirhip_lancir_band_source_rows( avirhip_lancir* l, int src_w, int src_h,
+	int new_w, int new_h, int el_count, const avirhip_lancir_params* params,
+	int in_type, int out_type, int row0, int row1, int* first, int* last )
+try
+{
+	if( first == nullptr || last == nullptr || row0 < 0 || row1 > new_h ||
+		row1 <= row0 )
+	{
+		set_error( "lancir_band_source_rows: bad arguments" );
+		return( AVIRHIP_EINVAL );
+	}
+
+	avirhip_lancir_desc* d = nullptr;
+	const int rc = avirhip_lancir_build_desc( l, src_w, src_h, new_w, new_h,
+		el_count, params, in_type, out_type, &d );
+
+	if( rc != 0 )
+	{
+		return( rc );
+	}
+
+	// the vertical windows in un-padded coordinates, clamped to the image
+	// (edge replication of the padding, lancir.h:1541-1594)
+	const avirhip_lancir_axis& v = d -> v;
+	const int a = v.pos[ row0 ].so - v.padl;
+	const int b = v.pos[ row1 - 1 ].so - v.padl + v.kernel_len - 1;
+	*first = std::max( 0, std::min( a, src_h - 1 ));
+	*last = std::max( 0, std::min( b, src_h - 1 ));
+	avirhip_lancir_desc_free( d );
+	return( AVIRHIP_OK );
+}
+AVIRHIP_CATCH( avirhip_lancir_band_source_rows )
 
 static int lancir_acquire( avirhip_lancir* l, int src_w, int src_h,
 	int new_w, int new_h, int el_count, const avirhip_lancir_params* params,

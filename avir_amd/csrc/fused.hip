@@ -940,8 +940,7 @@ static int launch_tiles( avirhip_plan* p, const TileGeom& G, bool useh,
 	P.maxA = G.maxA; P.maxB = G.maxB; P.maxC = G.maxC;
 
 	const int ntiles = G.ntx * ( ty1 - P.ty0 + 1 );
-	AVIRHIP_HIPCHECK( hipFuncSetAttribute( (const void*) k_tile,
-		hipFuncAttributeMaxDynamicSharedMemorySize, (int) G.lds ));
+	AVIRHIP_HIPCHECK( AVIRHIP_DYN_LDS( k_tile, G.lds ));
 
 #ifdef U2_DBG
 	static unsigned long long* dclk = nullptr;

@@ -1707,18 +1707,16 @@ int launch_errd( const float* res, void* dst, int out_type, int w, int h,
 
 			if( out_type == AVIRHIP_U8 )
 			{
-				AVIRHIP_HIPCHECK( hipFuncSetAttribute(
-					(const void*) k_errd_mp< uint8_t >,
-					hipFuncAttributeMaxDynamicSharedMemorySize, EJ_LDS ));
+				AVIRHIP_HIPCHECK( AVIRHIP_DYN_LDS(( k_errd_mp< uint8_t > ),
+					EJ_LDS ));
 				hipLaunchKernelGGL(( k_errd_mp< uint8_t > ), grid, dim3( 512 ),
 					EJ_LDS, st, res, (uint8_t*) dst, w, h, ch, trm, trmi, pk,
 					gamma, alpha_index, ogm, line, flags, epoch, p0 );
 			}
 			else
 			{
-				AVIRHIP_HIPCHECK( hipFuncSetAttribute(
-					(const void*) k_errd_mp< uint16_t >,
-					hipFuncAttributeMaxDynamicSharedMemorySize, EJ_LDS ));
+				AVIRHIP_HIPCHECK( AVIRHIP_DYN_LDS(( k_errd_mp< uint16_t > ),
+					EJ_LDS ));
 				hipLaunchKernelGGL(( k_errd_mp< uint16_t > ), grid, dim3( 512 ),
 					EJ_LDS, st, res, (uint16_t*) dst, w, h, ch, trm, trmi, pk,
 					gamma, alpha_index, ogm, line, flags, epoch, p0 );

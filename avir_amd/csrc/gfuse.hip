@@ -356,8 +356,7 @@ int gfuse_launch( GFParams& P, double k_v, hipStream_t st )
 	const int nch = ( rows + P.chunk - 1 ) / P.chunk;
 	const size_t lds = lds_fix + (size_t) P.chunk * ( 12 + 1 ) * 4 + 64;
 
-	AVIRHIP_HIPCHECK( hipFuncSetAttribute( (const void*) k_gf,
-		hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds ));
+	AVIRHIP_HIPCHECK( AVIRHIP_DYN_LDS( k_gf, lds ));
 
 	hipLaunchKernelGGL( k_gf, dim3( P.nstrips * nch ), dim3( 64 ), lds, st, P );
 	AVIRHIP_HIPCHECK( hipGetLastError() );

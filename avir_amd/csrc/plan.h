@@ -19,6 +19,7 @@
 #include <stdint.h>
 #include <string>
 #include <vector>
+#include <atomic>
 #include <mutex>
 #include <thread>
 #include "../../include/avirhip.h"
@@ -231,6 +232,36 @@ void set_error( const char* fmt, ... );
 int guard_fail( const char* fn ) noexcept;
 #define AVIRHIP_CATCH( fn ) catch( ... ) { return( avirhip::guard_fail( #fn )); }
 
+// hipFuncAttributeMaxDynamicSharedMemorySize belongs to a loaded function on a
+// device, not to a launch: it is raised when a launch needs more dynamic LDS
+// than any earlier one asked for, not once per frame (a driver call on the hot
+// path otherwise). `have` is the call site's own record, one slot per device.
+inline hipError_t ensure_dyn_lds( const void* fn, const size_t bytes,
+	std::atomic< int >* have )
+{
+	int dev = 0;
+	(void) hipGetDevice( &dev );
+	std::atomic< int >& h = have[ dev & 31 ];
+
+	if( h.load( std::memory_order_relaxed ) >= (int) bytes )
+	{
+		return( hipSuccess );
+	}
+
+	const hipError_t e = hipFuncSetAttribute( fn,
+		hipFuncAttributeMaxDynamicSharedMemorySize, (int) bytes );
+
+	if( e == hipSuccess )
+	{
+		h.store( (int) bytes, std::memory_order_relaxed );
+	}
+
+	return( e );
+}
+#define AVIRHIP_DYN_LDS( fn, bytes ) ( [&]() -> hipError_t { \
+	static std::atomic< int > have_[ 32 ]; \
+	return( avirhip::ensure_dyn_lds( (const void*) ( fn ), ( bytes ), have_ )); }() )
+
 // a * b * c * d without wrapping; false when the product does not fit size_t
 bool mul_fits( size_t a, size_t b, size_t c, size_t d, size_t* out = nullptr );
 // Geometry every entry point checks before it allocates: row lengths in
@@ -274,6 +305,12 @@ bool gamma_u8_thresholds( float ogm, int use_tr, float trm, float trmi,
 	float pk, float* thr );
 // the input range [ia, ib] an op reads for outputs [a, b] (api.cpp)
 void need_range( const LOp& op, int a, int b, int& ia, int& ib );
+// the source rows [*first, *last] the outputs [row0, row1) of a lowered axis
+// read; the same from a plan description's vertical axis (host only)
+void axis_src_range( const LAxis& ax, int row0, int row1, int src_len,
+	int* first, int* last );
+int desc_band_src_rows( const avirhip_plan_desc* d, int row0, int row1,
+	int* first, int* last );
 
 // generic64.hip: the double pipeline (plan -> f64), output rows [row0, row1)
 int exec_f64( avirhip_plan* p, const void* src, void* dst, int row0, int row1,

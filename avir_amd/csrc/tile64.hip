@@ -656,8 +656,7 @@ template< int CH >
 static void launch_h64( const T64Params& P, int in_type, int ntiles, size_t lds,
 	hipStream_t st )
 {
-#define TH( T ) do { (void) hipFuncSetAttribute( (const void*) k_h64< CH, T >, \
-	hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds ); \
+#define TH( T ) do { (void) AVIRHIP_DYN_LDS(( k_h64< CH, T > ), lds ); \
 	hipLaunchKernelGGL(( k_h64< CH, T > ), dim3( ntiles ), dim3( 256 ), lds, st, \
 	P ); } while( 0 )
 
@@ -675,8 +674,7 @@ template< int CH >
 static void launch_v64( const T64Params& P, int out_type, int ntiles,
 	size_t lds, hipStream_t st )
 {
-#define TV( T ) do { (void) hipFuncSetAttribute( (const void*) k_v64< CH, T >, \
-	hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds ); \
+#define TV( T ) do { (void) AVIRHIP_DYN_LDS(( k_v64< CH, T > ), lds ); \
 	hipLaunchKernelGGL(( k_v64< CH, T > ), dim3( ntiles ), dim3( 256 ), lds, st, \
 	P ); } while( 0 )
 

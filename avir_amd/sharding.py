@@ -4,8 +4,10 @@
 The path shards two ways:
   * one frame split into contiguous output-row bands, one per rank, computed
     with avirhip_resize_band() (global indices => bit-identical to the rows of
-    a full resize) and stitched on a root rank with point-to-point transfers
-    over xGMI -- BASELINE.json configs[2], what `bench.py --gpus N` measures;
+    a full resize) from the band's source window alone (rank_source_rows /
+    place_window / scatter_source_windows: only those rows travel) and
+    stitched on a root rank with point-to-point transfers over xGMI --
+    BASELINE.json configs[2], what `bench.py --gpus N` measures;
   * independent frames per rank -- no data-path collective (reported beside it).
 
 Band heights differ by at most one row, so the stitch is send/recv rather than
@@ -32,6 +34,79 @@ def band_views(full, world):
     """Row-band views of the root's full image tensor, one per rank."""
     h = full.shape[0]
     return [full[slice(*band_rows(h, world, r))] for r in range(world)]
+
+
+# ---- source distribution (SURVEY.md 8e: "GPU g receives source rows
+# [r0 - halo, r1 + halo]") -------------------------------------------------
+# A rank never needs the whole source: the rows its band's vertical windows read
+# (avirhip_band_source_rows / the host-only avirhip_*_band_source_rows) are all
+# that travels -- host -> device, or root -> rank over xGMI when the frame starts
+# on one GPU. They are placed at their own offsets in a frame-sized device
+# buffer, so the band call indexes the frame as ever (image borders are the
+# frame's, never the window's) and the bytes outside the window are never
+# initialised: no row of them influences a result.
+
+def rank_source_rows(resizer, sw, sh, nw, nh, ch, rank, world, **kw):
+    """(first, last) inclusive source rows of `rank`'s band; (0, -1) for an
+    empty band. `resizer` is an avir_amd.CImageResizer or CLancIR (host-only
+    planner query)."""
+    r0, r1 = band_rows(nh, world, rank)
+    if r1 <= r0:
+        return 0, -1
+    return resizer.band_source_rows(sw, sh, nw, nh, ch, r0, r1, **kw)
+
+
+def place_window(src_host, first, last, device, poison=None):
+    """A frame-sized device tensor in which only rows [first, last] of the host
+    frame `src_host` (numpy, (H, W, C)) are uploaded. `poison` (e.g. NaN) fills
+    the rest first -- tests and bench.py use it to PROVE the band does not
+    depend on it; production leaves those bytes uninitialised."""
+    import torch
+    t = torch.empty(src_host.shape, dtype=torch.from_numpy(src_host[:0]).dtype,
+                    device=device)
+    if poison is not None:
+        t.fill_(poison)
+    if last >= first:
+        t[first:last + 1].copy_(torch.from_numpy(src_host[first:last + 1]),
+                                non_blocking=False)
+    return t
+
+
+def scatter_source_windows(src_root, windows, frame_shape, dtype, device, rank,
+                           world, dist, root=0, poison=None):
+    """The frame starts on `root` (tensor `src_root`, None elsewhere): every
+    other rank receives its window rows -- and only those -- into a frame-sized
+    buffer of its own; the root keeps using its frame. `windows[r]` = (first,
+    last) of rank r. Returns this rank's source tensor."""
+    import torch
+    if rank == root:
+        ops, keep = [], []
+        for r in range(world):
+            a, b = windows[r]
+            if r == root or b < a:
+                continue
+            view = src_root[a:b + 1]
+            if _p2p_needs_host(dist, view):
+                keep.append(view.cpu())
+                ops.append(dist.isend(keep[-1], r))
+            else:
+                ops.append(dist.isend(view, r))
+        for w in ops:
+            w.wait()
+        return src_root
+    t = torch.empty(frame_shape, dtype=dtype, device=device)
+    if poison is not None:
+        t.fill_(poison)
+    a, b = windows[rank]
+    if b >= a:
+        view = t[a:b + 1]
+        if _p2p_needs_host(dist, view):
+            tmp = torch.empty(view.shape, dtype=dtype)
+            dist.irecv(tmp, root).wait()
+            view.copy_(tmp)
+        else:
+            dist.irecv(view, root).wait()
+    return t
 
 
 def _p2p_needs_host(dist, t):

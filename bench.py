@@ -10,12 +10,20 @@ roofline achieved by the dominant kernel.
 A "step" is one full resize of one synthetic 4K frame already resident in HBM
 (H pass + V pass). N > 1 (launched by torch.distributed.run, one rank per GPU)
 is BASELINE.json configs[2]: the ONE frame is split into N contiguous output-row
-bands, one per GPU (every rank holds the source; bands are computed with global
-indices, bit-identical to the rows of a full resize), and stitched on rank 0
-with RCCL send/recv over xGMI, sub-band by sub-band under the kernels
-(avir_amd/sharding.py BandPipeline). `value` = stitched frames * Mpix over the
-max-over-ranks wall time (strong scaling). After the timed region (never inside
-it) rank 0 also reports, in the same JSON line:
+bands, one per GPU (each rank uploads ONLY the source rows its band reads --
+band + halo, SURVEY.md 8e -- into a frame-sized buffer whose other rows are NaN;
+bands are computed with global indices, bit-identical to the rows of a full
+resize), and stitched on rank 0 with RCCL send/recv over xGMI, sub-band by
+sub-band under the kernels (avir_amd/sharding.py BandPipeline). `value` =
+stitched frames * Mpix over the max-over-ranks wall time (strong scaling). If
+the band pipeline fails, `value` is null and the exit code is 3: a line whose
+number changed meaning must not look like a success. After the timed region
+(never inside it) rank 0 also reports, in the same JSON line:
+  configs       (N == 1) every other BASELINE.json config that runs on one GPU
+                -- cfg1, cfg2, cfg4, cfg5 -- timed the same way: ms_per_step,
+                Mpix/s, roofline fraction, counter traffic from the committed
+                PMC passes, exec path, and the FNV-1a-64 of the timed buffer
+                against the golden hash of the reference's output
   roofline      dominant-kernel launch duration from HIP events on the launch
                 stream -> algorithmic bytes / s against the 8 TB/s HBM peak
   cpu_baseline  the reference's own CPU path (oracle/_ref) timed on the host
@@ -86,6 +94,96 @@ OTHER = {"cfg1": ("avir", 640, 480, 1024, 768, 3, "u8", 8),
 
 
 XGMI_LINK_GBS = 153.0  # per link, both directions (7 links per GPU)
+
+# FNV-1a-64 of the reference's output for the BASELINE configs
+GOLDEN = {"cfg1": "a6ed3dcbbad502b9", "cfg2": "a493459fe7df54bd",
+          "cfg3": "38d7739587151f6e", "cfg4": "ddaf080cee37dfcc",
+          "cfg5": "a966d7a452c1b91d"}
+CONFIG_TEXT = {
+    "cfg1": "640x480->1024x768 RGB uint8, avir::CImageResizer<>(8)",
+    "cfg2": "1920x1080->3840x2160 RGBA float32, avir::CImageResizer<>(16)",
+    "cfg3": "3840x2160->7680x4320 RGBA float32, avir::CImageResizer<>(16)",
+    "cfg4": "3840x2160->1280x720 RGBA float32, avir::CImageResizer<>(16)",
+    "cfg5": "3840x2160->7680x4320 RGBA float32, avir::CLancIR"}
+
+
+def read_config_traffic(name):
+    """HBM bytes per step of a BASELINE config from the committed counter
+    passes (profiles/pmc_traffic.json, written by tools/summarize_configs.py
+    from this round's rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs), or None."""
+    p = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    try:
+        with open(p) as f:
+            return json.load(f).get("configs", {}).get(name, {}).get(
+                "traffic_bytes_per_step")
+    except (OSError, ValueError):
+        return None
+
+
+def time_config(name, steps, warmup, settle_ms):
+    """One BASELINE.json config on cuda:0, device-resident, timed like the
+    headline: settle, W warm-up steps, K steps between synchronisations (wall
+    clock) with HIP events on the launch stream around the same K steps."""
+    import torch
+    import avir_amd
+    from avir_amd import abi, synth
+    api, sw, sh, nw, nh, ch, dt, bits = OTHER[name]
+    lib = abi.load()
+    dev = torch.device("cuda", torch.cuda.current_device())
+    src = torch.from_numpy(_workload_src(name)).to(dev)
+    dst = torch.empty((nh, nw, ch), dtype=src.dtype, device=dev)
+    tcode = abi.U8 if dt == "u8" else abi.F32
+    esz = 1 if dt == "u8" else 4
+    if api == "avir":
+        obj = avir_amd.CImageResizer(bits)
+        plan = obj.plan(sw, sh, nw, nh, ch, 0.0, None, tcode, tcode)
+    else:
+        obj = avir_amd.CLancIR()
+        plan = obj.plan(sw, sh, nw, nh, ch, None, tcode, tcode)
+    st = torch.cuda.current_stream(dev).cuda_stream
+
+    def step():
+        abi.check(lib.avirhip_resize(plan, src.data_ptr(), abi.MEM_DEVICE,
+                                     dst.data_ptr(), abi.MEM_DEVICE, st),
+                  "resize")
+    t_settle = time.perf_counter()
+    while (time.perf_counter() - t_settle) * 1e3 < settle_ms:
+        for _ in range(50):
+            step()
+        torch.cuda.synchronize(dev)
+    for _ in range(warmup):
+        step()
+    torch.cuda.synchronize(dev)
+    e0 = torch.cuda.Event(enable_timing=True)
+    e1 = torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    e0.record()
+    for _ in range(steps):
+        step()
+    e1.record()
+    torch.cuda.synchronize(dev)
+    wall_ms = (time.perf_counter() - t0) * 1e3 / steps
+    ev_ms = e0.elapsed_time(e1) / steps
+    algo = (sw * sh + nw * nh) * ch * esz
+    h = synth.fnv(dst.cpu().numpy())
+    path = lib.avirhip_plan_get_path(plan)
+    traffic = read_config_traffic(name)
+    return {"config": name, "workload": CONFIG_TEXT.get(name, name),
+            "ms_per_step": round(wall_ms, 4), "event_ms": round(ev_ms, 4),
+            "steps": steps,
+            "value": round(nw * nh / 1e6 / (wall_ms * 1e-3), 1),
+            "unit": "Mpixels/s", "dtype": dt,
+            "exec_path": path,
+            "roofline": {"bound": "hbm", "algorithmic_bytes": algo,
+                         "achieved": round(algo / (wall_ms * 1e-3) / 1e9, 1),
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(algo / (wall_ms * 1e-3) / 1e9
+                                       / HBM_PEAK_GBS, 4),
+                         "frac_events": round(algo / (ev_ms * 1e-3) / 1e9
+                                              / HBM_PEAK_GBS, 4),
+                         "traffic": traffic},
+            "fnv1a64": h, "golden": GOLDEN.get(name),
+            "parity_ok": h == GOLDEN.get(name)}
 
 
 def _workload_src(name):
@@ -310,7 +408,18 @@ def read_traffic():
     p = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     try:
         with open(p) as f:
-            return json.load(f).get("traffic_bytes_per_launch")
+            j = json.load(f)
+        return (j.get("configs", {}).get("cfg3", {}).get(
+            "traffic_bytes_per_step") or j.get("traffic_bytes_per_launch"))
+    except (OSError, ValueError):
+        return None
+
+
+def traffic_provenance():
+    p = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    try:
+        with open(p) as f:
+            return json.load(f).get("collected")
     except (OSError, ValueError):
         return None
 
@@ -332,6 +441,9 @@ def main():
     ap.add_argument("--backend", default="nccl",
                     help="torch.distributed backend for --gpus > 1 (nccl = "
                          "RCCL; gloo only for dry runs of the rank logic)")
+    ap.add_argument("--no-configs", action="store_true",
+                    help="skip the cfg1 / cfg2 / cfg4 / cfg5 lines (profiler "
+                         "runs that want the headline kernel alone)")
     ap.add_argument("--no-sustained", action="store_true",
                     help="skip the 5-second sustained leg (counter-collection "
                          "runs serialise every launch)")
@@ -429,12 +541,36 @@ def main():
     abi.check(lib.avirhip_init(local), "avirhip_init")
 
     src_np = synth.lcg_f32((SRC_H, SRC_W, CH))  # SURVEY.md 8(c) generator
-    src = torch.from_numpy(src_np).to(dev)
+    rz = avir_amd.CImageResizer(16)
+    sharded_run = world > 1 or args.pg_smoke
+    src_window = None
+    if sharded_run:
+        # a rank receives the source rows its band reads (band +
+        # halo) and nothing else. They go to their own offsets of a frame-sized
+        # buffer; every other row is NaN, so the golden hash of the stitched
+        # frame also proves that no rank depended on rows it was not given.
+        from avir_amd import sharding
+        wa, wb = sharding.rank_source_rows(rz, SRC_W, SRC_H, NEW_W, NEW_H, CH,
+                                           rank, world)
+        src = sharding.place_window(src_np, wa, wb, dev, poison=float("nan"))
+        src_window = {"first_row": wa, "last_row": wb,
+                      "rows": wb - wa + 1, "of": SRC_H,
+                      "bytes_uploaded": (wb - wa + 1) * SRC_W * CH * 4}
+    else:
+        src = torch.from_numpy(src_np).to(dev)
     if os.environ.get("AVIRHIP_BENCH_FILL") == "zero":
         src.zero_()  # power experiment only (the parity field then says false)
     dst = torch.empty((NEW_H, NEW_W, CH), dtype=torch.float32, device=dev)
+    src_full = [None if sharded_run else src]
 
-    rz = avir_amd.CImageResizer(16)
+    def whole_source():
+        """The whole frame on this rank: only the secondary legs of an N > 1
+        run (independent frames, whole-frame roofline) ask for it, after the
+        headline."""
+        if src_full[0] is None:
+            src_full[0] = torch.from_numpy(src_np).to(dev)
+        return src_full[0]
+
     plan = rz.plan(SRC_W, SRC_H, NEW_W, NEW_H, CH)
     if args.path:
         abi.check(lib.avirhip_plan_set_path(plan, args.path), "set_path")
@@ -443,11 +579,15 @@ def main():
     mpix = NEW_W * NEW_H / 1e6
 
     def full_frame():
-        abi.check(lib.avirhip_resize(plan, src.data_ptr(), abi.MEM_DEVICE,
-                                     dst.data_ptr(), abi.MEM_DEVICE, stream),
-                  "avirhip_resize")
+        abi.check(lib.avirhip_resize(plan, whole_source().data_ptr(),
+                                     abi.MEM_DEVICE, dst.data_ptr(),
+                                     abi.MEM_DEVICE, stream), "avirhip_resize")
+
+    fail_pipe = os.environ.get("AVIRHIP_BENCH_FAIL_PIPELINE") == "1"
 
     def resize_rows(rows, a, b):
+        if fail_pipe:  # test aid: what the line and exit code say on failure
+            raise RuntimeError("AVIRHIP_BENCH_FAIL_PIPELINE")
         abi.check(lib.avirhip_resize_band(
             plan, src.data_ptr(), abi.MEM_DEVICE, rows.data_ptr(),
             abi.MEM_DEVICE, a, b, stream), "avirhip_resize_band")
@@ -478,8 +618,7 @@ def main():
 
     pipe = None
     sharded_error = None
-    if world > 1 or args.pg_smoke:
-        from avir_amd import sharding
+    if sharded_run:
         try:
             pipe = sharding.BandPipeline(NEW_H, NEW_W, CH, torch.float32, dev,
                                          rank, world, dist, resize_rows,
@@ -491,6 +630,10 @@ def main():
             sharded_error = "%s: %s" % (type(e).__name__, e)
             pipe = None
 
+    if sharded_run and pipe is None:
+        # (the secondary legs below still run, so that the line says what DID
+        # work; `value` stays null and the exit code says failure)
+        whole_source()
     step = full_frame if pipe is None else pipe.step
     finish = None if pipe is None else pipe.finish
 
@@ -515,9 +658,13 @@ def main():
             raise
         sharded_error = "%s: %s" % (type(e).__name__, e)
         pipe, step, finish = None, full_frame, None
+        whole_source()
         t, ev_ms = timed(step, args.steps, finish)
-    frames = args.steps if pipe is not None else world * args.steps
-    value = frames * mpix / t
+    # A sharded run whose band pipeline failed measured something else
+    # (independent frames): that number is reported under its own name, `value`
+    # is null and the process exits 3.
+    failed = sharded_run and pipe is None
+    value = None if failed else args.steps * mpix / t
 
     exec_path = {1: "generic per-step kernels",
                  2: "LDS-tiled two-pass kernels",
@@ -533,17 +680,19 @@ def main():
                  "over xGMI under the kernels; two frame slots"
                  % args.sub_bands)
     else:
-        shard = ("independent frames per GPU (band pipeline failed: %s)"
-                 % sharded_error)
+        shard = ("FAILED: the band pipeline raised (%s); what was timed is "
+                 "independent frames per GPU, reported as "
+                 "value_independent_frames, never as `value`" % sharded_error)
     out = {
         "metric": "Mpixels/sec (output) for 4K->8K RGBA resize",
-        "value": round(value, 1), "unit": "Mpixels/s",
+        "value": None if value is None else round(value, 1),
+        "unit": "Mpixels/s",
         "n_gpus": world, "ranks_seen": ranks_seen, "devices": devices,
         "steps": args.steps, "warmup": args.warmup,
         "settle_ms": args.settle_ms,
         "ms_per_step": round(t / args.steps * 1e3, 4),
         "higher_is_better": True,
-        "scaling": "strong" if pipe is not None or world == 1 else "weak",
+        "scaling": "strong",
         "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": "cfg3: 3840x2160->7680x4320 RGBA float32, "
@@ -551,6 +700,11 @@ def main():
                                "frame resident in HBM",
                    "sharding": shard, "exec_path": exec_path},
     }
+    if failed:
+        out["error"] = "band pipeline failed: %s" % sharded_error
+        out["value_independent_frames"] = round(world * args.steps * mpix / t, 1)
+    if src_window is not None:
+        out["config"]["source_rows_on_this_rank"] = src_window
 
     # parity spot check on the very buffer that was timed (N > 1: the frame
     # stitched on rank 0 in the last step)
@@ -567,18 +721,33 @@ def main():
             full_frame()
         _, ev_ms = timed(full_frame, max(20, min(args.steps, 200)))
     if rank == 0:
-        achieved = ALGO_BYTES / (ev_ms * 1e-3) / 1e9
+        # One launch per step (path 4): the step IS the kernel. `frac` is priced
+        # on the SAME clock as ms_per_step -- the wall time of the K timed steps
+        # between the synchronisations, the number the driver's own clock can
+        # check; the HIP-event time of the same K steps (a few % shorter: it
+        # leaves out the synchronisation at either end) is kept beside it, and
+        # the sustained leg below adds the same fraction over >= 5 s.
+        wall_ms = (t / args.steps * 1e3) if world == 1 else ev_ms
+        achieved = ALGO_BYTES / (wall_ms * 1e-3) / 1e9
         out["roofline"] = {
             "bound": "hbm", "achieved": round(achieved, 1),
             "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 4),
+            "clock": ("ms_per_step (wall, K steps between synchronisations)"
+                      if world == 1 else
+                      "HIP events over whole-frame launches on rank 0 (N > 1: "
+                      "ms_per_step times the band pipeline, not the kernel)"),
+            "kernel_ms": round(wall_ms, 4),
+            "event_ms": round(ev_ms, 4),
+            "frac_events": round(ALGO_BYTES / (ev_ms * 1e-3) / 1e9
+                                 / HBM_PEAK_GBS, 4),
             "traffic": read_traffic(),
             "traffic_source": "profiles/pmc_traffic.json (static: the "
                               "committed rocprofv3 --pmc passes of this "
                               "kernel, FETCH_SIZE x2 + WRITE_SIZE; not "
-                              "collected by this run)",
+                              "collected by this run): %s"
+                              % traffic_provenance(),
             "algorithmic_bytes": ALGO_BYTES,
-            "kernel_ms": round(ev_ms, 4),
             "kernels_per_step": {1: 5, 2: 2, 3: 1, 4: 1, 5: 2}.get(path)}
         vi = read_valu_instr()
         if vi and path == 4:
@@ -628,6 +797,8 @@ def main():
         out["sustained"] = {"steps": n, "seconds": round(ts, 3),
                             "ms_per_step": round(ts / n * 1e3, 4),
                             "value": round(n * mpix / ts, 1)}
+        out["roofline"]["frac_sustained"] = round(
+            ALGO_BYTES / (ts / n) / 1e9 / HBM_PEAK_GBS, 4)
         # clock / power of this box while the sustained leg ran (one sample)
         out["telemetry"] = dict(tele, sampled="rocm-smi, 2 s into the "
                                 "sustained leg")
@@ -660,6 +831,20 @@ def main():
         full_frame()  # (dst holds the real frame again)
         torch.cuda.synchronize(dev)
 
+    if rank == 0 and world == 1 and not args.pg_smoke and not args.no_configs:
+        # every other BASELINE.json config that runs on one GPU, the same way
+        # (only cfg3 used to reach the driver's line)
+        out["configs"] = []
+        for name in ("cfg1", "cfg2", "cfg4", "cfg5"):
+            try:
+                out["configs"].append(time_config(
+                    name, max(args.steps, 100), args.warmup,
+                    min(args.settle_ms, 120.0)))
+            except Exception as e:  # noqa: BLE001 -- never the headline's fate
+                out["configs"].append({"config": name, "error": "%s: %s" % (
+                    type(e).__name__, e)})
+        out["configs_parity_ok"] = all(c.get("parity_ok") for c in out["configs"])
+
     if rank == 0 and world == 1 and not args.no_cpu:
         # the drop-in call as a host program makes it: host pointers in and
         # out, staged over PCIe inside the library. Reported
@@ -688,6 +873,9 @@ def main():
     if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
+
+    if failed:
+        sys.exit(3)
 
 
 def sample_telemetry(device_index, delay_s, out):

@@ -174,6 +174,32 @@ int main()
 		printf( "lancir_legacy rc=%d %016llx\n", rcl, (unsigned long long)
 			fnv1a64( OutP.data(), OutP.size() * sizeof( float )));
 
+		// double and uint32_t elements (lancir.h:373-381: "`uint32_t` type is
+		// treated as `uint16_t`")
+		{
+			std :: vector< double > InD( InF.begin(), InF.end() );
+			std :: vector< double > OutD( 400 * 300 * 4 );
+			const int rcd = LancIR.resizeImage< double, double >( InD.data(),
+				640, 480, OutD.data(), 400, 300, 4 );
+
+			printf( "lancir_f64 rc=%d %016llx\n", rcd, (unsigned long long)
+				fnv1a64( OutD.data(), OutD.size() * sizeof( double )));
+
+			std :: vector< uint32_t > Out32( 1024 * 768 * 3 );
+			const int rcu = LancIR.resizeImage( In8.data(), 640, 480,
+				Out32.data(), 1024, 768, 3 );
+
+			printf( "lancir_u8_u32 rc=%d %016llx\n", rcu, (unsigned long long)
+				fnv1a64( Out32.data(), Out32.size() * sizeof( uint32_t )));
+
+			std :: vector< uint8_t > OutD8( 1024 * 768 * 4 );
+			const int rcb = LancIR.resizeImage( InD.data(), 640, 480,
+				OutD8.data(), 1024, 768, 4 );
+
+			printf( "lancir_f64_u8 rc=%d %016llx\n", rcb, (unsigned long long)
+				fnv1a64( OutD8.data(), OutD8.size() ));
+		}
+
 		// parameter error -> 0, like the reference
 		printf( "lancir_err rc=%d\n", LancIR.resizeImage( InF.data(), 640, 480,
 			OutF.data(), 0, 768, 4 ));

@@ -295,11 +295,29 @@ int avirhip_resize_band(avirhip_plan* plan, const void* src, int src_mem,
 /* The source rows [*first, *last] (inclusive) that output rows [row0, row1)
  * read -- the reference's vertical windows with their replicated edges folded
  * in (avir.h:6560-6619 resizeScanlineV over FltBuf columns; lancir.h:560-640).
- * A band call touches no other row of `src`: a caller that streams the source
- * (row bands of a frame arriving over a link, tiles of a larger image) only
- * has to have these rows in place. */
+ * No other row of `src` influences the band (tools/fuzz_values.py poisons them
+ * with NaNs): a caller that streams the source -- row bands of a frame arriving
+ * over a link, tiles of a larger image -- only has to have these rows in place
+ * when it makes the call. `src` must still address a whole, mapped frame: the
+ * marching kernels start their chunks at chunk-aligned rows and may LOAD rows
+ * outside the range (their results are discarded, never stored). A caller that
+ * holds only the window passes avirhip_resize_window() its rows instead. */
 int avirhip_band_source_rows(const avirhip_plan* plan, int row0, int row1,
 	int* first, int* last);
+
+/* Row-band execution from a WINDOW of the source: `src_rows` holds only the
+ * source rows [first_row, first_row + n_rows) (same row pitch as the plan's
+ * source), which must cover avirhip_band_source_rows(row0, row1) -- otherwise
+ * AVIRHIP_EINVAL. This is the multi-GPU distribution of SURVEY.md 8(e): rank g
+ * receives its band's rows plus the halo and nothing else (the reference's
+ * analogue: scanlines dealt to worker threads, avir.h:4885-4890, 4967-4971);
+ * image borders are the frame's, never the window's, so the band is
+ * bit-identical to the same rows of avirhip_resize(). The window is copied
+ * (host or device memory) to its place in a frame-sized staging buffer of the
+ * plan; no other source byte moves. */
+int avirhip_resize_window(avirhip_plan* plan, const void* src_rows,
+	int src_mem, int first_row, int n_rows, void* dst_band, int dst_mem,
+	int row0, int row1, void* stream);
 
 /* One frame sharded over several devices of THIS process:
  * the destination rows are split into `n_gpus` contiguous bands, band g is
@@ -437,6 +455,14 @@ int avirhip_resizer_resize(avirhip_resizer* r, const void* src, int src_mem,
 	int new_w, int new_h, int el_count_io, double k,
 	const avirhip_vars* vars, int in_type, int out_type, void* stream);
 
+/* Host-only (no GPU needed): avirhip_band_source_rows() for a geometry, from
+ * the planner alone -- what a host that deals source rows to the ranks of a
+ * sharded frame needs before any device plan exists. */
+int avirhip_resizer_band_source_rows(avirhip_resizer* r, int src_w, int src_h,
+	int src_scanline_size, int new_w, int new_h, int el_count_io, double k,
+	const avirhip_vars* vars, int in_type, int out_type, int row0, int row1,
+	int* first, int* last);
+
 /* Returns (and caches) the device plan resizeImage() would use for this
  * geometry; owned by the resizer. */
 int avirhip_resizer_get_plan(avirhip_resizer* r, int src_w, int src_h,
@@ -468,6 +494,11 @@ int avirhip_lancir_resize(avirhip_lancir* l, const void* src, int src_mem,
 	int src_w, int src_h, void* dst, int dst_mem, int new_w, int new_h,
 	int el_count, const avirhip_lancir_params* params, int in_type,
 	int out_type, void* stream);
+
+/* Host-only: avirhip_band_source_rows() for a CLancIR geometry. */
+int avirhip_lancir_band_source_rows(avirhip_lancir* l, int src_w, int src_h,
+	int new_w, int new_h, int el_count, const avirhip_lancir_params* params,
+	int in_type, int out_type, int row0, int row1, int* first, int* last);
 
 int avirhip_lancir_get_plan(avirhip_lancir* l, int src_w, int src_h,
 	int new_w, int new_h, int el_count, const avirhip_lancir_params* params,

@@ -20,9 +20,10 @@ REF_SIMD_PATH = os.path.join(_ROOT, "oracle", "_ref", "libavir_ref_simd.so")
 ORC_PATH = os.path.join(_ROOT, "oracle", "liboracle.so")
 
 _DT = {np.dtype(np.uint8): abi.U8, np.dtype(np.uint16): abi.U16,
-       np.dtype(np.float32): abi.F32, np.dtype(np.float64): abi.F64}
+       np.dtype(np.float32): abi.F32, np.dtype(np.float64): abi.F64,
+       np.dtype(np.uint32): abi.U32}
 NP_OF = {abi.U8: np.uint8, abi.U16: np.uint16, abi.F32: np.float32,
-         abi.F64: np.float64}
+         abi.F64: np.float64, abi.U32: np.uint32}
 
 _ref = None
 _orc = None

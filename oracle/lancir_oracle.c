@@ -402,6 +402,21 @@ static void output_scanline( const float* ip, void* op, size_t oo, int l,
 		return;
 	}
 
+	if( out_type == ORACLE_F64 )
+	{
+		/* (T) ip[ i ] or (T) ( ip[ i ] * OutMul ): the product is a float
+		 * product, widened afterwards (lancir.h:1786-1856) */
+		double* o = (double*) op + oo;
+
+		for( i = 0; i < l; i++ )
+		{
+			const float v = ( isunitymul ? ip[ i ] : ip[ i ] * outmul );
+			o[ i ] = (double) v;
+		}
+
+		return;
+	}
+
 	{
 		const int l4 = ( l >> 2 ) << 2;
 
@@ -428,6 +443,13 @@ static void output_scanline( const float* ip, void* op, size_t oo, int l,
 				((uint8_t*) op )[ oo + i ] = (uint8_t) r;
 			}
 			else
+			if( out_type == ORACLE_U32 )
+			{
+				/* sizeof( op[ 0 ]) == 4: the four cvtps results stored whole
+				 * (lancir.h:1869-1887), the tail as (T) roundclamp() */
+				((uint32_t*) op )[ oo + i ] = (uint32_t) r;
+			}
+			else
 			{
 				((uint16_t*) op )[ oo + i ] = (uint16_t) r;
 			}
@@ -441,6 +463,8 @@ static float load_in( const void* p, size_t i, int t )
 	{
 		case ORACLE_U8: return( (float) ((const uint8_t*) p )[ i ]);
 		case ORACLE_U16: return( (float) ((const uint16_t*) p )[ i ]);
+		case ORACLE_U32: return( (float) ((const uint32_t*) p )[ i ]);
+		case ORACLE_F64: return( (float) ((const double*) p )[ i ]);
 		default: return( ((const float*) p )[ i ]);
 	}
 }
@@ -462,14 +486,19 @@ int oracle_lancir_resize( const void* src, int sw, int sh, void* dst, int nw,
 	int x, y, t, c;
 
 	if( sw < 0 || sh < 0 || nw <= 0 || nh <= 0 || src == NULL ||
-		dst == NULL || src == dst || la < 2.0 || in_type > ORACLE_F32 ||
-		out_type > ORACLE_F32 || ch < 1 || ch > 4 )
+		dst == NULL || src == dst || la < 2.0 || in_type > ORACLE_U32 ||
+		out_type > ORACLE_U32 || in_type < 0 || out_type < 0 || ch < 1 ||
+		ch > 4 )
 	{
 		return( 0 );
 	}
 
-	szin = ( in_type == ORACLE_U8 ? 1 : in_type == ORACLE_U16 ? 2 : 4 );
-	szout = ( out_type == ORACLE_U8 ? 1 : out_type == ORACLE_U16 ? 2 : 4 );
+	/* sizeof( Tin ) / sizeof( Tout ): uint8_t, uint16_t, float, double, uint32_t */
+	{
+		static const int tsz[ 5 ] = { 1, 2, 4, 8, 4 };
+		szin = tsz[ in_type ];
+		szout = tsz[ out_type ];
+	}
 	newss = (size_t) ( new_ssize < 1 ? nw * ch : new_ssize );
 
 	if( sw == 0 || sh == 0 )
@@ -519,8 +548,8 @@ int oracle_lancir_resize( const void* src, int sw, int sh, void* dst, int nw,
 	rs_update( &rsh, sw, nw, ox, rfh );
 
 	/* lancir.h:526-533 */
-	isinfloat = ( in_type == ORACLE_F32 );
-	isoutfloat = ( out_type == ORACLE_F32 );
+	isinfloat = ( in_type == ORACLE_F32 || in_type == ORACLE_F64 );
+	isoutfloat = ( out_type == ORACLE_F32 || out_type == ORACLE_F64 );
 	isunitymul = ( isinfloat && isoutfloat ) ||
 		( isinfloat == isoutfloat && szin == szout );
 

@@ -26,6 +26,7 @@ extern "C" {
 #define ORACLE_U16 1
 #define ORACLE_F32 2
 #define ORACLE_F64 3
+#define ORACLE_U32 4 /* CLancIR only: "treated as uint16_t", lancir.h:376-377 */
 
 /* avir::CImageResizer<fpclass_def<float>>::resizeImage<Tin,Tout>()
  * (avir.h:4680-5092). `params` = 8 doubles {CorrFltAlpha, CorrFltLen,

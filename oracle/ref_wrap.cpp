@@ -554,6 +554,23 @@ int ref_lancir_resize( const void* src, int sw, int sh, void* dst, int nw,
 	CASE( AVIRHIP_F32, AVIRHIP_U8, float, uint8_t )
 	CASE( AVIRHIP_F32, AVIRHIP_U16, float, uint16_t )
 	CASE( AVIRHIP_F32, AVIRHIP_F32, float, float )
+	/* double, and uint32_t "treated as uint16_t" (lancir.h:373-381) */
+	CASE( AVIRHIP_F64, AVIRHIP_F64, double, double )
+	CASE( AVIRHIP_F64, AVIRHIP_F32, double, float )
+	CASE( AVIRHIP_F64, AVIRHIP_U8, double, uint8_t )
+	CASE( AVIRHIP_F64, AVIRHIP_U16, double, uint16_t )
+	CASE( AVIRHIP_F64, AVIRHIP_U32, double, uint32_t )
+	CASE( AVIRHIP_F32, AVIRHIP_F64, float, double )
+	CASE( AVIRHIP_U8, AVIRHIP_F64, uint8_t, double )
+	CASE( AVIRHIP_U16, AVIRHIP_F64, uint16_t, double )
+	CASE( AVIRHIP_U32, AVIRHIP_F64, uint32_t, double )
+	CASE( AVIRHIP_U32, AVIRHIP_U32, uint32_t, uint32_t )
+	CASE( AVIRHIP_U32, AVIRHIP_U16, uint32_t, uint16_t )
+	CASE( AVIRHIP_U32, AVIRHIP_U8, uint32_t, uint8_t )
+	CASE( AVIRHIP_U32, AVIRHIP_F32, uint32_t, float )
+	CASE( AVIRHIP_U8, AVIRHIP_U32, uint8_t, uint32_t )
+	CASE( AVIRHIP_U16, AVIRHIP_U32, uint16_t, uint32_t )
+	CASE( AVIRHIP_F32, AVIRHIP_U32, float, uint32_t )
 #undef CASE
 	return( -1 );
 }

@@ -1,7 +1,51 @@
-"""Shared helpers for the test-suite: product-side wrappers over the C ABI."""
+"""Shared helpers for the test-suite: product-side wrappers over the C ABI,
+and the ONE rule for which checker a GPU test compares with."""
 import ctypes as C
+import os
 import numpy as np
+import pytest
 from avir_amd import abi
+from tests import refbind as rb
+
+
+def _checker(ref_fn, orc_fn, args, kw):
+    """Reference output: the real reference (oracle/_ref, prebuilt where
+    /root/reference exists; it travels to the GPU box). A box without it FAILS
+    -- silently checking against the restatement would downgrade the run --
+    unless AVIRHIP_TEST_ORACLE=restatement asks for the plain-C restatement
+    (itself pinned to the reference by tests/test_oracle.py). Every GPU test,
+    AVIR and LANCIR alike, takes its expected result through here."""
+    if rb.have_ref():
+        return ref_fn(*args, **kw)
+    if os.environ.get("AVIRHIP_TEST_ORACLE") == "restatement":
+        kw.pop("threads", None)  # (the restatement is single-threaded)
+        return orc_fn(*args, **kw)
+    pytest.fail("oracle/_ref/libavir_ref.so is missing: build it where "
+                "/root/reference exists (make -C oracle ref), or set "
+                "AVIRHIP_TEST_ORACLE=restatement to check against "
+                "oracle/liboracle.so instead")
+
+
+def need_ref(what):
+    """For checks only the real reference can make (classes the restatement
+    does not have): True when oracle/_ref is there; otherwise the test FAILS,
+    unless AVIRHIP_TEST_ORACLE=restatement declared the downgrade (-> False:
+    the caller leaves that check out)."""
+    if rb.have_ref():
+        return True
+    if os.environ.get("AVIRHIP_TEST_ORACLE") == "restatement":
+        return False
+    pytest.fail("oracle/_ref/libavir_ref.so is missing (%s needs the real "
+                "reference); AVIRHIP_TEST_ORACLE=restatement leaves the check "
+                "out" % what)
+
+
+def checker_avir(*args, **kw):
+    return _checker(rb.ref_avir, rb.orc_avir, args, kw)
+
+
+def checker_lancir(*args, **kw):
+    return _checker(rb.ref_lancir, rb.orc_lancir, args, kw)
 
 
 def product_desc(sw, sh, nw, nh, ch, k=0.0, in_type=abi.F32, out_type=abi.F32,

@@ -30,6 +30,16 @@ def test_bench_single_gpu_line():
     assert d["roofline"]["bound"] == "hbm" and 0 < d["roofline"]["frac"] < 1
     assert d["sustained"]["seconds"] >= 1.0
     assert d["config"]["exec_path"].startswith("exact-2x")
+    # one clock for ms_per_step and the roofline fraction
+    assert abs(d["roofline"]["kernel_ms"] - d["ms_per_step"]) < 1e-3
+    assert 0 < d["roofline"]["frac_sustained"] < 1
+    # every other BASELINE.json config rides on the same line, golden-equal
+    cf = {c["config"]: c for c in d["configs"]}
+    assert sorted(cf) == ["cfg1", "cfg2", "cfg4", "cfg5"]
+    for name, c in cf.items():
+        assert c["parity_ok"] and c["fnv1a64"] == c["golden"], c
+        assert 0 < c["roofline"]["frac"] < 1 and c["ms_per_step"] > 0, c
+    assert d["configs_parity_ok"]
 
 
 @gpu
@@ -53,6 +63,27 @@ def test_bench_two_ranks_band_pipeline_gloo_dry_run():
     assert s["compute_only"]["value"] > 0 and s["independent_frames"]["value"] > 0
     assert d["value_distributed"] == s["compute_only"]["value"]
     assert d["value_independent_frames"] == s["independent_frames"]["value"]
+    # rank 0 was given its band's source rows only (SURVEY.md 8e), the rest NaN
+    w = d["config"]["source_rows_on_this_rank"]
+    assert w["first_row"] == 0 and w["rows"] < 1200 and w["of"] == 2160, w
+
+
+@gpu
+def test_bench_band_pipeline_failure_is_not_a_success_line():
+    """If the stitch fails, `value` must not silently become something else:
+    null value, an error field, exit code 3 (VERDICT r4 #13)."""
+    env = dict(os.environ, AVIRHIP_BENCH_FAIL_PIPELINE="1",
+               MASTER_ADDR="127.0.0.1",
+               MASTER_PORT=str(29300 + os.getpid() % 150))
+    r = subprocess.run([sys.executable, "bench.py", "--steps", "3", "--warmup",
+                        "1", "--settle-ms", "0", "--no-cpu", "--pg-smoke",
+                        "--backend", "gloo"], cwd=ROOT, env=env,
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 3, (r.returncode, r.stderr[-2000:])
+    d = _last_json(r.stdout)
+    assert d["value"] is None and "band pipeline failed" in d["error"]
+    assert d["value_independent_frames"] > 0
+    assert d["config"]["sharding"].startswith("FAILED")
 
 
 @gpu

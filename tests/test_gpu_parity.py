@@ -9,6 +9,7 @@ import pytest
 import avir_amd
 from avir_amd import abi
 from tests import refbind as rb
+from tests import helpers as H
 
 pytestmark = pytest.mark.gpu
 
@@ -20,20 +21,8 @@ def _device():
     abi.check(lib.avirhip_init(0), "init")
 
 
-def _checker_avir(src, nw, nh, **kw):
-    """Reference output: the real reference (oracle/_ref, prebuilt where
-    /root/reference exists; it travels to the GPU box). A box without it FAILS
-    -- silently checking against the restatement would downgrade the run --
-    unless AVIRHIP_TEST_ORACLE=restatement asks for the plain-C restatement
-    (itself pinned to the reference by tests/test_oracle.py)."""
-    if rb.have_ref():
-        return rb.ref_avir(src, nw, nh, **kw)
-    if os.environ.get("AVIRHIP_TEST_ORACLE") == "restatement":
-        return rb.orc_avir(src, nw, nh, **kw)
-    pytest.fail("oracle/_ref/libavir_ref.so is missing: build it where "
-                "/root/reference exists (make -C oracle ref), or set "
-                "AVIRHIP_TEST_ORACLE=restatement to check against "
-                "oracle/liboracle.so instead")
+_checker_avir = H.checker_avir      # (the loud-failing rule lives in
+_checker_lancir = H.checker_lancir  # tests/helpers.py, for every GPU test)
 
 
 def _bits(a):
@@ -207,8 +196,7 @@ def test_avir_exact_2x_random_shapes_agree_with_generic_kernels():
             if not isinstance(obj, avir_amd.CLancIR):
                 avir_out = outs[0]
         # ... and both against the reference (outs: k_lanc2, LANCIR generic)
-        _assert_same(outs[0], rb.ref_lancir(src, 2 * sw, 2 * sh)
-                     if rb.have_ref() else rb.orc_lancir(src, 2 * sw, 2 * sh),
+        _assert_same(outs[0], _checker_lancir(src, 2 * sw, 2 * sh),
                      "lancir vs reference %dx%d" % (sw, sh))
         if avir_out is not None:
             _assert_same(avir_out, _checker_avir(src, 2 * sw, 2 * sh,
@@ -627,8 +615,7 @@ def test_large_frames_beyond_the_headline_size():
     nthr = min(64, os.cpu_count() or 1)
     for (sw, sh, nw, nh) in [(7680, 4320, 15360, 8640), (7680, 4320, 2560, 1440)]:
         src = rb.lcg_f32((sh, sw, 4), seed=2024)
-        want = rb.ref_avir(src, nw, nh, resbits=16, threads=nthr) \
-            if rb.have_ref() else rb.orc_avir(src, nw, nh, resbits=16)
+        want = _checker_avir(src, nw, nh, resbits=16, threads=nthr)
         dsrc = torch.from_numpy(src).to("cuda:0")
         got = avir_amd.CImageResizer(16).resize(dsrc, nw, nh)
         torch.cuda.synchronize()
@@ -865,8 +852,8 @@ def test_concurrent_calls_on_one_object():
     r = avir_amd.CImageResizer(8)
     lan = avir_amd.CLancIR()
     srcl = rb.lcg_f32((60, 80, 4), seed=14)
-    wantl2 = (rb.ref_lancir if rb.have_ref() else rb.orc_lancir)(srcl, 160, 120)
-    wantl3 = (rb.ref_lancir if rb.have_ref() else rb.orc_lancir)(srcl, 100, 77)
+    wantl2 = _checker_lancir(srcl, 160, 120)
+    wantl3 = _checker_lancir(srcl, 100, 77)
     errs = []
 
     def worker(i):
@@ -980,8 +967,7 @@ LANCIR_CASES = [(37, 21, 74, 42), (64, 48, 100, 77), (300, 200, 100, 67),
 @pytest.mark.parametrize("sw,sh,nw,nh", LANCIR_CASES)
 def test_lancir_rgba_f32(sw, sh, nw, nh):
     src = rb.lcg_f32((sh, sw, 4), seed=4242)
-    want = rb.ref_lancir(src, nw, nh) if rb.have_ref() else \
-        rb.orc_lancir(src, nw, nh)
+    want = _checker_lancir(src, nw, nh)
     got = avir_amd.CLancIR().resize(src, nw, nh)
     _assert_same(got, want, "lancir")
 
@@ -1007,7 +993,7 @@ def test_lancir_channels_and_io_types(ch, tin, tout):
     """resize1..4 summation orders (lancir.h:2102-2544) and outputScanline's
     scaling / clamp / nearest-even-vs-truncate rounding (lancir.h:1772-2056),
     bit-exact for every channel count and element type."""
-    checker = rb.ref_lancir if rb.have_ref() else rb.orc_lancir
+    checker = _checker_lancir
     for (sw, sh, nw, nh) in [(37, 21, 74, 42), (64, 48, 100, 77),
                              (300, 200, 100, 67), (120, 100, 45, 77),
                              (9, 7, 31, 5), (300, 200, 33, 29)]:
@@ -1024,12 +1010,100 @@ def test_lancir_channels_and_io_types(ch, tin, tout):
             ch, np.dtype(tin), np.dtype(tout), sw, sh))
 
 
+@pytest.mark.parametrize("tin,tout", [
+    (np.float64, np.float64), (np.float64, np.float32), (np.float32, np.float64),
+    (np.float64, np.uint8), (np.float64, np.uint16), (np.float64, np.uint32),
+    (np.uint8, np.float64), (np.uint16, np.float64), (np.uint32, np.float64),
+    (np.uint32, np.uint32), (np.uint32, np.uint16), (np.uint32, np.uint8),
+    (np.uint32, np.float32), (np.uint8, np.uint32), (np.uint16, np.uint32),
+    (np.float32, np.uint32)])
+def test_lancir_double_and_uint32_types(tin, tout):
+    """CLancIR's documented element types beyond uint8 / uint16 / float
+    (lancir.h:373-381): `double`, and `uint32_t` "treated as `uint16_t`" --
+    1-4 channels, upsizing, downsizing, exact 2x (the fast kernels run between
+    the pack pass and the output stage), padded rows, host and device
+    buffers, the generic kernels; bit for bit against the reference."""
+    import torch
+    from tests.test_oracle import lancir_wide_source
+    lib = abi.load()
+    for (sw, sh, nw, nh, ch) in [(37, 21, 74, 42, 4), (64, 48, 100, 77, 3),
+                                 (300, 200, 100, 67, 1), (9, 7, 31, 5, 2),
+                                 (120, 100, 240, 200, 4), (300, 200, 33, 29, 4),
+                                 (160, 120, 320, 240, 3)]:
+        s = lancir_wide_source(sh, sw, ch, tin, tout)
+        want = _checker_lancir(s, nw, nh, out_dtype=tout)
+        what = "lancir %s->%s ch%d %dx%d->%dx%d" % (
+            np.dtype(tin), np.dtype(tout), ch, sw, sh, nw, nh)
+        l = avir_amd.CLancIR()
+        _assert_same(l.resize(s, nw, nh, out_dtype=tout), want, what)
+        # the generic kernels read / store the elements themselves
+        p = l.plan(sw, sh, nw, nh, ch, in_type=rb._DT[np.dtype(tin)],
+                   out_type=rb._DT[np.dtype(tout)])
+        abi.check(lib.avirhip_plan_set_path(p, abi.PATH_GENERIC), "set_path")
+        _assert_same(l.resize(s, nw, nh, out_dtype=tout), want, what + " generic")
+        abi.check(lib.avirhip_plan_set_path(p, abi.PATH_AUTO), "set_path")
+        # row bands
+        for a, b in [(0, nh // 3), (nh // 3, nh)]:
+            if b > a:
+                band = np.empty((b - a, nw, ch), tout)
+                abi.check(lib.avirhip_resize_band(
+                    p, s.ctypes.data, abi.MEM_HOST, band.ctypes.data,
+                    abi.MEM_HOST, a, b, None), "band")
+                _assert_same(band, want[a:b], what + " band [%d,%d)" % (a, b))
+    # device-resident buffers (torch has float64; uint32 where it exists)
+    tmap = {np.dtype(np.float64): torch.float64, np.dtype(np.float32): torch.float32,
+            np.dtype(np.uint8): torch.uint8}
+    for nm in ("uint16", "uint32"):
+        if hasattr(torch, nm):
+            tmap[np.dtype(nm)] = getattr(torch, nm)
+    if np.dtype(tin) in tmap and np.dtype(tout) in tmap:
+        s = lancir_wide_source(200, 300, 4, tin, tout)
+        want = _checker_lancir(s, 450, 300, out_dtype=tout)
+        got = avir_amd.CLancIR().resize(torch.from_numpy(s).to("cuda:0"), 450,
+                                        300, out_dtype=tmap[np.dtype(tout)])
+        torch.cuda.synchronize()
+        _assert_same(got.cpu().numpy(), want, "device buffers")
+    # padded rows (CLancIRParams::SrcSSize / NewSSize)
+    s = lancir_wide_source(48, 64, 3, tin, tout)
+    want = _checker_lancir(s, 100, 77, out_dtype=tout, spad=5, npad=7)
+    rc, got = rb._lancir_call(
+        lambda sp, sw, sh, dp, nw, nh, ch, ti, to, ss, ns, kx, ky, ox, oy, la:
+        _lancir_abi(sp, sw, sh, dp, nw, nh, ch, ti, to, ss, ns),
+        s, 100, 77, tout, 0.0, 0.0, 0.0, 0.0, 3.0, spad=5, npad=7)
+    assert rc == 77
+    _assert_same(got, want, "padded rows")
+
+
+def _lancir_abi(sp, sw, sh, dp, nw, nh, ch, ti, to, ss, ns):
+    """avirhip_lancir_resize on host buffers with explicit scanline sizes."""
+    lib = abi.load()
+    import ctypes as C
+    h = C.c_void_p()
+    abi.check(lib.avirhip_lancir_create(C.byref(h)), "create")
+    P = abi.LancirParams()
+    lib.avirhip_lancir_params_default(C.byref(P))
+    P.SrcSSize, P.NewSSize = ss, ns
+    rc = lib.avirhip_lancir_resize(h, sp, abi.MEM_HOST, sw, sh, dp,
+                                   abi.MEM_HOST, nw, nh, ch, C.byref(P), ti, to,
+                                   None)
+    lib.avirhip_lancir_destroy(h)
+    return abi.check(rc, "lancir_resize")
+
+
+def test_lancir_wide_types_are_refused_by_cimageresizer():
+    """uint32 is CLancIR's quirk only: avir::CImageResizer documents uint8_t,
+    uint16_t, float, double (avir.h:4670-4677)."""
+    with pytest.raises(avir_amd.AvirHipError):
+        avir_amd.CImageResizer(8).resize(
+            np.zeros((8, 8, 3), np.uint32), 16, 16)
+
+
 @pytest.mark.parametrize("sw,sh", [(37, 21), (64, 48), (300, 200), (129, 65),
                                    (1, 1), (5, 300), (300, 5), (640, 480)])
 def test_lancir_exact_2x_kernel(sw, sh):
     """lanc2.hip (path 4 of LANCIR plans): 2x RGBA float, both passes fused."""
     lib = abi.load()
-    checker = rb.ref_lancir if rb.have_ref() else rb.orc_lancir
+    checker = _checker_lancir
     src = rb.lcg_f32((sh, sw, 4), seed=77 + sw)
     want = checker(src, 2 * sw, 2 * sh)
     l = avir_amd.CLancIR()
@@ -1055,7 +1129,7 @@ def test_lancir_integer_rgba_runs_the_fast_kernels_in_row_bands():
     run in an inner plan between the pack pass and the output stage; whole
     frames and row bands equal the generic kernels' result."""
     lib = abi.load()
-    checker = rb.ref_lancir if rb.have_ref() else rb.orc_lancir
+    checker = _checker_lancir
     for (sw, sh, nw, nh, ch, tin, tout) in [
             (96, 70, 192, 140, 4, np.uint8, np.uint8),     # exact 2x kernel
             (200, 150, 77, 58, 4, np.uint8, np.uint8),     # pass kernels
@@ -1090,7 +1164,7 @@ def test_lancir_integer_rgba_runs_the_fast_kernels_in_row_bands():
 
 
 def test_lancir_params_steps_offsets_la():
-    checker = rb.ref_lancir if rb.have_ref() else rb.orc_lancir
+    checker = _checker_lancir
     s = rb.lcg_f32((60, 80, 4), seed=9)
     for kw in [dict(kx=0.7, ky=1.9), dict(kx=-1.5, ky=-0.6, ox=0.4, oy=-0.2),
                dict(la=2.0), dict(la=4.5, kx=2.2, ky=2.2)]:
@@ -1238,7 +1312,7 @@ def test_lancir_scanline_sizes(sw, sh, nw, nh, ch, spad, npad, tin, tout):
     buffers; the destination's padding must stay untouched."""
     import torch
     s = rb.lcg_u8((sh, sw, ch)) if tin == np.uint8 else rb.lcg_f32((sh, sw, ch))
-    want = (rb.ref_lancir if rb.have_ref() else rb.orc_lancir)(
+    want = _checker_lancir(
         s, nw, nh, out_dtype=tout, spad=spad, npad=npad)
     ss = sw * ch + spad
     ns = nw * ch + npad
@@ -1510,7 +1584,7 @@ def test_lancir_fused_upsizing_kernel():
     non-default parameters (offsets, la), integer results through the owner's
     output stage."""
     lib = abi.load()
-    ref_l = rb.ref_lancir if rb.have_ref() else rb.orc_lancir
+    ref_l = _checker_lancir
     for (sw, sh, nw, nh, kw) in [
             (64, 48, 100, 77, {}), (129, 67, 513, 259, {}),
             (90, 300, 200, 720, {}), (300, 40, 1001, 47, {"ox": 0.4, "oy": -0.2}),
@@ -1558,9 +1632,8 @@ def test_avir_fused_upsizing_is_the_default_for_large_frames():
     abi.check(lib.avirhip_plan_set_variant(p, abi.VARIANT_UPG_TWO_PASS), "v")
     two = r.resize(torch.from_numpy(src).to("cuda:0"), 5760, 3240).cpu().numpy()
     _assert_same(got, two, "fused vs two-pass, 1080p x3")
-    if rb.have_ref():
-        _assert_same(got, rb.ref_avir(src, 5760, 3240, resbits=16, threads=8),
-                     "fused vs reference, 1080p x3")
+    _assert_same(got, _checker_avir(src, 5760, 3240, resbits=16, threads=8),
+                 "fused vs reference, 1080p x3")
 
 
 def _same_but_nan_payloads(got, want, what):
@@ -1668,7 +1741,7 @@ def test_avir_pass_kernels_are_the_default_for_general_ratios():
 def test_lancir_pass_kernels(sw, sh, nw, nh):
     lib = abi.load()
     src = rb.lcg_f32((sh, sw, 4), seed=sw + nh)
-    want = (rb.ref_lancir if rb.have_ref() else rb.orc_lancir)(src, nw, nh)
+    want = _checker_lancir(src, nw, nh)
     l = avir_amd.CLancIR()
     p = l.plan(sw, sh, nw, nh, 4)
     abi.check(lib.avirhip_plan_set_path(p, abi.PATH_GPASS), "set_path")
@@ -1678,7 +1751,7 @@ def test_lancir_pass_kernels(sw, sh, nw, nh):
         P = avir_amd.CLancIRParams(0, 0, kw.get("kx", 0), kw.get("ky", 0),
                                    kw.get("ox", 0), kw.get("oy", 0))
         P.la = kw.get("la", 3.0)
-        want = (rb.ref_lancir if rb.have_ref() else rb.orc_lancir)(
+        want = _checker_lancir(
             src, nw, nh, **kw)
         _assert_same(l.resize(src, nw, nh, aParams=P), want, "lancir %s" % kw)
 
@@ -1708,7 +1781,7 @@ def test_execution_paths_agree_on_random_plans():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, os.path.join(root, "tools",
                                                      "fuzz_paths.py"),
-                        "600", "3"] + (["ref"] if rb.have_ref() else []),
+                        "600", "3"] + (["ref"] if H.need_ref("fuzz vs reference") else []),
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
 
@@ -1824,7 +1897,7 @@ def test_host_pointer_calls_run_the_band_pipeline(case):
             np.uint16: torch.uint16}[tout], aVars=v).cpu().numpy()
         got = obj.resize(src, nw, nh, out_dtype=tout, aVars=v)
         again = obj.resize(src, nw, nh, out_dtype=tout, aVars=v)
-        if api == "avir-gamma" and rb.have_ref():
+        if api == "avir-gamma" and H.need_ref("sRGB gamma"):
             _assert_same(want, rb.ref_avir(
                 src, nw, nh, out_dtype=tout, gamma=True, alpha=v.AlphaIndex,
                 resbits=16 if tout == np.uint16 else 8), "gamma vs reference")
@@ -1950,7 +2023,7 @@ def test_lancir_integer_plans_allocate_no_float_copies():
     lib = abi.load()
     sw, sh, nw, nh, ch = 1200, 800, 1700, 1100, 3
     src = rb.lcg_u8((sh, sw, ch), seed=5)
-    want = (rb.ref_lancir if rb.have_ref() else rb.orc_lancir)(src, nw, nh)
+    want = _checker_lancir(src, nw, nh)
     l = avir_amd.CLancIR()
     got = l.resize(src, nw, nh)
     _assert_same(got, want, "lancir u8")
@@ -1993,7 +2066,7 @@ def test_avir_fpclass_def_double(tin, tout, bits, gamma, alpha):
     through the output stage. Bit for bit against the reference built the
     same way (oracle/_ref, variant 4); whole frames and row bands."""
     if not rb.have_ref():
-        pytest.skip("oracle/_ref not built")
+        pytest.fail("oracle/_ref is needed: the restatement has no double class")
     lib = abi.load()
     for (sw, sh, nw, nh) in F64_CASES:
         for ch in ((4,) if alpha >= 0 else (1, 3, 4)):

@@ -4,6 +4,7 @@ max-over-ranks timing rule. The per-band pixels come from the oracle here (no
 GPU in this container); on the GPU box the same stitch is exercised by
 bench.py --gpus N and test_gpu_parity.py::test_band_execution_matches_full
 proves the device bands equal the rows of a full resize."""
+import ctypes as C
 import os
 import numpy as np
 import pytest
@@ -34,6 +35,31 @@ def _worker(rank, world, port, q, use_gpu=False):
         whole = torch.from_numpy(rb.orc_avir(src, nw, nh, resbits=16))
         r0, r1 = sharding.band_rows(nh, world, rank)
         dev = torch.device("cuda", 0) if use_gpu else torch.device("cpu")
+        # ---- source distribution: the frame starts on rank 0,
+        # every other rank receives ONLY the rows its band reads (host-only
+        # planner query); everything else in its buffer is NaN
+        import avir_amd
+        rz0 = avir_amd.CImageResizer(16)
+        windows = [sharding.rank_source_rows(rz0, 90, 60, nw, nh, 4, r, world)
+                   for r in range(world)]
+        wa, wb = windows[rank]
+        assert 0 <= wa <= wb < 60
+        if world > 1:
+            assert wb - wa + 1 < 60  # a true window, not the frame
+        src_root = torch.from_numpy(src).to(dev) if rank == 0 else None
+        mine = sharding.scatter_source_windows(
+            src_root, windows, (60, 90, 4), torch.float32, dev, rank, world,
+            dist, poison=float("nan"))
+        if rank == 0:
+            # (the root too computes from its window alone)
+            mine = sharding.place_window(src, wa, wb, dev, poison=float("nan"))
+        win_ok = bool(torch.isnan(mine.cpu()).sum() ==
+                      (60 - (wb - wa + 1)) * 90 * 4)
+        # the reference's algorithm itself, run on the poisoned frame, gives
+        # this rank's rows bit for bit: the window is sufficient
+        onp = rb.orc_avir(mine.cpu().numpy(), nw, nh, resbits=16)
+        win_ok = win_ok and bool(np.array_equal(
+            onp[r0:r1].view(np.uint32), whole[r0:r1].numpy().view(np.uint32)))
         if use_gpu:
             # the product's band kernel feeds the stitch (both ranks share
             # the one device of the GPU box)
@@ -43,13 +69,37 @@ def _worker(rank, world, port, q, use_gpu=False):
             abi.check(lib.avirhip_init(0), "init")
             rz = avir_amd.CImageResizer(16)
             plan = rz.plan(90, 60, nw, nh, 4)
-            dsrc = torch.from_numpy(src).to(dev)
+            dsrc = mine  # window rows only, NaN elsewhere
             st = torch.cuda.current_stream(dev).cuda_stream
+            fa, fb = C.c_int(), C.c_int()
+            abi.check(lib.avirhip_band_source_rows(plan, r0, r1, C.byref(fa),
+                                                   C.byref(fb)), "rows")
+            assert (fa.value, fb.value) == (wa, wb)  # device plan == planner
 
             def resize_rows(dst_rows, a, b):
                 abi.check(lib.avirhip_resize_band(
                     plan, dsrc.data_ptr(), abi.MEM_DEVICE, dst_rows.data_ptr(),
                     abi.MEM_DEVICE, a, b, st), "band")
+
+            # ... and from a COMPACT window (avirhip_resize_window): host rows
+            # and device rows
+            wband = torch.empty((r1 - r0, nw, 4), dtype=torch.float32,
+                                device=dev)
+            compact = np.ascontiguousarray(src[wa:wb + 1])
+            for ptr, mem in ((compact.ctypes.data, abi.MEM_HOST),
+                             (torch.from_numpy(compact).to(dev).data_ptr(),
+                              abi.MEM_DEVICE)):
+                wband.fill_(-1.0)
+                abi.check(lib.avirhip_resize_window(
+                    plan, ptr, mem, wa, wb - wa + 1, wband.data_ptr(),
+                    abi.MEM_DEVICE, r0, r1, st), "window")
+                torch.cuda.synchronize()
+                win_ok = win_ok and bool(torch.equal(wband.cpu(), whole[r0:r1]))
+            # a window that misses a needed row is refused
+            if wb - wa >= 2:
+                assert lib.avirhip_resize_window(
+                    plan, compact.ctypes.data, abi.MEM_HOST, wa + 1, wb - wa,
+                    wband.data_ptr(), abi.MEM_DEVICE, r0, r1, st) == abi.EINVAL
         else:
             def resize_rows(dst_rows, a, b):
                 dst_rows.copy_(whole[a:b])
@@ -60,9 +110,9 @@ def _worker(rank, world, port, q, use_gpu=False):
                 if rank == 0 else None)
         sharding.gather_bands(band, full, rank, world, dist)
         t = sharding.max_over_ranks(1.0 + rank, dist, dev)
-        ok = True
+        ok = win_ok
         if rank == 0:
-            ok = bool(torch.equal(full.cpu(), whole))
+            ok = ok and bool(torch.equal(full.cpu(), whole))
         # the overlapped form: sub-bands, receives posted first, two frame
         # slots; three frames so that a slot is reused
         pipe = sharding.BandPipeline(nh, nw, 4, torch.float32, dev, rank,
