@@ -60,6 +60,8 @@ OTHER = {"cfg1": ("avir", 640, 480, 1024, 768, 3, "u8", 8),
          "lanc_dn3": ("lancir", 3840, 2160, 1280, 720, 4, "f32", 16),
          "lanc_up2_rgba8": ("lancir", 1920, 1080, 3840, 2160, 4, "u8", 8),
          "lanc_up2_u8": ("lancir", 1920, 1080, 3840, 2160, 3, "u8", 8),
+         # CLancIR on the README's photo case
+         "lanc_readme_u8": ("lancir", 5184, 3456, 1920, 1280, 3, "u8", 8),
          "half": ("avir", 3840, 2160, 1920, 1080, 4, "f32", 16),
          "triple": ("avir", 1920, 1080, 5760, 3240, 4, "f32", 16),
          "nonint_u8": ("avir", 1920, 1080, 2500, 1400, 3, "u8", 8),
@@ -780,7 +782,7 @@ def main():
         except Exception as e:  # noqa: BLE001
             out["sharded"] = {"error": "%s: %s" % (type(e).__name__, e)}
 
-    if world == 1 and "value_distributed" not in out:
+    if world == 1 and "value_distributed" not in out and not failed:
         out["value_distributed"] = out["value"]
         out["value_independent_frames"] = out["value"]
 
