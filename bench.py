@@ -674,7 +674,7 @@ def main():
                  4: "exact-2x marching kernel (single launch)",
                  5: "general-ratio pass kernels (H launch + V launch)"
                  }.get(path, str(path))
-    if world == 1:
+    if world == 1 and not sharded_run:
         shard = "one GPU, whole frame"
     elif pipe is not None:
         shard = ("row bands of ONE frame, one band per GPU (global indices), "

@@ -8,7 +8,7 @@
 // doResize / doResize2 over the zero-stuffed view, then the correction filter,
 // avir.h:3884-4328 + 3748-3866) without a window and without a run-in.
 //
-// What the other kernels of path 5 pay for on such an axis:
+// What the other kernels of path 5 pay for on such an axis (NOTEBOOK.md 4.2d/e):
 // the gather kernels keep an NT-deep window per lane (NT = 13 .. 64 rows of
 // 16 bytes: registers or a 42-KiB LDS ring, one or two waves per SIMD); the
 // streaming-accumulation kernels keep 16 accumulator slots instead, but a work
