@@ -23,6 +23,17 @@ ran = {}
 
 
 def make(sh, sw, ch, dt, seed):
+    if dt == np.uint32:
+        # CLancIR's "uint32_t treated as uint16_t": the uint16 range, and a few
+        # elements beyond it (the loader does not clamp)
+        a = synth.lcg_u8((sh, sw, ch, 2), seed=seed).view(np.uint16).reshape(
+            sh, sw, ch).astype(np.uint32)
+        a[::5, ::7] += 70000
+        return a
+    if dt == np.float64:
+        # more mantissa bits than a float holds
+        return (synth.lcg_f32((sh, sw, ch), seed=seed).astype(np.float64) +
+                synth.lcg_f32((sh, sw, ch), seed=seed + 1) * 2.0 ** -26)
     if np.dtype(dt).kind == "u":
         a = synth.lcg_u8((sh, sw, ch, np.dtype(dt).itemsize), seed=seed)
         return a.view(dt).reshape(sh, sw, ch)
@@ -41,10 +52,18 @@ for it in range(N):
     ch = int(rng.randint(1, 5))
     tin = DT[rng.randint(0, 3)]
     tout = DT[rng.randint(0, 3)]
-    src = make(sh, sw, ch, tin, it + 7)
-    if tin == np.float32 and tout != np.float32:
-        src = src * 1.2 - 0.1  # float sources are [0, 1]: exercise both clamps
     lanc = rng.rand() < 0.35
+    if rng.rand() < 0.25:
+        # the wide element types: double everywhere, uint32 for CLancIR only
+        # (lancir.h:373-381)
+        wide = [np.float64, np.uint32] if lanc else [np.float64]
+        if rng.rand() < 0.6:
+            tin = wide[rng.randint(0, len(wide))]
+        if rng.rand() < 0.6:
+            tout = wide[rng.randint(0, len(wide))]
+    src = make(sh, sw, ch, tin, it + 7)
+    if np.dtype(tin).kind == "f" and np.dtype(tout).kind == "u":
+        src = src * 1.2 - 0.1  # float sources are [0, 1]: exercise both clamps
     res = {}
     bits = int(rng.choice([8, 10, 16]))
     v = avir_amd.CImageResizerVars()
