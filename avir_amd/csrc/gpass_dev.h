@@ -751,7 +751,9 @@ __device__ __forceinline__ f4 gp_load_raw( const void* const base,
 	return( o );
 }
 
+#ifndef GV_PF
 #define GV_PF 5 // k_gv: DMA groups in flight (one of them is read a step ahead)
+#endif
 #define GV_QB (( GV_PF + 2 ) * 1024 ) // landing queue: GV_PF + 1 slots, a dump
 
 // Rows per work item. The vertical pass kernel is bound by vector-ALU issue,

@@ -387,7 +387,7 @@ __global__ void __launch_bounds__( 64 ) k_gv( const GVParams P )
 
 	VT qnext = (VT) 0.0f; // the next step's row of the queue
 
-	GP_WAIT_VM( 4 ); // the first group has landed
+	gp_wait_vm( GV_PF - 1 ); // the first group has landed
 
 	if( MODE == GP_PRE || RW > 0 )
 	{
@@ -440,7 +440,7 @@ __global__ void __launch_bounds__( 64 ) k_gv( const GVParams P )
 #ifdef GP_DBG
 				if( !( P.dbg & 4 ))
 #endif
-				GP_WAIT_VM( 4 ); // == GV_PF - 1
+				gp_wait_vm( GV_PF - 1 );
 
 				qr = ( qr == GV_PF ? 0 : qr + 1 );
 			}
