@@ -787,7 +787,8 @@ static int exec_device( avirhip_plan* p, const void* src, void* dst,
 		// the inner plan's first pass reads this image itself where it can;
 		// otherwise the pack pass makes its float RGBA copy
 		q -> lraw.on = ( getenv( "AVIRHIP_NO_FUSED_OUT" ) == nullptr && in_fast &&
-			( gpass_lancir_takes_raw( q ) || ( lanc2_takes_raw( q, src,
+			( gpass_lancir_takes_raw( q, src, p -> in_type, p -> io_ch,
+			p -> src_stride ) || ( lanc2_takes_raw( q, src,
 			p -> in_type, p -> io_ch, p -> src_stride ) &&
 			// (RGBA: its integer stage stores a lane's two elements at once)
 			( p -> io_ch == 3 || ( p -> new_stride & 1 ) == 0 ) &&

@@ -1121,14 +1121,34 @@ static void v_source_rows( const GPData* D, int row0, int row1, int& a, int& b )
 // back.
 // LANCIR (an inner plan): whether its vertical pass -- the first one -- can
 // read the owner's integer / narrower image itself (whole-pixel lanes).
-bool gpass_lancir_takes_raw( const avirhip_plan* p )
+// Whether the vertical pass of a LANCIR plan reads the owner's image as it is
+// (`raw`: element type, channels, elements per row): its rows travel as bytes
+// by LDS-DMA, so the base and the row pitch have to be dword-aligned, the image
+// under 2 GiB, and the tap count one of the register-window variants of k_gv
+// (the LDS-window form keeps a ring of float pixels).
+bool gpass_lancir_takes_raw( const avirhip_plan* p, const void* raw, int type,
+	int ch, long stride )
 {
 	const GPData* D = (const GPData*) p -> gpass;
 	const int lpath = ( p -> path != 0 ? p -> path : p -> auto_path );
+	const long esz = ( type == AVIRHIP_U8 ? 1 : ( type == AVIRHIP_U16 ? 2 : 4 ));
+	static const bool off = ( getenv( "AVIRHIP_GV_RAWDMA" ) != nullptr &&
+		atoi( getenv( "AVIRHIP_GV_RAWDMA" )) == 0 ); // (A/B: the pack pass instead)
 
-	return( D != nullptr && p -> is_lancir && lpath == 5 && D -> v_geom &&
+	if( D == nullptr || off )
+	{
+		return( false );
+	}
+
+	const int nt = D -> v.a.nt;
+
+	return( p -> is_lancir && lpath == 5 && D -> v_geom &&
 		D -> h_geom && p -> src_w > 48 &&
-		( D -> v_rs + D -> v_rc ) * 1024 + GV_QB + 6 * 1024 <= 64 * 1024 );
+		( D -> v_rs + D -> v_rc ) * 1024 + GV_QB + 6 * 1024 <= 64 * 1024 &&
+		nt >= 6 && nt <= 24 && ( nt & 1 ) == 0 &&
+		( (uintptr_t) raw & 3 ) == 0 && (( stride * esz ) & 3 ) == 0 &&
+		( (long) ( p -> src_h - 1 ) * stride + (long) p -> src_w * ch ) * esz <
+		( 1L << 31 ));
 }
 
 // Whether the first pass reads the caller's image as it is (integer types,
@@ -1278,6 +1298,9 @@ int gpass_run( avirhip_plan* p, const float* src, long src_stride, float* dst,
 				row0, row1, st, nullptr, p -> lraw.ptr, p -> lraw.type,
 				p -> lraw.ch, p -> lraw.stride );
 
+			// (the kernel refused the image after all: the owner makes the
+			// float copy and calls again)
+			if( rc == 1 ) return( AVIRHIP_NEED_SRC );
 			if( rc != 0 ) return( rc );
 		}
 		else

@@ -60,6 +60,17 @@ __device__ __forceinline__ void gp_dma( const __amdgpu_buffer_rsrc_t rs,
 		: "memory" );
 }
 
+// ... of 64 x 4 bytes: lane l's dword lands at lds + l * 4 (raw integer rows,
+// coefficient tables)
+__device__ __forceinline__ void gp_dma4( const __amdgpu_buffer_rsrc_t rs,
+	const unsigned lds, const int voff )
+{
+	asm volatile( "s_mov_b32 m0, %0\n\t"
+		"buffer_load_dword %1, %2, 0 offen lds"
+		:: "s"( __builtin_amdgcn_readfirstlane( lds )), "v"( voff ), "s"( rs )
+		: "memory" );
+}
+
 #define GP_WAIT_VM( n ) asm volatile( "s_waitcnt vmcnt(" #n ")" ::: "memory" )
 
 // s_waitcnt takes an immediate: a wave-uniform count picks its instruction.
@@ -403,6 +414,9 @@ struct GVParams
 	long raw_ss;         // (integer / narrower pixels), elements per row,
 	int raw_ch, raw_kind; // channels, 1 uint8 / 2 uint16 / 3 float
 	long raw_elems;      // elements of that image (the loader's bound)
+	int raw_dma;         // the rows travel as bytes by LDS-DMA (dword-aligned
+	                     // base and row pitch, < 2 GiB): bytes per pixel, else 0
+	int raw_bytes;       // bytes of that image (the DMA's range check)
 };
 
 struct GHParams

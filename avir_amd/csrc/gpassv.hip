@@ -54,6 +54,27 @@ int gpass_run_v( const GPAxis& A_, int v_blk, int v_rs, int v_rc,
 		return( 1 );
 	}
 
+	// raw rows travel as bytes by LDS-DMA (k_gv, LVAR bit 1): dword-aligned base
+	// and row pitch, under 2 GiB -- what gpass_lancir_takes_raw promised
+	P.raw_dma = 0; P.raw_bytes = 0;
+
+	if( raw != nullptr )
+	{
+		const long esz = ( raw_type == AVIRHIP_U8 ? 1 :
+			( raw_type == AVIRHIP_U16 ? 2 : 4 ));
+		const long bytes = P.raw_elems * esz;
+		const int nt = A_.nt;
+
+		if(( (uintptr_t) raw & 3 ) != 0 || (( raw_stride * esz ) & 3 ) != 0 ||
+			bytes >= ( 1L << 31 ) || !A_.lanc || nt < 6 || nt > 24 || ( nt & 1 ))
+		{
+			return( 1 );
+		}
+
+		P.raw_dma = (int) ( esz * raw_ch );
+		P.raw_bytes = (int) bytes;
+	}
+
 	if( out != nullptr )
 	{
 		P.out = *out;

@@ -174,7 +174,9 @@ __global__ void __launch_bounds__( 64 ) k_gv( const GVParams P )
 #ifdef GP_DBG
 		if(( P.dbg & 1 ) && o.x != 1234.5f ) return;
 #endif
-		if( WP == 2 && P.out.on != 0 )
+		// (LANCIR's output stage lives in its LAST pass, the horizontal one:
+		// GPLOut in k_gh; its vertical pass never stores integer pixels)
+		if( !LANC && WP == 2 && P.out.on != 0 )
 		{
 			{
 				f4 o4;
@@ -348,47 +350,108 @@ __global__ void __launch_bounds__( 64 ) k_gv( const GVParams P )
 		gp_dma( rsrc, slot, r * srow_b + dpx * 16 );
 	};
 
-	// Raw sources (integer / narrower pixels, whole-pixel lanes): a lane loads
-	// its pixel of row u + 2 during step u, converts and writes it into the
-	// queue slot (or ring row) of row u + 1 at the start of the next step --
-	// the (float) cast and zero padding of the pack pass, in the loader.
-	const bool typed = ( WP == 2 && ( LVAR & 2 ) != 0 && P.raw != nullptr );
+	// Raw sources (integer / narrower pixels, whole-pixel lanes; LVAR bit 1):
+	// the rows travel as BYTES by LDS-DMA into the landing queue, GV_PF rows
+	// ahead like float rows, and a lane converts its pixel when it reads the
+	// queue -- the (float) cast and zero padding of the pack pass, in the loader.
+	// The host only picks these variants for images whose base and row pitch
+	// are dword-aligned (gpass_lancir_takes_raw; a 64-pixel segment starts at a
+	// multiple of 64 pixels). A row is `tdn` dword instructions of 256 bytes.
+	// (The first form had every lane load its own pixel one step ahead and carried
+	// three loaders in one kernel: 92-96 KB of code for the 18-tap variants
+	// against the float form's 38 -- more than the instruction cache holds -- and
+	// a step as long as a global-memory round trip: CLancIR 5184x3456 ->
+	// 1920x1280 RGB uint8 spent 118 of its 153 us in this pass. NOTEBOOK 9.8.)
+	constexpr bool TD = ( WP == 2 && ( LVAR & 2 ) != 0 );
+	const int tbpp = P.raw_dma;
+	const int tdn = ( 64 * tbpp + 255 ) >> 8;
+	const __amdgpu_buffer_rsrc_t rraw = __builtin_amdgcn_make_buffer_rsrc(
+		(void*) P.raw, 0, P.raw_bytes, 0x00020000 );
+	const int trow_b = (int) P.raw_ss * ( P.raw_kind == 1 ? 1 :
+		( P.raw_kind == 2 ? 2 : 4 ));
 
-	f4 trv = (f4) 0.0f;
-
-	auto t_load = [&]( const int u )
+	auto issue_raw = [&]( const int p )
 	{
-		trv = gp_load_raw( P.raw, P.raw_kind, P.raw_ch, (long) gp_clamp( u,
-			slast ) * P.raw_ss + (long) dpx * P.raw_ch, P.raw_elems );
-	};
+		const bool live = ( p <= pb );
+		const int r = gp_clamp( min( p, pb ), slast );
+		const unsigned slot = ( !live ? qbase + (unsigned) ( GV_PF + 1 ) * 1024 :
+			qbase + (unsigned) qi * 1024 );
 
-	auto t_store = [&]( const int u ) // row u: queue slot qr, or its ring row
-	{
-		const f4 o = trv;
-		const int off = ( MODE == GP_PRE || RW > 0 ?
-			( P.rs + P.rc ) * ROWB + qr * 1024 : ( u & smask ) * ROWB );
+		qi = ( !live ? qi : ( qi == GV_PF ? 0 : qi + 1 ));
 
-		((f4*) ( smem + off ))[ lane ] = o;
-	};
+		// (bytes past the image's end read as zeros: the buffer's range check;
+		// bytes past the row's end are the next row's -- lanes beyond the width,
+		// never stored)
+		const int boff = r * trow_b + x0 * tbpp + lane * 4;
 
-	if( typed )
-	{
-		t_load( pa );
-		t_store( pa );
-		t_load( pa + 1 );
-	}
-	else
-	{
-		for( int k = 0; k < GV_PF; k++ )
+		for( int k = 0; k < tdn; k++ )
 		{
-			issue_pair( pa + k );
+			gp_dma4( rraw, slot + (unsigned) k * 256, boff + k * 256 );
 		}
+	};
+
+	// this lane's pixel of the row in queue slot `q`: packScanline's (float)
+	// cast and zero padding (avir.h:2777-2840; copyScanline*v, lancir.h:1406)
+	auto raw_px = [&]( const int q ) -> f4
+	{
+		const char* const rp = smem + ( P.rs + P.rc ) * ROWB + q * 1024 +
+			lane * tbpp;
+		float v[ 4 ];
+
+		// four elements whatever the channel count (what lies behind a pixel is
+		// the next pixel, inside the slot), the padding selected to zero after:
+		// no branch per channel in a loop body that is unrolled 32 times
+		if( P.raw_kind == 1 )
+		{
+#pragma unroll
+			for( int c = 0; c < 4; c++ )
+			{
+				v[ c ] = (float) ((const unsigned char*) rp )[ c ];
+			}
+		}
+		else
+		if( P.raw_kind == 2 )
+		{
+#pragma unroll
+			for( int c = 0; c < 4; c++ )
+			{
+				v[ c ] = (float) ((const unsigned short*) rp )[ c ];
+			}
+		}
+		else
+		{
+#pragma unroll
+			for( int c = 0; c < 4; c++ )
+			{
+				v[ c ] = ((const float*) rp )[ c ];
+			}
+		}
+#pragma unroll
+		for( int c = 1; c < 4; c++ )
+		{
+			v[ c ] = ( c < P.raw_ch ? v[ c ] : 0.0f );
+		}
+
+		f4 o; o.x = v[ 0 ]; o.y = v[ 1 ]; o.z = v[ 2 ]; o.w = v[ 3 ];
+		return( o );
+	};
+
+	for( int k = 0; k < GV_PF; k++ )
+	{
+		if( TD ) issue_raw( pa + k ); else issue_pair( pa + k );
 	}
 
 	VT qnext = (VT) 0.0f; // the next step's row of the queue
 
-	gp_wait_vm( GV_PF - 1 ); // the first group has landed
+	gp_wait_vm(( GV_PF - 1 ) * ( TD ? tdn : 1 )); // the first group has landed
 
+	if( TD )
+	{
+		const f4 o = raw_px( 0 );
+		qnext[ 0 ] = o.x; qnext[ 1 ] = o.y;
+		qnext[ WP == 2 ? 2 : 0 ] = o.z; qnext[ WP == 2 ? 3 : 0 ] = o.w;
+	}
+	else
 	if( MODE == GP_PRE || RW > 0 )
 	{
 		qnext = *(const VT*) ( smem + ( P.rs + P.rc ) * ROWB +
@@ -418,11 +481,12 @@ __global__ void __launch_bounds__( 64 ) k_gv( const GVParams P )
 			return;
 		}
 
-		if( typed )
+		if( TD )
 		{
+			issue_raw( u + GV_PF );
+			// (row u + 1 opens the oldest group in flight: `tdn` operations each)
+			gp_wait_vm(( GV_PF - 1 ) * tdn );
 			qr = ( qr == GV_PF ? 0 : qr + 1 );
-			t_store( u + 1 );
-			t_load( u + 2 );
 		}
 		else
 		{
@@ -449,6 +513,13 @@ __global__ void __launch_bounds__( 64 ) k_gv( const GVParams P )
 		// this step's row was read from the queue during the last one
 		const VT qcur = qnext;
 
+		if( TD )
+		{
+			const f4 o = raw_px( qr );
+			qnext[ 0 ] = o.x; qnext[ 1 ] = o.y;
+			qnext[ WP == 2 ? 2 : 0 ] = o.z; qnext[ WP == 2 ? 3 : 0 ] = o.w;
+		}
+		else
 		if( MODE == GP_PRE || RW > 0 )
 		{
 			qnext = *(const VT*) ( smem + ( P.rs + P.rc ) * ROWB + qr * 1024 +

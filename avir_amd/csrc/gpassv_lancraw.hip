@@ -21,7 +21,9 @@ void launch_gv_lanc_raw( const GVParams& P, int items, size_t lds,
 		case 20: GV_LAUNCH_LR( 20, 32 ); break;
 		case 22: GV_LAUNCH_LR( 22, 32 ); break;
 		case 24: GV_LAUNCH_LR( 24, 32 ); break;
-		default: GV_LAUNCH_LR( 0, 0 ); break;
+		// (other tap counts keep their window in an LDS ring of pixels, which
+		// raw bytes cannot feed: gpass_lancir_takes_raw refuses them)
+		default: break;
 	}
 }
 

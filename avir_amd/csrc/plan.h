@@ -371,7 +371,8 @@ void gpass_release( avirhip_plan* p );
 bool gpass_ok( const avirhip_plan* p );
 bool gpass_preferred( const avirhip_plan* p );
 bool gpass_takes_raw( const avirhip_plan* p );
-bool gpass_lancir_takes_raw( const avirhip_plan* p );
+bool gpass_lancir_takes_raw( const avirhip_plan* p, const void* raw, int type,
+	int ch, long stride );
 int gpass_run( avirhip_plan* p, const float* src, long src_stride, float* dst,
 	int row0, int row1, hipStream_t st, const void* raw = nullptr,
 	int raw_type = 0, int raw_ch = 0, long raw_stride = 0,

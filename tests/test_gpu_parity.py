@@ -1090,6 +1090,46 @@ def _lancir_abi(sp, sw, sh, dp, nw, nh, ch, ti, to, ss, ns):
     return abi.check(rc, "lancir_resize")
 
 
+@pytest.mark.parametrize("tin", [np.uint8, np.uint16])
+def test_lancir_raw_rows_travel_as_bytes(tin):
+    """The vertical pass of CLancIR plans with integer pixels (k_gv, raw
+    variants): rows by LDS-DMA as bytes when the image's base and row pitch are
+    dword-aligned, the pack pass otherwise -- widths that are and are not,
+    1-4 channels, padded rows, up- and downsizing (register-window tap counts
+    6 .. 24 and the LDS-window fallback), whole frames and row bands."""
+    lib = abi.load()
+    for (sw, sh, nw, nh) in [(256, 200, 95, 74), (257, 129, 95, 48),
+                             (300, 220, 111, 81), (128, 96, 333, 250),
+                             (515, 300, 64, 40), (640, 480, 80, 60)]:
+        for ch in (1, 2, 3, 4):
+            s = rb.lcg_u8((sh, sw, ch, np.dtype(tin).itemsize), seed=sw + ch)
+            s = s.view(tin).reshape(sh, sw, ch)
+            want = _checker_lancir(s, nw, nh)
+            l = avir_amd.CLancIR()
+            what = "%s ch%d %dx%d->%dx%d" % (np.dtype(tin), ch, sw, sh, nw, nh)
+            _assert_same(l.resize(s, nw, nh), want, what)
+            p = l.plan(sw, sh, nw, nh, ch, in_type=rb._DT[np.dtype(tin)],
+                       out_type=rb._DT[np.dtype(tin)])
+            cut = nh // 3 + 1
+            for a, b in ((0, cut), (cut, nh)):
+                band = np.empty((b - a, nw, ch), tin)
+                abi.check(lib.avirhip_resize_band(
+                    p, s.ctypes.data, abi.MEM_HOST, band.ctypes.data,
+                    abi.MEM_HOST, a, b, None), "band")
+                _assert_same(band, want[a:b], what + " band")
+    # padded source rows: a pitch that is / is not a multiple of 4 bytes
+    for spad in (1, 4, 6):
+        s = rb.lcg_u8((120, 200, 3, np.dtype(tin).itemsize), seed=9)
+        s = s.view(tin).reshape(120, 200, 3)
+        want = _checker_lancir(s, 70, 41, spad=spad)
+        rc, got = rb._lancir_call(
+            lambda sp, sw, sh, dp, nw, nh, ch, ti, to, ss, ns, kx, ky, ox, oy, la:
+            _lancir_abi(sp, sw, sh, dp, nw, nh, ch, ti, to, ss, ns),
+            s, 70, 41, tin, 0.0, 0.0, 0.0, 0.0, 3.0, spad=spad)
+        assert rc == 41
+        _assert_same(got, want, "padded rows +%d" % spad)
+
+
 def test_lancir_wide_types_are_refused_by_cimageresizer():
     """uint32 is CLancIR's quirk only: avir::CImageResizer documents uint8_t,
     uint16_t, float, double (avir.h:4670-4677)."""
