@@ -337,10 +337,7 @@ __global__ void __launch_bounds__( 64 ) k_gh( const GHParams P )
 
 		if( LANC && P.lout.on != 0 )
 		{
-			if( jok )
-			{
-				gp_store_lancir( P.lout, r - P.dst_row0, j, o );
-			}
+			gp_store_lancir_row< 0 >( P.lout, r - P.dst_row0, j, o, jok );
 		}
 		else
 		if( jok )
@@ -765,9 +762,9 @@ int gpass_prepare( avirhip_plan* p )
 		D -> v_blk = 1; D -> v_rs = rs; D -> v_rc = rc;
 	}
 
-	// ---- LANCIR upsizing, both kernels 6 taps, RGBA order: the fused launch's
-	// strips -- the widest whose source segments fit one 64-pixel piece
-	if( p -> is_lancir && D -> h.a.lanc == 4 && D -> v.a.lanc == 4 &&
+	// ---- LANCIR upsizing, both kernels 6 taps: the fused launch's strips --
+	// the widest whose source segments fit one 64-pixel piece
+	if( p -> is_lancir && D -> h.a.lanc != 0 && D -> v.a.lanc == D -> h.a.lanc &&
 		D -> h.a.nt == 6 && D -> v.a.nt == 6 &&
 		getenv( "AVIRHIP_NO_LFUSE" ) == nullptr )
 	{
@@ -1231,7 +1228,20 @@ int gpass_run( avirhip_plan* p, const float* src, long src_stride, float* dst,
 		getenv( "AVIRHIP_NO_GFUSE" ) == nullptr );
 
 	// ... and so do LANCIR's upsizing plans of float RGBA pixels (lfuse.hip)
-	const bool use_lf = ( p -> is_lancir && D -> lf_ow != 0 && !p -> lraw.on &&
+	// (with the owner's image as the source where its rows can travel as bytes
+	// -- what gpass_lancir_takes_raw promised covers it). With an INTEGER result
+	// the fusion pays up to about 2.5x horizontally: the vertical stage works on
+	// the 64 / ratio + 6 source columns of a strip's 64 lanes, and the two pass
+	// kernels' intermediate image is no longer small against a uint8 result
+	// (1920x1080 RGB uint8, same box, fused / two passes: x1.5 0.033 / 0.042 ms,
+	// x2.1 0.057 / 0.060, x2.5 0.076 / 0.075, x3 0.107 / 0.097, x4 0.192 / 0.152;
+	// float results: fused wins at every ratio, x3 0.085 / 0.126)
+	const bool lf_pays = ( !p -> lfuse.on || p -> lfuse.type == AVIRHIP_F32 ||
+		(long) p -> new_w * 10 <= (long) p -> src_w * 24 ||
+		( p -> variant & AVIRHIP_VARIANT_UPG_FUSED ) != 0 );
+	const bool use_lf = ( p -> is_lancir && D -> lf_ow != 0 && lf_pays &&
+		( !p -> lraw.on || lfuse_takes_raw( p -> lraw.ptr, p -> lraw.type,
+		p -> lraw.ch, p -> lraw.stride, p -> src_h, p -> src_w )) &&
 		( p -> variant & AVIRHIP_VARIANT_UPG_TWO_PASS ) == 0 );
 
 	if( D -> mid == nullptr && !use_gf && !use_lf )
@@ -1271,6 +1281,20 @@ int gpass_run( avirhip_plan* p, const float* src, long src_stride, float* dst,
 			G.row_lo = row0; G.row_hi = row1;
 			G.nstrips = D -> lf_nstrips; G.ow = D -> lf_ow;
 			G.seg = D -> d_lfseg; G.vtab = D -> d_lfvtab;
+
+			if( p -> lraw.on )
+			{
+				// (an inner plan: the owner's image, read as it is)
+				const int esz = ( p -> lraw.type == AVIRHIP_U8 ? 1 :
+					( p -> lraw.type == AVIRHIP_U16 ? 2 : 4 ));
+
+				G.raw = p -> lraw.ptr; G.raw_ss = p -> lraw.stride;
+				G.raw_kind = ( esz == 1 ? 1 : ( esz == 2 ? 2 : 3 ));
+				G.raw_ch = p -> lraw.ch; G.raw_bpp = esz * p -> lraw.ch;
+				G.raw_bytes = (int) (( (long) ( p -> src_h - 1 ) * p -> lraw.stride +
+					(long) p -> src_w * p -> lraw.ch ) * esz );
+				G.raw_tdn = ( 64 * G.raw_bpp + ( G.raw_bpp & 3 ? 3 : 0 ) + 255 ) >> 8;
+			}
 
 			if( p -> lfuse.on )
 			{

@@ -384,6 +384,148 @@ __device__ __forceinline__ void gp_store_lancir( const GPLOut& O,
 	}
 }
 
+// The same, called by EVERY lane of the wave (`ok`: this lane's pixel exists;
+// lanes are consecutive pixels x of one row). uint8 pixels of 3 or 4 channels
+// leave as whole dwords -- RGBA: the lane's own four bytes; RGB: a quad of lanes
+// holds 12 contiguous bytes, lane q builds dword q from its packed pixel and its
+// right neighbour's (one DPP move), lanes 0-2 store -- one store instruction per
+// row instead of three or four with 64 scattered bytes each. uint16 RGBA: one
+// 8-byte store. The rounding rule is a property of the ELEMENT's position, and
+// the 1-3 element tail of a scanline lies in its last pixel: a wave none of
+// whose pixels reaches it (one ballot) rounds to nearest-even in straight-line
+// code; the first form branched per element and channel -- 25 branches per
+// output row, more cycles than the two dot products before them.
+// KIND: 0 = whatever O says; 1 / 2 = uint8 RGB / RGBA known at compile time.
+template< int KIND >
+__device__ __forceinline__ void gp_store_lancir_row( const GPLOut& O,
+	const long row, const int x, const f4 o, const bool ok )
+{
+	const int type = ( KIND != 0 ? AVIRHIP_U8 : O.type );
+	const int ch = ( KIND == 1 ? 3 : ( KIND == 2 ? 4 : O.ch ));
+	const bool b8 = ( type == AVIRHIP_U8 && ch >= 3 );
+	const bool b16 = ( type == AVIRHIP_U16 && ch == 4 );
+
+	if( !b8 && !b16 )
+	{
+		if( ok )
+		{
+			gp_store_lancir( O, row, x, o );
+		}
+
+		return;
+	}
+
+	const float vv[ 4 ] = { o.x, o.y, o.z, o.w };
+	// (x * 1.0f is x: no branch on O.unity)
+	const float mulv = ( O.unity ? 1.0f : O.out_mul );
+	unsigned int q[ 4 ] = { 0, 0, 0, 0 };
+	const bool tail = ( __builtin_amdgcn_ballot_w64( ok &&
+		x * ch + ch > O.l4 ) != 0 );
+
+	if( !tail )
+	{
+#pragma unroll
+		for( int c = 0; c < ( KIND == 1 ? 3 : 4 ); c++ )
+		{
+			float v = vv[ c ] * mulv;
+			v = ( v < O.clampv ? v : O.clampv );
+			v = ( v > 0.0f ? v : 0.0f );
+			q[ c ] = (unsigned int) (int) rintf( v );
+		}
+	}
+	else
+	{
+#pragma unroll
+		for( int c = 0; c < 4; c++ )
+		{
+			float v = vv[ c ] * mulv;
+
+			if( x * ch + c < O.l4 )
+			{
+				v = ( v < O.clampv ? v : O.clampv );
+				v = ( v > 0.0f ? v : 0.0f );
+				q[ c ] = (unsigned int) (int) rintf( v );
+			}
+			else
+			{
+				q[ c ] = (unsigned int) (int) (( v > O.clampv ? O.clampv :
+					( v < 0.0f ? 0.0f : v )) + 0.5f );
+			}
+		}
+	}
+
+	typedef unsigned int u32u __attribute__(( aligned( 1 )));
+
+	if( b16 )
+	{
+		if( ok )
+		{
+			unsigned short* const p = (unsigned short*) O.base +
+				row * O.stride + (long) x * 4;
+			typedef unsigned int u32h __attribute__(( aligned( 2 )));
+			((u32h*) p )[ 0 ] = ( q[ 0 ] & 0xffffu ) | ( q[ 1 ] << 16 );
+			((u32h*) p )[ 1 ] = ( q[ 2 ] & 0xffffu ) | ( q[ 3 ] << 16 );
+		}
+
+		return;
+	}
+
+	const unsigned int pk = ( q[ 0 ] & 0xffu ) | (( q[ 1 ] & 0xffu ) << 8 ) |
+		(( q[ 2 ] & 0xffu ) << 16 ) | ( q[ 3 ] << 24 );
+
+	if( ch == 4 )
+	{
+		if( ok )
+		{
+			*(u32u*) ((unsigned char*) O.base + row * O.stride +
+				(long) x * 4 ) = pk;
+		}
+
+		return;
+	}
+
+	const int lane = (int) __builtin_amdgcn_mbcnt_hi( ~0u,
+		__builtin_amdgcn_mbcnt_lo( ~0u, 0u ));
+	const int qd = lane & 3;
+	// the right neighbour's packed pixel (quad_perm [1, 2, 3, 3])
+	const unsigned int nx = (unsigned int) __builtin_amdgcn_mov_dpp( (int) pk,
+		0xF9, 0xF, 0xF, true );
+	const unsigned long long m = __builtin_amdgcn_ballot_w64( ok );
+	const bool full = ((( m >> ( lane & ~3 )) & 0xFull ) == 0xFull );
+	unsigned char* const p = (unsigned char*) O.base + row * O.stride +
+		(long) x * 3;
+
+	// (dword qd of the quad's 12 bytes: at the quad's first byte + 4 qd = this
+	// lane's pixel + qd bytes)
+	const unsigned int dw = (( pk & 0xffffffu ) >> ( 8 * qd )) |
+		( nx << ( 24 - 8 * qd ));
+
+	if( m == ~0ull )
+	{
+		if( qd < 3 )
+		{
+			*(u32u*) ( p + qd ) = dw;
+		}
+
+		return;
+	}
+
+	if( full )
+	{
+		if( qd < 3 )
+		{
+			*(u32u*) ( p + qd ) = dw;
+		}
+	}
+	else
+	if( ok )
+	{
+		p[ 0 ] = (unsigned char) pk;
+		p[ 1 ] = (unsigned char) ( pk >> 8 );
+		p[ 2 ] = (unsigned char) ( pk >> 16 );
+	}
+}
+
 // Host side of a recognised axis.
 struct GPAxisHost
 {
@@ -457,7 +599,7 @@ struct LFParams
 {
 	const float* src; long src_ss;  // float RGBA source, floats per row
 	float* dst; long dst_ss; int dst_row0;
-	GPAxis hx, vx;       // both LANCIR (lanc == 4), 6 taps
+	GPAxis hx, vx;       // both LANCIR (the same summation order), 6 taps
 	int row_lo, row_hi;  // output rows to produce
 	int nstrips, ow, chunk; // strips of `ow` outputs (segment <= 64 source px)
 	const int* seg;      // [nstrips][2]: first source column, count
@@ -465,9 +607,17 @@ struct LFParams
 	                     // output row (its phase's, zero padded)
 	GPLOut lout;         // on != 0: the owner's output stage in the store
 	int dbg;
+	// raw != nullptr: the owner's image as it is (integer / narrower pixels)
+	// -- rows travel as bytes, lfuse.hip
+	const void* raw; long raw_ss;   // elements per row
+	int raw_kind, raw_ch;           // 1 uint8, 2 uint16, 3 float; 1..4 channels
+	int raw_bpp, raw_bytes, raw_tdn; // bytes per pixel, of the image; DMA
+	                                // instructions per row segment
 };
 
 int lfuse_launch( LFParams& P, hipStream_t st );
+bool lfuse_takes_raw( const void* raw, int type, int ch, long stride,
+	int in_len_v, int width );
 
 // One gather output: tap t reads ld( t ); cf4( b ) returns the coefficients
 // of taps 4b .. 4b + 3 (rows are padded to a multiple of four; padded taps are

@@ -45,8 +45,21 @@ namespace avirhip {
 #define LF_ON( bit ) true
 #endif
 
+// TDN = 0: float RGBA rows, a pixel per lane and DMA instruction. TDN > 0: raw
+// rows (uint8 / uint16 / 1-3 channel float pixels) as BYTES -- a row's segment
+// is TDN dword instructions of 256 bytes from the dword at or below its first
+// pixel, and a lane converts its pixel when it reads the row buffer
+// (copyScanline*v's cast and zero padding, lancir.h:1406-1594); the host only
+// picks these for dword-aligned bases and pitches (lfuse_takes_raw).
+// SRC = 0: float RGBA; 1: uint8 pixels (always one DMA instruction); 2 .. 4: any
+// raw kind with SRC - 1 instructions. OUTK: the output stage's compile-time
+// kind (gp_store_lancir_row; 0 = whatever P.lout says).
+template< int SRC, int OUTK >
 __global__ void __launch_bounds__( 64 ) k_lf( const LFParams P )
 {
+	constexpr bool RAW = ( SRC > 0 );
+	constexpr int TDN = ( SRC <= 1 ? SRC : SRC - 1 );
+	const int raw_kind = ( SRC == 1 ? 1 : P.raw_kind );
 	constexpr int NT = 6;   // taps of both kernels (la = 3, upsizing)
 	constexpr int NTP = 8;  // ... padded to whole f4 rows
 	constexpr int RW = 8;   // vertical window (ring slots, >= NT)
@@ -89,20 +102,90 @@ __global__ void __launch_bounds__( 64 ) k_lf( const LFParams P )
 	// ---- vertical side: this lane's source column (clamped: the padded view)
 	gp_cint* const a_start = (gp_cint*) (unsigned long) VA.start;
 	const int vslast = VA.in_len - 1;
+	const int lord = VA.lanc; // the image's channel count picks the order
 	const int ga = y0, gb = y1 - 1;
 	const int u_a = a_start[ ga ];
 	const int u_b = a_start[ gb ] + NT - 1;
 
 	// ---- the feed: source row clamp( u ) of step u, 64 pixels from slo on
 	const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
-		(void*) P.src, 0, 0x7fffffff, 0x00020000 );
-	const int srow_b = (int) P.src_ss * 4;
-	const int xoff = gp_clamp( slo + lane, hslast ) * 16;
+		(void*) ( RAW ? P.raw : (const void*) P.src ), 0,
+		( RAW ? P.raw_bytes : 0x7fffffff ), 0x00020000 );
+	const int srow_b = ( RAW ? (int) P.raw_ss * ( raw_kind == 1 ? 1 :
+		( raw_kind == 2 ? 2 : 4 )) : (int) P.src_ss * 4 );
+	// (raw: the segment's first byte, its dword, this lane's pixel behind it;
+	// bytes past the image's end read as zeros -- the buffer's range check)
+	const int sa = gp_clamp( slo, hslast );
+	const int b0 = sa * P.raw_bpp;
+	const int poff = ( b0 & 3 ) + ( gp_clamp( slo + lane, hslast ) - sa ) *
+		P.raw_bpp;
+	const int xoff = ( RAW ? ( b0 & ~3 ) + lane * 4 :
+		gp_clamp( slo + lane, hslast ) * 16 );
 
 	auto issue_row = [&]( const int u, const int buf )
 	{
-		gp_dma( rsrc, sbuf_lds + ( buf * 64 ) * 16, gp_clamp( u, vslast ) *
-			srow_b + xoff );
+		const int boff = gp_clamp( u, vslast ) * srow_b + xoff;
+
+		if( RAW )
+		{
+#pragma unroll
+			for( int k = 0; k < ( RAW ? TDN : 1 ); k++ )
+			{
+				gp_dma4( rsrc, sbuf_lds + ( buf * 64 ) * 16 + k * 256,
+					boff + k * 256 );
+			}
+		}
+		else
+		{
+			gp_dma( rsrc, sbuf_lds + ( buf * 64 ) * 16, boff );
+		}
+	};
+
+	// this lane's pixel of a row buffer: four elements whatever the channel
+	// count, the padding selected to zero (no branch per channel)
+	auto row_px = [&]( const int buf ) -> f4
+	{
+		if( !RAW )
+		{
+			return( sbuf[ buf * 64 + lane ]);
+		}
+
+		const char* const rp = smem + buf * 1024 + poff;
+		float v[ 4 ];
+
+		if( raw_kind == 1 )
+		{
+#pragma unroll
+			for( int c = 0; c < 4; c++ )
+			{
+				v[ c ] = (float) ((const unsigned char*) rp )[ c ];
+			}
+		}
+		else
+		if( raw_kind == 2 )
+		{
+#pragma unroll
+			for( int c = 0; c < 4; c++ )
+			{
+				v[ c ] = (float) ((const unsigned short*) rp )[ c ];
+			}
+		}
+		else
+		{
+#pragma unroll
+			for( int c = 0; c < 4; c++ )
+			{
+				v[ c ] = ((const float*) rp )[ c ];
+			}
+		}
+#pragma unroll
+		for( int c = 1; c < 4; c++ )
+		{
+			v[ c ] = ( c < P.raw_ch ? v[ c ] : 0.0f );
+		}
+
+		f4 o; o.x = v[ 0 ]; o.y = v[ 1 ]; o.z = v[ 2 ]; o.w = v[ 3 ];
+		return( o );
 	};
 
 	for( int k = 0; k < LF_NB - 1 && u_a + k <= u_b; k++ )
@@ -186,7 +269,7 @@ __global__ void __launch_bounds__( 64 ) k_lf( const LFParams P )
 			c = gp_dot< true, f4, NT >( NT,
 				[&]( const int t ) { return( win[ ( I - ( NT - 1 ) + t + 4 * RW ) &
 					( RW - 1 )]); },
-				[&]( const int b ) { return( cpre[ b ]); });
+				[&]( const int b ) { return( cpre[ b ]); }, lord );
 
 			if( LF_ON( 2 ))
 			mbuf[ lane ] = c;
@@ -212,15 +295,12 @@ __global__ void __launch_bounds__( 64 ) k_lf( const LFParams P )
 						q.x = cf[ ( 4 * b ) % NTP ]; q.y = cf[ ( 4 * b + 1 ) % NTP ];
 						q.z = cf[ ( 4 * b + 2 ) % NTP ]; q.w = cf[ ( 4 * b + 3 ) % NTP ];
 						return( q );
-					});
+					}, lord );
 			}
 
 			if( P.lout.on != 0 )
 			{
-				if( jok )
-				{
-					gp_store_lancir( P.lout, orow, j, o );
-				}
+				gp_store_lancir_row< OUTK >( P.lout, orow, j, o, jok );
 
 				orow++;
 			}
@@ -266,14 +346,14 @@ __global__ void __launch_bounds__( 64 ) k_lf( const LFParams P )
 		// what it saves.
 		if( u_b - u >= LF_NB - 1 )
 		{
-			GP_WAIT_VM( 7 );
+			gp_wait_vm(( LF_NB - 1 ) * ( RAW ? TDN : 1 ));
 		}
 		else
 		{
-			gp_wait_vm( u_b - u );
+			gp_wait_vm(( u_b - u ) * ( RAW ? TDN : 1 ));
 		}
 
-		win[ i & ( RW - 1 )] = sbuf[ buf * 64 + lane ];
+		win[ i & ( RW - 1 )] = row_px( buf );
 		drain( u, IC );
 	};
 
@@ -317,9 +397,45 @@ int lfuse_launch( LFParams& P, hipStream_t st )
 	static const int dbg = ( getenv( "AVIRHIP_LF_DBG" ) != nullptr ?
 		atoi( getenv( "AVIRHIP_LF_DBG" )) : 0 );
 	P.dbg = dbg;
-	hipLaunchKernelGGL( k_lf, dim3( P.nstrips * nch ), dim3( 64 ), lds, st, P );
+	const dim3 grid( P.nstrips * nch );
+
+	const int src_kind = ( P.raw == nullptr ? 0 : ( P.raw_kind == 1 ? 1 :
+		P.raw_tdn + 1 ));
+	const int out_kind = ( P.lout.on != 0 && P.lout.type == AVIRHIP_U8 &&
+		P.lout.ch >= 3 && src_kind <= 1 ? P.lout.ch - 2 : 0 );
+
+#define LF_GO( S, O ) hipLaunchKernelGGL(( k_lf< S, O > ), grid, dim3( 64 ), lds, st, P )
+	switch( src_kind * 4 + out_kind )
+	{
+		case 0: LF_GO( 0, 0 ); break;
+		case 1: LF_GO( 0, 1 ); break;
+		case 2: LF_GO( 0, 2 ); break;
+		case 4: LF_GO( 1, 0 ); break;
+		case 5: LF_GO( 1, 1 ); break;
+		case 6: LF_GO( 1, 2 ); break;
+		case 8: LF_GO( 2, 0 ); break;
+		case 12: LF_GO( 3, 0 ); break;
+		case 16: LF_GO( 4, 0 ); break;
+		default: return( 1 );
+	}
+#undef LF_GO
+
 	AVIRHIP_HIPCHECK( hipGetLastError() );
 	return( AVIRHIP_OK );
+}
+
+// Whether k_lf can read the owner's image as it is: dword-aligned base and row
+// pitch (a segment starts at the dword at or below its first pixel), byte
+// offsets in 31 bits.
+bool lfuse_takes_raw( const void* raw, int type, int ch, long stride,
+	int in_len_v, int width )
+{
+	const long esz = ( type == AVIRHIP_U8 ? 1 : ( type == AVIRHIP_U16 ? 2 : 4 ));
+	const long bytes = ( (long) ( in_len_v - 1 ) * stride + (long) width * ch ) * esz;
+
+	return( raw != nullptr && ( (uintptr_t) raw & 3 ) == 0 &&
+		(( stride * esz ) & 3 ) == 0 && bytes >= 4 && bytes < ( 1L << 31 ) &&
+		ch >= 1 && ch <= 4 && esz * ch < 16 );
 }
 
 } // namespace avirhip

@@ -64,6 +64,9 @@ OTHER = {"cfg1": ("avir", 640, 480, 1024, 768, 3, "u8", 8),
          "lanc_readme_u8": ("lancir", 5184, 3456, 1920, 1280, 3, "u8", 8),
          "lanc_dn3_rgba8": ("lancir", 3840, 2160, 1280, 720, 4, "u8", 8),
          "lanc_nonint_u8": ("lancir", 1920, 1080, 2500, 1400, 3, "u8", 8),
+         "lanc_nonint_rgba8": ("lancir", 1920, 1080, 2500, 1400, 4, "u8", 8),
+         "lanc_triple_u8": ("lancir", 1920, 1080, 5760, 3240, 3, "u8", 8),
+         "lanc_triple": ("lancir", 1920, 1080, 5760, 3240, 4, "f32", 16),
          "half": ("avir", 3840, 2160, 1920, 1080, 4, "f32", 16),
          "triple": ("avir", 1920, 1080, 5760, 3240, 4, "f32", 16),
          "nonint_u8": ("avir", 1920, 1080, 2500, 1400, 3, "u8", 8),

@@ -1657,6 +1657,63 @@ def test_lancir_fused_upsizing_kernel():
                 _assert_same(out, want, "lancir fused bands")
 
 
+@pytest.mark.parametrize("tin", [np.uint8, np.uint16, np.float32, np.float64])
+def test_lancir_fused_upsizing_kernel_reads_raw_images(tin):
+    """k_lf with the owner's image as its source (uint8 / uint16 / 1-3 channel
+    float rows as bytes by LDS-DMA from the dword at or below a segment's first
+    pixel) and with resize1..3's summation orders (lancir.h:2102-2466; float64
+    sources reach it through the pack pass): widths and pitches that are and
+    are not dword multiples, segments that start at odd bytes, 1-4 channels,
+    integer and float results, whole frames and row bands -- against the
+    reference and against the two pass kernels."""
+    lib = abi.load()
+    for (sw, sh, nw, nh) in [(128, 96, 333, 250), (129, 67, 513, 259),
+                             (61, 45, 100, 77), (90, 300, 200, 720),
+                             (301, 40, 1001, 47), (17, 9, 60, 31),
+                             (3, 50, 7, 120), (640, 480, 1024, 768)]:
+        for ch in (1, 2, 3, 4):
+            if np.dtype(tin).kind == "f":
+                s = rb.lcg_f32((sh, sw, ch), seed=sw + ch).astype(tin)
+            else:
+                s = rb.lcg_u8((sh, sw, ch, np.dtype(tin).itemsize), seed=sw + ch)
+                s = s.view(tin).reshape(sh, sw, ch)
+            for tout in (tin, np.float32, np.uint8):
+                want = _checker_lancir(s, nw, nh, out_dtype=tout)
+                what = "%s->%s ch%d %dx%d->%dx%d" % (
+                    np.dtype(tin), np.dtype(tout), ch, sw, sh, nw, nh)
+                l = avir_amd.CLancIR()
+                p = l.plan(sw, sh, nw, nh, ch, in_type=rb._DT[np.dtype(tin)],
+                           out_type=rb._DT[np.dtype(tout)])
+                for variant in (0, abi.VARIANT_UPG_TWO_PASS,
+                                abi.VARIANT_UPG_FUSED):
+                    abi.check(lib.avirhip_plan_set_variant(p, variant), "variant")
+                    got = np.empty((nh, nw, ch), tout)
+                    abi.check(lib.avirhip_resize(
+                        p, s.ctypes.data, abi.MEM_HOST, got.ctypes.data,
+                        abi.MEM_HOST, None), "resize")
+                    _assert_same(got, want, what + " variant %d" % variant)
+                abi.check(lib.avirhip_plan_set_variant(p, 0), "variant")
+                cut = nh // 3 + 1
+                for a, b in ((0, cut), (cut, nh)):
+                    band = np.empty((b - a, nw, ch), tout)
+                    abi.check(lib.avirhip_resize_band(
+                        p, s.ctypes.data, abi.MEM_HOST, band.ctypes.data,
+                        abi.MEM_HOST, a, b, None), "band")
+                    _assert_same(band, want[a:b], what + " band")
+    if np.dtype(tin).kind == "u":
+        # padded source rows: a pitch that is / is not a multiple of 4 bytes
+        for spad in (1, 4, 6):
+            s = rb.lcg_u8((60, 100, 3, np.dtype(tin).itemsize), seed=9)
+            s = s.view(tin).reshape(60, 100, 3)
+            want = _checker_lancir(s, 170, 141, spad=spad)
+            rc, got = rb._lancir_call(
+                lambda sp, sw, sh, dp, nw, nh, ch, ti, to, ss, ns, kx, ky, ox, oy, la:
+                _lancir_abi(sp, sw, sh, dp, nw, nh, ch, ti, to, ss, ns),
+                s, 170, 141, tin, 0.0, 0.0, 0.0, 0.0, 3.0, spad=spad)
+            assert rc == 141
+            _assert_same(got, want, "padded rows +%d" % spad)
+
+
 def test_avir_fused_upsizing_is_the_default_for_large_frames():
     """1920x1080 -> 5760x3240 (18.7 Mpixels of output) takes k_gf by itself:
     the hash of the reference's result (tests/golden/make_golden.py wrote it
@@ -2069,10 +2126,20 @@ def test_lancir_integer_plans_allocate_no_float_copies():
     _assert_same(got, want, "lancir u8")
     p = l.plan(sw, sh, nw, nh, ch, None, abi.U8, abi.U8)
     used = lib.avirhip_plan_device_bytes(p)
-    # what is left: the pass kernels' intermediate [new_h][src_w] float RGBA,
-    # the staging copies of the two host images, tables
-    allowed = nh * sw * 16 + (sw * sh + nw * nh) * ch + (2 << 20)
-    assert 0 < used < allowed < used + min(sw * sh, nw * nh) * 16, used
+    # what is left: the staging copies of the two host images and tables (an
+    # upsizing plan: both passes in one launch, no intermediate either)
+    allowed = (sw * sh + nw * nh) * ch + (2 << 20)
+    assert 0 < used < allowed < min(sw * sh, nw * nh) * 16, used
+    # ... and a downsizing plan keeps the pass kernels' intermediate
+    # [new_h][src_w] float RGBA only
+    l3 = avir_amd.CLancIR()
+    src3 = rb.lcg_u8((nh, nw, ch), seed=6)
+    _assert_same(l3.resize(src3, sw, sh), _checker_lancir(src3, sw, sh),
+                 "lancir u8 down")
+    p3 = l3.plan(nw, nh, sw, sh, ch, None, abi.U8, abi.U8)
+    used3 = lib.avirhip_plan_device_bytes(p3)
+    allowed3 = sh * nw * 16 + (sw * sh + nw * nh) * ch + (2 << 20)
+    assert 0 < used3 < allowed3 < used3 + min(sw * sh, nw * nh) * 16, used3
     l2 = avir_amd.CLancIR()
     p2 = l2.plan(sw, sh, nw, nh, ch, None, abi.U8, abi.U8)
     abi.check(lib.avirhip_plan_set_path(p2, abi.PATH_GENERIC), "set_path")

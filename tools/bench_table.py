@@ -2,7 +2,7 @@
 """Every bench.py workload on its automatic path in ONE process (one torch
 import, one device context): the table of README.md / NOTEBOOK.md.
 
-usage: python tools/bench_table.py [steps] [workload ...]
+usage: python tools/bench_table.py [steps] [workload | name=api,sw,sh,nw,nh,ch,dtype,resbits ...]
 """
 import os
 import sys
@@ -20,6 +20,12 @@ names = sys.argv[2:] or [
     "lanc_nonint", "lanc_dn3", "lanc_up2_rgba8", "lanc_up2_u8", "lanc_readme_u8",
     "cfg2_dbl", "cfg3_dbl", "cfg4_dbl", "nonint_dbl"]
 for n in names:
+    if "=" in n:
+        # an ad-hoc geometry: name=api,sw,sh,nw,nh,ch,dtype,resbits
+        n, spec = n.split("=", 1)
+        f = spec.split(",")
+        bench.OTHER[n] = (f[0], int(f[1]), int(f[2]), int(f[3]), int(f[4]),
+                          int(f[5]), f[6], int(f[7]))
     if n not in bench.OTHER:
         print("%-15s (unknown workload)" % n)
         continue
