@@ -484,8 +484,16 @@ __global__ void __launch_bounds__( 64 ) k_gv( const GVParams P )
 		if( TD )
 		{
 			issue_raw( u + GV_PF );
-			// (row u + 1 opens the oldest group in flight: `tdn` operations each)
-			gp_wait_vm(( GV_PF - 1 ) * tdn );
+
+			// (row u + 1 opens the oldest group in flight: `tdn` operations
+			// each. The count picks an s_waitcnt immediate: spelled out per
+			// `tdn` it is two compares -- through gp_wait_vm's 25-way ladder
+			// it was ten branches in every step of the unrolled loop)
+			if( tdn == 1 ) gp_wait_vm(( GV_PF - 1 ) * 1 );
+			else if( tdn == 2 ) gp_wait_vm(( GV_PF - 1 ) * 2 );
+			else if( tdn == 3 ) gp_wait_vm(( GV_PF - 1 ) * 3 );
+			else gp_wait_vm(( GV_PF - 1 ) * 4 );
+
 			qr = ( qr == GV_PF ? 0 : qr + 1 );
 		}
 		else
