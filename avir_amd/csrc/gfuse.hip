@@ -246,7 +246,19 @@ __global__ void __launch_bounds__( 64 ) k_gf( const GFParams P )
 		}
 		else
 		{
-			gp_wait_vm( min( GF_NB - 1, u_b - u ) * P.nseg );
+			// (steady state: the count per segment count spelled out -- the
+			// general count walks gp_wait_vm's 25-way ladder, ten branches a row)
+			if( u_b - u >= GF_NB - 1 && P.nseg <= 4 )
+			{
+				if( P.nseg == 1 ) gp_wait_vm(( GF_NB - 1 ) * 1 );
+				else if( P.nseg == 2 ) gp_wait_vm(( GF_NB - 1 ) * 2 );
+				else if( P.nseg == 3 ) gp_wait_vm(( GF_NB - 1 ) * 3 );
+				else gp_wait_vm(( GF_NB - 1 ) * 4 );
+			}
+			else
+			{
+				gp_wait_vm( min( GF_NB - 1, u_b - u ) * P.nseg );
+			}
 		}
 
 		// H: FIR7 along x of the segment (clamped source view; C above the

@@ -216,7 +216,19 @@ __global__ void __launch_bounds__( 64 ) k_gh( const GHParams P )
 			// -- so they may only make this wait longer, never shorter. Rounds
 			// 3-4 added them to the count here; no mismatch was ever seen, but
 			// it was a race.)
-			gp_wait_vm( min( GH_NB - 1, r1 - 1 - r ) * P.nseg );
+			// (steady state: the count per segment count spelled out -- the
+			// general count walks gp_wait_vm's 25-way ladder, ten branches a row)
+			if( r1 - 1 - r >= GH_NB - 1 && P.nseg <= 4 )
+			{
+				if( P.nseg == 1 ) gp_wait_vm(( GH_NB - 1 ) * 1 );
+				else if( P.nseg == 2 ) gp_wait_vm(( GH_NB - 1 ) * 2 );
+				else if( P.nseg == 3 ) gp_wait_vm(( GH_NB - 1 ) * 3 );
+				else gp_wait_vm(( GH_NB - 1 ) * 4 );
+			}
+			else
+			{
+				gp_wait_vm( min( GH_NB - 1, r1 - 1 - r ) * P.nseg );
+			}
 		}
 
 		if( MODE != GP_PRE && slo + scnt - 1 > A.view_mmax )
