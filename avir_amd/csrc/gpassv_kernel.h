@@ -45,7 +45,8 @@ template<> struct GVLane< 2 > { typedef f4 T; };
 
 // LVAR (LANCIR variants only -- compiled in, they cost the float RGBA kernels
 // 35 .. 50 registers): bit 0 = the four-lane summation orders of 1-3 channel
-// images (gp_dot), bit 1 = the raw-source loader.
+// images (gp_dot), bit 1 = the raw-source loader, bit 2 = ... of uint8 pixels
+// (the element type known at compile time: no dispatch in the step).
 template< int MODE, bool LANC, int NTC, int RW, int WP, int LVAR >
 __global__ void __launch_bounds__( 64 ) k_gv( const GVParams P )
 {
@@ -356,7 +357,14 @@ __global__ void __launch_bounds__( 64 ) k_gv( const GVParams P )
 	// queue -- the (float) cast and zero padding of the pack pass, in the loader.
 	// The host only picks these variants for images whose base and row pitch
 	// are dword-aligned (gpass_lancir_takes_raw; a 64-pixel segment starts at a
-	// multiple of 64 pixels). A row is `tdn` dword instructions of 256 bytes.
+	// multiple of 64 pixels). A row is ONE 16-byte-per-lane instruction issued
+	// by the first 4 x (bytes per pixel) lanes: 64 pixels x bytes per pixel,
+	// contiguous. (As 1-4 dword instructions of 256 bytes the count was a
+	// run-time loop and picked the s_waitcnt immediate through a branch chain in
+	// every step; with the element-type dispatch of the conversion a step was 68
+	// scalar instructions for 46 vector ones -- the pass was bound by the CU's
+	// scalar unit: rocprofv3 SQ_INSTS_SALU 21.5 M against SQ_INSTS_VALU 14.5 M per
+	// launch, profiles/r05_lanc.)
 	// (The first form had every lane load its own pixel one step ahead and carried
 	// three loaders in one kernel: 92-96 KB of code for the 18-tap variants
 	// against the float form's 38 -- more than the instruction cache holds -- and
@@ -364,11 +372,12 @@ __global__ void __launch_bounds__( 64 ) k_gv( const GVParams P )
 	// 1920x1280 RGB uint8 spent 118 of its 153 us in this pass. NOTEBOOK 9.8.)
 	constexpr bool TD = ( WP == 2 && ( LVAR & 2 ) != 0 );
 	const int tbpp = P.raw_dma;
-	const int tdn = ( 64 * tbpp + 255 ) >> 8;
+	const int raw_kind = (( LVAR & 4 ) ? 1 : P.raw_kind );
 	const __amdgpu_buffer_rsrc_t rraw = __builtin_amdgcn_make_buffer_rsrc(
 		(void*) P.raw, 0, P.raw_bytes, 0x00020000 );
-	const int trow_b = (int) P.raw_ss * ( P.raw_kind == 1 ? 1 :
-		( P.raw_kind == 2 ? 2 : 4 ));
+	const int trow_b = (int) P.raw_ss * ( raw_kind == 1 ? 1 :
+		( raw_kind == 2 ? 2 : 4 ));
+	const bool tlane = ( lane < 4 * tbpp );
 
 	auto issue_raw = [&]( const int p )
 	{
@@ -382,11 +391,11 @@ __global__ void __launch_bounds__( 64 ) k_gv( const GVParams P )
 		// (bytes past the image's end read as zeros: the buffer's range check;
 		// bytes past the row's end are the next row's -- lanes beyond the width,
 		// never stored)
-		const int boff = r * trow_b + x0 * tbpp + lane * 4;
+		const int boff = r * trow_b + x0 * tbpp + lane * 16;
 
-		for( int k = 0; k < tdn; k++ )
+		if( tlane )
 		{
-			gp_dma4( rraw, slot + (unsigned) k * 256, boff + k * 256 );
+			gp_dma( rraw, slot, boff );
 		}
 	};
 
@@ -401,7 +410,7 @@ __global__ void __launch_bounds__( 64 ) k_gv( const GVParams P )
 		// four elements whatever the channel count (what lies behind a pixel is
 		// the next pixel, inside the slot), the padding selected to zero after:
 		// no branch per channel in a loop body that is unrolled 32 times
-		if( P.raw_kind == 1 )
+		if( raw_kind == 1 )
 		{
 #pragma unroll
 			for( int c = 0; c < 4; c++ )
@@ -410,7 +419,7 @@ __global__ void __launch_bounds__( 64 ) k_gv( const GVParams P )
 			}
 		}
 		else
-		if( P.raw_kind == 2 )
+		if( raw_kind == 2 )
 		{
 #pragma unroll
 			for( int c = 0; c < 4; c++ )
@@ -443,7 +452,7 @@ __global__ void __launch_bounds__( 64 ) k_gv( const GVParams P )
 
 	VT qnext = (VT) 0.0f; // the next step's row of the queue
 
-	gp_wait_vm(( GV_PF - 1 ) * ( TD ? tdn : 1 )); // the first group has landed
+	gp_wait_vm( GV_PF - 1 ); // the first group has landed
 
 	if( TD )
 	{
@@ -484,16 +493,8 @@ __global__ void __launch_bounds__( 64 ) k_gv( const GVParams P )
 		if( TD )
 		{
 			issue_raw( u + GV_PF );
-
-			// (row u + 1 opens the oldest group in flight: `tdn` operations
-			// each. The count picks an s_waitcnt immediate: spelled out per
-			// `tdn` it is two compares -- through gp_wait_vm's 25-way ladder
-			// it was ten branches in every step of the unrolled loop)
-			if( tdn == 1 ) gp_wait_vm(( GV_PF - 1 ) * 1 );
-			else if( tdn == 2 ) gp_wait_vm(( GV_PF - 1 ) * 2 );
-			else if( tdn == 3 ) gp_wait_vm(( GV_PF - 1 ) * 3 );
-			else gp_wait_vm(( GV_PF - 1 ) * 4 );
-
+			// (row u + 1 opens the oldest group in flight)
+			gp_wait_vm( GV_PF - 1 );
 			qr = ( qr == GV_PF ? 0 : qr + 1 );
 		}
 		else
@@ -658,10 +659,17 @@ __global__ void __launch_bounds__( 64 ) k_gv( const GVParams P )
 	if( P.ax.lanc != 4 ) GV_LAUNCH_L1( NT, RW, 2, 3 ); \
 	else GV_LAUNCH_L1( NT, RW, 2, 2 ); } while( 0 )
 
+// (uint8 pixels: gpassv_lancraw8.hip)
+#define GV_LAUNCH_LR8( NT, RW ) do { \
+	if( P.ax.lanc != 4 ) GV_LAUNCH_L1( NT, RW, 2, 7 ); \
+	else GV_LAUNCH_L1( NT, RW, 2, 6 ); } while( 0 )
+
 // the launchers of the variant groups (one translation unit each)
 void launch_gv_lanc( const GVParams& P, int wp, int items, size_t lds,
 	hipStream_t st );
 void launch_gv_lanc_raw( const GVParams& P, int items, size_t lds,
+	hipStream_t st );
+void launch_gv_lanc_raw8( const GVParams& P, int items, size_t lds,
 	hipStream_t st );
 void launch_gv_post( const GVParams& P, int wp, int items, size_t lds,
 	hipStream_t st );

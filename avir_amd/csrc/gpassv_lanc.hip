@@ -11,7 +11,15 @@ void launch_gv_lanc( const GVParams& P, int wp, int items, size_t lds,
 
 	if( wp == 2 && P.raw != nullptr )
 	{
-		launch_gv_lanc_raw( P, items, lds, st );
+		if( P.raw_kind == 1 )
+		{
+			launch_gv_lanc_raw8( P, items, lds, st );
+		}
+		else
+		{
+			launch_gv_lanc_raw( P, items, lds, st );
+		}
+
 		return;
 	}
 
