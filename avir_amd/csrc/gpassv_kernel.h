@@ -568,7 +568,8 @@ __global__ void __launch_bounds__( 64 ) k_gv( const GVParams P )
 			{
 				VT v = qcur;
 
-				if( u > A.view_mmax )
+				// (the zero-stuffed view's tail: AVIR plans only)
+				if( !LANC && u > A.view_mmax )
 				{
 					v = (VT) 0.0f;
 				}
