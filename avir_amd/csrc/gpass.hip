@@ -49,7 +49,9 @@ namespace avirhip {
 // horizontal pass
 // ---------------------------------------------------------------------
 
+#ifndef GH_NB
 #define GH_NB 4 // source row buffers: rows r .. r + 3 are in LDS or in flight
+#endif
 
 // SRC: 0 float RGBA by LDS-DMA; 1 uint8, 2 uint16, 3 float pixels of raw_ch
 // channels, read as they are (packScanline's cast and zero padding,
@@ -988,6 +990,23 @@ static void launch_gh2( const GHParams& P, int items, size_t lds,
 		}
 	}
 
+	// (LANCIR downsizing: the even counts up to 24, as gpassv_lanc.hip has them.
+	// Through the run-time tap loop a row was 18 dependent LDS round trips: the
+	// horizontal pass of CLancIR 5184x3456 -> 1920x1280 took 33 us for 3 us of
+	// arithmetic, and ran slower the longer its chunks were)
+	if constexpr( LANC && SRC == 0 && MODE == GP_NONE )
+	{
+#define GH_L( N ) case N: hipLaunchKernelGGL(( k_gh< MODE, LANC, N, 0 > ), \
+	dim3( items ), dim3( 64 ), lds, st, P ); return
+		switch( nt )
+		{
+			GH_L( 8 ); GH_L( 10 ); GH_L( 14 ); GH_L( 16 ); GH_L( 18 );
+			GH_L( 20 ); GH_L( 22 ); GH_L( 24 );
+			default: break;
+		}
+#undef GH_L
+	}
+
 	// (gather-then-FIR7 axes, 1 < k < 2: 13 .. 25 taps -- one variant with the
 	// coefficient row in registers for any count up to 28)
 	if constexpr( MODE == GP_POST && !LANC )
@@ -1061,6 +1080,8 @@ static int run_h( const GPData* D, const float* src, long src_ss, int src_w,
 	const int rows = row_hi - row_lo;
 	// (tap counts 6 and 12 keep the coefficient row in registers: no LDS table)
 	const bool regcoef = ( P.ax.nt == 6 || P.ax.nt == 12 ||
+		( P.ax.lanc && raw == nullptr && P.ax.nt >= 6 && P.ax.nt <= 24 &&
+		( P.ax.nt & 1 ) == 0 ) ||
 		( P.ax.mode == GP_POST && !P.ax.lanc && P.ax.nt <= 28 ));
 	const size_t lds_h = (size_t) ( GH_NB * P.sbuf + P.mbuf ) * 16 +
 		( regcoef ? 0 : (size_t) (( P.ax.nt + 3 ) & ~3 ) * 64 * 4 );
@@ -1071,6 +1092,12 @@ static int run_h( const GPData* D, const float* src, long src_ss, int src_w,
 	// (a chunk's fixed cost: its coefficient row load and three rows of DMA
 	// lead, about two rows of work)
 	P.chunk = balanced_chunk( rows, P.nstrips, 4, rows, 2, wpc, false );
+
+	if( getenv( "AVIRHIP_GH_CHUNK" ) != nullptr ) // tuning aid
+	{
+		P.chunk = std::max( 1, std::min( atoi( getenv( "AVIRHIP_GH_CHUNK" )), rows ));
+	}
+
 	const int nch = ( rows + P.chunk - 1 ) / P.chunk;
 	const int items = P.nstrips * nch;
 	const size_t lds = lds_h;

@@ -270,7 +270,11 @@ __global__ void __launch_bounds__( 64 ) k_gv( const GVParams P )
 	{
 		constexpr int I = decltype( IC )::value;
 
-		while( g <= gb && g_need <= u )
+		// (after the chunk's last output g_need is 0x7fffffff -- prefetch_tabs'
+		// sentinel --, so one compare decides a step without an output: with
+		// `g <= gb` in front the addresses of the loop body were computed
+		// before the second test, ~14 scalar instructions in every step)
+		while( g_need <= u )
 		{
 			const int s0 = g_need - nt + 1;
 			const float* const cr = ctab + ( g - ga ) * ntp;
@@ -330,6 +334,7 @@ __global__ void __launch_bounds__( 64 ) k_gv( const GVParams P )
 	const unsigned qbase = lds0 + (unsigned) ( P.rs + P.rc ) * ROWB;
 	const int pa = ( RPG == 2 ? u_a >> 1 : u_a ); // first group (floor)
 	const int pb = ( RPG == 2 ? u_b >> 1 : u_b );
+	const int pbs = min( pb, slast );
 
 	int qi = 0; // landing-queue slot of the next pair issued ...
 	int qr = 0; // ... and of the pair being read (both count modulo GV_PF + 1)
@@ -337,18 +342,28 @@ __global__ void __launch_bounds__( 64 ) k_gv( const GVParams P )
 	auto issue_pair = [&]( const int p )
 	{
 		// past the last group: the count of operations per step stays
-		// uniform -- a load nobody reads, into the dump slot (no branch)
-		const bool live = ( p <= pb );
-		const int r = gp_clamp( min( p, pb ) * RPG +
-			( RPG == 2 ? lane >> 5 : 0 ), slast );
+		// uniform -- the last group again, into the slot the next group would
+		// have taken (nobody reads it; no branch, no dump slot)
+		if( MODE == GP_PRE || RW > 0 )
+		{
+			const int r = ( RPG == 2 ? gp_clamp( min( p, pb ) * 2 + ( lane >> 5 ),
+				slast ) : max( min( p, pbs ), 0 ));
 
-		const unsigned slot = ( !live ? qbase + (unsigned) ( GV_PF + 1 ) * 1024 :
-			( MODE == GP_PRE || RW > 0 ? qbase + (unsigned) qi * 1024 :
-			lds0 + (unsigned) (( p * RPG ) & smask ) * ROWB ));
+			gp_dma( rsrc, qbase + (unsigned) qi * 1024, r * srow_b + dpx * 16 );
+			qi = ( qi == GV_PF ? 0 : qi + 1 );
+		}
+		else
+		{
+			// (straight into the source ring: rows past the last one must not
+			// overwrite ring rows still in use -- the dump slot)
+			const bool live = ( p <= pb );
+			const int r = gp_clamp( min( p, pb ) * RPG +
+				( RPG == 2 ? lane >> 5 : 0 ), slast );
+			const unsigned slot = ( !live ? qbase + (unsigned) ( GV_PF + 1 ) * 1024 :
+				lds0 + (unsigned) (( p * RPG ) & smask ) * ROWB );
 
-		qi = ( !live ? qi : ( qi == GV_PF ? 0 : qi + 1 ));
-
-		gp_dma( rsrc, slot, r * srow_b + dpx * 16 );
+			gp_dma( rsrc, slot, r * srow_b + dpx * 16 );
+		}
 	};
 
 	// Raw sources (integer / narrower pixels, whole-pixel lanes; LVAR bit 1):
@@ -381,12 +396,11 @@ __global__ void __launch_bounds__( 64 ) k_gv( const GVParams P )
 
 	auto issue_raw = [&]( const int p )
 	{
-		const bool live = ( p <= pb );
-		const int r = gp_clamp( min( p, pb ), slast );
-		const unsigned slot = ( !live ? qbase + (unsigned) ( GV_PF + 1 ) * 1024 :
-			qbase + (unsigned) qi * 1024 );
+		// (past the last row: the last row again, into the next slot)
+		const int r = max( min( p, pbs ), 0 );
+		const unsigned slot = qbase + (unsigned) qi * 1024;
 
-		qi = ( !live ? qi : ( qi == GV_PF ? 0 : qi + 1 ));
+		qi = ( qi == GV_PF ? 0 : qi + 1 );
 
 		// (bytes past the image's end read as zeros: the buffer's range check;
 		// bytes past the row's end are the next row's -- lanes beyond the width,
