@@ -96,13 +96,35 @@ __global__ void __launch_bounds__( 64 ) k_gh( const GHParams P )
 	// per-lane source pixels of the DMA pieces (clamped: the extended view)
 	const int slast = A.in_len - 1;
 
+	// (the clamped columns once, not per row: four registers)
+	int xb[ 4 ];
+#pragma unroll
+	for( int k = 0; k < 4; k++ )
+	{
+		xb[ k ] = gp_clamp( slo + k * 64 + lane, slast ) * 16;
+	}
+
 	auto issue_row = [&]( const int r, const int buf )
 	{
+		const int rb = r * srow_b;
+		const unsigned lb = sbuf_lds + ( buf * P.sbuf ) * 16;
+
+		if( P.nseg <= 4 )
+		{
+#pragma unroll
+			for( int k = 0; k < 4; k++ )
+			{
+				if( k < P.nseg )
+				{
+					gp_dma( rsrc, lb + k * 1024, rb + xb[ k ]);
+				}
+			}
+		}
+		else
 		for( int k = 0; k < P.nseg; k++ )
 		{
 			const int x = gp_clamp( slo + k * 64 + lane, slast );
-			gp_dma( rsrc, sbuf_lds + ( buf * P.sbuf + k * 64 ) * 16,
-				r * srow_b + x * 16 );
+			gp_dma( rsrc, lb + k * 1024, rb + x * 16 );
 		}
 	};
 
@@ -222,10 +244,16 @@ __global__ void __launch_bounds__( 64 ) k_gh( const GHParams P )
 			// general count walks gp_wait_vm's 25-way ladder, ten branches a row)
 			if( r1 - 1 - r >= GH_NB - 1 && P.nseg <= 4 )
 			{
-				if( P.nseg == 1 ) gp_wait_vm(( GH_NB - 1 ) * 1 );
-				else if( P.nseg == 2 ) gp_wait_vm(( GH_NB - 1 ) * 2 );
-				else if( P.nseg == 3 ) gp_wait_vm(( GH_NB - 1 ) * 3 );
-				else gp_wait_vm(( GH_NB - 1 ) * 4 );
+				if( P.nseg <= 2 )
+				{
+					if( P.nseg == 1 ) gp_wait_vm(( GH_NB - 1 ) * 1 );
+					else gp_wait_vm(( GH_NB - 1 ) * 2 );
+				}
+				else
+				{
+					if( P.nseg == 3 ) gp_wait_vm(( GH_NB - 1 ) * 3 );
+					else gp_wait_vm(( GH_NB - 1 ) * 4 );
+				}
 			}
 			else
 			{
@@ -233,7 +261,7 @@ __global__ void __launch_bounds__( 64 ) k_gh( const GHParams P )
 			}
 		}
 
-		if( MODE != GP_PRE && slo + scnt - 1 > A.view_mmax )
+		if( !LANC && MODE != GP_PRE && slo + scnt - 1 > A.view_mmax )
 		{
 			// zero-stuffed view of the source: its tail reads 0
 			for( int x = lane; x < scnt; x += 64 )
