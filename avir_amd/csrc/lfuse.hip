@@ -54,7 +54,8 @@ namespace avirhip {
 // SRC = 0: float RGBA; 1: uint8 pixels (always one DMA instruction); 2 .. 4: any
 // raw kind with SRC - 1 instructions. OUTK: the output stage's compile-time
 // kind (gp_store_lancir_row; 0 = whatever P.lout says).
-template< int SRC, int OUTK >
+// LORD: the summation order at compile time (3, 4), or 0 = the axis' own.
+template< int SRC, int OUTK, int LORD >
 __global__ void __launch_bounds__( 64 ) k_lf( const LFParams P )
 {
 	constexpr bool RAW = ( SRC > 0 );
@@ -102,7 +103,8 @@ __global__ void __launch_bounds__( 64 ) k_lf( const LFParams P )
 	// ---- vertical side: this lane's source column (clamped: the padded view)
 	gp_cint* const a_start = (gp_cint*) (unsigned long) VA.start;
 	const int vslast = VA.in_len - 1;
-	const int lord = VA.lanc; // the image's channel count picks the order
+	// the image's channel count picks the order
+	const int lord = ( LORD != 0 ? LORD : VA.lanc );
 	const int ga = y0, gb = y1 - 1;
 	const int u_a = a_start[ ga ];
 	const int u_b = a_start[ gb ] + NT - 1;
@@ -260,7 +262,8 @@ __global__ void __launch_bounds__( 64 ) k_lf( const LFParams P )
 	{
 		constexpr int I = decltype( IC )::value;
 
-		while( g <= gb && g_need <= u )
+		// (after the chunk's last output g_need is prefetch_tabs' 0x7fffffff)
+		while( g_need <= u )
 		{
 			// V: this lane's source column, the last NT rows
 			f4 c = win[ I & ( RW - 1 )];
@@ -403,19 +406,29 @@ int lfuse_launch( LFParams& P, hipStream_t st )
 		P.raw_tdn + 1 ));
 	const int out_kind = ( P.lout.on != 0 && P.lout.type == AVIRHIP_U8 &&
 		P.lout.ch >= 3 && src_kind <= 1 ? P.lout.ch - 2 : 0 );
+	// (the order at compile time where the kinds above leave one variant)
+	const int lord = P.vx.lanc;
+	const int lk = (( out_kind == 1 && lord == 3 ) || ( out_kind != 1 &&
+		src_kind <= 1 && lord == 4 ) ? lord : 0 );
 
-#define LF_GO( S, O ) hipLaunchKernelGGL(( k_lf< S, O > ), grid, dim3( 64 ), lds, st, P )
-	switch( src_kind * 4 + out_kind )
+#define LF_GO( S, O, L ) hipLaunchKernelGGL(( k_lf< S, O, L > ), grid, dim3( 64 ), lds, st, P )
+	switch( src_kind * 100 + out_kind * 10 + lk )
 	{
-		case 0: LF_GO( 0, 0 ); break;
-		case 1: LF_GO( 0, 1 ); break;
-		case 2: LF_GO( 0, 2 ); break;
-		case 4: LF_GO( 1, 0 ); break;
-		case 5: LF_GO( 1, 1 ); break;
-		case 6: LF_GO( 1, 2 ); break;
-		case 8: LF_GO( 2, 0 ); break;
-		case 12: LF_GO( 3, 0 ); break;
-		case 16: LF_GO( 4, 0 ); break;
+		case 0: LF_GO( 0, 0, 0 ); break;
+		case 4: LF_GO( 0, 0, 4 ); break;
+		case 10: LF_GO( 0, 1, 0 ); break;
+		case 13: LF_GO( 0, 1, 3 ); break;
+		case 20: LF_GO( 0, 2, 0 ); break;
+		case 24: LF_GO( 0, 2, 4 ); break;
+		case 100: LF_GO( 1, 0, 0 ); break;
+		case 104: LF_GO( 1, 0, 4 ); break;
+		case 110: LF_GO( 1, 1, 0 ); break;
+		case 113: LF_GO( 1, 1, 3 ); break;
+		case 120: LF_GO( 1, 2, 0 ); break;
+		case 124: LF_GO( 1, 2, 4 ); break;
+		case 200: LF_GO( 2, 0, 0 ); break;
+		case 300: LF_GO( 3, 0, 0 ); break;
+		case 400: LF_GO( 4, 0, 0 ); break;
 		default: return( 1 );
 	}
 #undef LF_GO
