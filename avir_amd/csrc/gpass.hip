@@ -62,9 +62,13 @@ template< int SRC > struct GHElem { typedef float T; };
 template<> struct GHElem< 1 > { typedef unsigned char T; };
 template<> struct GHElem< 2 > { typedef unsigned short T; };
 
-template< int MODE, bool LANC, int NTC, int SRC >
+// (LANCIR plans have float RGBA sources only: there the fourth parameter is the
+// compile-time kind of the output stage, gp_store_lancir_row)
+template< int MODE, bool LANC, int NTC, int SX >
 __global__ void __launch_bounds__( 64 ) k_gh( const GHParams P )
 {
+	constexpr int SRC = ( LANC ? 0 : SX );
+	constexpr int OUTK = ( LANC ? SX : 0 );
 	extern __shared__ __attribute__(( aligned( 16 ))) char smem[];
 	const GPAxis& A = P.ax;
 	f4* const sbuf = (f4*) smem;                    // [GH_NB][sbuf px]
@@ -379,7 +383,7 @@ __global__ void __launch_bounds__( 64 ) k_gh( const GHParams P )
 
 		if( LANC && P.lout.on != 0 )
 		{
-			gp_store_lancir_row< 0 >( P.lout, r - P.dst_row0, j, o, jok );
+			gp_store_lancir_row< OUTK >( P.lout, r - P.dst_row0, j, o, jok );
 		}
 		else
 		if( jok )
@@ -990,29 +994,32 @@ bool gpass_preferred( const avirhip_plan* p )
 		(long) p -> new_w * p -> new_h >= 2000000L );
 }
 
-template< int MODE, bool LANC, int SRC >
+template< int MODE, bool LANC, int SX >
 static void launch_gh2( const GHParams& P, int items, size_t lds,
 	hipStream_t st )
 {
 	const int nt = P.ax.nt;
+	// (SX: AVIR plans -- the raw source's element type; LANCIR plans -- the
+	// output stage's kind, the source is float RGBA)
+	constexpr bool FSRC = ( LANC || SX == 0 );
 
 	// (register-resident coefficient rows for the tap counts that occur: 6
 	// LANCIR, 12 AVIR upsizing; raw sources only come with AVIR plans)
-	if constexpr( SRC == 0 )
+	if constexpr( FSRC )
 	{
 		if( nt == 6 )
 		{
-			hipLaunchKernelGGL(( k_gh< MODE, LANC, 6, 0 > ), dim3( items ),
+			hipLaunchKernelGGL(( k_gh< MODE, LANC, 6, SX > ), dim3( items ),
 				dim3( 64 ), lds, st, P );
 			return;
 		}
 	}
 
-	if constexpr( SRC == 0 || MODE == GP_PRE )
+	if constexpr( FSRC || MODE == GP_PRE )
 	{
 		if( nt == 12 )
 		{
-			hipLaunchKernelGGL(( k_gh< MODE, LANC, 12, SRC > ), dim3( items ),
+			hipLaunchKernelGGL(( k_gh< MODE, LANC, 12, SX > ), dim3( items ),
 				dim3( 64 ), lds, st, P );
 			return;
 		}
@@ -1022,9 +1029,9 @@ static void launch_gh2( const GHParams& P, int items, size_t lds,
 	// Through the run-time tap loop a row was 18 dependent LDS round trips: the
 	// horizontal pass of CLancIR 5184x3456 -> 1920x1280 took 33 us for 3 us of
 	// arithmetic, and ran slower the longer its chunks were)
-	if constexpr( LANC && SRC == 0 && MODE == GP_NONE )
+	if constexpr( LANC && MODE == GP_NONE )
 	{
-#define GH_L( N ) case N: hipLaunchKernelGGL(( k_gh< MODE, LANC, N, 0 > ), \
+#define GH_L( N ) case N: hipLaunchKernelGGL(( k_gh< MODE, LANC, N, SX > ), \
 	dim3( items ), dim3( 64 ), lds, st, P ); return
 		switch( nt )
 		{
@@ -1041,27 +1048,26 @@ static void launch_gh2( const GHParams& P, int items, size_t lds,
 	{
 		if( nt <= 28 )
 		{
-			hipLaunchKernelGGL(( k_gh< MODE, LANC, -1, SRC > ), dim3( items ),
+			hipLaunchKernelGGL(( k_gh< MODE, LANC, -1, SX > ), dim3( items ),
 				dim3( 64 ), lds, st, P );
 			return;
 		}
 	}
 
-	hipLaunchKernelGGL(( k_gh< MODE, LANC, 0, SRC > ), dim3( items ),
+	hipLaunchKernelGGL(( k_gh< MODE, LANC, 0, SX > ), dim3( items ),
 		dim3( 64 ), lds, st, P );
 }
 
 // src_kind: 0 float RGBA (LDS-DMA); 1 uint8, 2 uint16, 3 float pixels read raw
+// (LANCIR plans: 1 / 2 = the output stage stores uint8 RGB / RGBA pixels)
 template< int MODE, bool LANC >
 static void launch_gh( const GHParams& P, int src_kind, int items, size_t lds,
 	hipStream_t st )
 {
-	switch( LANC ? 0 : src_kind )
+	switch( src_kind )
 	{
-		case 1: launch_gh2< MODE, LANC, ( LANC ? 0 : 1 ) >( P, items, lds, st );
-			break;
-		case 2: launch_gh2< MODE, LANC, ( LANC ? 0 : 2 ) >( P, items, lds, st );
-			break;
+		case 1: launch_gh2< MODE, LANC, 1 >( P, items, lds, st ); break;
+		case 2: launch_gh2< MODE, LANC, 2 >( P, items, lds, st ); break;
 		case 3: launch_gh2< MODE, LANC, ( LANC ? 0 : 3 ) >( P, items, lds, st );
 			break;
 		default: launch_gh2< MODE, LANC, 0 >( P, items, lds, st ); break;
@@ -1133,7 +1139,9 @@ static int run_h( const GPData* D, const float* src, long src_ss, int src_w,
 
 	if( A.lanc )
 	{
-		launch_gh< GP_NONE, true >( P, 0, items, lds, st );
+		launch_gh< GP_NONE, true >( P, ( P.lout.on != 0 &&
+			P.lout.type == AVIRHIP_U8 && P.lout.ch >= 3 ? P.lout.ch - 2 : 0 ),
+			items, lds, st );
 	}
 	else
 	if( A.mode == GP_PRE )
