@@ -1305,14 +1305,19 @@ int gpass_run( avirhip_plan* p, const float* src, long src_stride, float* dst,
 	// ... and so do LANCIR's upsizing plans of float RGBA pixels (lfuse.hip)
 	// (with the owner's image as the source where its rows can travel as bytes
 	// -- what gpass_lancir_takes_raw promised covers it). With an INTEGER result
-	// the fusion pays up to about 2.5x horizontally: the vertical stage works on
-	// the 64 / ratio + 6 source columns of a strip's 64 lanes, and the two pass
-	// kernels' intermediate image is no longer small against a uint8 result
-	// (1920x1080 RGB uint8, same box, fused / two passes: x1.5 0.033 / 0.042 ms,
-	// x2.1 0.057 / 0.060, x2.5 0.076 / 0.075, x3 0.107 / 0.097, x4 0.192 / 0.152;
-	// float results: fused wins at every ratio, x3 0.085 / 0.126)
+	// the fusion pays up to about 2.7x horizontally (RGBA: 3.2x): the vertical
+	// stage works on the 64 / ratio + 6 source columns of a strip's 64 lanes,
+	// and the two pass kernels' intermediate image is no longer small against a
+	// uint8 result (1920x1080 RGB uint8, same box, fused / two passes: x1.5
+	// 0.028 / 0.034 ms, x2.1 0.047 / 0.051, x2.5 0.064 / 0.065, x3 0.092 /
+	// 0.086, x4 0.166 / 0.136; RGBA uint8 x3 0.086 / 0.088, x4 0.152 / 0.140;
+	// float results: fused wins at every ratio, x3 0.082 / 0.126;
+	// profiles/r05_lanc, tools/r05_lf2.sh)
+	static const double lf_ratio = ( getenv( "AVIRHIP_LF_INT_RATIO" ) != nullptr ?
+		atof( getenv( "AVIRHIP_LF_INT_RATIO" )) : -1.0 ); // (tuning aid)
 	const bool lf_pays = ( !p -> lfuse.on || p -> lfuse.type == AVIRHIP_F32 ||
-		(long) p -> new_w * 10 <= (long) p -> src_w * 24 ||
+		(double) p -> new_w <= (double) p -> src_w * ( lf_ratio >= 0.0 ?
+		lf_ratio : ( p -> lfuse.ch == 4 ? 3.2 : 2.7 )) ||
 		( p -> variant & AVIRHIP_VARIANT_UPG_FUSED ) != 0 );
 	const bool use_lf = ( p -> is_lancir && D -> lf_ow != 0 && lf_pays &&
 		( !p -> lraw.on || lfuse_takes_raw( p -> lraw.ptr, p -> lraw.type,

@@ -263,7 +263,7 @@ int avirhip_plan_get_path(const avirhip_plan* plan);
 #define AVIRHIP_VARIANT_UPG_TWO_PASS 8
 /* ... and the fused launch whatever the frame size (automatically: frames of
  * 7 Mpixels of output and more; CLancIR plans with integer results: up to
- * 2.4x horizontally) */
+ * about 3x horizontally) */
 #define AVIRHIP_VARIANT_UPG_FUSED 16
 /* float RGBA sources on downsizing axes: the branch-free accumulation kernels
  * run optimistically (exact kernels behind an alarm) as they do for float
