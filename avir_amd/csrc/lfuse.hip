@@ -338,6 +338,15 @@ __global__ void __launch_bounds__( 64 ) k_lf( const LFParams P )
 
 		if( u + LF_NB - 1 <= u_b && LF_ON( 8 ))
 		{
+			// The row goes into the buffer of row u - 1, whose pixels the step
+			// before read into the window -- and nothing has waited for that
+			// read yet when the step had no output (a chunk's first five
+			// steps). Under a full chip the LDS queue can hold a read longer
+			// than a row that sits in L2 takes to arrive: the read then
+			// returned the NEW row (found by the round-5 fuzz campaign at
+			// 834x546 -> 2030x1112, chunks of ten and more output rows, nine
+			// runs in ten; the kernel had carried the race since round 4).
+			asm volatile( "s_waitcnt lgkmcnt(0)" ::: "memory" );
 			issue_row( u + LF_NB - 1, ( buf + LF_NB - 1 ) & ( LF_NB - 1 ));
 		}
 

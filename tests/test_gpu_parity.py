@@ -1714,6 +1714,40 @@ def test_lancir_fused_upsizing_kernel_reads_raw_images(tin):
             _assert_same(got, want, "padded rows +%d" % spad)
 
 
+@pytest.mark.parametrize("tin,ch", [(np.float32, 4), (np.uint8, 3),
+                                    (np.uint8, 4)])
+def test_lancir_fused_upsizing_kernel_under_a_full_chip(tin, ch):
+    """k_lf on a frame that fills every wave slot, in chunks longer than its
+    eight row buffers: a row's LDS-DMA must not overwrite the buffer of the row
+    before it while that row's read is still queued (the first steps of a
+    chunk have no output that would have waited for it). The round-5 fuzz
+    campaign found this geometry failing nine runs in ten, in random strips of
+    the lower half of the frame; whole-frame calls, repeated."""
+    lib = abi.load()
+    sw, sh, nw, nh = 834, 546, 2030, 1112
+    if np.dtype(tin).kind == "f":
+        s = rb.lcg_f32((sh, sw, ch), seed=1367)
+    else:
+        s = rb.lcg_u8((sh, sw, ch), seed=1367)
+    want = _checker_lancir(s, nw, nh)
+    for rep in range(6):
+        l = avir_amd.CLancIR()
+        p = l.plan(sw, sh, nw, nh, ch, None, rb._DT[np.dtype(tin)],
+                   rb._DT[np.dtype(tin)])
+        got = np.empty((nh, nw, ch), tin)
+        # (device-resident: the serial whole-frame launch, not the host
+        # pipeline's bands)
+        import torch
+        ds = torch.from_numpy(s).to("cuda:0")
+        dd = torch.empty((nh, nw, ch), dtype=ds.dtype, device="cuda:0")
+        abi.check(lib.avirhip_resize(p, ds.data_ptr(), abi.MEM_DEVICE,
+                                     dd.data_ptr(), abi.MEM_DEVICE, None),
+                  "resize")
+        torch.cuda.synchronize()
+        got = dd.cpu().numpy()
+        _assert_same(got, want, "full chip, repeat %d" % rep)
+
+
 def test_avir_fused_upsizing_is_the_default_for_large_frames():
     """1920x1080 -> 5760x3240 (18.7 Mpixels of output) takes k_gf by itself:
     the hash of the reference's result (tests/golden/make_golden.py wrote it

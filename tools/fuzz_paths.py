@@ -144,6 +144,19 @@ for it in range(N):
                                        v.UseSRGBGamma, v.AlphaIndex,
                                        v.BuildMode, kstep))
             bad += 1
+    if os.environ.get("FUZZ_DETAIL") and int(os.environ["FUZZ_DETAIL"]) == it:
+        # where a case's paths differ from the generic kernels (debugging aid)
+        print("case", it, (sw, sh, nw, nh, ch, tin, tout, lanc), "lp",
+              None if lp is None else (lp.kx, lp.ky, lp.ox, lp.oy, lp.la))
+        for path, got in res.items():
+            d = np.argwhere(got != res[1]) if 1 in res else []
+            print(" path", path, "differ", len(d))
+            if len(d):
+                print("  columns", np.unique(d[:, 1])[:48], "rows",
+                      np.unique(d[:, 0])[:24], len(np.unique(d[:, 0])))
+                i = tuple(d[0])
+                print("  first", i, got[i], res[1][i])
+        sys.exit(0)
     for path, got in res.items():
         if path != 1 and 1 in res and got.tobytes() != res[1].tobytes():
             print("MISMATCH", it, (sw, sh, nw, nh, ch, tin.__name__,
