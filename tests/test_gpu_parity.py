@@ -2254,6 +2254,23 @@ def test_fast_paths_under_concurrent_memory_traffic():
     assert "0 mismatching frames" in r.stdout
 
 
+def test_fast_paths_over_random_large_geometries():
+    """tools/stress_geom.py: frames big enough to take every wave slot, in
+    random shapes (chunks of every length), resized repeatedly on the automatic
+    path and compared with the generic kernels bit for bit -- the kind of race
+    k_lf carried (a ring slot handed to the next LDS-DMA before the read of the
+    row it held was waited for) needs shape AND load to show."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools",
+                                                     "stress_geom.py"), "400",
+                        "7", "4"],
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert " 0 problems" in r.stdout
+
+
 @pytest.mark.parametrize("ch,tin,tout,bits", [
     (3, np.uint8, np.uint8, 8), (4, np.uint8, np.uint8, 8),
     (1, np.uint8, np.uint8, 8), (2, np.uint16, np.uint16, 16),

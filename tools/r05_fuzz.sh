@@ -8,3 +8,4 @@ python tools/fuzz_sacc.py 1500 631 > $O/sacc_631.txt 2>&1; tail -1 $O/sacc_631.t
 python tools/fuzz_dnf.py 600 641 > $O/dnf_641.txt 2>&1; tail -1 $O/dnf_641.txt
 python tools/fuzz_f64.py 600 651 > $O/f64_651.txt 2>&1; tail -1 $O/f64_651.txt
 python tools/stress_race.py > $O/stress_race.txt 2>&1; tail -2 $O/stress_race.txt
+for s in 2 3 4 5 6; do python tools/stress_geom.py 1000 $s 4 > $O/stress_geom_$s.txt 2>&1; tail -1 $O/stress_geom_$s.txt; done

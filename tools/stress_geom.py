@@ -1,0 +1,96 @@
+#!/usr/bin/env python3
+"""Race hunt over GEOMETRIES: random large frames (every wave slot of the chip
+taken, chunks of every length) on the automatic path, each resized several
+times device-resident and compared bit for bit with the generic kernels' result
+(path 1: one launch per op, no LDS-DMA rings).
+
+Why: k_lf carried a race from round 4 to round 5 that needed a frame big enough
+to fill the chip AND chunks longer than its eight row buffers AND a step
+without an output right before a ring slot was reused -- 834x546 -> 2030x1112
+failed nine runs in ten, the test suite's and the fuzzers' (mostly small)
+geometries never. tools/stress_race.py varies the timing of fixed workloads;
+this tool varies the shape.
+
+usage: python tools/stress_geom.py [cases, default 120] [seed] [repeats, default 4]
+"""
+import os
+import sys
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+import numpy as np  # noqa: E402
+
+
+def main():
+    import torch
+    import avir_amd
+    from avir_amd import abi, synth
+    n = int(sys.argv[1]) if len(sys.argv) > 1 else 120
+    rng = np.random.RandomState(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+    reps = int(sys.argv[3]) if len(sys.argv) > 3 else 4
+    lib = abi.load()
+    dev = torch.device("cuda", 0)
+    bad = 0
+    seen = {}
+    for it in range(n):
+        lanc = rng.rand() < 0.5
+        sw, sh = int(rng.randint(500, 2600)), int(rng.randint(400, 1800))
+        kx = float(np.exp(rng.uniform(np.log(0.28), np.log(3.6))))
+        ky = kx * float(rng.uniform(0.8, 1.25)) if rng.rand() < 0.7 else \
+            float(np.exp(rng.uniform(np.log(0.28), np.log(3.6))))
+        nw, nh = max(16, int(sw * kx)), max(16, int(sh * ky))
+        if nw * nh > 12_000_000 or sw * sh > 6_000_000:
+            continue
+        ch = int(rng.choice([1, 3, 3, 4, 4]))
+        tin = [np.uint8, np.uint16, np.float32][rng.randint(0, 3)]
+        tout = tin if rng.rand() < 0.7 else [np.uint8, np.uint16,
+                                             np.float32][rng.randint(0, 3)]
+        if np.dtype(tin).kind == "u":
+            s = synth.lcg_u8((sh, sw, ch, np.dtype(tin).itemsize),
+                             seed=it + 11).view(tin).reshape(sh, sw, ch)
+        else:
+            s = synth.lcg_f32((sh, sw, ch), seed=it + 11)
+        ds = torch.from_numpy(s).to(dev)
+        tt = {np.uint8: torch.uint8, np.uint16: torch.uint16,
+              np.float32: torch.float32}[tout]
+        res = {}
+        for path in (1, 0):
+            if lanc:
+                r = avir_amd.CLancIR()
+                p = r.plan(sw, sh, nw, nh, ch, None,
+                           avir_amd._NP2T[np.dtype(tin)],
+                           avir_amd._NP2T[np.dtype(tout)])
+            else:
+                r = avir_amd.CImageResizer(8 if tout == np.uint8 else 16)
+                p = r.plan(sw, sh, nw, nh, ch, 0.0, None,
+                           avir_amd._NP2T[np.dtype(tin)],
+                           avir_amd._NP2T[np.dtype(tout)])
+            if lib.avirhip_plan_set_path(p, path) != 0:
+                continue
+            for k in range(1 if path == 1 else reps):
+                dd = torch.empty((nh, nw, ch), dtype=tt, device=dev)
+                abi.check(lib.avirhip_resize(p, ds.data_ptr(), abi.MEM_DEVICE,
+                                             dd.data_ptr(), abi.MEM_DEVICE,
+                                             None), "resize")
+                torch.cuda.synchronize()
+                if path == 1:
+                    res[1] = dd
+                elif 1 in res and not torch.equal(
+                        dd.view(torch.uint8), res[1].view(torch.uint8)):
+                    nd = int((dd.view(torch.uint8) !=
+                              res[1].view(torch.uint8)).sum())
+                    print("MISMATCH", it, ("lancir" if lanc else "avir", sw, sh,
+                                           nw, nh, ch, np.dtype(tin).name,
+                                           np.dtype(tout).name),
+                          "repeat", k, "differs in", nd, "bytes", flush=True)
+                    bad += 1
+                    break
+            if path == 0:
+                xp = lib.avirhip_plan_get_path(p)
+                seen[xp] = seen.get(xp, 0) + 1
+    print("stress_geom: %d cases, %d problems; automatic paths %r" % (
+        n, bad, seen))
+    sys.exit(1 if bad else 0)
+
+
+if __name__ == "__main__":
+    main()
