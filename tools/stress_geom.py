@@ -38,6 +38,14 @@ def main():
         ky = kx * float(rng.uniform(0.8, 1.25)) if rng.rand() < 0.7 else \
             float(np.exp(rng.uniform(np.log(0.28), np.log(3.6))))
         nw, nh = max(16, int(sw * kx)), max(16, int(sh * ky))
+        exact = rng.rand()
+        if exact < 0.12:    # the exact-2x marching kernels
+            sw, sh = min(sw, 1700), min(sh, 1200)
+            nw, nh = 2 * sw, 2 * sh
+        elif exact < 0.2:   # whole-ratio downsizing (k_dnf)
+            d = int(rng.choice([2, 3]))
+            nw, nh = max(16, sw // d), max(16, sh // d)
+            sw, sh = nw * d, nh * d
         if nw * nh > 12_000_000 or sw * sh > 6_000_000:
             continue
         ch = int(rng.choice([1, 3, 3, 4, 4]))
