@@ -95,6 +95,50 @@ def main():
             if path == 0:
                 xp = lib.avirhip_plan_get_path(p)
                 seen[xp] = seen.get(xp, 0) + 1
+                if 1 in res and xp == 5 and nw >= sw and nh >= sh and \
+                        rng.rand() < 0.5:
+                    # ... the other form of an upsizing plan (two pass kernels
+                    # / the fused launch), which the automatic choice hides
+                    for variant in (8, 16):
+                        abi.check(lib.avirhip_plan_set_variant(p, variant), "v")
+                        for k in range(2):
+                            dd = torch.empty((nh, nw, ch), dtype=tt, device=dev)
+                            abi.check(lib.avirhip_resize(
+                                p, ds.data_ptr(), abi.MEM_DEVICE, dd.data_ptr(),
+                                abi.MEM_DEVICE, None), "resize")
+                            torch.cuda.synchronize()
+                            if not torch.equal(dd.view(torch.uint8),
+                                               res[1].view(torch.uint8)):
+                                print("MISMATCH", it, (
+                                    "lancir" if lanc else "avir", sw, sh, nw, nh,
+                                    ch, np.dtype(tin).name, np.dtype(tout).name),
+                                    "variant", variant, flush=True)
+                                bad += 1
+                                break
+                        seen["v%d" % variant] = seen.get("v%d" % variant, 0) + 1
+                    abi.check(lib.avirhip_plan_set_variant(p, 0), "v")
+                if 1 in res and nh > 8 and rng.rand() < 0.35:
+                    # ... and in row bands (other chunk boundaries, run-ins at
+                    # other rows)
+                    dd = torch.zeros((nh, nw, ch), dtype=tt, device=dev)
+                    cuts = sorted(set([0, nh] + [int(c) for c in rng.randint(
+                        1, nh, size=int(rng.randint(1, 4)))]))
+                    rb_ = nw * ch * dd.element_size()
+                    for a_, b_ in zip(cuts[:-1], cuts[1:]):
+                        abi.check(lib.avirhip_resize_band(
+                            p, ds.data_ptr(), abi.MEM_DEVICE,
+                            dd.data_ptr() + a_ * rb_, abi.MEM_DEVICE, a_, b_,
+                            None), "band")
+                    torch.cuda.synchronize()
+                    seen["bands"] = seen.get("bands", 0) + 1
+                    if not torch.equal(dd.view(torch.uint8),
+                                       res[1].view(torch.uint8)):
+                        print("MISMATCH", it, ("lancir" if lanc else "avir", sw,
+                                               sh, nw, nh, ch,
+                                               np.dtype(tin).name,
+                                               np.dtype(tout).name),
+                              "bands", cuts, flush=True)
+                        bad += 1
     print("stress_geom: %d cases, %d problems; automatic paths %r" % (
         n, bad, seen))
     sys.exit(1 if bad else 0)
