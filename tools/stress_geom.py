@@ -33,7 +33,9 @@ def main():
     seen = {}
     for it in range(n):
         lanc = rng.rand() < 0.5
-        sw, sh = int(rng.randint(500, 2600)), int(rng.randint(400, 1800))
+        big = os.environ.get("STRESS_BIG") is not None  # (4K-class frames)
+        sw, sh = int(rng.randint(500, 5300 if big else 2600)), \
+            int(rng.randint(400, 3500 if big else 1800))
         kx = float(np.exp(rng.uniform(np.log(0.28), np.log(3.6))))
         ky = kx * float(rng.uniform(0.8, 1.25)) if rng.rand() < 0.7 else \
             float(np.exp(rng.uniform(np.log(0.28), np.log(3.6))))
@@ -46,7 +48,8 @@ def main():
             d = int(rng.choice([2, 3]))
             nw, nh = max(16, sw // d), max(16, sh // d)
             sw, sh = nw * d, nh * d
-        if nw * nh > 12_000_000 or sw * sh > 6_000_000:
+        if nw * nh > ( 36_000_000 if big else 12_000_000 ) or \
+                sw * sh > ( 20_000_000 if big else 6_000_000 ):
             continue
         ch = int(rng.choice([1, 3, 3, 4, 4]))
         tin = [np.uint8, np.uint16, np.float32][rng.randint(0, 3)]
