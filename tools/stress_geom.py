@@ -120,6 +120,23 @@ def main():
                                 break
                         seen["v%d" % variant] = seen.get("v%d" % variant, 0) + 1
                     abi.check(lib.avirhip_plan_set_variant(p, 0), "v")
+                if 1 in res and os.environ.get("STRESS_HOST") is not None:
+                    # ... and as the drop-in call makes it: host pointers (frames
+                    # of 16 MiB and more run the 16-band copy / compute pipeline)
+                    for k in range(2):
+                        hd = np.empty((nh, nw, ch), tout)
+                        abi.check(lib.avirhip_resize(
+                            p, s.ctypes.data, abi.MEM_HOST, hd.ctypes.data,
+                            abi.MEM_HOST, None), "resize")
+                        if not np.array_equal(hd.view(np.uint8), res[1].cpu(
+                                ).numpy().view(np.uint8)):
+                            print("MISMATCH", it, (
+                                "lancir" if lanc else "avir", sw, sh, nw, nh, ch,
+                                np.dtype(tin).name, np.dtype(tout).name),
+                                "host call", k, flush=True)
+                            bad += 1
+                            break
+                    seen["host"] = seen.get("host", 0) + 1
                 if 1 in res and nh > 8 and rng.rand() < 0.35:
                     # ... and in row bands (other chunk boundaries, run-ins at
                     # other rows)

@@ -31,7 +31,8 @@ def main():
         "cfg1", "cfg2", "cfg4", "cfg5", "nonint", "triple", "half",
         "readme", "readme_f32", "readme_rgbf", "dn15", "dn15_u8",
         "nonint_u8", "up2_u8", "cfg4_u8", "lanc_nonint", "lanc_dn3",
-        "cfg2_dbl"]
+        "lanc_nonint_u8", "lanc_nonint_rgba8", "lanc_triple_u8",
+        "lanc_dn3_rgba8", "lanc_readme_u8", "lanc_up2_u8", "cfg2_dbl"]
     lib = abi.load()
     dev = torch.device("cuda", 0)
     abi.check(lib.avirhip_init(0), "init")
