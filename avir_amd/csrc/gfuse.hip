@@ -179,7 +179,8 @@ __global__ void __launch_bounds__( 64 ) k_gf( const GFParams P )
 	{
 		constexpr int I = decltype( IC )::value;
 
-		while( g <= gb && g_need <= u )
+		// (after the chunk's last output g_need is prefetch_tabs' 0x7fffffff)
+		while( g_need <= u )
 		{
 			const f4 o = gp_dot< false, f4, NT >( NT,
 				[&]( const int t ) { return( win[ ( I - ( NT - 1 ) + t + 4 * RW ) &
@@ -200,6 +201,9 @@ __global__ void __launch_bounds__( 64 ) k_gf( const GFParams P )
 		(void*) P.src, 0, 0x7fffffff, 0x00020000 );
 	const int srow_b = (int) P.src_ss * 4;
 
+	// (the clamped columns are recomputed per row: four registers for them
+	// take the kernel from 254 to 256 VGPRs -- one wave per SIMD instead of two,
+	// 1920x1080 -> 5760x3240 0.105 -> 0.159 ms)
 	auto issue_row = [&]( const int u, const int buf )
 	{
 		const int r = gp_clamp( u, vslast );
@@ -250,10 +254,16 @@ __global__ void __launch_bounds__( 64 ) k_gf( const GFParams P )
 			// general count walks gp_wait_vm's 25-way ladder, ten branches a row)
 			if( u_b - u >= GF_NB - 1 && P.nseg <= 4 )
 			{
-				if( P.nseg == 1 ) gp_wait_vm(( GF_NB - 1 ) * 1 );
-				else if( P.nseg == 2 ) gp_wait_vm(( GF_NB - 1 ) * 2 );
-				else if( P.nseg == 3 ) gp_wait_vm(( GF_NB - 1 ) * 3 );
-				else gp_wait_vm(( GF_NB - 1 ) * 4 );
+				if( P.nseg <= 2 )
+				{
+					if( P.nseg == 1 ) gp_wait_vm(( GF_NB - 1 ) * 1 );
+					else gp_wait_vm(( GF_NB - 1 ) * 2 );
+				}
+				else
+				{
+					if( P.nseg == 3 ) gp_wait_vm(( GF_NB - 1 ) * 3 );
+					else gp_wait_vm(( GF_NB - 1 ) * 4 );
+				}
 			}
 			else
 			{
