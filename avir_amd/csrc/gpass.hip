@@ -100,12 +100,15 @@ __global__ void __launch_bounds__( 64 ) k_gh( const GHParams P )
 	// per-lane source pixels of the DMA pieces (clamped: the extended view)
 	const int slast = A.in_len - 1;
 
-	// (the clamped columns once, not per row: four registers)
+	// (the clamped columns once, not per row: four registers -- which the
+	// any-tap-count variant, NTC == -1, does not have: 168 -> 172 VGPRs is three
+	// waves per SIMD -> two)
+	constexpr bool XB = ( NTC != -1 );
 	int xb[ 4 ];
 #pragma unroll
 	for( int k = 0; k < 4; k++ )
 	{
-		xb[ k ] = gp_clamp( slo + k * 64 + lane, slast ) * 16;
+		xb[ k ] = ( XB ? gp_clamp( slo + k * 64 + lane, slast ) * 16 : 0 );
 	}
 
 	auto issue_row = [&]( const int r, const int buf )
@@ -113,7 +116,7 @@ __global__ void __launch_bounds__( 64 ) k_gh( const GHParams P )
 		const int rb = r * srow_b;
 		const unsigned lb = sbuf_lds + ( buf * P.sbuf ) * 16;
 
-		if( P.nseg <= 4 )
+		if( XB && P.nseg <= 4 )
 		{
 #pragma unroll
 			for( int k = 0; k < 4; k++ )
