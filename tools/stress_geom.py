@@ -31,14 +31,33 @@ def main():
     dev = torch.device("cuda", 0)
     bad = 0
     seen = {}
+    if os.environ.get("STRESS_HAMMER") is not None:
+        # ... under long, jittery memory latencies: another stream copies
+        # gigabytes back and forth meanwhile (as tools/stress_race.py does)
+        import threading
+        big_a = torch.empty(512 << 20, dtype=torch.uint8, device=dev)
+        big_b = torch.empty(512 << 20, dtype=torch.uint8, device=dev)
+        hs = torch.cuda.Stream(dev)
+        stop = []
+
+        def hammer():
+            while not stop:
+                with torch.cuda.stream(hs):
+                    for _ in range(8):
+                        big_b.copy_(big_a, non_blocking=True)
+                        big_a.copy_(big_b, non_blocking=True)
+                hs.synchronize()
+        th = threading.Thread(target=hammer, daemon=True)
+        th.start()
     for it in range(n):
         lanc = rng.rand() < 0.5
         big = os.environ.get("STRESS_BIG") is not None  # (4K-class frames)
         sw, sh = int(rng.randint(500, 5300 if big else 2600)), \
             int(rng.randint(400, 3500 if big else 1800))
-        kx = float(np.exp(rng.uniform(np.log(0.28), np.log(3.6))))
+        lo_k, hi_k = (0.1, 7.0) if os.environ.get("STRESS_WIDE") else (0.28, 3.6)
+        kx = float(np.exp(rng.uniform(np.log(lo_k), np.log(hi_k))))
         ky = kx * float(rng.uniform(0.8, 1.25)) if rng.rand() < 0.7 else \
-            float(np.exp(rng.uniform(np.log(0.28), np.log(3.6))))
+            float(np.exp(rng.uniform(np.log(lo_k), np.log(hi_k))))
         nw, nh = max(16, int(sw * kx)), max(16, int(sh * ky))
         exact = rng.rand()
         if exact < 0.12:    # the exact-2x marching kernels
@@ -159,6 +178,9 @@ def main():
                                                np.dtype(tout).name),
                               "bands", cuts, flush=True)
                         bad += 1
+    if os.environ.get("STRESS_HAMMER") is not None:
+        stop.append(1)
+        th.join()
     print("stress_geom: %d cases, %d problems; automatic paths %r" % (
         n, bad, seen))
     sys.exit(1 if bad else 0)
