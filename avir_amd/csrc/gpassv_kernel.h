@@ -336,6 +336,13 @@ __global__ void __launch_bounds__( 64 ) k_gv( const GVParams P )
 	const int pb = ( RPG == 2 ? u_b >> 1 : u_b );
 	const int pbs = min( pb, slast );
 
+	// (Slot reuse: the DMA of group p + GV_PF takes the slot group p - 1 held.
+	// That slot was read into `qnext` two steps earlier and `qnext` was consumed
+	// -- copied into the window, converted, or run through the FIR, each behind
+	// an lgkmcnt wait -- one step earlier: an LDS-DMA may only take a slot whose
+	// reads have been WAITED for, not merely issued. k_lf, whose reads go
+	// straight into distinct window registers, needed an explicit wait: NOTEBOOK
+	// 9.13.)
 	int qi = 0; // landing-queue slot of the next pair issued ...
 	int qr = 0; // ... and of the pair being read (both count modulo GV_PF + 1)
 
