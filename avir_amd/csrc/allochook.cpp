@@ -1,12 +1,21 @@
-// allochook.cpp -- the library's own operator new / delete, so that the test
-// hook avirhip_debug_fail_alloc() (include/avirhip.h) can make any host
-// allocation of the planning / plan-creation code fail on demand. The linker's
-// version script (avirhip.map) keeps these definitions LOCAL to libavirhip.so:
-// they replace nothing in the host application, and only allocations made by
-// code inside the library -- its std::vector, std::map, std::thread ... --
-// go through them. Memory comes from malloc / free (what libstdc++'s own
-// operators use), so blocks may cross to libstdc++'s operator delete.
+// allochook.cpp -- failure injection for the host allocations of the planning /
+// plan-creation code: the test hook avirhip_debug_fail_alloc() (include/avirhip.h)
+// makes the calling thread's n-th allocation inside the library throw.
+//
+// The library defines operator new (LOCAL to libavirhip.so: the linker's
+// version script avirhip.map exports avirhip_* only, so nothing in the host
+// application is replaced) but NOT operator delete, and its operator new hands
+// every request to the process-global operator new, looked up once with
+// dlsym( RTLD_DEFAULT ): libstdc++'s, or whatever the host application or a
+// sanitizer runtime replaced it with. So every block -- whether it was
+// requested by code compiled into this library or by libstdc++'s out-of-line
+// code on its behalf (std::string growth and the like) -- comes from the global
+// allocator and goes back to the global operator delete: no block ever crosses
+// between two allocators, whatever the host uses (the previous form
+// paired its own malloc-based new with free(), which a host with a non-malloc
+// operator new, or ASan's alloc-dealloc-mismatch check, does not survive).
 
+#include <dlfcn.h>
 #include <stdlib.h>
 #include <stddef.h>
 #include <new>
@@ -16,39 +25,31 @@ namespace {
 thread_local long g_countdown = 0; // > 0: that many allocations to the failure
 thread_local long g_count = 0;     // allocations seen since the last hook call
 
-inline void* hooked_alloc( size_t n, size_t al )
+// true: this allocation is the one that has to fail
+inline bool hook_fails()
 {
 	g_count++;
-
-	if( g_countdown > 0 && --g_countdown == 0 )
-	{
-		return( nullptr );
-	}
-
-	if( n == 0 )
-	{
-		n = 1;
-	}
-
-	if( al <= alignof( ::max_align_t ))
-	{
-		return( malloc( n ));
-	}
-
-	void* p = nullptr;
-	return( posix_memalign( &p, al, n ) == 0 ? p : nullptr );
+	return( g_countdown > 0 && --g_countdown == 0 );
 }
 
-inline void* alloc_or_throw( size_t n, size_t al )
-{
-	void* p = hooked_alloc( n, al );
+typedef void* ( *fn_new )( size_t );
+typedef void* ( *fn_new_nt )( size_t, const std::nothrow_t& );
+typedef void* ( *fn_new_al )( size_t, std::align_val_t );
+typedef void* ( *fn_new_al_nt )( size_t, std::align_val_t, const std::nothrow_t& );
 
-	if( p == nullptr )
+// the process-global operators, by their Itanium-ABI names (this library's own
+// definitions are local symbols: the global scope cannot return them)
+template< typename F >
+inline F global_op( const char* const mangled )
+{
+	void* const f = dlsym( RTLD_DEFAULT, mangled );
+
+	if( f == nullptr )
 	{
-		throw std::bad_alloc();
+		abort(); // no C++ runtime in the process: cannot happen
 	}
 
-	return( p );
+	return( (F) f );
 }
 
 } // namespace
@@ -61,32 +62,60 @@ extern "C" long avirhip_debug_fail_alloc( long nth )
 	return( seen );
 }
 
-void* operator new( size_t n ) { return( alloc_or_throw( n, 1 )); }
-void* operator new[]( size_t n ) { return( alloc_or_throw( n, 1 )); }
-void* operator new( size_t n, const std::nothrow_t& ) noexcept
-	{ return( hooked_alloc( n, 1 )); }
-void* operator new[]( size_t n, const std::nothrow_t& ) noexcept
-	{ return( hooked_alloc( n, 1 )); }
-void* operator new( size_t n, std::align_val_t a )
-	{ return( alloc_or_throw( n, (size_t) a )); }
-void* operator new[]( size_t n, std::align_val_t a )
-	{ return( alloc_or_throw( n, (size_t) a )); }
-void* operator new( size_t n, std::align_val_t a, const std::nothrow_t& ) noexcept
-	{ return( hooked_alloc( n, (size_t) a )); }
-void* operator new[]( size_t n, std::align_val_t a, const std::nothrow_t& ) noexcept
-	{ return( hooked_alloc( n, (size_t) a )); }
+void* operator new( size_t n )
+{
+	static const fn_new f = global_op< fn_new >( "_Znwm" );
+	if( hook_fails() ) throw std::bad_alloc();
+	return( f( n ));
+}
 
-void operator delete( void* p ) noexcept { free( p ); }
-void operator delete[]( void* p ) noexcept { free( p ); }
-void operator delete( void* p, size_t ) noexcept { free( p ); }
-void operator delete[]( void* p, size_t ) noexcept { free( p ); }
-void operator delete( void* p, const std::nothrow_t& ) noexcept { free( p ); }
-void operator delete[]( void* p, const std::nothrow_t& ) noexcept { free( p ); }
-void operator delete( void* p, std::align_val_t ) noexcept { free( p ); }
-void operator delete[]( void* p, std::align_val_t ) noexcept { free( p ); }
-void operator delete( void* p, size_t, std::align_val_t ) noexcept { free( p ); }
-void operator delete[]( void* p, size_t, std::align_val_t ) noexcept { free( p ); }
-void operator delete( void* p, std::align_val_t, const std::nothrow_t& ) noexcept
-	{ free( p ); }
-void operator delete[]( void* p, std::align_val_t, const std::nothrow_t& ) noexcept
-	{ free( p ); }
+void* operator new[]( size_t n )
+{
+	static const fn_new f = global_op< fn_new >( "_Znam" );
+	if( hook_fails() ) throw std::bad_alloc();
+	return( f( n ));
+}
+
+void* operator new( size_t n, const std::nothrow_t& t ) noexcept
+{
+	static const fn_new_nt f = global_op< fn_new_nt >( "_ZnwmRKSt9nothrow_t" );
+	if( hook_fails() ) return( nullptr );
+	return( f( n, t ));
+}
+
+void* operator new[]( size_t n, const std::nothrow_t& t ) noexcept
+{
+	static const fn_new_nt f = global_op< fn_new_nt >( "_ZnamRKSt9nothrow_t" );
+	if( hook_fails() ) return( nullptr );
+	return( f( n, t ));
+}
+
+void* operator new( size_t n, std::align_val_t a )
+{
+	static const fn_new_al f = global_op< fn_new_al >( "_ZnwmSt11align_val_t" );
+	if( hook_fails() ) throw std::bad_alloc();
+	return( f( n, a ));
+}
+
+void* operator new[]( size_t n, std::align_val_t a )
+{
+	static const fn_new_al f = global_op< fn_new_al >( "_ZnamSt11align_val_t" );
+	if( hook_fails() ) throw std::bad_alloc();
+	return( f( n, a ));
+}
+
+void* operator new( size_t n, std::align_val_t a, const std::nothrow_t& t ) noexcept
+{
+	static const fn_new_al_nt f = global_op< fn_new_al_nt >(
+		"_ZnwmSt11align_val_tRKSt9nothrow_t" );
+	if( hook_fails() ) return( nullptr );
+	return( f( n, a, t ));
+}
+
+void* operator new[]( size_t n, std::align_val_t a, const std::nothrow_t& t ) noexcept
+{
+	static const fn_new_al_nt f = global_op< fn_new_al_nt >(
+		"_ZnamSt11align_val_tRKSt9nothrow_t" );
+	if( hook_fails() ) return( nullptr );
+	return( f( n, a, t ));
+}

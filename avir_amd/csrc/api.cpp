@@ -29,6 +29,13 @@ void set_error( const char* fmt, ... )
 	va_end( ap );
 }
 
+// (every extern "C" entry point begins with this: the message belongs to the
+// calling thread's most recent call, never to an older failure)
+void clear_error()
+{
+	g_err[ 0 ] = 0;
+}
+
 size_t dtype_size( int t )
 {
 	return( t == AVIRHIP_U8 ? 1 : t == AVIRHIP_U16 ? 2 : t == AVIRHIP_F32 ? 4 :
@@ -1553,14 +1560,23 @@ static int exec_any( avirhip_plan* p, const void* src, int src_mem, void* dst,
 		int need_a = 0, need_b = -1;
 		band_src_rows( p, row0, row1, &need_a, &need_b );
 
-		if( win_first < 0 || win_first + win_rows > p -> src_h ||
+		// (compared in long: win_first + win_rows of a hostile caller must not
+		// wrap; the window has to lie inside the frame whatever the band reads)
+		if( win_first < 0 || (long) win_first + win_rows > (long) p -> src_h ||
 			( need_b >= need_a && ( need_a < win_first ||
-			need_b >= win_first + win_rows )))
+			(long) need_b >= (long) win_first + win_rows )))
 		{
 			set_error( "resize_window: output rows [%d, %d) read source rows "
 				"[%d, %d], the window holds [%d, %d)", row0, row1, need_a,
 				need_b, win_first, win_first + win_rows );
 			return( AVIRHIP_EINVAL );
+		}
+
+		// an empty band reads nothing and stores nothing: done before any copy
+		// of the window is made
+		if( row1 <= row0 )
+		{
+			return( AVIRHIP_OK );
 		}
 	}
 
@@ -1982,6 +1998,7 @@ int avirhip_device_count( void )
 int avirhip_init( int device )
 try
 {
+	avirhip::clear_error();
 	if( avirhip_device_count() < 1 )
 	{
 		set_error( "no gfx950 device visible" );
@@ -2006,6 +2023,7 @@ const char* avirhip_version( void )
 int avirhip_plan_create( const avirhip_plan_desc* d, avirhip_plan** out )
 try
 {
+	avirhip::clear_error();
 	if( d == nullptr || out == nullptr )
 	{
 		set_error( "null argument" );
@@ -2331,6 +2349,7 @@ int avirhip_resize_sharded( avirhip_plan* p, int n_gpus, const int* devices,
 	double* t_gather_ms )
 try
 {
+	avirhip::clear_error();
 	if( p == nullptr || n_gpus < 1 || src == nullptr || dst == nullptr ||
 		( devices == nullptr && n_gpus > 1 ) || gather_root < 0 ||
 		gather_root >= n_gpus )
@@ -2615,6 +2634,7 @@ int avirhip_lancir_plan_create( const avirhip_lancir_desc* d,
 	avirhip_plan** out )
 try
 {
+	avirhip::clear_error();
 	if( d == nullptr || out == nullptr )
 	{
 		set_error( "null argument" );
@@ -2732,6 +2752,7 @@ void avirhip_plan_destroy( avirhip_plan* p )
 int avirhip_plan_set_path( avirhip_plan* p, int path )
 try
 {
+	avirhip::clear_error();
 	if( p == nullptr || path < 0 || path > 5 )
 	{
 		set_error( "bad path" );
@@ -2783,6 +2804,7 @@ unsigned long long avirhip_plan_device_bytes( avirhip_plan* p )
 int avirhip_plan_set_variant( avirhip_plan* p, int variant )
 try
 {
+	avirhip::clear_error();
 	if( p == nullptr || variant < 0 || variant > 63 )
 	{
 		set_error( "bad variant" );
@@ -2824,6 +2846,7 @@ int avirhip_band_source_rows( const avirhip_plan* p, int row0, int row1,
 	int* first, int* last )
 try
 {
+	avirhip::clear_error();
 	if( p == nullptr || first == nullptr || last == nullptr || row0 < 0 ||
 		row1 > p -> new_h || row1 <= row0 )
 	{
@@ -2839,6 +2862,7 @@ AVIRHIP_CATCH( avirhip_band_source_rows )
 int avirhip_plan_get_path( const avirhip_plan* p )
 try
 {
+	avirhip::clear_error();
 	if( p == nullptr )
 	{
 		return( AVIRHIP_EINVAL );
@@ -2852,6 +2876,7 @@ int avirhip_resize( avirhip_plan* p, const void* src, int src_mem, void* dst,
 	int dst_mem, void* stream )
 try
 {
+	avirhip::clear_error();
 	if( p == nullptr )
 	{
 		set_error( "null plan" );
@@ -2866,6 +2891,7 @@ int avirhip_resize_band( avirhip_plan* p, const void* src, int src_mem,
 	void* dst_band, int dst_mem, int row0, int row1, void* stream )
 try
 {
+	avirhip::clear_error();
 	return( exec_any( p, src, src_mem, dst_band, dst_mem, row0, row1,
 		stream ));
 }
@@ -2876,6 +2902,7 @@ int avirhip_resize_window( avirhip_plan* p, const void* src_rows, int src_mem,
 	void* stream )
 try
 {
+	avirhip::clear_error();
 	if( p == nullptr || n_rows < 1 )
 	{
 		set_error( "resize_window: bad arguments" );
@@ -2891,6 +2918,7 @@ int avirhip_time_resize( avirhip_plan* p, const void* src, void* dst,
 	int iters, void* stream, double* avg_ms )
 try
 {
+	avirhip::clear_error();
 	if( p == nullptr || iters < 1 || avg_ms == nullptr )
 	{
 		set_error( "bad arguments" );

@@ -222,6 +222,7 @@ int avirhip_resizer_create( int res_bit_depth, int src_bit_depth,
 	const avirhip_params* params, avirhip_resizer** out )
 try
 {
+	avirhip::clear_error();
 	if( out == nullptr || res_bit_depth < 1 || res_bit_depth > 16 ||
 		src_bit_depth < 0 || src_bit_depth > 16 )
 	{
@@ -255,6 +256,7 @@ AVIRHIP_CATCH( avirhip_resizer_create )
 int avirhip_resizer_set_ditherer( avirhip_resizer* r, int dither )
 try
 {
+	avirhip::clear_error();
 	if( r == nullptr || ( dither != AVIRHIP_DITHER_DEF &&
 		dither != AVIRHIP_DITHER_ERRD ))
 	{
@@ -271,6 +273,7 @@ AVIRHIP_CATCH( avirhip_resizer_set_ditherer )
 int avirhip_resizer_set_fpclass( avirhip_resizer* r, int fppack )
 try
 {
+	avirhip::clear_error();
 	if( r == nullptr || ( fppack != 1 && fppack != 4 &&
 		fppack != AVIRHIP_FPCLASS_DOUBLE ))
 	{
@@ -304,6 +307,7 @@ int avirhip_resizer_build_desc( avirhip_resizer* r, int src_w, int src_h,
 	avirhip_plan_desc** out )
 try
 {
+	avirhip::clear_error();
 	if( r == nullptr || out == nullptr )
 	{
 		set_error( "build_desc: null argument" );
@@ -355,6 +359,7 @@ int avirhip_resizer_band_source_rows( avirhip_resizer* r, int src_w, int src_h,
 	int* first, int* last )
 try
 {
+	avirhip::clear_error();
 	if( r == nullptr || first == nullptr || last == nullptr || row0 < 0 ||
 		row1 > new_h || row1 <= row0 )
 	{
@@ -462,6 +467,7 @@ int avirhip_resizer_get_plan( avirhip_resizer* r, int src_w, int src_h,
 	const avirhip_vars* vars, int in_type, int out_type, avirhip_plan** out )
 try
 {
+	avirhip::clear_error();
 	if( r == nullptr || out == nullptr )
 	{
 		set_error( "get_plan: null argument" );
@@ -580,6 +586,7 @@ int avirhip_resizer_vars_base( avirhip_resizer* r, int src_w, int src_h,
 	avirhip_vars_base* out )
 try
 {
+	avirhip::clear_error();
 	if( r == nullptr || out == nullptr )
 	{
 		set_error( "vars_base: null argument" );
@@ -660,6 +667,7 @@ int avirhip_resizer_resize( avirhip_resizer* r, const void* src, int src_mem,
 	int in_type, int out_type, void* stream )
 try
 {
+	avirhip::clear_error();
 	if( r == nullptr || out_type < 0 || out_type > 3 )
 	{
 		set_error( "resize: bad arguments" );
@@ -727,6 +735,7 @@ void avirhip_lancir_params_default( avirhip_lancir_params* p )
 int avirhip_lancir_create( avirhip_lancir** out )
 try
 {
+	avirhip::clear_error();
 	if( out == nullptr )
 	{
 		set_error( "lancir_create: null argument" );
@@ -754,6 +763,7 @@ int avirhip_lancir_build_desc( avirhip_lancir* l, int src_w, int src_h,
 	int in_type, int out_type, avirhip_lancir_desc** out )
 try
 {
+	avirhip::clear_error();
 	if( out == nullptr )
 	{
 		set_error( "lancir_build_desc: null argument" );
@@ -803,6 +813,7 @@ int avirhip_lancir_band_source_rows( avirhip_lancir* l, int src_w, int src_h,
 	int in_type, int out_type, int row0, int row1, int* first, int* last )
 try
 {
+	avirhip::clear_error();
 	if( first == nullptr || last == nullptr || row0 < 0 || row1 > new_h ||
 		row1 <= row0 )
 	{
@@ -914,6 +925,7 @@ int avirhip_lancir_get_plan( avirhip_lancir* l, int src_w, int src_h,
 	int in_type, int out_type, avirhip_plan** out )
 try
 {
+	avirhip::clear_error();
 	if( l == nullptr || out == nullptr )
 	{
 		set_error( "lancir_get_plan: null argument" );
@@ -931,6 +943,7 @@ int avirhip_lancir_resize( avirhip_lancir* l, const void* src, int src_mem,
 	int out_type, void* stream )
 try
 {
+	avirhip::clear_error();
 	// Parameter errors return 0, lancir.h:392-407.
 	if( l == nullptr || src_w < 0 || src_h < 0 || new_w <= 0 || new_h <= 0 ||
 		src == nullptr || dst == nullptr || src == dst ||

@@ -1222,8 +1222,9 @@ bool gpass_lancir_takes_raw( const avirhip_plan* p, const void* raw, int type,
 		( D -> v_rs + D -> v_rc ) * 1024 + GV_QB + 6 * 1024 <= 64 * 1024 &&
 		nt >= 6 && nt <= 24 && ( nt & 1 ) == 0 &&
 		( (uintptr_t) raw & 3 ) == 0 && (( stride * esz ) & 3 ) == 0 &&
-		( (long) ( p -> src_h - 1 ) * stride + (long) p -> src_w * ch ) * esz <
-		( 1L << 31 ));
+		// (the DMA's num_records is this rounded up to a dword, in an int)
+		( (long) ( p -> src_h - 1 ) * stride + (long) p -> src_w * ch ) * esz <=
+		0x7ffffffcL );
 }
 
 // Whether the first pass reads the caller's image as it is (integer types,
@@ -1374,8 +1375,9 @@ int gpass_run( avirhip_plan* p, const float* src, long src_stride, float* dst,
 				G.raw = p -> lraw.ptr; G.raw_ss = p -> lraw.stride;
 				G.raw_kind = ( esz == 1 ? 1 : ( esz == 2 ? 2 : 3 ));
 				G.raw_ch = p -> lraw.ch; G.raw_bpp = esz * p -> lraw.ch;
-				G.raw_bytes = (int) (( (long) ( p -> src_h - 1 ) * p -> lraw.stride +
-					(long) p -> src_w * p -> lraw.ch ) * esz );
+				// (rounded up to whole dwords, as in gpass_run_v)
+				G.raw_bytes = (int) (((( (long) ( p -> src_h - 1 ) * p -> lraw.stride +
+					(long) p -> src_w * p -> lraw.ch ) * esz ) + 3 ) & ~3L );
 				G.raw_tdn = ( 64 * G.raw_bpp + ( G.raw_bpp & 3 ? 3 : 0 ) + 255 ) >> 8;
 			}
 

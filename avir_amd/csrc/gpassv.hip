@@ -10,14 +10,14 @@ namespace avirhip {
 // upsizing (FIR7 then gather), 13-25 for AVIR 1 < k < 2 downsizing (gather
 // then FIR7, gpassv_post.hip), the even counts 6-24 for LANCIR
 // (gpassv_lanc.hip); the LDS-window kernel takes everything else.
-static void launch_gv( const GVParams& P, int wp, int items, size_t lds,
+static int launch_gv( const GVParams& P, int wp, int items, size_t lds,
 	hipStream_t st )
 {
 	const int nt = P.ax.nt;
 
 	if( P.ax.lanc )
 	{
-		launch_gv_lanc( P, wp, items, lds, st );
+		return( launch_gv_lanc( P, wp, items, lds, st ));
 	}
 	else
 	if( P.ax.mode == GP_PRE )
@@ -34,6 +34,8 @@ static void launch_gv( const GVParams& P, int wp, int items, size_t lds,
 	{
 		GV_LAUNCH( GP_NONE, false, 0, 0 );
 	}
+
+	return( 0 );
 }
 
 int gpass_run_v( const GPAxis& A_, int v_blk, int v_rs, int v_rc,
@@ -66,13 +68,16 @@ int gpass_run_v( const GPAxis& A_, int v_blk, int v_rs, int v_rc,
 		const int nt = A_.nt;
 
 		if(( (uintptr_t) raw & 3 ) != 0 || (( raw_stride * esz ) & 3 ) != 0 ||
-			bytes >= ( 1L << 31 ) || !A_.lanc || nt < 6 || nt > 24 || ( nt & 1 ))
+			bytes > 0x7ffffffcL || !A_.lanc || nt < 6 || nt > 24 || ( nt & 1 ))
 		{
 			return( 1 );
 		}
 
 		P.raw_dma = (int) ( esz * raw_ch );
-		P.raw_bytes = (int) bytes;
+		// (whole dwords: base and pitch are dword-aligned and device allocations
+		// dword-granular, so the row's last partial dword is fetched whichever
+		// way the range check treats a dword that straddles num_records)
+		P.raw_bytes = (int) (( bytes + 3 ) & ~3L );
 	}
 
 	if( out != nullptr )
@@ -182,7 +187,12 @@ int gpass_run_v( const GPAxis& A_, int v_blk, int v_rs, int v_rc,
 			P.ax.nt, P.ax.mode );
 	}
 #endif
-	launch_gv( P, wp, items, lds, st );
+	// (1: no kernel of the variant group takes this plan -- the caller falls
+	// back, api.cpp turns an unexpected 1 into AVIRHIP_NEED_SRC / the generic path)
+	if( launch_gv( P, wp, items, lds, st ) != 0 )
+	{
+		return( 1 );
+	}
 
 	AVIRHIP_HIPCHECK( hipGetLastError() );
 	return( AVIRHIP_OK );

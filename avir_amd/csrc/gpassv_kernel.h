@@ -687,11 +687,13 @@ __global__ void __launch_bounds__( 64 ) k_gv( const GVParams P )
 	else GV_LAUNCH_L1( NT, RW, 2, 6 ); } while( 0 )
 
 // the launchers of the variant groups (one translation unit each)
-void launch_gv_lanc( const GVParams& P, int wp, int items, size_t lds,
+// (0, or 1 when the variant group has no kernel for the plan: nothing was
+// launched)
+int launch_gv_lanc( const GVParams& P, int wp, int items, size_t lds,
 	hipStream_t st );
-void launch_gv_lanc_raw( const GVParams& P, int items, size_t lds,
+int launch_gv_lanc_raw( const GVParams& P, int items, size_t lds,
 	hipStream_t st );
-void launch_gv_lanc_raw8( const GVParams& P, int items, size_t lds,
+int launch_gv_lanc_raw8( const GVParams& P, int items, size_t lds,
 	hipStream_t st );
 void launch_gv_post( const GVParams& P, int wp, int items, size_t lds,
 	hipStream_t st );

@@ -4,23 +4,15 @@
 
 namespace avirhip {
 
-void launch_gv_lanc( const GVParams& P, int wp, int items, size_t lds,
+int launch_gv_lanc( const GVParams& P, int wp, int items, size_t lds,
 	hipStream_t st )
 {
 	const int nt = P.ax.nt;
 
 	if( wp == 2 && P.raw != nullptr )
 	{
-		if( P.raw_kind == 1 )
-		{
-			launch_gv_lanc_raw8( P, items, lds, st );
-		}
-		else
-		{
-			launch_gv_lanc_raw( P, items, lds, st );
-		}
-
-		return;
+		return( P.raw_kind == 1 ? launch_gv_lanc_raw8( P, items, lds, st ) :
+			launch_gv_lanc_raw( P, items, lds, st ));
 	}
 
 	switch( nt )
@@ -37,6 +29,8 @@ void launch_gv_lanc( const GVParams& P, int wp, int items, size_t lds,
 		case 24: GV_LAUNCH_L( 24, 32 ); break;
 		default: GV_LAUNCH_L( 0, 0 ); break;
 	}
+
+	return( 0 );
 }
 
 } // namespace avirhip

@@ -4,7 +4,8 @@
 
 namespace avirhip {
 
-void launch_gv_lanc_raw( const GVParams& P, int items, size_t lds,
+// returns 1 when no variant exists for the plan's tap count (nothing launched)
+int launch_gv_lanc_raw( const GVParams& P, int items, size_t lds,
 	hipStream_t st )
 {
 	const int nt = P.ax.nt;
@@ -22,9 +23,12 @@ void launch_gv_lanc_raw( const GVParams& P, int items, size_t lds,
 		case 22: GV_LAUNCH_LR( 22, 32 ); break;
 		case 24: GV_LAUNCH_LR( 24, 32 ); break;
 		// (other tap counts keep their window in an LDS ring of pixels, which
-		// raw bytes cannot feed: gpass_lancir_takes_raw refuses them)
-		default: break;
+		// raw bytes cannot feed: gpass_lancir_takes_raw refuses them -- a caller
+		// that comes here all the same must not take silence for success)
+		default: return( 1 );
 	}
+
+	return( 0 );
 }
 
 } // namespace avirhip

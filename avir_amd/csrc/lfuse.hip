@@ -456,7 +456,7 @@ bool lfuse_takes_raw( const void* raw, int type, int ch, long stride,
 	const long bytes = ( (long) ( in_len_v - 1 ) * stride + (long) width * ch ) * esz;
 
 	return( raw != nullptr && ( (uintptr_t) raw & 3 ) == 0 &&
-		(( stride * esz ) & 3 ) == 0 && bytes >= 4 && bytes < ( 1L << 31 ) &&
+		(( stride * esz ) & 3 ) == 0 && bytes >= 4 && bytes <= 0x7ffffffcL &&
 		ch >= 1 && ch <= 4 && esz * ch < 16 );
 }
 

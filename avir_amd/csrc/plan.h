@@ -216,6 +216,7 @@ struct avirhip_plan
 namespace avirhip {
 
 void set_error( const char* fmt, ... );
+void clear_error();
 #define AVIRHIP_HIPCHECK( expr ) do { hipError_t e_ = ( expr ); \
 	if( e_ != hipSuccess ) { avirhip::set_error( "%s: %s (%s:%d)", #expr, \
 		hipGetErrorString( e_ ), __FILE__, __LINE__ ); \

@@ -2,6 +2,12 @@
 // pipeline's floating-point type (the reference's `fptype`: tables are stored,
 // accumulated and read back in it, avir.h:5128-6270). Included twice by
 // planner.cpp: FT = float in namespace pl32, FT = double in namespace pl64.
+//
+// A declared derived work: this file restates avir.h:460-2100, 5128-6270 of
+// AVIR v3.1 (Copyright (c) 2015-2025 Aleksey Vaneev, MIT License -- the licence
+// text is at the top of planner.cpp, which is the only file that includes this
+// one; NOTICE.md) statement by statement, because the parity contract is
+// bit-identical filter tables and that fixes every expression and its order.
 
 namespace avirhip {
 

@@ -734,16 +734,19 @@ def main():
         # check; the HIP-event time of the same K steps (a few % shorter: it
         # leaves out the synchronisation at either end) is kept beside it, and
         # the sustained leg below adds the same fraction over >= 5 s.
-        wall_ms = (t / args.steps * 1e3) if world == 1 else ev_ms
+        # (--pg-smoke is world 1 but times the band pipeline like N > 1 does)
+        one_kernel_step = (world == 1 and not sharded_run)
+        wall_ms = (t / args.steps * 1e3) if one_kernel_step else ev_ms
         achieved = ALGO_BYTES / (wall_ms * 1e-3) / 1e9
         out["roofline"] = {
             "bound": "hbm", "achieved": round(achieved, 1),
             "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 4),
             "clock": ("ms_per_step (wall, K steps between synchronisations)"
-                      if world == 1 else
-                      "HIP events over whole-frame launches on rank 0 (N > 1: "
-                      "ms_per_step times the band pipeline, not the kernel)"),
+                      if one_kernel_step else
+                      "HIP events over whole-frame launches on rank 0 (N > 1 "
+                      "and --pg-smoke: ms_per_step times the band pipeline, "
+                      "not the kernel)"),
             "kernel_ms": round(wall_ms, 4),
             "event_ms": round(ev_ms, 4),
             "frac_events": round(ALGO_BYTES / (ev_ms * 1e-3) / 1e9

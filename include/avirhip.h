@@ -219,7 +219,9 @@ typedef struct avirhip_plan avirhip_plan;
 int avirhip_device_count(void);
 /* Binds the calling thread to `device` (hipSetDevice). */
 int avirhip_init(int device);
-/* Thread-local message for the most recent failing call. */
+/* Thread-local message of the calling thread's most recent avirhip_* call that
+ * returns a status: every such entry point empties it when it begins, so the
+ * text never outlives the call it describes ("" after a call that succeeded). */
 const char* avirhip_last_error(void);
 /* Library version string. */
 const char* avirhip_version(void);
