@@ -394,6 +394,83 @@ def cpu_baseline(src_np, threads):
             "builds": rows}
 
 
+def config_cpu_baseline(name, mt_threads, budget_s=2.5):
+    """The reference's CPU path beside one of the other BASELINE configs
+    (BASELINE.md 4 item 5), bounded to `budget_s` per leg,
+    1-3 frames each, best of runs: avir::CImageResizer<>(bits) -- the parity
+    build, -O3 -ffp-contract=off -- on 1 thread and on `mt_threads` (the thread
+    count the cfg3 sweep found fastest, through the same persistent
+    CImageResizerThreadPool); avir::CLancIR (single-threaded by design,
+    lancir.h:319-349) on 1 thread and as `mt_threads` independent objects, one
+    per thread -- the way a host serves several frames at once (lancir.h:386-713
+    has no internal threading to time)."""
+    import threading
+    from oracle import bind as rb  # the checker: CPU baseline legs only
+    if not rb.have_ref():
+        return None
+    api, sw, sh, nw, nh, ch, dt, bits = OTHER[name]
+    src_np = _workload_src(name)
+    mpix = nw * nh / 1e6
+
+    def best_of(fn):
+        ts = []
+        stop = time.perf_counter() + budget_s
+        while len(ts) < 3 and (not ts or time.perf_counter() < stop):
+            t0 = time.perf_counter()
+            fn()
+            ts.append(time.perf_counter() - t0)
+        return min(ts)
+    if api == "avir":
+        t1 = best_of(lambda: rb.ref_avir(src_np, nw, nh, resbits=bits, threads=1))
+        tn = t1
+        nthr = 1
+        if mt_threads > 1:
+            tn = best_of(lambda: rb.ref_avir(src_np, nw, nh, resbits=bits,
+                                             threads=mt_threads))
+            nthr = mt_threads
+        if tn > t1:
+            tn, nthr = t1, 1
+        return {"value": round(mpix / tn, 2), "unit": "Mpixels/s",
+                "ms_per_frame": round(tn * 1e3, 2), "threads": nthr,
+                "single_thread_ms": round(t1 * 1e3, 2),
+                "build": "avir::CImageResizer<>(%d), fpclass_def<float>, -O3 "
+                         "-ffp-contract=off (the parity build)" % bits,
+                "kind": "reference",
+                "sample": "1-3 frames per thread count, best of runs"}
+    t1 = best_of(lambda: rb.ref_lancir(src_np, nw, nh))
+    out = {"value": round(mpix / t1, 2), "unit": "Mpixels/s",
+           "ms_per_frame": round(t1 * 1e3, 2), "threads": 1,
+           "single_thread_ms": round(t1 * 1e3, 2),
+           "build": "avir::CLancIR (x86-64 SSE2), -O3 -ffp-contract=off",
+           "kind": "reference", "sample": "1-3 frames, best of runs"}
+    # N objects on N threads (each its own CLancIR, source and destination):
+    # bounded by host memory -- a destination frame of cfg5 is 531 MB
+    n = max(1, min(mt_threads, 16))
+    if n > 1:
+        srcs = [src_np.copy() for _ in range(n)]
+        dts = [0.0] * n
+
+        def one(i):
+            rb.ref_lancir(srcs[i], nw, nh)
+        th = [threading.Thread(target=one, args=(i,)) for i in range(n)]
+        t0 = time.perf_counter()
+        for x in th:
+            x.start()
+        for x in th:
+            x.join()
+        ta = time.perf_counter() - t0
+        out["aggregate"] = {"objects": n, "threads": n,
+                            "seconds": round(ta, 3),
+                            "value": round(n * mpix / ta, 2),
+                            "note": "N independent CLancIR objects, one frame "
+                                    "each, started together (ctypes releases "
+                                    "the GIL)"}
+        if n * mpix / ta > out["value"]:
+            out["value"] = out["aggregate"]["value"]
+            out["threads"] = n
+    return out
+
+
 VALU_NONFMA_PEAK_TFLOPS = 68.0  # profiles/r01_microbench_valu_lds_copy.txt
 
 
@@ -876,6 +953,22 @@ def main():
                     "(16 bands, PCIe both ways at once); 663.6 MB over PCIe",
             "parity_ok": synth.fnv(hdst) == "38d7739587151f6e"}
         out["cpu_baseline"] = cpu_baseline(src_np, os.cpu_count() or 1)
+        # ... and the reference beside every other config of the line
+        # (VERDICT r5 #6): the parity build at the thread count the sweep
+        # above found fastest, CLancIR on one thread and as N objects
+        mt = int(out["cpu_baseline"].get("builds", [{}])[0].get("threads", 1)
+                 if out["cpu_baseline"].get("kind") == "reference" else 1)
+        for c in out.get("configs", []):
+            if "error" in c:
+                continue
+            try:
+                cb = config_cpu_baseline(c["config"], mt)
+            except Exception as e:  # noqa: BLE001 -- never the headline's fate
+                cb = {"error": "%s: %s" % (type(e).__name__, e)}
+            if cb is not None:
+                c["cpu_baseline"] = cb
+                if cb.get("value"):
+                    c["gpu_over_cpu"] = round(c["value"] / cb["value"], 1)
 
     if rank == 0:
         print(json.dumps(out), flush=True)

@@ -1128,6 +1128,22 @@ def test_lancir_raw_rows_travel_as_bytes(tin):
             s, 70, 41, tin, 0.0, 0.0, 0.0, 0.0, 3.0, spad=spad)
         assert rc == 41
         _assert_same(got, want, "padded rows +%d" % spad)
+    # ... and rows that END in a partial dword behind a dword-aligned pitch
+    # (width * channels * element size not a multiple of 4): the last 1-3
+    # elements of the image's last row sit in a dword that straddles the DMA's
+    # range -- num_records is rounded up to whole dwords for them
+    for (w, spad) in ((201, 1), (203, 3), (203, 1), (205, 1), (202, 2)):
+        for (nw, nh) in ((70, 41), (333, 190)):
+            s = rb.lcg_u8((120, w, 3, np.dtype(tin).itemsize), seed=w + spad)
+            s = s.view(tin).reshape(120, w, 3)
+            want = _checker_lancir(s, nw, nh, spad=spad)
+            rc, got = rb._lancir_call(
+                lambda sp, sw, sh, dp, nw_, nh_, ch, ti, to, ss, ns, kx, ky, ox,
+                oy, la: _lancir_abi(sp, sw, sh, dp, nw_, nh_, ch, ti, to, ss, ns),
+                s, nw, nh, tin, 0.0, 0.0, 0.0, 0.0, 3.0, spad=spad)
+            assert rc == nh
+            _assert_same(got, want, "partial last dword w%d +%d -> %dx%d"
+                         % (w, spad, nw, nh))
 
 
 def test_lancir_wide_types_are_refused_by_cimageresizer():
