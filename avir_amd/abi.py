@@ -243,6 +243,41 @@ def load():
     return lib
 
 
+def load_path(path):
+    """A SECOND build of the library (e.g. lib/libavirhip_paranoid.so, `make
+    paranoid`), loaded beside the product one and never cached: the differential
+    race hunt (tools/stress_geom.py --against) runs both in one process."""
+    if not os.path.exists(path):
+        raise RuntimeError("%s missing (make -C avir_amd/csrc paranoid)" % path)
+    _preload_hip_runtime()
+    lib = C.CDLL(path)
+    for name, (res, args) in PROTOTYPES.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    return lib
+
+
+class using(object):
+    """`with abi.using(other):` -- front-end objects constructed inside bind to
+    `other` (they keep the library they were created with)."""
+
+    def __init__(self, lib):
+        self.lib = lib
+
+    def __enter__(self):
+        global _lib
+        load()
+        self.keep = _lib
+        _lib = self.lib
+        return self.lib
+
+    def __exit__(self, *a):
+        global _lib
+        _lib = self.keep
+        return False
+
+
 class AvirHipError(RuntimeError):
     pass
 

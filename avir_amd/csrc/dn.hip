@@ -247,7 +247,7 @@ __global__ void __launch_bounds__( 256 ) k_dnh( const DnHParams P )
 			sS[ wave ]);
 	}
 
-	asm volatile( "s_waitcnt vmcnt(0)" ::: "memory" );
+	AVIRHIP_WAIT_VM( 0 );
 
 	// ---- resize: R consecutive outputs per lane
 	{

@@ -20,7 +20,7 @@ namespace avirhip {
 __device__ __forceinline__ void df_dma( const __amdgpu_buffer_rsrc_t rs,
 	const unsigned lds, const int voff, const unsigned soff )
 {
-	asm volatile( "s_mov_b32 m0, %0\n\t"
+	asm volatile( AVIRHIP_HANDOVER "s_mov_b32 m0, %0\n\t"
 		"s_nop 0\n\t"
 		"buffer_load_dwordx4 %1, %2, %3 offen lds"
 		:: "s"( lds ), "v"( voff ), "s"( rs ), "s"( soff ) : "memory" );
@@ -170,7 +170,7 @@ __device__ __forceinline__ void df_wait( DfBatch< B >& d )
 	{
 		if constexpr( LEFT == 0 )
 		{
-			asm volatile( "s_waitcnt lgkmcnt(0)"
+			asm volatile( AVIRHIP_WAITCNT_LGKM( 0 )
 				: "+v"( d.v[ 0 ]), "+v"( d.v[ 1 ]), "+v"( d.v[ 2 ]),
 				"+v"( d.v[ 3 ]), "+v"( d.v[ 4 ]), "+v"( d.v[ 5 ]),
 				"+v"( d.v[ 6 ]), "+v"( d.v[ 7 ]), "+v"( d.v[ 8 ]),
@@ -178,7 +178,7 @@ __device__ __forceinline__ void df_wait( DfBatch< B >& d )
 		}
 		else
 		{
-			asm volatile( "s_waitcnt lgkmcnt(11)"
+			asm volatile( AVIRHIP_WAITCNT_LGKM( 11 )
 				: "+v"( d.v[ 0 ]), "+v"( d.v[ 1 ]), "+v"( d.v[ 2 ]),
 				"+v"( d.v[ 3 ]), "+v"( d.v[ 4 ]), "+v"( d.v[ 5 ]),
 				"+v"( d.v[ 6 ]), "+v"( d.v[ 7 ]), "+v"( d.v[ 8 ]),
@@ -189,14 +189,14 @@ __device__ __forceinline__ void df_wait( DfBatch< B >& d )
 	{
 		if constexpr( LEFT == 0 )
 		{
-			asm volatile( "s_waitcnt lgkmcnt(0)"
+			asm volatile( AVIRHIP_WAITCNT_LGKM( 0 )
 				: "+v"( d.v[ 0 ]), "+v"( d.v[ 1 ]), "+v"( d.v[ 2 ]),
 				"+v"( d.v[ 3 ]), "+v"( d.v[ 4 ]), "+v"( d.v[ 5 ]),
 				"+v"( d.v[ 6 ]));
 		}
 		else
 		{
-			asm volatile( "s_waitcnt lgkmcnt(7)"
+			asm volatile( AVIRHIP_WAITCNT_LGKM( 7 )
 				: "+v"( d.v[ 0 ]), "+v"( d.v[ 1 ]), "+v"( d.v[ 2 ]),
 				"+v"( d.v[ 3 ]), "+v"( d.v[ 4 ]), "+v"( d.v[ 5 ]),
 				"+v"( d.v[ 6 ]));

@@ -137,7 +137,7 @@ __device__ __forceinline__ void run_op( const TOp& op, const f4* in,
 				}
 			}
 
-			asm volatile( "s_waitcnt vmcnt(0)" ::: "memory" );
+			AVIRHIP_WAIT_VM( 0 );
 		}
 		else
 		{
@@ -430,7 +430,7 @@ __global__ void __launch_bounds__( 256 ) k_tile( const TileParams P )
 				cols, wave, lane );
 		}
 
-		asm volatile( "s_waitcnt vmcnt(0)" ::: "memory" );
+		AVIRHIP_WAIT_VM( 0 );
 		__syncthreads();
 
 		// zero-stuffed first views: their tail reads 0 (rare: the tile must

@@ -1386,7 +1386,7 @@ __device__ __forceinline__ void eo_put( ErrdOut& o, const unsigned long long a,
 __device__ __forceinline__ void ej_dma( const __amdgpu_buffer_rsrc_t rs,
 	const unsigned lds, const int voff )
 {
-	asm volatile( "s_mov_b32 m0, %0\n\t"
+	asm volatile( AVIRHIP_HANDOVER "s_mov_b32 m0, %0\n\t"
 		"s_nop 0\n\t"
 		"buffer_load_dwordx4 %1, %2, 0 offen lds"
 		:: "s"( lds ), "v"( voff ), "s"( rs ) : "memory" );
@@ -1396,7 +1396,7 @@ __device__ __forceinline__ void ej_dma( const __amdgpu_buffer_rsrc_t rs,
 __device__ __forceinline__ void ej_dma_sc( const __amdgpu_buffer_rsrc_t rs,
 	const unsigned lds, const int voff )
 {
-	asm volatile( "s_mov_b32 m0, %0\n\t"
+	asm volatile( AVIRHIP_HANDOVER "s_mov_b32 m0, %0\n\t"
 		"s_nop 0\n\t"
 		"buffer_load_dwordx4 %1, %2, 0 offen sc0 sc1 lds"
 		:: "s"( lds ), "v"( voff ), "s"( rs ) : "memory" );
@@ -1513,13 +1513,13 @@ __global__ void __launch_bounds__( 512 ) k_errd_mp( const float* res,
 				burst( t );
 				// bursts t, t - 2, t - 4 may be in flight: t - 6 (first read
 				// at step t + 2) has landed
-				asm volatile( "s_waitcnt vmcnt(45)" ::: "memory" );
+				AVIRHIP_WAIT_VM( 45 );
 			}
 
 			__syncthreads();
 		}
 
-		asm volatile( "s_waitcnt vmcnt(0)" ::: "memory" );
+		AVIRHIP_WAIT_VM( 0 );
 		return;
 	}
 
@@ -1649,7 +1649,7 @@ __global__ void __launch_bounds__( 512 ) k_errd_mp( const float* res,
 
 			if(( p & 7 ) == 0 || p == w )
 			{
-				asm volatile( "s_waitcnt vmcnt(0)" ::: "memory" );
+				AVIRHIP_WAIT_VM( 0 );
 				__hip_atomic_store( &flags[ pass ], ( epoch << 20 ) |
 					(unsigned) p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT );
 			}

@@ -369,7 +369,8 @@ int gfuse_launch( GFParams& P, double k_v, hipStream_t st )
 	// and window filling (~140 instructions each) before the first output,
 	// against ~140 per source row and ~60 per output row afterwards
 	const int warm = (int) ( 18.0 * 140.0 / ( 140.0 * k_v + 60.0 ) + 0.5 );
-	static const int force = ( getenv( "AVIRHIP_GF_CHUNK" ) != nullptr ?
+	// (read per call: tools/stress_geom.py varies it case by case)
+	const int force = ( getenv( "AVIRHIP_GF_CHUNK" ) != nullptr ?
 		atoi( getenv( "AVIRHIP_GF_CHUNK" )) : 0 );
 
 	P.chunk = ( force > 0 ? std::min( force, max_chunk ) :

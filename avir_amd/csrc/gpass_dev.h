@@ -54,7 +54,7 @@ __device__ __forceinline__ int gp_clamp( int i, int hi )
 __device__ __forceinline__ void gp_dma( const __amdgpu_buffer_rsrc_t rs,
 	const unsigned lds, const int voff )
 {
-	asm volatile( "s_mov_b32 m0, %0\n\t"
+	asm volatile( AVIRHIP_HANDOVER "s_mov_b32 m0, %0\n\t"
 		"buffer_load_dwordx4 %1, %2, 0 offen lds"
 		:: "s"( __builtin_amdgcn_readfirstlane( lds )), "v"( voff ), "s"( rs )
 		: "memory" );
@@ -65,13 +65,14 @@ __device__ __forceinline__ void gp_dma( const __amdgpu_buffer_rsrc_t rs,
 __device__ __forceinline__ void gp_dma4( const __amdgpu_buffer_rsrc_t rs,
 	const unsigned lds, const int voff )
 {
-	asm volatile( "s_mov_b32 m0, %0\n\t"
+	asm volatile( AVIRHIP_HANDOVER "s_mov_b32 m0, %0\n\t"
 		"buffer_load_dword %1, %2, 0 offen lds"
 		:: "s"( __builtin_amdgcn_readfirstlane( lds )), "v"( voff ), "s"( rs )
 		: "memory" );
 }
 
-#define GP_WAIT_VM( n ) asm volatile( "s_waitcnt vmcnt(" #n ")" ::: "memory" )
+// (waits.h: a counted wait in the product build, a full drain in `make paranoid`)
+#define GP_WAIT_VM( n ) AVIRHIP_WAIT_VM( n )
 
 // s_waitcnt takes an immediate: a wave-uniform count picks its instruction.
 // Waiting for MORE than `n` to retire is always safe (loads retire in order).

@@ -70,7 +70,7 @@ __device__ __forceinline__ Taps12 load_taps12( const float* p )
 	Taps12 t;
 	asm volatile( "s_load_dwordx8 %0, %2, 0x0\n\t"
 		"s_load_dwordx4 %1, %2, 0x20\n\t"
-		"s_waitcnt lgkmcnt(0)"
+		AVIRHIP_WAITCNT_LGKM( 0 )
 		: "=&s"( t.a ), "=&s"( t.b ) : "s"( p ) : "memory" );
 	return( t );
 }
@@ -251,6 +251,7 @@ __global__ void __launch_bounds__( L2_NT ) k_lanc2( const Lanc2Params P )
 #undef VB
 		}
 
+		AVIRHIP_BARRIER_DRAIN();
 		__syncthreads();
 
 		// next step's source rows start their trip from HBM now
@@ -430,6 +431,7 @@ __global__ void __launch_bounds__( L2_NT ) k_lanc2( const Lanc2Params P )
 #undef HB
 		}
 
+		AVIRHIP_BARRIER_DRAIN();
 		__syncthreads();
 	}
 }

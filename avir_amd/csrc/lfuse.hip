@@ -346,7 +346,11 @@ __global__ void __launch_bounds__( 64 ) k_lf( const LFParams P )
 			// returned the NEW row (found by the round-5 fuzz campaign at
 			// 834x546 -> 2030x1112, chunks of ten and more output rows, nine
 			// runs in ten; the kernel had carried the race since round 4).
-			asm volatile( "s_waitcnt lgkmcnt(0)" ::: "memory" );
+			// (-DLF_OLD_RACE restores the round-4 kernel WITHOUT this wait: the
+			// known-bad build the differential harness must catch, `make lfrace`)
+#ifndef LF_OLD_RACE
+			AVIRHIP_WAIT_LGKM( 0 );
+#endif
 			issue_row( u + LF_NB - 1, ( buf + LF_NB - 1 ) & ( LF_NB - 1 ));
 		}
 
@@ -398,7 +402,8 @@ int lfuse_launch( LFParams& P, hipStream_t st )
 
 	// (a chunk's run-in: six row loads and the table staging, about three
 	// output rows' worth)
-	static const int force = ( getenv( "AVIRHIP_LF_CHUNK" ) != nullptr ?
+	// (read per call: tools/stress_geom.py varies it case by case)
+	const int force = ( getenv( "AVIRHIP_LF_CHUNK" ) != nullptr ?
 		atoi( getenv( "AVIRHIP_LF_CHUNK" )) : 0 );
 
 	P.chunk = ( force > 0 ? std::min( force, max_chunk ) :

@@ -15,6 +15,7 @@
 //   VIEW_RAW    in[i + prefix] of a materialised filtered-upsample buffer
 //
 #pragma once
+#include "waits.h"
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <string>

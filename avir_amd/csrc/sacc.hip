@@ -186,7 +186,7 @@ struct SAV
 __device__ __forceinline__ void sa_dma4( const __amdgpu_buffer_rsrc_t rs,
 	const unsigned lds, const int voff )
 {
-	asm volatile( "s_mov_b32 m0, %0\n\t"
+	asm volatile( AVIRHIP_HANDOVER "s_mov_b32 m0, %0\n\t"
 		"buffer_load_dword %1, %2, 0 offen lds"
 		:: "s"( __builtin_amdgcn_readfirstlane( lds )), "v"( voff ), "s"( rs )
 		: "memory" );
@@ -766,7 +766,7 @@ __global__ void __launch_bounds__( 64 ) k_sacc( const SAParams P )
 
 typedef float f16v __attribute__(( ext_vector_type( 16 )));
 
-#define SA2_LGKM_WAIT() asm volatile( "s_waitcnt lgkmcnt(0)" ::: "memory" )
+#define SA2_LGKM_WAIT() AVIRHIP_WAIT_LGKM( 0 )
 
 // W dwords as one register tuple
 template< int W > struct SA2Vec
@@ -803,7 +803,7 @@ __device__ __forceinline__ void sa2_gload( V& d, const unsigned char* const p )
 template< class V >
 __device__ __forceinline__ void sa2_landed( V& a, V& b )
 {
-	asm volatile( "s_waitcnt vmcnt(0)" : "+v"( a ), "+v"( b ) :: "memory" );
+	asm volatile( AVIRHIP_WAITCNT_VM( 0 ) : "+v"( a ), "+v"( b ) :: "memory" );
 }
 
 template<> struct SA2Vec< 1 >

@@ -2287,6 +2287,28 @@ def test_fast_paths_over_random_large_geometries():
     assert " 0 problems" in r.stdout
 
 
+def test_counted_waits_against_the_paranoid_build():
+    """The differential race hunt: lib/libavirhip_paranoid.so
+    (`make paranoid`: every counted s_waitcnt a full drain, a full drain in front
+    of every LDS-DMA instruction -- csrc/waits.h) is loaded beside the product
+    library and both run the automatic path of 400 random large geometries, with
+    the chunk lengths of the marching / pass kernels forced below, at and above
+    their ring depths; the product build repeats each frame and must agree bit
+    for bit. A wait that counts wrong shows here whatever the seed of the fuzzers
+    (the round-4 k_lf race: `make lfrace` + profiles/r06_paranoid/)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    par = os.path.join(root, "avir_amd", "lib", "libavirhip_paranoid.so")
+    assert os.path.exists(par), "build it: make -C avir_amd/csrc paranoid"
+    r = subprocess.run([sys.executable, os.path.join(root, "tools",
+                                                     "stress_geom.py"), "400",
+                        "23", "3", "--against", par, "--chunks"],
+                       capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert " 0 problems" in r.stdout
+
+
 @pytest.mark.parametrize("ch,tin,tout,bits", [
     (3, np.uint8, np.uint8, 8), (4, np.uint8, np.uint8, 8),
     (1, np.uint8, np.uint8, 8), (2, np.uint16, np.uint16, 16),
