@@ -1782,29 +1782,77 @@ static int exec_any( avirhip_plan* p, const void* src, int src_mem, void* dst,
 	const void* dsrc = src;
 	void* ddst = dst;
 
-	if( src_mem == AVIRHIP_MEM_HOST || windowed )
+	// A window on the marching kernels (exact-2x float RGBA plans: the sharded
+	// configurations of BASELINE.json): the kernels take a VIRTUAL frame base,
+	// window - win_first rows, and clamp their row indices to the window -- for
+	// every access that reaches a result "clamp to the window" IS "clamp to the
+	// frame" (a needed row outside the frame is the frame's first / last row,
+	// which avirhip_band_source_rows then names, so the window holds it). No
+	// frame-sized buffer: a device window is read where it lies (zero copy), a
+	// host window is uploaded into a window-sized staging buffer.
+	const size_t win_off = (size_t) win_first * p -> src_stride *
+		dtype_size( p -> in_type );
+	const bool dst_direct = ( dst_mem == AVIRHIP_MEM_DEVICE );
+	bool win_native = false;
+
+	if( windowed && !overlap && getenv( "AVIRHIP_NO_NATIVE_WINDOW" ) == nullptr )
 	{
-		if( p -> stage_src_bytes < src_bytes )
+		// (alignment of the pointers the kernel will see: the staging buffers
+		// are 256-byte aligned, win_off is a multiple of the row pitch)
+		const void* const vsrc = (const char*) ( src_mem == AVIRHIP_MEM_DEVICE ?
+			src : (const void*) (uintptr_t) 256 ) - ( win_off & 255 );
+		const void* const vdst = ( dst_direct ? dst : (void*) (uintptr_t) 256 );
+
+		win_native = ( xpath == 4 && ( p -> is_lancir ?
+			lanc2_takes_window( p, vsrc, vdst ) :
+			up2_takes_window( p, vsrc, vdst )));
+	}
+
+	// (the window fields are the plan's for this call only: the lock is held)
+	struct WindowScope
+	{
+		avirhip_plan* p;
+		~WindowScope() { p -> win_first = 0; p -> win_rows = 0; }
+	} winscope = { p };
+
+	if( src_mem == AVIRHIP_MEM_HOST || ( windowed && !win_native ))
+	{
+		const size_t need = ( win_native ? win_bytes : src_bytes );
+
+		if( p -> stage_src_bytes < need )
 		{
 			void* q;
-			int rc = dev_alloc( p, src_bytes, &q );
+			int rc = dev_alloc( p, need, &q );
 			if( rc != 0 ) return( rc );
 			p -> stage_src = q;
-			p -> stage_src_bytes = src_bytes;
+			p -> stage_src_bytes = need;
 		}
 
 		dsrc = p -> stage_src;
 	}
 
-	// A window's rows go to their place in the plan's frame-sized staging
-	// buffer -- the only source bytes that move ("GPU g receives
-	// source rows [r0 - halo, r1 + halo]"); the kernels then run as on a whole
-	// frame, and whatever they load outside the window never reaches a result
-	// (avirhip_band_source_rows).
+	if( windowed && win_native )
+	{
+		if( src_mem == AVIRHIP_MEM_HOST )
+		{
+			AVIRHIP_HIPCHECK( hipMemcpyAsync( p -> stage_src, src, win_bytes,
+				hipMemcpyHostToDevice, st ));
+		}
+
+		// (pointer arithmetic only: nothing below row win_first is ever read)
+		dsrc = (const void*) ( (uintptr_t) dsrc - win_off );
+		p -> win_first = win_first;
+		p -> win_rows = win_rows;
+	}
+	else
 	if( windowed )
 	{
-		AVIRHIP_HIPCHECK( hipMemcpyAsync( (char*) p -> stage_src +
-			(size_t) win_first * p -> src_stride * dtype_size( p -> in_type ),
+		// Other plans: the window's rows go to their place in a frame-sized
+		// staging buffer of the plan -- the only source bytes that move (SURVEY.md
+		// 8e: "GPU g receives source rows [r0 - halo, r1 + halo]"); the kernels
+		// then run as on a whole frame, and whatever they load outside the window
+		// never reaches a result (avirhip_band_source_rows).
+		AVIRHIP_HIPCHECK( hipMemcpyAsync( (char*) p -> stage_src + win_off,
 			src, win_bytes, ( src_mem == AVIRHIP_MEM_HOST ?
 			hipMemcpyHostToDevice : hipMemcpyDeviceToDevice ), st ));
 	}
@@ -1945,6 +1993,7 @@ static avirhip_plan* new_plan()
 	p -> packed = nullptr; p -> resbuf = nullptr; p -> lres = nullptr;
 	p -> stage_src = nullptr; p -> stage_dst = nullptr;
 	p -> stage_src_bytes = 0; p -> stage_dst_bytes = 0;
+	p -> win_first = 0; p -> win_rows = 0;
 	p -> shard_band = nullptr; p -> shard_band_bytes = 0; p -> shard_ldev = -1;
 	p -> last_done = nullptr; p -> last_stream = nullptr; p -> last_used = false;
 	p -> last_recorded = false;

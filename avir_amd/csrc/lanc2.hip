@@ -42,6 +42,7 @@ typedef float f8 __attribute__(( ext_vector_type( 8 )));
 struct Lanc2Params
 {
 	const float* src; long src_ss; int sw, sh;
+	int rmin, rmax; // source rows that exist behind `src` (a window: plan.h)
 	float* dst; long dst_ss; int dst_row0; int nw, nh;
 	int srow_lo, srow_hi;
 	int nstrips, chunk0, cq;
@@ -172,7 +173,7 @@ __global__ void __launch_bounds__( L2_NT ) k_lanc2( const Lanc2Params P )
 #pragma unroll
 			for( int r = 0; r < L2_RB; r++ )
 			{
-				const int sy = min( max( ub + r, 0 ), P.sh - 1 );
+				const int sy = min( max( ub + r, P.rmin ), P.rmax );
 
 				if constexpr( S8 )
 				{
@@ -532,6 +533,20 @@ bool lanc2_takes_raw( const avirhip_plan* q, const void* raw, int type, int ch,
 		(long) q -> new_w * 4 < ( 1L << 30 ));
 }
 
+// The plain float RGBA call lanc2_run cannot refuse (its own checks with io ==
+// 0, sk == 0): a source window may then be handed over as a virtual frame base.
+bool lanc2_takes_window( const avirhip_plan* p, const void* src, const void* dst )
+{
+	return( p -> lanc2 != nullptr && p -> is_lancir && p -> inner == nullptr &&
+		!p -> lfuse.on && !p -> lraw.on && p -> ch == 4 && p -> io_ch == 4 &&
+		p -> in_type == AVIRHIP_F32 && p -> out_type == AVIRHIP_F32 &&
+		p -> l_unity && dst != nullptr &&
+		( (uintptr_t) src & 7 ) == 0 && ( (uintptr_t) dst & 7 ) == 0 &&
+		( p -> src_stride & 1 ) == 0 &&
+		(long) p -> src_h * p -> src_stride < ( 1L << 31 ) &&
+		(long) p -> new_w * 4 < ( 1L << 30 ));
+}
+
 // p -> lfuse.on (an inner plan, set by its owner around the call): the
 // horizontal phase runs the owner's output stage and stores into its image;
 // dst is not used then. Sets p -> lfuse.done.
@@ -592,6 +607,8 @@ int lanc2_run( avirhip_plan* p, const float* src, float* dst, int row0,
 	Lanc2Params P;
 	P.src = src; P.src_ss = p -> src_stride; P.sw = p -> src_w;
 	P.sh = p -> src_h;
+	P.rmin = ( p -> win_rows > 0 ? p -> win_first : 0 );
+	P.rmax = ( p -> win_rows > 0 ? p -> win_first + p -> win_rows : p -> src_h ) - 1;
 	P.dst = dst; P.dst_ss = (long) p -> new_w * 4; P.dst_row0 = row0;
 	P.nw = p -> new_w; P.nh = p -> new_h;
 	P.srow_lo = row0; P.srow_hi = row1;

@@ -212,6 +212,13 @@ struct avirhip_plan
 	void* stage_src; // host-pointer staging
 	void* stage_dst;
 	size_t stage_src_bytes, stage_dst_bytes;
+	// avirhip_resize_window on the marching kernels (k_up2, k_lanc2): the source
+	// pointer handed to them is a VIRTUAL frame base -- window - win_first rows
+	// -- and only rows [win_first, win_first + win_rows) exist behind it: the
+	// kernels clamp their row indices to that range instead of [0, src_h)
+	// (set by exec_any under the plan's lock for the duration of one call;
+	// win_rows == 0: the whole frame)
+	int win_first, win_rows;
 };
 
 namespace avirhip {
@@ -387,6 +394,10 @@ void up2_release( avirhip_plan* p );
 int up2_run( avirhip_plan* p, const float* src, long src_stride, float* dst,
 	int row0, int row1, hipStream_t st, void* iout = nullptr );
 bool up2_stores_io( const avirhip_plan* p );
+// whether up2_run / lanc2_run take this float RGBA call for certain (no refusal,
+// no fall-back to kernels that know nothing of a source window)
+bool up2_takes_window( const avirhip_plan* p, const void* src, const void* dst );
+bool lanc2_takes_window( const avirhip_plan* p, const void* src, const void* dst );
 
 // lanc2.hip: LANCIR exact-2x RGBA float kernel (path 4 of LANCIR plans)
 int lanc2_prepare( avirhip_plan* p );

@@ -63,6 +63,7 @@ typedef unsigned u2 __attribute__(( ext_vector_type( 2 )));
 struct Up2Params
 {
 	const float* src; long src_ss; int sw, sh;
+	int rmin, rmax; // source rows that exist behind `src` (a window: plan.h)
 	float* dst; long dst_ss; int dst_row0; int nw, nh;
 	int srow_lo, srow_hi;
 	int nstrips, chunk0, nchunks, cq; // cq: source rows (output row pairs) per chunk
@@ -295,7 +296,7 @@ __attribute__(( amdgpu_waves_per_eu( 4, 4 ))) k_up2( const Up2Params P )
 	// 64-bit flat address -- store issue cost is proportional to the dwords a
 	// wave sends to the memory pipeline. Both resources are based at this work
 	// item's first row so every offset fits 31 bits for any image size.
-	const int ubase = max( u0, 0 );
+	const int ubase = max( u0, P.rmin );
 	const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
 		(void*) ( P.src + (long) ubase * P.src_ss ), 0, 0x7fffffff, 0x00020000 );
 	const __amdgpu_buffer_rsrc_t rdst = __builtin_amdgcn_make_buffer_rsrc(
@@ -414,7 +415,7 @@ __attribute__(( amdgpu_waves_per_eu( 4, 4 ))) k_up2( const Up2Params P )
 
 	auto prefetch = [&]( const int ub )
 	{
-		if( VT && ub >= 0 && ub + U2_RB <= P.sh )
+		if( VT && ub >= P.rmin && ub + U2_RB <= P.rmax + 1 )
 		{
 			// (interior rows: the lane offset is the persistent one)
 			if( pvoff >= 0 )
@@ -443,7 +444,7 @@ __attribute__(( amdgpu_waves_per_eu( 4, 4 ))) k_up2( const Up2Params P )
 			return;
 		}
 
-		if( ub >= 0 && ub + U2_RB <= P.sh )
+		if( ub >= P.rmin && ub + U2_RB <= P.rmax + 1 )
 		{
 #pragma unroll
 			for( int k = 0; k < NDMA; k++ )
@@ -459,7 +460,9 @@ __attribute__(( amdgpu_waves_per_eu( 4, 4 ))) k_up2( const Up2Params P )
 			for( int k = 0; k < NDMA; k++ )
 			{
 				// image top / bottom: rows clamp individually (rare path)
-				const int sy = clampi( ub + k * RPI + pr_r, P.sh - 1 );
+				// (the frame's first / last row -- or a window's: rows outside it
+				// only feed results nobody stores, avirhip_band_source_rows)
+				const int sy = min( max( ub + k * RPI + pr_r, P.rmin ), P.rmax );
 				__builtin_amdgcn_raw_ptr_buffer_load_lds( rsrc,
 					(ldsptr) ((char*) sS + k * RPI * U2_SW * 16 + wave_b ), 16,
 					( sy - ubase ) * srow_b + pr_sx * 16, 0, 0, U2_LDAUX );
@@ -1302,6 +1305,19 @@ bool up2_stores_io( const avirhip_plan* p )
 		( p -> out_type == AVIRHIP_F32 && p -> io_ch < 4 )));
 }
 
+// The float RGBA call up2_run cannot refuse (its own checks, io == 0): a source
+// window may then be handed over as a virtual frame base.
+bool up2_takes_window( const avirhip_plan* p, const void* src, const void* dst )
+{
+	return( p -> up2 != nullptr && !p -> is_lancir && p -> ch == 4 &&
+		p -> io_ch == 4 && p -> in_type == AVIRHIP_F32 &&
+		p -> out_type == AVIRHIP_F32 && !p -> gamma &&
+		( (uintptr_t) src & 15 ) == 0 && ( (uintptr_t) dst & 7 ) == 0 &&
+		( p -> src_stride & 3 ) == 0 &&
+		(long) p -> src_stride * 4 < ( 1L << 22 ) &&
+		(long) p -> new_w * 16 < ( 1L << 22 ));
+}
+
 // `iout` != nullptr: the caller's image (the band's first row) -- uint8 /
 // uint16 without bit-depth truncation, or float pixels of 1-3 channels: the
 // vertical phase converts and stores there (no float result, no epilogue
@@ -1363,6 +1379,8 @@ int up2_run( avirhip_plan* p, const float* src, long src_stride, float* dst,
 
 	Up2Params P;
 	P.src = src; P.src_ss = src_stride; P.sw = p -> src_w; P.sh = p -> src_h;
+	P.rmin = ( p -> win_rows > 0 ? p -> win_first : 0 );
+	P.rmax = ( p -> win_rows > 0 ? p -> win_first + p -> win_rows : p -> src_h ) - 1;
 	P.dst = dst; P.dst_ss = (long) p -> new_w * 4; P.dst_row0 = row0;
 	P.nw = p -> new_w; P.nh = p -> new_h;
 	P.srow_lo = row0; P.srow_hi = row1;

@@ -41,10 +41,13 @@ def band_views(full, world):
 # A rank never needs the whole source: the rows its band's vertical windows read
 # (avirhip_band_source_rows / the host-only avirhip_*_band_source_rows) are all
 # that travels -- host -> device, or root -> rank over xGMI when the frame starts
-# on one GPU. They are placed at their own offsets in a frame-sized device
-# buffer, so the band call indexes the frame as ever (image borders are the
-# frame's, never the window's) and the bytes outside the window are never
-# initialised: no row of them influences a result.
+# on one GPU. Two forms: a WINDOW-sized tensor handed to avirhip_resize_window
+# (upload_window / receive_window: O(window) device memory, what bench.py --gpus
+# N uses), or the rows placed at their own offsets in a frame-sized buffer for
+# avirhip_resize_band (place_window / scatter_source_windows; with `poison` the
+# tests use it to PROVE that no other row influences a result). Either way the
+# band is computed with the frame's global indices: image borders are the
+# frame's, never the window's.
 
 def rank_source_rows(resizer, sw, sh, nw, nh, ch, rank, world, **kw):
     """(first, last) inclusive source rows of `rank`'s band; (0, -1) for an
@@ -70,6 +73,45 @@ def place_window(src_host, first, last, device, poison=None):
         t[first:last + 1].copy_(torch.from_numpy(src_host[first:last + 1]),
                                 non_blocking=False)
     return t
+
+
+def upload_window(src_host, first, last, device):
+    """Rows [first, last] of the host frame `src_host` (numpy, (H, W, C)) as a
+    WINDOW-sized device tensor -- O(window) device memory, nothing else of the
+    frame exists on this rank. Hand it to avirhip_resize_window(first_row=first,
+    n_rows=last - first + 1): the exact-2x marching kernels read it where it
+    lies (no staging, no copy); other plans stage it inside the library."""
+    import torch
+    n = max(0, last - first + 1)
+    t = torch.empty((n,) + tuple(src_host.shape[1:]),
+                    dtype=torch.from_numpy(src_host[:0]).dtype, device=device)
+    if n:
+        t.copy_(torch.from_numpy(src_host[first:last + 1]), non_blocking=False)
+    return t
+
+
+def receive_window(src_root, windows, row_shape, dtype, device, rank, world,
+                   dist, root=0):
+    """scatter_source_windows() into WINDOW-sized tensors: the frame starts on
+    `root` (tensor `src_root`, None elsewhere); every other rank receives its
+    window rows straight into a tensor of exactly those rows. Returns (tensor,
+    first_row): on the root the frame itself and 0."""
+    import torch
+    if rank == root:
+        scatter_source_windows(src_root, windows, None, dtype, device, rank,
+                               world, dist, root)
+        return src_root, 0
+    a, b = windows[rank]
+    n = max(0, b - a + 1)
+    t = torch.empty((n,) + tuple(row_shape), dtype=dtype, device=device)
+    if n:
+        if _p2p_needs_host(dist, t):
+            tmp = torch.empty(t.shape, dtype=dtype)
+            dist.irecv(tmp, root).wait()
+            t.copy_(tmp)
+        else:
+            dist.irecv(t, root).wait()
+    return t, a
 
 
 def scatter_source_windows(src_root, windows, frame_shape, dtype, device, rank,

@@ -628,18 +628,28 @@ def main():
     rz = avir_amd.CImageResizer(16)
     sharded_run = world > 1 or args.pg_smoke
     src_window = None
+    frame_window = False
     if sharded_run:
         # a rank receives the source rows its band reads (band +
-        # halo) and nothing else. They go to their own offsets of a frame-sized
-        # buffer; every other row is NaN, so the golden hash of the stitched
-        # frame also proves that no rank depended on rows it was not given.
+        # halo) and nothing else -- as a WINDOW-sized tensor (O(window) device
+        # memory per rank; nothing else of the frame exists here, so the golden
+        # hash of the stitched frame also proves that no rank depended on rows
+        # it was not given). avirhip_resize_window reads it where it lies.
+        # AVIRHIP_BENCH_FRAME_WINDOW=1: the round-5 form -- the rows at their
+        # offsets in a frame-sized buffer, everything else NaN (A/B).
         from avir_amd import sharding
         wa, wb = sharding.rank_source_rows(rz, SRC_W, SRC_H, NEW_W, NEW_H, CH,
                                            rank, world)
-        src = sharding.place_window(src_np, wa, wb, dev, poison=float("nan"))
+        frame_window = os.environ.get("AVIRHIP_BENCH_FRAME_WINDOW") == "1"
+        if frame_window:
+            src = sharding.place_window(src_np, wa, wb, dev,
+                                        poison=float("nan"))
+        else:
+            src = sharding.upload_window(src_np, wa, wb, dev)
         src_window = {"first_row": wa, "last_row": wb,
                       "rows": wb - wa + 1, "of": SRC_H,
-                      "bytes_uploaded": (wb - wa + 1) * SRC_W * CH * 4}
+                      "bytes_uploaded": (wb - wa + 1) * SRC_W * CH * 4,
+                      "device_tensor_rows": int(src.shape[0])}
     else:
         src = torch.from_numpy(src_np).to(dev)
     if os.environ.get("AVIRHIP_BENCH_FILL") == "zero":
@@ -672,6 +682,12 @@ def main():
     def resize_rows(rows, a, b):
         if fail_pipe:  # test aid: what the line and exit code say on failure
             raise RuntimeError("AVIRHIP_BENCH_FAIL_PIPELINE")
+        if sharded_run and not frame_window:
+            abi.check(lib.avirhip_resize_window(
+                plan, src.data_ptr(), abi.MEM_DEVICE, wa, wb - wa + 1,
+                rows.data_ptr(), abi.MEM_DEVICE, a, b, stream),
+                "avirhip_resize_window")
+            return
         abi.check(lib.avirhip_resize_band(
             plan, src.data_ptr(), abi.MEM_DEVICE, rows.data_ptr(),
             abi.MEM_DEVICE, a, b, stream), "avirhip_resize_band")

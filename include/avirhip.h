@@ -315,9 +315,16 @@ int avirhip_band_source_rows(const avirhip_plan* plan, int row0, int row1,
  * receives its band's rows plus the halo and nothing else (the reference's
  * analogue: scanlines dealt to worker threads, avir.h:4885-4890, 4967-4971);
  * image borders are the frame's, never the window's, so the band is
- * bit-identical to the same rows of avirhip_resize(). The window is copied
- * (host or device memory) to its place in a frame-sized staging buffer of the
- * plan; no other source byte moves. */
+ * bit-identical to the same rows of avirhip_resize(). No other source byte
+ * moves, and for the plans the sharded configurations run -- exact 2x, float
+ * RGBA in and out: the marching kernels k_up2 / k_lanc2 -- the plan holds
+ * O(window) device memory: a DEVICE window is read where it lies (no staging,
+ * no copy; nothing outside [src_rows, src_rows + n_rows rows) is touched -- the
+ * kernels clamp their row indices to the window, which for every access that
+ * reaches a result is the frame's own edge replication), a HOST window is
+ * uploaded into a window-sized staging buffer. Other plans copy the window to
+ * its place in a frame-sized staging buffer of the plan (their kernels index
+ * the frame; what they load outside the window never reaches a result). */
 int avirhip_resize_window(avirhip_plan* plan, const void* src_rows,
 	int src_mem, int first_row, int n_rows, void* dst_band, int dst_mem,
 	int row0, int row1, void* stream);

@@ -1,0 +1,209 @@
+// window_guard.cpp -- avirhip_resize_window with NOTHING around the window.
+//
+// The window's rows live in a virtual-memory mapping that is exactly as large
+// as the window: the address range in front of it and behind it is reserved but
+// has no physical memory, so a kernel that loads a single byte outside the
+// window faults and takes the process down ("Memory access fault by GPU").
+// The band computed from it must equal the band computed from the whole frame
+// bit for bit, and the plan must hold no frame-sized buffer afterwards
+// (O(window) device memory per rank).
+//
+// Built and run by tests/test_gpu_parity.py (g++, host-only HIP calls).
+#include "avirhip.h"
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <vector>
+
+#define CK( e ) do { hipError_t e_ = ( e ); if( e_ != hipSuccess ) { \
+	printf( "HIP error %s at %s:%d\n", hipGetErrorString( e_ ), __FILE__, \
+	__LINE__ ); return( 2 ); } } while( 0 )
+#define AK( e ) do { int r_ = ( e ); if( r_ < 0 ) { printf( "avirhip error %d " \
+	"(%s) at %s:%d\n", r_, avirhip_last_error(), __FILE__, __LINE__ ); \
+	return( 3 ); } } while( 0 )
+
+static unsigned lcg = 12345u;
+static float frand() { lcg = lcg * 1664525u + 1013904223u;
+	return( (float) ( lcg >> 8 ) / 16777216.0f ); }
+
+// one band of one plan: whole frame vs. guarded window
+static int run( avirhip_plan* plan, const char* what, const std::vector< float >& src,
+	int sw, int sh, int nw, int nh, int row0, int row1, float* dsrc_full )
+{
+	int a = 0, b = -1;
+	AK( avirhip_band_source_rows( plan, row0, row1, &a, &b ));
+	const size_t pitch = (size_t) sw * 16;
+
+	hipMemAllocationProp prop;
+	memset( &prop, 0, sizeof( prop ));
+	prop.type = hipMemAllocationTypePinned;
+	prop.location.type = hipMemLocationTypeDevice;
+	prop.location.id = 0;
+	size_t gran = 0;
+	CK( hipMemGetAllocationGranularity( &gran, &prop,
+		hipMemAllocationGranularityMinimum ));
+
+	if( gran % pitch != 0 )
+	{
+		printf( "%s: granularity %zu is not a whole number of rows\n", what, gran );
+		return( 4 );
+	}
+
+	// the window: the needed rows, widened to whole granules so that the
+	// mapping begins and ends exactly with it
+	const int rpg = (int) ( gran / pitch );
+	const int wfirst = ( a / rpg ) * rpg;
+	int wend = (( b + rpg ) / rpg ) * rpg;
+
+	if( wend > sh )
+	{
+		printf( "%s: source height must be a multiple of %d rows\n", what, rpg );
+		return( 4 );
+	}
+
+	const int wrows = wend - wfirst;
+	const size_t wbytes = (size_t) wrows * pitch;
+
+	void* va = nullptr;
+	CK( hipMemAddressReserve( &va, wbytes + 2 * gran, gran, nullptr, 0 ));
+	hipMemGenericAllocationHandle_t h;
+	CK( hipMemCreate( &h, wbytes, &prop, 0 ));
+	char* const win = (char*) va + gran;
+	CK( hipMemMap( win, wbytes, 0, h, 0 ));
+	hipMemAccessDesc acc;
+	memset( &acc, 0, sizeof( acc ));
+	acc.location = prop.location;
+	acc.flags = hipMemAccessFlagsProtReadWrite;
+	CK( hipMemSetAccess( win, wbytes, &acc, 1 ));
+	CK( hipMemcpy( win, src.data() + (size_t) wfirst * sw * 4, wbytes,
+		hipMemcpyHostToDevice ));
+
+	const size_t bbytes = (size_t) ( row1 - row0 ) * nw * 16;
+	float *d0 = nullptr, *d1 = nullptr;
+	CK( hipMalloc( &d0, bbytes ));
+	CK( hipMalloc( &d1, bbytes ));
+	CK( hipMemset( d0, 0x11, bbytes ));
+	CK( hipMemset( d1, 0x22, bbytes ));
+
+	AK( avirhip_resize_band( plan, dsrc_full, AVIRHIP_MEM_DEVICE, d0,
+		AVIRHIP_MEM_DEVICE, row0, row1, nullptr ));
+	CK( hipDeviceSynchronize() );
+	const unsigned long long before = avirhip_plan_device_bytes( plan );
+
+	for( int rep = 0; rep < 3; rep++ )
+	{
+		AK( avirhip_resize_window( plan, win, AVIRHIP_MEM_DEVICE, wfirst, wrows,
+			d1, AVIRHIP_MEM_DEVICE, row0, row1, nullptr ));
+	}
+
+	CK( hipDeviceSynchronize() );
+	const unsigned long long after = avirhip_plan_device_bytes( plan );
+
+	// ... and from a HOST window: a window-sized staging buffer, no more
+	float* d2 = nullptr;
+	CK( hipMalloc( &d2, bbytes ));
+	CK( hipMemset( d2, 0x33, bbytes ));
+	AK( avirhip_resize_window( plan, src.data() + (size_t) wfirst * sw * 4,
+		AVIRHIP_MEM_HOST, wfirst, wrows, d2, AVIRHIP_MEM_DEVICE, row0, row1,
+		nullptr ));
+	CK( hipDeviceSynchronize() );
+	const unsigned long long after_host = avirhip_plan_device_bytes( plan );
+
+	std::vector< char > r0( bbytes ), r1( bbytes ), r2( bbytes );
+	CK( hipMemcpy( r0.data(), d0, bbytes, hipMemcpyDeviceToHost ));
+	CK( hipMemcpy( r1.data(), d1, bbytes, hipMemcpyDeviceToHost ));
+	CK( hipMemcpy( r2.data(), d2, bbytes, hipMemcpyDeviceToHost ));
+	const bool same = ( memcmp( r0.data(), r1.data(), bbytes ) == 0 &&
+		memcmp( r0.data(), r2.data(), bbytes ) == 0 );
+	const size_t frame = (size_t) sh * pitch;
+
+	printf( "%s: rows [%d,%d) need source rows [%d,%d], window [%d,%d) = %zu "
+		"bytes of a %zu-byte frame; plan device bytes %llu -> %llu (device "
+		"window) -> %llu (host window); %s\n", what, row0, row1, a, b, wfirst,
+		wend, wbytes, frame, before, after, after_host,
+		same ? "identical" : "DIFFERENT" );
+
+	CK( hipFree( d0 )); CK( hipFree( d1 )); CK( hipFree( d2 ));
+	CK( hipMemUnmap( win, wbytes ));
+	CK( hipMemRelease( h ));
+	CK( hipMemAddressFree( va, wbytes + 2 * gran ));
+
+	if( !same )
+	{
+		return( 5 );
+	}
+
+	// no frame-sized buffer: the device window costs nothing, the host window
+	// its own size
+	if( after != before || after_host > before + wbytes + 4096 )
+	{
+		printf( "%s: the plan grew by more than the window\n", what );
+		return( 6 );
+	}
+
+	return( 0 );
+}
+
+int main()
+{
+	if( avirhip_device_count() < 1 )
+	{
+		printf( "no gfx950 device\n" );
+		return( 1 );
+	}
+
+	AK( avirhip_init( 0 ));
+	// 2048 px x 16 B = 32 KiB per row: 64 rows per 2-MiB granule
+	const int sw = 2048, sh = 1536, nw = 4096, nh = 3072;
+	std::vector< float > src( (size_t) sw * sh * 4 );
+
+	for( size_t i = 0; i < src.size(); i++ )
+	{
+		src[ i ] = frand();
+	}
+
+	float* dfull = nullptr;
+	CK( hipMalloc( &dfull, src.size() * 4 ));
+	CK( hipMemcpy( dfull, src.data(), src.size() * 4, hipMemcpyHostToDevice ));
+
+	avirhip_resizer* rz = nullptr;
+	AK( avirhip_resizer_create( 16, 0, nullptr, &rz ));
+	avirhip_plan* plan = nullptr;
+	AK( avirhip_resizer_get_plan( rz, sw, sh, 0, nw, nh, 4, 0.0, nullptr,
+		AVIRHIP_F32, AVIRHIP_F32, &plan ));
+
+	avirhip_lancir* lz = nullptr;
+	AK( avirhip_lancir_create( &lz ));
+	avirhip_plan* lplan = nullptr;
+	AK( avirhip_lancir_get_plan( lz, sw, sh, nw, nh, 4, nullptr, AVIRHIP_F32,
+		AVIRHIP_F32, &lplan ));
+
+	int rc = 0;
+	// an inner band, the frame's first rows, its last rows, one eighth
+	const int bands[ 5 ][ 2 ] = { { 1000, 1300 }, { 0, 384 }, { 2688, 3072 },
+		{ 1536, 1920 }, { 777, 778 } };
+
+	for( int i = 0; i < 5 && rc == 0; i++ )
+	{
+		rc = run( plan, "CImageResizer 2x (k_up2)", src, sw, sh, nw, nh,
+			bands[ i ][ 0 ], bands[ i ][ 1 ], dfull );
+
+		if( rc == 0 )
+		{
+			rc = run( lplan, "CLancIR 2x (k_lanc2)", src, sw, sh, nw, nh,
+				bands[ i ][ 0 ], bands[ i ][ 1 ], dfull );
+		}
+	}
+
+	avirhip_resizer_destroy( rz );
+	avirhip_lancir_destroy( lz );
+	CK( hipFree( dfull ));
+
+	if( rc == 0 )
+	{
+		printf( "OK\n" );
+	}
+
+	return( rc );
+}

@@ -2287,6 +2287,30 @@ def test_fast_paths_over_random_large_geometries():
     assert " 0 problems" in r.stdout
 
 
+def test_source_window_with_nothing_around_it(tmp_path):
+    """avirhip_resize_window on the marching kernels holds O(window) device
+    memory: tests/cpp/window_guard.cpp maps EXACTLY the window's
+    rows into a reserved address range -- the granules in front of it and behind
+    it have no memory, one byte loaded outside the window is a GPU memory fault
+    that ends the process -- and compares the band with the one computed from
+    the whole frame (k_up2 and k_lanc2; inner band, first rows, last rows, a
+    single row; device and host windows); the plan may not grow by a frame."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    lib = os.path.join(root, "avir_amd", "lib")
+    exe = str(tmp_path / "window_guard")
+    subprocess.run(["g++", "-O1", "-std=c++17", "-D__HIP_PLATFORM_AMD__",
+                    "-I/opt/rocm/include", "-I" + os.path.join(root, "include"),
+                    os.path.join(root, "tests", "cpp", "window_guard.cpp"),
+                    "-L" + lib, "-lavirhip", "-L/opt/rocm/lib", "-lamdhip64",
+                    "-Wl,-rpath," + lib, "-Wl,-rpath,/opt/rocm/lib", "-o", exe],
+                   check=True)
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and out.stdout.strip().endswith("OK"), \
+        out.stdout[-3000:] + out.stderr[-2000:]
+    assert out.stdout.count("identical") == 10
+
+
 def test_counted_waits_against_the_paranoid_build():
     """The differential race hunt: lib/libavirhip_paranoid.so
     (`make paranoid`: every counted s_waitcnt a full drain, a full drain in front
