@@ -25,7 +25,23 @@
 #ifndef AVIRHIP_WAITS_H
 #define AVIRHIP_WAITS_H
 
-#ifdef AVIRHIP_PARANOID_WAITS
+#if defined( AVIRHIP_PARANOID_ONLY_WAITS )
+// (bisection aids: only the counted waits / only the handover drains)
+#define AVIRHIP_WAITCNT_VM( n ) "s_waitcnt vmcnt(0) lgkmcnt(0)"
+#define AVIRHIP_WAITCNT_LGKM( n ) "s_waitcnt vmcnt(0) lgkmcnt(0)"
+#define AVIRHIP_HANDOVER ""
+#define AVIRHIP_PARANOID 0
+#elif defined( AVIRHIP_PARANOID_ONLY_HANDOVER )
+#define AVIRHIP_WAITCNT_VM( n ) "s_waitcnt vmcnt(" #n ")"
+#define AVIRHIP_WAITCNT_LGKM( n ) "s_waitcnt lgkmcnt(" #n ")"
+#define AVIRHIP_HANDOVER "s_waitcnt vmcnt(0) lgkmcnt(0)\n\t"
+#define AVIRHIP_PARANOID 0
+#elif defined( AVIRHIP_PARANOID_ONLY_HANDOVER_LGKM )
+#define AVIRHIP_WAITCNT_VM( n ) "s_waitcnt vmcnt(" #n ")"
+#define AVIRHIP_WAITCNT_LGKM( n ) "s_waitcnt lgkmcnt(" #n ")"
+#define AVIRHIP_HANDOVER "s_waitcnt lgkmcnt(0)\n\t"
+#define AVIRHIP_PARANOID 0
+#elif defined( AVIRHIP_PARANOID_WAITS )
 #define AVIRHIP_WAITCNT_VM( n ) "s_waitcnt vmcnt(0) lgkmcnt(0)"
 #define AVIRHIP_WAITCNT_LGKM( n ) "s_waitcnt vmcnt(0) lgkmcnt(0)"
 #define AVIRHIP_HANDOVER "s_waitcnt vmcnt(0) lgkmcnt(0)\n\t"
