@@ -337,12 +337,11 @@ __global__ void __launch_bounds__( 64 ) k_gv( const GVParams P )
 	const int pbs = min( pb, slast );
 
 	// (Slot reuse: the DMA of group p + GV_PF takes the slot group p - 1 held.
-	// That slot was read into `qnext` two steps earlier and `qnext` was consumed
-	// -- copied into the window, converted, or run through the FIR, each behind
-	// an lgkmcnt wait -- one step earlier: an LDS-DMA may only take a slot whose
-	// reads have been WAITED for, not merely issued. k_lf, whose reads go
-	// straight into distinct window registers, needed an explicit wait: NOTEBOOK
-	// 9.13.)
+	// That slot was read into `qnext` two steps earlier; the step waits
+	// lgkmcnt(0) right before its DMA: an LDS-DMA may only take a slot whose
+	// reads have been WAITED for, not merely issued. Until round 6
+	// this relied on `qnext` having been "consumed" a step earlier, which for the
+	// register window is a rename, not a wait: see step(). k_lf: NOTEBOOK 9.13.)
 	int qi = 0; // landing-queue slot of the next pair issued ...
 	int qr = 0; // ... and of the pair being read (both count modulo GV_PF + 1)
 
@@ -509,6 +508,29 @@ __global__ void __launch_bounds__( 64 ) k_gv( const GVParams P )
 		if( u > ( pb * RPG + RPG - 1 ))
 		{
 			return;
+		}
+
+		// The DMA below takes the queue slot that was read into `qnext` two
+		// steps ago. "Consumed one step ago" is not a wait when the consumer is
+		// the register window (a rename; the first real use is the output's dot
+		// product, steps later): in a chunk's run-in, steps without an output
+		// are a few dozen instructions, and with many short-chunk waves on a CU
+		// the sub-dword queue reads of 1-3 channel integer rows can sit in the
+		// LDS queue longer than a row that hits in L2 takes to arrive -- the
+		// read then returns the NEW row (found in round 6 by the differential
+		// against the paranoid build: CLancIR 3555x2951 -> 3135x2672 RGB uint16,
+		// chunks of 2-4 rows, a tenth of the frames; NOTEBOOK 10).
+		// One s_waitcnt lgkmcnt(0) before the DMA goes out -- as in k_lf: every
+		// LDS read this wave has issued, the queue row of two steps ago among
+		// them, has RETURNED (the rule of waits.h: a slot's reads are waited
+		// for, not merely issued). Same box, three alternations: no workload
+		// that runs k_gv changes (profiles/r06_paranoid/gv_fix_variants_ab.txt;
+		// pinning the queue row in registers instead cost CLancIR 3840x2160 ->
+		// 1280x720 RGBA uint8 6 %). PRE runs the row through the FIR in the step
+		// that takes it over -- arithmetic, i.e. a wait -- and needs none.
+		if( MODE != GP_PRE )
+		{
+			AVIRHIP_WAIT_LGKM( 0 );
 		}
 
 		if( TD )

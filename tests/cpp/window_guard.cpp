@@ -44,15 +44,17 @@ static int run( avirhip_plan* plan, const char* what, const std::vector< float >
 	CK( hipMemGetAllocationGranularity( &gran, &prop,
 		hipMemAllocationGranularityMinimum ));
 
-	if( gran % pitch != 0 )
+	if( gran % pitch != 0 && pitch % gran != 0 )
 	{
-		printf( "%s: granularity %zu is not a whole number of rows\n", what, gran );
+		printf( "%s: granularity %zu and row pitch %zu do not nest\n", what, gran,
+			pitch );
 		return( 4 );
 	}
 
 	// the window: the needed rows, widened to whole granules so that the
-	// mapping begins and ends exactly with it
-	const int rpg = (int) ( gran / pitch );
+	// mapping begins and ends exactly with it (4-KiB granules on this driver:
+	// every row boundary is one)
+	const int rpg = (int) ( gran >= pitch ? gran / pitch : 1 );
 	const int wfirst = ( a / rpg ) * rpg;
 	int wend = (( b + rpg ) / rpg ) * rpg;
 
@@ -65,11 +67,13 @@ static int run( avirhip_plan* plan, const char* what, const std::vector< float >
 	const int wrows = wend - wfirst;
 	const size_t wbytes = (size_t) wrows * pitch;
 
+	// (guard regions: reserved, never mapped -- at least four rows each)
+	const size_t guard = (( 4 * pitch + gran - 1 ) / gran ) * gran;
 	void* va = nullptr;
-	CK( hipMemAddressReserve( &va, wbytes + 2 * gran, gran, nullptr, 0 ));
+	CK( hipMemAddressReserve( &va, wbytes + 2 * guard, gran, nullptr, 0 ));
 	hipMemGenericAllocationHandle_t h;
 	CK( hipMemCreate( &h, wbytes, &prop, 0 ));
-	char* const win = (char*) va + gran;
+	char* const win = (char*) va + guard;
 	CK( hipMemMap( win, wbytes, 0, h, 0 ));
 	hipMemAccessDesc acc;
 	memset( &acc, 0, sizeof( acc ));
@@ -127,7 +131,7 @@ static int run( avirhip_plan* plan, const char* what, const std::vector< float >
 	CK( hipFree( d0 )); CK( hipFree( d1 )); CK( hipFree( d2 ));
 	CK( hipMemUnmap( win, wbytes ));
 	CK( hipMemRelease( h ));
-	CK( hipMemAddressFree( va, wbytes + 2 * gran ));
+	CK( hipMemAddressFree( va, wbytes + 2 * guard ));
 
 	if( !same )
 	{

@@ -2311,6 +2311,51 @@ def test_source_window_with_nothing_around_it(tmp_path):
     assert out.stdout.count("identical") == 10
 
 
+@pytest.mark.parametrize("tin,ch", [(np.uint16, 3), (np.uint8, 3),
+                                    (np.uint16, 1)])
+def test_vertical_pass_queue_slot_handover_in_short_chunks(tin, ch):
+    """The race the paranoid differential found in round 6 (NOTEBOOK 10): k_gv
+    handed a landing-queue slot to the next LDS-DMA while the sub-dword reads of
+    the 1-3 channel integer row it held could still sit in the LDS queue -- in a
+    chunk's run-in, with chunks of 2-4 output rows and the chip full of short
+    waves: CLancIR 3555x2951 -> 3135x2672, a tenth of the frames differed, always
+    in a chunk's first row. The step now pins the queue row before its DMA goes
+    out. Chunks of 2, 3, 4 rows, 40 frames each, against the generic kernels."""
+    import torch
+    lib = abi.load()
+    sw, sh, nw, nh = 3555, 2951, 3135, 2672
+    s = rb.lcg_u8((sh, sw, ch, np.dtype(tin).itemsize), seed=391)
+    s = s.view(tin).reshape(sh, sw, ch)
+    ds = torch.from_numpy(s).to("cuda:0")
+    tt = {np.uint8: torch.uint8, np.uint16: torch.uint16}[tin]
+    l = avir_amd.CLancIR()
+    code = rb._DT[np.dtype(tin)]
+    p = l.plan(sw, sh, nw, nh, ch, in_type=code, out_type=code)
+
+    def run():
+        dd = torch.empty((nh, nw, ch), dtype=tt, device="cuda:0")
+        abi.check(lib.avirhip_resize(p, ds.data_ptr(), abi.MEM_DEVICE,
+                                     dd.data_ptr(), abi.MEM_DEVICE, None), "r")
+        torch.cuda.synchronize()
+        return dd
+    abi.check(lib.avirhip_plan_set_path(p, abi.PATH_GENERIC), "set_path")
+    want = run()
+    abi.check(lib.avirhip_plan_set_path(p, abi.PATH_AUTO), "set_path")
+    keep = os.environ.get("AVIRHIP_GV_CHUNK")
+    try:
+        for chunk in (2, 3, 4):
+            os.environ["AVIRHIP_GV_CHUNK"] = str(chunk)
+            for k in range(40):
+                got = run()
+                assert torch.equal(got.view(torch.uint8), want.view(torch.uint8)), \
+                    "chunk %d frame %d" % (chunk, k)
+    finally:
+        if keep is None:
+            os.environ.pop("AVIRHIP_GV_CHUNK", None)
+        else:
+            os.environ["AVIRHIP_GV_CHUNK"] = keep
+
+
 def test_counted_waits_against_the_paranoid_build():
     """The differential race hunt: lib/libavirhip_paranoid.so
     (`make paranoid`: every counted s_waitcnt a full drain, a full drain in front

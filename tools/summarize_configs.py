@@ -1,11 +1,11 @@
 #!/usr/bin/env python3
-"""Summarises tools/r05_profiles.sh's rocprofv3 output (per BASELINE config: a
+"""Summarises tools/rNN_profiles.sh's rocprofv3 output (per BASELINE config: a
 kernel trace and separate FETCH_SIZE / WRITE_SIZE passes) into
-  <dst>/r05_<cfg>/rocprofv3_kernel_stats.csv, rocprofv3_pmc_summary.json
+  <dst>/rNN_<cfg>/rocprofv3_kernel_stats.csv, rocprofv3_pmc_summary.json
   <dst>/pmc_traffic.json   (copied to profiles/pmc_traffic.json; bench.py
                             reads roofline.traffic of every line from it)
 
-usage: python tools/summarize_configs.py <rocprof output dir> <dst dir>
+usage: python tools/summarize_configs.py <rocprof output dir> <dst dir> [rNN]
 
 Counter correction (MI355X_MICROARCH.md, HBM section): on gfx950 FETCH_SIZE
 reports half the bytes of wide coalesced streaming reads (16 B per lane,
@@ -23,6 +23,7 @@ import shutil
 import sys
 
 src, dst = sys.argv[1], sys.argv[2]
+RND = sys.argv[3] if len(sys.argv) > 3 else "r05"  # directory prefix (round)
 os.makedirs(dst, exist_ok=True)
 ALGO = {"cfg1": 640 * 480 * 3 + 1024 * 768 * 3,
         "cfg2": (1920 * 1080 + 3840 * 2160) * 16,
@@ -30,13 +31,13 @@ ALGO = {"cfg1": 640 * 480 * 3 + 1024 * 768 * 3,
         "cfg4": (3840 * 2160 + 1280 * 720) * 16,
         "cfg5": (3840 * 2160 + 7680 * 4320) * 16}
 STEPS_PMC = 20 + 3  # bench.py --steps 20 --warmup 3 --settle-ms 0
-out = {"collected": "round 5, tools/r05_profiles.sh on one MI355X "
+out = {"collected": "round " + RND[1:].lstrip("0") + ", tools/" + RND + "_profiles.sh on one MI355X "
                     "(rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate "
                     "runs of bench.py --workload cfgN; FETCH_SIZE x2 as "
                     "MI355X_MICROARCH.md prescribes for 16-byte-per-lane reads)",
        "configs": {}}
 for cfg in ("cfg1", "cfg2", "cfg3", "cfg4", "cfg5", "headline"):
-    d = os.path.join(dst, "r05_" + cfg)
+    d = os.path.join(dst, RND + "_" + cfg)
     os.makedirs(d, exist_ok=True)
     for f in glob.glob(os.path.join(src, cfg, "trace", "**", "*kernel_stats.csv"),
                        recursive=True):
@@ -93,7 +94,7 @@ if c3:
     out["traffic_bytes_per_launch"] = c3["traffic_bytes_per_step"]
     out["algorithmic_bytes"] = c3["algorithmic_bytes"]
     out["traffic_over_algorithmic"] = c3["traffic_over_algorithmic"]
-    v = json.load(open(os.path.join(dst, "r05_cfg3",
+    v = json.load(open(os.path.join(dst, RND + "_cfg3",
                                     "rocprofv3_pmc_summary.json")))
     for k, cs in v.items():
         if "k_up2" in k and "SQ_INSTS_VALU" in cs:
@@ -102,7 +103,17 @@ if c3:
 json.dump(out, open(os.path.join(dst, "pmc_traffic.json"), "w"), indent=1)
 print(json.dumps(out, indent=1)[:3000])
 for cfg in ("cfg1", "cfg2", "cfg3", "cfg4", "cfg5", "headline"):
-    f = os.path.join(dst, "r05_" + cfg, "rocprofv3_kernel_stats.csv")
+    f = os.path.join(dst, RND + "_" + cfg, "rocprofv3_kernel_stats.csv")
     if os.path.exists(f):
         print("==", cfg)
         print(open(f).read())
+
+# the durations a README row may quote: straight from the CSVs above
+print("== kernel averages (us) for profiles/README.md, from the CSVs:")
+for cfg in ("cfg1", "cfg2", "cfg3", "cfg4", "cfg5", "headline"):
+    f = os.path.join(dst, RND + "_" + cfg, "rocprofv3_kernel_stats.csv")
+    if os.path.exists(f):
+        for r in csv.DictReader(open(f)):
+            print("  %s %s: %.2f us over %s launches" % (
+                cfg, r["Name"].split("(")[0].replace("void avirhip::", ""),
+                float(r["AverageNs"]) / 1e3, r["Calls"]))
