@@ -391,6 +391,9 @@ __global__ void __launch_bounds__( 64 ) k_gh( const GHParams P )
 		else
 		if( jok )
 		{
+#ifdef GP_DBG
+			if( !( P.dbg & 1 ) || o.x == 1234.5f )
+#endif
 			*(f4*) ( P.dst + (long) ( r - P.dst_row0 ) * P.dst_ss +
 				(long) j * 4 ) = o;
 		}
@@ -1084,6 +1087,11 @@ static int run_h( const GPData* D, const float* src, long src_ss, int src_w,
 {
 	GHParams P;
 	memset( &P.lout, 0, sizeof( P.lout ));
+	P.dbg = 0;
+#ifdef GP_DBG
+	P.dbg = ( getenv( "AVIRHIP_GP_DBG" ) != nullptr ?
+		atoi( getenv( "AVIRHIP_GP_DBG" )) : 0 );
+#endif
 
 	if( lout != nullptr )
 	{

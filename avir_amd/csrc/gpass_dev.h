@@ -577,6 +577,7 @@ struct GHParams
 	int raw_ch;
 	long raw_elems;      // elements of that image (the loader's bound)
 	GPLOut lout;         // on != 0: LANCIR's output stage in the store
+	int dbg;             // timing ablations (GP_DBG builds only): 1 no stores
 };
 
 // gfuse.hip: both passes of an upsizing plan in one launch (k_gf)
