@@ -439,10 +439,28 @@ double sacc_k( const SAData* D );
 // sources. Float pixels of 1-3 channels run optimistically (gpass_run: two
 // more launches) and take it from k = 1.7 on (RGBA, optimistic: k = 1.5 0.139
 // vs 0.126, k = 1.75 0.113 vs 0.115, k = 1.92 0.111 vs 0.118).
-static bool sa_wanted( const SAData* sa, const bool always )
+// Round 6: FLOAT RGBA sources on 1 < k < 2 axes go back to the gather kernels
+// (`frgba`). k_gh's gather-then-FIR form ran its 13 .. 25 taps through the
+// any-count variant -- a wave-uniform branch and an LDS round trip per block of
+// four taps; with the tap count a compile-time constant (the whole window read at
+// once, as the LANCIR variants have had it since round 5) the horizontal pass of
+// 3840x2160 -> 2560x1440 takes 51 instead of 70 us and the plan 0.097 instead of
+// 0.118 ms on the accumulation kernels (same box; -> 2000x1125 0.092 vs 0.111,
+// -> 2200x1238 0.091 vs 0.107: profiles/r06_gh_post/). Integer sources keep the
+// branch-free accumulation kernels, which read them raw (RGB uint8 k = 1.5:
+// 0.104 vs 0.133). AVIRHIP_SA_ZS_FRGBA=1: the round-5 routing (A/B).
+static bool sa_wanted( const SAData* sa, const bool always,
+	const bool frgba = false )
 {
 	static const double kmin = ( getenv( "AVIRHIP_SA_ZS_KMIN" ) != nullptr ?
 		atof( getenv( "AVIRHIP_SA_ZS_KMIN" )) : 1.7 ); // (tuning aid)
+	static const bool zs_frgba = ( getenv( "AVIRHIP_SA_ZS_FRGBA" ) != nullptr &&
+		atoi( getenv( "AVIRHIP_SA_ZS_FRGBA" )) != 0 );
+
+	if( sa != nullptr && frgba && !zs_frgba && sacc_is_zs( sa ))
+	{
+		return( false );
+	}
 
 	return( sa != nullptr && ( always || !sacc_is_zs( sa ) ||
 		sacc_k( sa ) >= kmin ));
@@ -456,6 +474,10 @@ struct GPData
 	bool h_geom, v_geom; // the gather kernels' launch geometry exists
 	int* d_hseg;
 	int h_nstrips, h_ow, h_nseg, h_sbuf, h_mbuf;
+	// k_gh2 (gpass_h2.hip: two gather outputs per lane on 1 < k < 2 axes):
+	// its own strips of up to 122 outputs; h2_ow == 0: no such geometry
+	int* d_h2seg;
+	int h2_nstrips, h2_ow, h2_nseg, h2_sbuf, h2_mbuf;
 	int v_blk, v_rs, v_rc;
 	float* mid;          // intermediate image between the passes
 	size_t mid_bytes;
@@ -619,6 +641,8 @@ int gpass_prepare( avirhip_plan* p )
 
 	GPData* D = new GPData();
 	D -> mid = nullptr; D -> mid_bytes = 0; D -> d_hseg = nullptr;
+	D -> d_h2seg = nullptr; D -> h2_ow = 0; D -> h2_nstrips = 0;
+	D -> h2_nseg = 0; D -> h2_sbuf = 0; D -> h2_mbuf = 0;
 	D -> nf_flag = nullptr;
 	D -> lf_ow = 0; D -> lf_nstrips = 0; D -> d_lfseg = nullptr;
 	D -> d_lfvtab = nullptr;
@@ -758,6 +782,78 @@ int gpass_prepare( avirhip_plan* p )
 		AVIRHIP_HIPCHECK( hipMemcpy( q, seg.data(), seg.size() * sizeof( int ),
 			hipMemcpyHostToDevice ));
 		D -> d_hseg = (int*) q;
+		}
+	}
+
+	// ---- ... and the strips of k_gh2: gather-then-FIR axes over the zero-
+	// stuffed view (1 < k < 2) with 13 .. 25 taps whose consecutive outputs
+	// start 1 or 2 source pixels apart -- a lane evaluates two of them from one
+	// window of NT + 2 pixels
+	{
+		const GPAxis& A = D -> h.a;
+		const std::vector< int >& st = D -> h.start;
+		bool ok = ( A.mode == GP_POST && !A.lanc && A.nt >= 13 && A.nt <= 25 &&
+			A.g_len >= 2 && A.out_len >= 2 );
+
+		for( int g = 0; ok && g + 1 < A.g_len; g++ )
+		{
+			const int d = st[ g + 1 ] - st[ g ];
+			ok = ( d == 1 || d == 2 );
+		}
+
+		int ow = 0, nstrips = 0, maxs = 0, maxm = 0;
+		std::vector< int > seg;
+		double best_cost = 0.0;
+
+		for( int cw = 122; ok && cw >= 16; cw-- )
+		{
+			const int cn = ( A.out_len + cw - 1 ) / cw;
+			std::vector< int > cseg( (size_t) cn * 4, 0 );
+			int cs = 0, cm = 0;
+
+			for( int sx = 0; sx < cn; sx++ )
+			{
+				const int ja = sx * cw;
+				const int jb = std::min( A.out_len, ja + cw ) - 1;
+				const int ga = std::max( 0, std::min( ja - A.e - 3, A.g_len - 1 ));
+				const int gb = std::max( 0, std::min( jb - A.e + 3, A.g_len - 1 ));
+				const int sa = st[ ga ], sb = st[ gb ] + A.nt - 1;
+
+				cseg[ sx * 4 ] = sa; cseg[ sx * 4 + 1 ] = sb - sa + 1;
+				cseg[ sx * 4 + 2 ] = ga; cseg[ sx * 4 + 3 ] = gb - ga + 1;
+				cs = std::max( cs, sb - sa + 1 );
+				cm = std::max( cm, gb - ga + 1 );
+			}
+
+			if( cs > 256 || cm > 128 )
+			{
+				continue;
+			}
+
+			// (pixels a wave moves by DMA, lanes it keeps busy, per output)
+			const double cost = ((( cs + 63 ) / 64 ) * 64 + 64 ) / (double) cw;
+
+			if( ow == 0 || cost < best_cost )
+			{
+				best_cost = cost;
+				ow = cw; nstrips = cn; maxs = cs; maxm = cm;
+				seg.swap( cseg );
+			}
+		}
+
+		if( ow != 0 )
+		{
+			void* q = nullptr;
+			AVIRHIP_HIPCHECK( hipMalloc( &q, seg.size() * sizeof( int )));
+			D -> allocs.push_back( q );
+			AVIRHIP_HIPCHECK( hipMemcpy( q, seg.data(), seg.size() * sizeof( int ),
+				hipMemcpyHostToDevice ));
+			D -> d_h2seg = (int*) q;
+			D -> h2_ow = ow; D -> h2_nstrips = nstrips;
+			D -> h2_nseg = ( maxs + 63 ) / 64;
+			D -> h2_sbuf = D -> h2_nseg * 64;
+			D -> h2_mbuf = 128;
+			(void) maxm;
 		}
 	}
 
@@ -953,8 +1049,8 @@ bool gpass_preferred( const avirhip_plan* p )
 	if( D -> sa_h != nullptr && D -> sa_v != nullptr && !p -> gamma &&
 		p -> in_type == AVIRHIP_F32 && sacc_has_two( D -> sa_h ) &&
 		sacc_has_two( D -> sa_v ) && !fused_dn_both( p ) &&
-		sa_wanted( D -> sa_h, p -> io_ch == 4 ) &&
-		sa_wanted( D -> sa_v, p -> io_ch == 4 ) &&
+		sa_wanted( D -> sa_h, p -> io_ch == 4, p -> io_ch == 4 ) &&
+		sa_wanted( D -> sa_v, p -> io_ch == 4, p -> io_ch == 4 ) &&
 		(long) p -> src_w * p -> src_h >= 6000000L )
 	{
 		return( true );
@@ -1048,8 +1144,29 @@ static void launch_gh2( const GHParams& P, int items, size_t lds,
 #undef GH_L
 	}
 
-	// (gather-then-FIR7 axes, 1 < k < 2: 13 .. 25 taps -- one variant with the
-	// coefficient row in registers for any count up to 28)
+	// (gather-then-FIR7 axes, 1 < k < 2: 13 .. 25 taps. Float RGBA sources get a
+	// compile-time tap count -- the whole window read at once, one LDS round
+	// trip per row instead of one per block of four taps in the any-count
+	// variant below: round 6, NOTEBOOK 10)
+	if constexpr( MODE == GP_POST && !LANC && FSRC )
+	{
+		if( getenv( "AVIRHIP_GH_POST_ANY" ) == nullptr ) // (A/B: the old variant)
+		{
+#define GH_L( N ) case N: hipLaunchKernelGGL(( k_gh< MODE, LANC, N, SX > ), \
+	dim3( items ), dim3( 64 ), lds, st, P ); return
+			switch( nt )
+			{
+				GH_L( 13 ); GH_L( 14 ); GH_L( 15 ); GH_L( 16 ); GH_L( 17 );
+				GH_L( 18 ); GH_L( 19 ); GH_L( 20 ); GH_L( 21 ); GH_L( 22 );
+				GH_L( 23 ); GH_L( 24 ); GH_L( 25 );
+				default: break;
+			}
+#undef GH_L
+		}
+	}
+
+	// (... any other count up to 28, and raw sources: one variant with the
+	// coefficient row in registers)
 	if constexpr( MODE == GP_POST && !LANC )
 	{
 		if( nt <= 28 )
@@ -1118,6 +1235,49 @@ static int run_h( const GPData* D, const float* src, long src_ss, int src_w,
 	P.dst = dst; P.dst_ss = dst_ss; P.dst_row0 = dst_row0; P.dst_w = dst_w;
 	P.ax = D -> h.a;
 	P.row_lo = row_lo; P.row_hi = row_hi;
+
+	// float RGBA rows of a 1 < k < 2 axis with 22 .. 25 taps (k from about 1.7):
+	// two outputs per lane (gpass_h2.hip). Same box, three alternations
+	// (profiles/r06_gh_post/): 3840x2160 -> 2200x1238 (22 taps) 0.0913 -> 0.0865 ms,
+	// -> 2000x1125 (25) 0.0924 -> 0.0861; -> 2560x1440 (19 taps, k = 1.5) LOSES,
+	// 0.0976 -> 0.1136: both forms issue the same number of vector instructions
+	// per output and run at the same issue rate -- k_gh2 only removes LDS work
+	// (reads 2.6 M -> 1.6 M, bank conflicts 7.2 M -> 0.2 M cycles per launch),
+	// which binds at k = 1.9 (lanes 30 bytes apart) and not at k = 1.5, where
+	// its half as many, twice as long waves cost more than they save.
+	// AVIRHIP_NO_GH2 / AVIRHIP_GH2_MIN_NT: A/B.
+	// (read per call: the GPU suite runs every form on every tap count)
+	const int gh2_min_nt = ( getenv( "AVIRHIP_GH2_MIN_NT" ) != nullptr ?
+		atoi( getenv( "AVIRHIP_GH2_MIN_NT" )) : 22 );
+
+	if( D -> h2_ow != 0 && raw == nullptr && lout == nullptr &&
+		P.ax.nt >= gh2_min_nt && getenv( "AVIRHIP_NO_GH2" ) == nullptr )
+	{
+		P.nstrips = D -> h2_nstrips; P.ow = D -> h2_ow;
+		P.seg = D -> d_h2seg; P.nseg = D -> h2_nseg;
+		P.sbuf = D -> h2_sbuf; P.mbuf = D -> h2_mbuf;
+		const int rows2 = row_hi - row_lo;
+		const size_t lds2 = (size_t) ( GH_NB * P.sbuf + P.mbuf ) * 16;
+		const int wpc2 = std::max( 1, std::min( 16, (int) ( 160 * 1024 /
+			( lds2 + 512 ))));
+
+		P.chunk = balanced_chunk( rows2, P.nstrips, 4, rows2, 2, wpc2, false );
+
+		if( getenv( "AVIRHIP_GH_CHUNK" ) != nullptr ) // tuning aid
+		{
+			P.chunk = std::max( 1, std::min( atoi( getenv( "AVIRHIP_GH_CHUNK" )),
+				rows2 ));
+		}
+
+		const int items2 = P.nstrips * (( rows2 + P.chunk - 1 ) / P.chunk );
+
+		if( launch_gh2( P, items2, lds2, st ) == 0 )
+		{
+			AVIRHIP_HIPCHECK( hipGetLastError() );
+			return( AVIRHIP_OK );
+		}
+	}
+
 	P.nstrips = D -> h_nstrips; P.ow = D -> h_ow;
 	P.seg = D -> d_hseg; P.nseg = D -> h_nseg;
 	P.sbuf = D -> h_sbuf; P.mbuf = D -> h_mbuf;
@@ -1245,7 +1405,7 @@ bool gpass_takes_raw( const avirhip_plan* p )
 
 	return( D != nullptr && !p -> is_lancir &&
 		( sa_wanted( D -> sa_h, int_src || ( p -> in_type == AVIRHIP_F32 &&
-		p -> io_ch == 4 )) ||
+		p -> io_ch == 4 ), p -> in_type == AVIRHIP_F32 && p -> io_ch == 4 ) ||
 		( D -> h_geom && D -> h_nseg <= 4 )));
 }
 
@@ -1511,8 +1671,9 @@ int gpass_run( avirhip_plan* p, const float* src, long src_stride, float* dst,
 	// (raw == nullptr: float RGBA -- the exact kernels unless the variant asks)
 	const bool sa_always = ( int_src || ( raw == nullptr && !opt_rgba &&
 		( p -> variant & AVIRHIP_VARIANT_SACC_OPTIMISTIC ) == 0 ));
-	const bool use_sa_h = sa_wanted( D -> sa_h, sa_always );
-	const bool use_sa_v = sa_wanted( D -> sa_v, sa_always );
+	// (raw == nullptr: a float RGBA source)
+	const bool use_sa_h = sa_wanted( D -> sa_h, sa_always, raw == nullptr );
+	const bool use_sa_v = sa_wanted( D -> sa_v, sa_always, raw == nullptr );
 
 	if( !int_src && fsrc && !ladder && !no_opt && opt_wanted && use_sa_h &&
 		use_sa_v &&

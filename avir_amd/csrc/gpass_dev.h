@@ -618,6 +618,8 @@ struct LFParams
 };
 
 int lfuse_launch( LFParams& P, hipStream_t st );
+// gpass_h2.hip: k_gh2 (two gather outputs per lane); 1: no variant for the tap count
+int launch_gh2( const GHParams& P, int items, size_t lds, hipStream_t st );
 bool lfuse_takes_raw( const void* raw, int type, int ch, long stride,
 	int in_len_v, int width );
 

@@ -118,8 +118,31 @@ static int run( avirhip_plan* plan, const char* what, const std::vector< float >
 	CK( hipMemcpy( r0.data(), d0, bbytes, hipMemcpyDeviceToHost ));
 	CK( hipMemcpy( r1.data(), d1, bbytes, hipMemcpyDeviceToHost ));
 	CK( hipMemcpy( r2.data(), d2, bbytes, hipMemcpyDeviceToHost ));
-	const bool same = ( memcmp( r0.data(), r1.data(), bbytes ) == 0 &&
-		memcmp( r0.data(), r2.data(), bbytes ) == 0 );
+	const bool same1 = ( memcmp( r0.data(), r1.data(), bbytes ) == 0 );
+	const bool same2 = ( memcmp( r0.data(), r2.data(), bbytes ) == 0 );
+	const bool same = ( same1 && same2 );
+
+	if( !same )
+	{
+		// (which form, where: the first elements that differ)
+		const float* f0 = (const float*) r0.data();
+		const float* fx = (const float*) ( same1 ? r2.data() : r1.data() );
+		size_t n = 0, first = 0;
+
+		for( size_t i = 0; i < bbytes / 4; i++ )
+		{
+			if( memcmp( &f0[ i ], &fx[ i ], 4 ) != 0 )
+			{
+				if( n++ == 0 ) first = i;
+			}
+		}
+
+		printf( "%s: %s window differs from the whole-frame band in %zu of %zu "
+			"floats, first at %zu (row %zu, element %zu): %g vs %g\n", what,
+			same1 ? "HOST" : "DEVICE", n, bbytes / 4, first,
+			first / ( (size_t) nw * 4 ), first % ( (size_t) nw * 4 ),
+			fx[ first ], f0[ first ]);
+	}
 	const size_t frame = (size_t) sh * pitch;
 
 	printf( "%s: rows [%d,%d) need source rows [%d,%d], window [%d,%d) = %zu "
@@ -129,9 +152,14 @@ static int run( avirhip_plan* plan, const char* what, const std::vector< float >
 		same ? "identical" : "DIFFERENT" );
 
 	CK( hipFree( d0 )); CK( hipFree( d1 )); CK( hipFree( d2 ));
-	CK( hipMemUnmap( win, wbytes ));
-	CK( hipMemRelease( h ));
-	CK( hipMemAddressFree( va, wbytes + 2 * guard ));
+	// (The mapping stays until the process ends, on purpose: unmapping it here
+	// and mapping the next band's window -- the driver hands out the same virtual
+	// range and the same physical pages again -- made the NEXT band's kernels read
+	// the previous window's bytes now and then (2 runs in 5 on one box, k_lanc2's
+	// plain loads only, never through a hipMalloc'ed buffer): stale translations or
+	// cache lines of the recycled pages, a property of the map / unmap cycle, not
+	// of the call under test.)
+	(void) h;
 
 	if( !same )
 	{

@@ -1457,6 +1457,57 @@ def test_avir_pass_kernels(sw, sh, nw, nh, bits):
     _assert_same(got, want, "gpass %dx%d->%dx%d b%d" % (sw, sh, nw, nh, bits))
 
 
+@pytest.mark.parametrize("form", ["auto", "two_per_lane", "one_per_lane",
+                                  "any_count"])
+def test_avir_downsizing_between_1_and_2_gather_kernels(form):
+    """Float RGBA frames downsized by 1 < k < 2 (the zero-stuffed 13 .. 25-tap
+    gather, then the correction FIR: avir.h:3260-3402 -> 4114-4328 -> 3748-3866)
+    on the gather pass kernels -- their automatic path since round 6 -- in every
+    form of the horizontal pass: k_gh with the tap count at compile time (the
+    whole window read at once), k_gh2 (gpass_h2.hip: two outputs per lane from
+    one window; automatic from 22 taps), the any-count variant. Ratios that give
+    every tap count, widths that end strips at every residue, bands; bit for bit
+    against the reference."""
+    lib = abi.load()
+    env = {"auto": {}, "two_per_lane": {"AVIRHIP_GH2_MIN_NT": "13"},
+           "one_per_lane": {"AVIRHIP_NO_GH2": "1"},
+           "any_count": {"AVIRHIP_NO_GH2": "1", "AVIRHIP_GH_POST_ANY": "1"}}[form]
+    keep = {k: os.environ.get(k) for k in ("AVIRHIP_GH2_MIN_NT", "AVIRHIP_NO_GH2",
+                                           "AVIRHIP_GH_POST_ANY")}
+    os.environ.update(env)
+    seen = set()
+    try:
+        for i, k in enumerate([1.04, 1.11, 1.18, 1.26, 1.34, 1.42, 1.5, 1.58,
+                               1.66, 1.745, 1.83, 1.92, 1.985]):
+            sw, sh = 520 + 37 * i, 300 + 11 * i
+            nw, nh = int(sw / k), int(sh / (k * 0.97 if k > 1.1 else k))
+            src = rb.lcg_f32((sh, sw, 4), seed=900 + i)
+            want = _checker_avir(src, nw, nh, resbits=16)
+            r = avir_amd.CImageResizer(16)
+            p = r.plan(sw, sh, nw, nh, 4, 0.0, None, abi.F32, abi.F32)
+            if lib.avirhip_plan_set_path(p, abi.PATH_GPASS) != 0:
+                continue
+            got = np.zeros((nh, nw, 4), np.float32)
+            abi.check(lib.avirhip_resize(p, src.ctypes.data, abi.MEM_HOST,
+                                         got.ctypes.data, abi.MEM_HOST, None), "r")
+            _assert_same(got, want, "%s k=%.3f %dx%d->%dx%d" % (form, k, sw, sh,
+                                                                 nw, nh))
+            out = np.zeros((nh, nw, 4), np.float32)
+            for a_, b_ in [(0, nh // 3), (nh // 3, nh // 3 + 1), (nh // 3 + 1, nh)]:
+                abi.check(lib.avirhip_resize_band(
+                    p, src.ctypes.data, abi.MEM_HOST, out[a_:b_].ctypes.data,
+                    abi.MEM_HOST, a_, b_, None), "band")
+            _assert_same(out, want, "%s k=%.3f bands" % (form, k))
+            seen.add(k)
+    finally:
+        for k_, v in keep.items():
+            if v is None:
+                os.environ.pop(k_, None)
+            else:
+                os.environ[k_] = v
+    assert len(seen) >= 10, seen
+
+
 SACC = [
     # (sw, sh, nw, nh): k >= 2 on both axes (24 .. 64 taps), mixed with other
     # kinds of axes, sizes that end strips / groups / chunks at every residue
