@@ -334,6 +334,15 @@ int tile64_run( avirhip_plan* p, const void* src, int src_type, long src_ss,
 	void* dst, int dst_type, long dst_ss, int row0, int row1, int ya, int yb,
 	hipStream_t st );
 
+// up64.hip: marching kernels of the double pipeline's upsizing chains
+// (FIR7 -> 12-tap gather over the zero-stuffed view), used by tile64_run for
+// the axes that have them; 1: the call was not taken
+bool up64_axis_ok( const LAxis& ax );
+int up64_run_h( const avirhip_plan* p, const void* src, int src_type,
+	long src_ss, double* fltbuf, int ya, int yb, hipStream_t st );
+int up64_run_v( const avirhip_plan* p, const double* fltbuf, void* dst,
+	int dst_type, long dst_ss, int row0, int row1, hipStream_t st );
+
 int launch_errd( const float* res, void* dst, int out_type, int w, int h,
 	int ch, int ech, double tr_mul, double pk_out, int gamma, int alpha_index,
 	float* line, hipStream_t st );

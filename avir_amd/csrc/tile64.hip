@@ -29,9 +29,11 @@
 // fuzz_f64.py compares both executors).
 
 #include "plan.h"
+#include "f64_dev.h"
 #include <algorithm>
 #include <string.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include <vector>
 
 namespace avirhip {
@@ -79,31 +81,11 @@ __device__ __forceinline__ int cl( int i, int hi )
 	return( i < 0 ? 0 : ( i > hi ? hi : i ));
 }
 
-// avir::round< double > with the x86-64 build's cvttsd2si (plan.h)
-__device__ __forceinline__ double round64( const double d )
-{
-	const double a = ( d < 0.0 ? 0.5 - d : d + 0.5 );
-	const double r = (double) ( fabs( a ) < 2147483648.0 ? (int) a :
-		( -2147483647 - 1 ));
-
-	return( d < 0.0 ? -r : r );
-}
-
+// (the output stage: f64_dev.h)
 template< typename Tout >
-__device__ __forceinline__ Tout out_stage( const T64Params& P, double v )
+__device__ __forceinline__ Tout out_stage( const T64Params& P, const double v )
 {
-	if( std::is_same< Tout, double >::value )
-	{
-		return( (Tout) v );
-	}
-
-	if( std::is_integral< Tout >::value )
-	{
-		v = ( P.use_tr ? round64( v * P.tr_muli ) * P.tr_mul : round64( v ));
-		v = ( v < 0.0 ? 0.0 : ( v > P.pk_out ? P.pk_out : v ));
-	}
-
-	return( (Tout) v );
+	return( out_stage64< Tout >( P.use_tr, P.tr_mul, P.tr_muli, P.pk_out, v ));
 }
 
 // One op over the tile in LDS. The chain's axis is "a", the other one "o".
@@ -422,6 +404,7 @@ struct T64Data
 {
 	T64Geom h, v;
 	double* fltbuf; // [src_h][new_w] pixels of ch doubles
+	bool uh, uv;    // the axis is an upsizing chain up64.hip's kernels run
 	std::vector< void* > allocs;
 };
 
@@ -610,6 +593,8 @@ int tile64_prepare( avirhip_plan* p )
 	T64Data* D = new T64Data();
 	D -> fltbuf = nullptr;
 	D -> h.ok = D -> v.ok = false;
+	D -> uh = up64_axis_ok( p -> h );
+	D -> uv = up64_axis_ok( p -> v );
 	p -> tile64 = D;
 	// (tile along the chain's axis, tile along the other one)
 	static const int ch_[][ 2 ] = { { 64, 8 }, { 128, 4 }, { 64, 4 }, { 32, 4 },
@@ -720,6 +705,24 @@ int tile64_run( avirhip_plan* p, const void* src, int src_type, long src_ss,
 	T64Params P;
 	memset( &P, 0, sizeof( P ));
 
+	// upsizing chains: the marching kernels of up64.hip (AVIRHIP_NO_UP64: the
+	// tiles below, for A/B timing and the differential tests)
+	const bool no_up64 = ( getenv( "AVIRHIP_NO_UP64" ) != nullptr );
+	bool hdone = false, vdone = false;
+
+	if( D -> uh && !no_up64 )
+	{
+		const int rc = up64_run_h( p, src, src_type, src_ss, D -> fltbuf, ya, yb,
+			st );
+
+		if( rc < 0 )
+		{
+			return( rc );
+		}
+
+		hdone = ( rc == 0 );
+	}
+
 	// ---- H chain over source rows [ya, yb]
 	fill64( p -> h, P );
 	P.xrng = D -> h.d_rng; P.ntx = D -> h.nta;
@@ -729,6 +732,8 @@ int tile64_run( avirhip_plan* p, const void* src, int src_type, long src_ss,
 	P.src_len_a = p -> src_w; P.src_len_o = p -> src_h;
 	P.dst = D -> fltbuf; P.dst_ss = (long) p -> new_w * ch; P.dst_row0 = 0;
 	P.maxA = D -> h.maxA; P.maxB = D -> h.maxB; P.maxC = D -> h.maxC;
+
+	if( !hdone )
 	{
 		const int nty = ( yb + 1 - ya + P.tsz_o - 1 ) / P.tsz_o;
 		const int nt = P.ntx * nty;
@@ -740,6 +745,25 @@ int tile64_run( avirhip_plan* p, const void* src, int src_type, long src_ss,
 			case 3: launch_h64< 3 >( P, src_type, nt, D -> h.lds, st ); break;
 			default: launch_h64< 4 >( P, src_type, nt, D -> h.lds, st ); break;
 		}
+	}
+
+	if( D -> uv && !no_up64 )
+	{
+		const int rc = up64_run_v( p, D -> fltbuf, dst, dst_type, dst_ss, row0,
+			row1, st );
+
+		if( rc < 0 )
+		{
+			return( rc );
+		}
+
+		vdone = ( rc == 0 );
+	}
+
+	if( vdone )
+	{
+		AVIRHIP_HIPCHECK( hipGetLastError() );
+		return( AVIRHIP_OK );
 	}
 
 	// ---- V chain over FltBuf columns, output rows [row0, row1)
