@@ -15,7 +15,8 @@
 //   k_uh64  horizontal pass, caller's pixels -> FltBuf (double). A workgroup owns
 //           256 consecutive ELEMENTS of an output row (channels are independent:
 //           a strip may start and end inside a pixel) and marches down its rows
-//           four at a time; a thread keeps the 12 coefficients of its output
+//           eight at a time (the next step's source rows travel in registers
+//           meanwhile); a thread keeps the 12 coefficients of its output
 //           column in registers for the whole march; the source segment is cast
 //           to double into LDS (packScanline, avir.h:2777-2840), the correction
 //           filter writes the C segment, the gather reads it.
@@ -51,7 +52,6 @@ namespace avirhip {
 namespace {
 
 #define U64_NT 12   // gather taps
-#define U64_RH 4    // rows per step of the horizontal kernel
 #define U64_PF 5    // rows in flight in the vertical kernel
 
 // (constant address space: wave-uniform tables through scalar loads -- a plain
@@ -75,17 +75,17 @@ struct U64HParams
 	double* flt; long fss;        // FltBuf: row y at flt + y * fss
 	int nel;                      // elements per FltBuf row (new_w * ch)
 	int ya, yb;                   // source rows [ya, yb]
-	int crows;                    // rows per chunk (multiple of U64_RH)
+	int crows;                    // rows per chunk (a whole number of steps)
 	int nstrips;
 	int maxSe, maxCe;             // LDS row pitches (elements)
 };
 
-template< int CH, typename Tin >
+template< int CH, typename Tin, int RH >
 __global__ void __launch_bounds__( 256 ) k_uh64( const U64HParams P )
 {
 	extern __shared__ __attribute__(( aligned( 16 ))) double u64_smem[];
 	double* const S = u64_smem;
-	double* const C = u64_smem + U64_RH * P.maxSe;
+	double* const C = u64_smem + RH * P.maxSe;
 
 	const int tid = threadIdx.x;
 	const int chunk = blockIdx.x / P.nstrips;
@@ -100,7 +100,7 @@ __global__ void __launch_bounds__( 256 ) k_uh64( const U64HParams P )
 	const int c_lo = P.start[ j_lo ];
 	const int c_hi = P.start[ j_hi ] + U64_NT - 1;
 	const int nCe = ( c_hi - c_lo + 1 ) * CH;
-	const int nSe = nCe + 6 * CH;
+	const int nSe = nCe + 6 * CH; // <= 512 (up64_run_h)
 
 	double cf[ U64_NT ];
 #pragma unroll
@@ -117,30 +117,66 @@ __global__ void __launch_bounds__( 256 ) k_uh64( const U64HParams P )
 	const int y1 = min( y0 + P.crows, P.yb + 1 );
 	const int xlast = P.src_w - 1;
 
-	for( int y = y0; y < y1; y += U64_RH )
-	{
-		// ---- the source segment [c_lo - 6, c_hi] of four rows, cast to double
-		// (virtual indices: addresses clamp to the row)
+	// the source elements this thread moves into LDS each step: segment
+	// [c_lo - 6, c_hi] as virtual indices, addresses clamped to the row
+	int soff[ 2 ];
+	bool sok[ 2 ];
 #pragma unroll
-		for( int r = 0; r < U64_RH; r++ )
+	for( int q = 0; q < 2; q++ )
+	{
+		const int x = q * 256 + tid;
+		const int px = x / CH;
+		const int kk = x - px * CH;
+		sok[ q ] = ( x < nSe );
+		soff[ q ] = u64_cl( c_lo - 6 + px, xlast ) * CH + kk;
+	}
+
+	const bool two = ( nSe > 256 );
+	Tin sv[ RH ][ 2 ];
+
+	auto fetch = [&]( const int y )
+	{
+#pragma unroll
+		for( int r = 0; r < RH; r++ )
 		{
 			const int row = min( y + r, P.yb );
 			const Tin* const sp = (const Tin*) P.src + (long) row * P.src_ss;
+			sv[ r ][ 0 ] = ( sok[ 0 ] ? sp[ soff[ 0 ]] : (Tin) 0 );
+			sv[ r ][ 1 ] = ( two && sok[ 1 ] ? sp[ soff[ 1 ]] : (Tin) 0 );
+		}
+	};
 
-			for( int x = tid; x < nSe; x += 256 )
+	fetch( y0 );
+
+	for( int y = y0; y < y1; y += RH )
+	{
+		// ---- the rows fetched during the previous step, cast to double
+		// (packScanline, avir.h:2777-2840)
+#pragma unroll
+		for( int r = 0; r < RH; r++ )
+		{
+			if( sok[ 0 ])
 			{
-				const int px = x / CH;
-				const int kk = x - px * CH;
-				S[ r * P.maxSe + x ] = (double) sp[ (long) u64_cl( c_lo - 6 +
-					px, xlast ) * CH + kk ];
+				S[ r * P.maxSe + tid ] = (double) sv[ r ][ 0 ];
+			}
+
+			if( two && sok[ 1 ])
+			{
+				S[ r * P.maxSe + 256 + tid ] = (double) sv[ r ][ 1 ];
 			}
 		}
 
 		__syncthreads();
 
+		// (the next step's rows travel while this one computes)
+		if( y + RH < y1 )
+		{
+			fetch( y + RH );
+		}
+
 		// ---- correction filter: C_v[i], i = c_lo + x / CH, centre S_v[i - 3]
 #pragma unroll
-		for( int r = 0; r < U64_RH; r++ )
+		for( int r = 0; r < RH; r++ )
 		{
 			for( int x = tid; x < nCe; x += 256 )
 			{
@@ -155,9 +191,9 @@ __global__ void __launch_bounds__( 256 ) k_uh64( const U64HParams P )
 
 		__syncthreads();
 
-		// ---- the gather: one element of each of the four rows per thread
+		// ---- the gather: one element of each of the rows per thread
 #pragma unroll
-		for( int r = 0; r < U64_RH; r++ )
+		for( int r = 0; r < RH; r++ )
 		{
 			const double* const c = C + r * P.maxCe + off;
 			double sum = 0.0;
@@ -173,7 +209,9 @@ __global__ void __launch_bounds__( 256 ) k_uh64( const U64HParams P )
 			}
 		}
 
-		__syncthreads();
+		// (two barriers per step are enough: the next step writes S before its
+		// first barrier -- nothing reads S after this step's second one -- and C
+		// after it, when every thread has finished this gather)
 	}
 }
 
@@ -192,6 +230,7 @@ struct U64VParams
 	int ngroups;                  // groups of 64 * EPL elements
 	int vec_st;                   // EPL == 2: rows are aligned for paired stores
 	int use_tr; double tr_mul, tr_muli, pk_out;
+	int dbg; // timing ablations (AVIRHIP_UP64_DBG): 1 coefficients from registers, 2 no stores
 };
 
 template< int EPL >
@@ -253,7 +292,7 @@ __device__ __forceinline__ void u64_vstep( const U64VParams& P,
 		dn_static_for< U64_NT >( [&]( auto tc )
 		{
 			constexpr int t = decltype( tc )::value;
-			const double c = cf[ t ];
+			const double c = (( P.dbg & 1 ) ? (( t & 1 ) ? f1 : f2 ) : cf[ t ]);
 #pragma unroll
 			for( int e = 0; e < EPL; e++ )
 			{
@@ -269,7 +308,7 @@ __device__ __forceinline__ void u64_vstep( const U64VParams& P,
 				P.pk_out, sum[ e ]);
 		}
 
-		if( ok )
+		if( ok && !( P.dbg & 2 ))
 		{
 			Tout* const q = (Tout*) P.dst + (long) ( jn - P.dst_row0 ) *
 				P.dst_ss + e0;
@@ -380,6 +419,13 @@ __global__ void __launch_bounds__( 256 ) k_uv64( const U64VParams P )
 // host side
 // ---------------------------------------------------------------------
 
+// tuning knobs (A/B sweeps, tools/r06_up64*.sh), read per call
+static int u64_env( const char* const name, const int dflt )
+{
+	const char* const e = getenv( name );
+	return( e != nullptr && atoi( e ) > 0 ? atoi( e ) : dflt );
+}
+
 // Whether an axis is the chain these kernels are written for (see the header).
 bool up64_axis_ok( const LAxis& ax )
 {
@@ -459,24 +505,28 @@ int up64_run_h( const avirhip_plan* p, const void* src, const int src_type,
 	P.nstrips = ( P.nel + 255 ) / 256;
 	up64_h_pitch( g, ch, P.nel, P.maxSe, P.maxCe );
 
-	const size_t lds = (size_t) U64_RH * ( P.maxSe + P.maxCe ) * 8;
+	const int rh = ( u64_env( "AVIRHIP_UP64_RH", 8 ) == 4 ? 4 : 8 );
+	const size_t lds = (size_t) rh * ( P.maxSe + P.maxCe ) * 8;
 
-	if( lds > 64 * 1024 )
+	if( lds > 64 * 1024 || P.maxSe > 512 )
 	{
 		return( 1 );
 	}
 
 	// ~3000 workgroups; a chunk is a whole number of steps
 	const int rows = yb - ya + 1;
-	const int want = std::max( 1, 3072 / P.nstrips );
+	const int hb = u64_env( "AVIRHIP_UP64_HB", 4096 );
+	const int want = std::max( 1, hb / P.nstrips );
 	int crows = ( rows + want - 1 ) / want;
-	crows = std::max( 4 * U64_RH, ( crows + U64_RH - 1 ) / U64_RH * U64_RH );
+	crows = std::max( 4 * rh, ( crows + rh - 1 ) / rh * rh );
 	P.crows = crows;
 	const int nchunks = ( rows + crows - 1 ) / crows;
 	const dim3 grid( (unsigned) ( P.nstrips * nchunks ));
 
-#define UH( CH, T ) do { (void) AVIRHIP_DYN_LDS(( k_uh64< CH, T > ), lds ); \
-	hipLaunchKernelGGL(( k_uh64< CH, T > ), grid, dim3( 256 ), lds, st, P ); \
+#define UHR( CH, T, R ) do { (void) AVIRHIP_DYN_LDS(( k_uh64< CH, T, R > ), lds ); \
+	hipLaunchKernelGGL(( k_uh64< CH, T, R > ), grid, dim3( 256 ), lds, st, P ); \
+	} while( 0 )
+#define UH( CH, T ) do { if( rh == 4 ) UHR( CH, T, 4 ); else UHR( CH, T, 8 ); \
 	} while( 0 )
 #define UHT( CH ) switch( src_type ) { \
 	case AVIRHIP_U8: UH( CH, uint8_t ); break; \
@@ -494,6 +544,7 @@ int up64_run_h( const avirhip_plan* p, const void* src, const int src_type,
 
 #undef UHT
 #undef UH
+#undef UHR
 	AVIRHIP_HIPCHECK( hipGetLastError() );
 	return( AVIRHIP_OK );
 }
@@ -518,9 +569,11 @@ int up64_run_v( const avirhip_plan* p, const double* fltbuf, void* dst,
 	P.row_lo = row0; P.row_hi = row1;
 	P.use_tr = ( p -> tr_mul != 1.0 ); P.tr_mul = p -> tr_mul;
 	P.tr_muli = 1.0 / p -> tr_mul; P.pk_out = p -> pk_out;
+	P.dbg = u64_env( "AVIRHIP_UP64_DBG", 0 );
 
 	// two elements per lane (16-byte loads) when rows hold an even number
-	const int epl = (( P.nel & 1 ) == 0 ? 2 : 1 );
+	const int epl = (( P.nel & 1 ) == 0 &&
+		u64_env( "AVIRHIP_UP64_EPL", 2 ) == 2 ? 2 : 1 );
 	const size_t osz = dtype_size( dst_type );
 	P.vec_st = ( epl == 2 && ( dst_ss & 1 ) == 0 &&
 		( (uintptr_t) dst % ( 2 * osz )) == 0 ? 1 : 0 );
@@ -528,7 +581,8 @@ int up64_run_v( const avirhip_plan* p, const double* fltbuf, void* dst,
 
 	// ~4000 waves; a chunk's run-in is 18 source rows
 	const int rows = row1 - row0;
-	const int want = std::max( 1, 4096 / P.ngroups );
+	const int vw = u64_env( "AVIRHIP_UP64_VW", 4096 );
+	const int want = std::max( 1, vw / P.ngroups );
 	P.crows = std::max( 48, ( rows + want - 1 ) / want );
 	const int nchunks = ( rows + P.crows - 1 ) / P.crows;
 	const dim3 grid( (unsigned) ((( P.ngroups + 3 ) / 4 ) * nchunks ));
