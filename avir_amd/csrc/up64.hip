@@ -230,7 +230,6 @@ struct U64VParams
 	int ngroups;                  // groups of 64 * EPL elements
 	int vec_st;                   // EPL == 2: rows are aligned for paired stores
 	int use_tr; double tr_mul, tr_muli, pk_out;
-	int dbg; // timing ablations (AVIRHIP_UP64_DBG): 1 coefficients from registers, 2 no stores
 };
 
 template< int EPL >
@@ -292,7 +291,7 @@ __device__ __forceinline__ void u64_vstep( const U64VParams& P,
 		dn_static_for< U64_NT >( [&]( auto tc )
 		{
 			constexpr int t = decltype( tc )::value;
-			const double c = (( P.dbg & 1 ) ? (( t & 1 ) ? f1 : f2 ) : cf[ t ]);
+			const double c = cf[ t ];
 #pragma unroll
 			for( int e = 0; e < EPL; e++ )
 			{
@@ -308,7 +307,7 @@ __device__ __forceinline__ void u64_vstep( const U64VParams& P,
 				P.pk_out, sum[ e ]);
 		}
 
-		if( ok && !( P.dbg & 2 ))
+		if( ok )
 		{
 			Tout* const q = (Tout*) P.dst + (long) ( jn - P.dst_row0 ) *
 				P.dst_ss + e0;
@@ -321,7 +320,11 @@ __device__ __forceinline__ void u64_vstep( const U64VParams& P,
 					t2 ov;
 					ov.x = o[ 0 ];
 					ov.y = o[ 1 ];
-					*(t2*) q = ov;
+
+					// (non-temporal: the result is not read again, FltBuf is --
+					// a 1080p source's FltBuf then stays in the last-level
+					// cache: cfg2 -8 %, profiles/r06_up64/)
+					__builtin_nontemporal_store( ov, (t2*) q );
 				}
 				else
 				{
@@ -569,7 +572,6 @@ int up64_run_v( const avirhip_plan* p, const double* fltbuf, void* dst,
 	P.row_lo = row0; P.row_hi = row1;
 	P.use_tr = ( p -> tr_mul != 1.0 ); P.tr_mul = p -> tr_mul;
 	P.tr_muli = 1.0 / p -> tr_mul; P.pk_out = p -> pk_out;
-	P.dbg = u64_env( "AVIRHIP_UP64_DBG", 0 );
 
 	// two elements per lane (16-byte loads) when rows hold an even number
 	const int epl = (( P.nel & 1 ) == 0 &&
