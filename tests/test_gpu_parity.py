@@ -2305,6 +2305,56 @@ def test_avir_fpclass_def_double(tin, tout, bits, gamma, alpha):
                         abi.MEM_HOST, a_, b_, None), "band")
             _assert_same(out, want, "f64 bands")
 
+@pytest.mark.parametrize("tin,tout", [(np.float32, np.float32),
+                                      (np.uint8, np.uint8),
+                                      (np.uint16, np.float64),
+                                      (np.float64, np.uint16)])
+def test_double_pipeline_upsizing_marching_kernels(tin, tout):
+    """up64.hip: the double pipeline's upsizing chains (FIR7 -> 12-tap gather
+    over the zero-stuffed view, doFilter avir.h:3748-3866 + doUpsample /
+    doResize2 avir.h:3260-3402, 4114-4328) on k_uh64 / k_uv64 instead of
+    tile64.hip's tiles: exact 2x, fractional ratios, more than two output rows
+    per source row (3.3x), one axis upsized and the other downsized (one pass
+    on each executor), 1-4 channels (odd row lengths take one element per lane,
+    unaligned rows scalar stores), frames of a few pixels, row bands -- against
+    the reference's double class and against the tiles (AVIRHIP_NO_UP64=1)."""
+    if not rb.have_ref():
+        pytest.fail("oracle/_ref is needed: the restatement has no double class")
+    lib = abi.load()
+    cases = [(96, 64, 192, 128, 4), (97, 33, 194, 66, 3), (64, 48, 100, 77, 4),
+             (50, 41, 165, 137, 1), (40, 30, 131, 20, 2), (30, 90, 20, 200, 4),
+             (3, 2, 7, 5, 3), (1, 1, 2, 2, 4), (301, 7, 640, 15, 1),
+             (200, 120, 333, 250, 3)]
+    for (sw, sh, nw, nh, ch) in cases:
+        if np.dtype(tin).kind == "u":
+            src = rb.lcg_u8((sh, sw, ch, np.dtype(tin).itemsize), seed=sw + ch)
+            src = src.view(tin).reshape(sh, sw, ch)
+        else:
+            src = (rb.lcg_f32((sh, sw, ch), seed=sw * 3 + ch) * 1.2 - 0.1
+                   ).astype(tin)
+            if np.dtype(tout).kind == "u":
+                src = (src * float(np.iinfo(tout).max)).astype(tin)
+        want = rb.ref_avir(src, nw, nh, resbits=16, out_dtype=tout, variant=4)
+        r = avir_amd.CImageResizer(16, aFpPack=abi.FPCLASS_DOUBLE)
+        got = r.resize(src, nw, nh, 0.0, tout)
+        _assert_same(got, want, "up64 %r" % ((sw, sh, nw, nh, ch),))
+        os.environ["AVIRHIP_NO_UP64"] = "1"
+        try:
+            tiles = r.resize(src, nw, nh, 0.0, tout)
+        finally:
+            del os.environ["AVIRHIP_NO_UP64"]
+        _assert_same(tiles, want, "tiles %r" % ((sw, sh, nw, nh, ch),))
+        p = r.plan(sw, sh, nw, nh, ch, 0.0, None, rb._DT[src.dtype],
+                   rb._DT[np.dtype(tout)])
+        out = np.zeros((nh, nw, ch), tout)
+        for a_, b_ in [(0, nh // 3), (nh // 3, nh // 3 + 1), (nh // 3 + 1, nh)]:
+            if b_ > a_:
+                abi.check(lib.avirhip_resize_band(
+                    p, src.ctypes.data, abi.MEM_HOST, out[a_:b_].ctypes.data,
+                    abi.MEM_HOST, a_, b_, None), "band")
+        _assert_same(out, want, "up64 bands %r" % ((sw, sh, nw, nh, ch),))
+
+
 def test_fast_paths_under_concurrent_memory_traffic():
     """tools/stress_race.py: the kernels prove "the row has landed" by counting
     outstanding vector-memory operations; a count that proves too little is a
