@@ -1484,7 +1484,7 @@ int gpass_run( avirhip_plan* p, const float* src, long src_stride, float* dst,
 	// 0.028 / 0.034 ms, x2.1 0.047 / 0.051, x2.5 0.064 / 0.065, x3 0.092 /
 	// 0.086, x4 0.166 / 0.136; RGBA uint8 x3 0.086 / 0.088, x4 0.152 / 0.140;
 	// float results: fused wins at every ratio, x3 0.082 / 0.126;
-	// profiles/r05_lanc, tools/r05_lf2.sh)
+	// profiles/r05_lanc, tools/rounds/r05_lf2.sh)
 	static const double lf_ratio = ( getenv( "AVIRHIP_LF_INT_RATIO" ) != nullptr ?
 		atof( getenv( "AVIRHIP_LF_INT_RATIO" )) : -1.0 ); // (tuning aid)
 	const bool lf_pays = ( !p -> lfuse.on || p -> lfuse.type == AVIRHIP_F32 ||

@@ -440,7 +440,7 @@ __global__ void __launch_bounds__( 256 ) k_uv64( const U64VParams P )
 // host side
 // ---------------------------------------------------------------------
 
-// tuning knobs (A/B sweeps, tools/r06_up64*.sh), read per call
+// tuning knobs (A/B sweeps, tools/rounds/r06_up64*.sh), read per call
 static int u64_env( const char* const name, const int dflt )
 {
 	const char* const e = getenv( name );

@@ -3,7 +3,7 @@
 mkdir -p gpurun_out/r05
 python -m pytest tests/test_bench.py -m gpu -q --timeout 900 > gpurun_out/r05/pytest_bench.txt 2>&1; echo "pytest rc $?" >> gpurun_out/r05/pytest_bench.txt
 tail -4 gpurun_out/r05/pytest_bench.txt
-bash tools/r05_profiles.sh > gpurun_out/r05/profiles_log.txt 2>&1
+bash tools/rounds/r05_profiles.sh > gpurun_out/r05/profiles_log.txt 2>&1
 cp gpurun_out/r05/profiles_out/pmc_traffic.json profiles/pmc_traffic.json
 python bench.py > gpurun_out/r05/bench.json 2> gpurun_out/r05/bench.err; echo "bench rc $?"
 python - <<'PY'

@@ -13,4 +13,4 @@ for c in d['configs']: print(c['config'], c['ms_per_step'], c['roofline']['frac'
 PY
 names="cfg1 cfg2 cfg3 cfg4 cfg5 nonint half triple readme readme_f32 readme_rgbf nonint_u8 up2_u8 up2_rgba8 up2_4k_u8 cfg4_u8 half_u8 dn15 dn192 dn17 dn15_u8 dn192_u8 dn15_1080_u8 dn15_720_u8 dnk_4k dnk_1080 dnk_720 lanc_nonint lanc_nonint_u8 lanc_nonint_rgba8 lanc_triple lanc_triple_u8 lanc_dn3 lanc_dn3_rgba8 lanc_up2_rgba8 lanc_up2_u8 lanc_readme_u8 cfg2_dbl cfg3_dbl cfg4_dbl nonint_dbl"
 python tools/bench_table.py 300 $names 2>&1 | grep -v amdgpu.ids > $O/workloads.txt; cat $O/workloads.txt
-for w in lanc_nonint_u8 lanc_nonint_rgba8 lanc_readme_u8 lanc_dn3_rgba8 lanc_triple_u8 lanc_nonint lanc_dn3; do echo "== $w"; bash tools/r05_kt.sh $w; done 2>&1 | grep -v amdgpu.ids | tee $O/kt_lanc.txt
+for w in lanc_nonint_u8 lanc_nonint_rgba8 lanc_readme_u8 lanc_dn3_rgba8 lanc_triple_u8 lanc_nonint lanc_dn3; do echo "== $w"; bash tools/rounds/r05_kt.sh $w; done 2>&1 | grep -v amdgpu.ids | tee $O/kt_lanc.txt

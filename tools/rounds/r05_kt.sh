@@ -1,5 +1,5 @@
 #!/bin/bash
-# kernel-trace stats of one workload: tools/r05_kt.sh <workload> [env assignments...]
+# kernel-trace stats of one workload: tools/rounds/r05_kt.sh <workload> [env assignments...]
 W=$1; shift
 OUT=$GRAFT_REPO_ROOT/gpurun_out/r05/kt_$W
 rm -rf $OUT; mkdir -p $OUT

@@ -1,5 +1,5 @@
 #!/bin/bash
-# instruction mix of a workload's kernels: tools/r05_mix.sh <workload>...
+# instruction mix of a workload's kernels: tools/rounds/r05_mix.sh <workload>...
 cd /tmp && export TMPDIR=/tmp
 for W in "$@"; do
 OUT=$GRAFT_REPO_ROOT/gpurun_out/r05/mix_$W; rm -rf $OUT; mkdir -p $OUT

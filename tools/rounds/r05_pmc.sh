@@ -1,5 +1,5 @@
 #!/bin/bash
-# counters of one workload's kernels: tools/r05_pmc.sh <workload> <kernel substring> [env assignments...]
+# counters of one workload's kernels: tools/rounds/r05_pmc.sh <workload> <kernel substring> [env assignments...]
 W=$1; K=$2; shift; shift
 OUT=$GRAFT_REPO_ROOT/gpurun_out/r05/pmc_$W
 rm -rf $OUT; mkdir -p $OUT

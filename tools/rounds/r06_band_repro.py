@@ -5,7 +5,7 @@ call, device window, host window -- each against the generic kernels' band.
 import os
 import sys
 
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
 import numpy as np  # noqa: E402
 
 

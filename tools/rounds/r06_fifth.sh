@@ -5,7 +5,7 @@ O=gpurun_out/r6e; mkdir -p $O
 L=$PWD/avir_amd/lib
 ( time timeout 1500 python -m pytest tests -m gpu -x -q ) > $O/gpu_tests.txt 2>&1; tail -4 $O/gpu_tests.txt
 ( for t in "3 uint16 uint16" "3 uint8 uint8" "1 uint16 uint16"; do for c in 2 3 4; do
-    AVIRHIP_GV_CHUNK=$c python tools/r06_repro.py lancir 3555 2951 3135 2672 $t 200; done; done ) > $O/repro_after_fix.txt 2>&1
+    AVIRHIP_GV_CHUNK=$c python tools/rounds/r06_repro.py lancir 3555 2951 3135 2672 $t 200; done; done ) > $O/repro_after_fix.txt 2>&1
 grep repro $O/repro_after_fix.txt | cut -c1-140
 for f in lanc_dn gpass_up lf sacc; do
   ( time STRESS_BIG=1 STRESS_HAMMER=1 timeout 1500 python tools/stress_geom.py 2000 71 3 --against $L/libavirhip_paranoid.so --family $f --chunks ) > $O/diff_$f.txt 2>&1

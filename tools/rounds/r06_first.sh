@@ -12,4 +12,4 @@ echo "== product build against paranoid, same cases: must be clean" >> $O/lfrace
 ( time timeout 900 python tools/stress_geom.py 400 5 4 --against $L/libavirhip_paranoid.so --family lf ) >> $O/lfrace.txt 2>&1
 grep -c MISMATCH $O/lfrace.txt; tail -2 $O/lfrace.txt
 timeout 600 python bench.py > $O/bench.json 2> $O/bench.err; tail -c 600 $O/bench.json
-AVIRHIP_LIB=$L/libavirhip_dbg.so timeout 600 python tools/r06_up2_ablate.py > $O/up2_ablate.txt 2>&1; cat $O/up2_ablate.txt
+AVIRHIP_LIB=$L/libavirhip_dbg.so timeout 600 python tools/rounds/r06_up2_ablate.py > $O/up2_ablate.txt 2>&1; cat $O/up2_ablate.txt

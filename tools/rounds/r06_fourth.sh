@@ -7,17 +7,17 @@ G="lancir 3555 2951 3135 2672 3 uint16 uint16"
 export NO_HAMMER=1
 ( for lib in "" _xONLY_WAITS _xONLY_HANDOVER _xONLY_HANDOVER_LGKM; do
     echo "== library libavirhip$lib.so"
-    AVIRHIP_LIB=$L/libavirhip$lib.so AVIRHIP_GV_CHUNK=4 python tools/r06_repro.py $G 200
+    AVIRHIP_LIB=$L/libavirhip$lib.so AVIRHIP_GV_CHUNK=4 python tools/rounds/r06_repro.py $G 200
   done
   echo "== chunk sweep (product)"
-  for c in 2 3 4 5 6 7 8 10 12 16; do AVIRHIP_GV_CHUNK=$c python tools/r06_repro.py $G 100; done
+  for c in 2 3 4 5 6 7 8 10 12 16; do AVIRHIP_GV_CHUNK=$c python tools/rounds/r06_repro.py $G 100; done
   echo "== types (product, chunk 4)"
   for t in "3 uint8 uint8" "4 uint8 uint8" "4 uint16 uint16" "1 float32 float32" "2 float32 float32" "3 uint16 float32" "3 float32 uint16" "1 uint16 uint16"; do
-    AVIRHIP_GV_CHUNK=4 python tools/r06_repro.py lancir 3555 2951 3135 2672 $t 100
+    AVIRHIP_GV_CHUNK=4 python tools/rounds/r06_repro.py lancir 3555 2951 3135 2672 $t 100
   done
   echo "== other geometries (product, chunk 4, RGB uint16)"
   for g in "1200 900 1000 800" "3555 2951 1777 1475" "2000 1500 1800 1400" "3555 2951 3135 2951" "3555 2951 3555 2672"; do
-    AVIRHIP_GV_CHUNK=4 python tools/r06_repro.py lancir $g 3 uint16 uint16 100
+    AVIRHIP_GV_CHUNK=4 python tools/rounds/r06_repro.py lancir $g 3 uint16 uint16 100
   done
 ) > $O/bisect.txt 2>&1
 grep -E "^==|^repro" $O/bisect.txt | cut -c1-260

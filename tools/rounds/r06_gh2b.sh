@@ -15,4 +15,4 @@ for l in open('gpurun_out/r6l/ab.txt'):
 for w in sorted(set(k[0] for k in r)):
     print(w, ' '.join('%s %.4f' % (a, sorted(r[(w,a)])[len(r[(w,a)])//2]) for a in ('gh_ntc','gh2','gh2_split')), 'hashes', h[w])
 PY
-python tools/r06_band_repro.py 100 2>&1 | tail -16
+python tools/rounds/r06_band_repro.py 100 2>&1 | tail -16

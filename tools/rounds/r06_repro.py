@@ -1,13 +1,13 @@
 #!/usr/bin/env python3
 """One geometry, many repeats, product library against the paranoid one
 (tools/stress_geom.py found the case): counts the frames that differ, under the
-memory hammer. usage: python tools/r06_repro.py lancir|avir sw sh nw nh ch tin tout
+memory hammer. usage: python tools/rounds/r06_repro.py lancir|avir sw sh nw nh ch tin tout
 [repeats=300] -- environment (AVIRHIP_*_CHUNK ...) as given."""
 import os
 import sys
 import threading
 
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
 import numpy as np  # noqa: E402
 
 
@@ -18,7 +18,7 @@ def main():
     api, sw, sh, nw, nh, ch = sys.argv[1], *[int(x) for x in sys.argv[2:7]]
     tin, tout = np.dtype(sys.argv[7]).type, np.dtype(sys.argv[8]).type
     reps = int(sys.argv[9]) if len(sys.argv) > 9 else 300
-    root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+    root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..")
     lib = abi.load()
     ref = abi.load_path(os.path.join(root, "avir_amd", "lib",
                                      "libavirhip_paranoid.so"))

@@ -4,7 +4,7 @@
 O=gpurun_out/r6f; mkdir -p $O
 L=$PWD/avir_amd/lib
 ( for v in 1 2 3; do for t in "3 uint16 uint16" "3 uint8 uint8"; do for c in 2 4; do
-    echo "fix$v"; AVIRHIP_LIB=$L/libavirhip_xfix$v.so AVIRHIP_GV_CHUNK=$c python tools/r06_repro.py lancir 3555 2951 3135 2672 $t 150; done; done; done ) > $O/repro_fix_variants.txt 2>&1
+    echo "fix$v"; AVIRHIP_LIB=$L/libavirhip_xfix$v.so AVIRHIP_GV_CHUNK=$c python tools/rounds/r06_repro.py lancir 3555 2951 3135 2672 $t 150; done; done; done ) > $O/repro_fix_variants.txt 2>&1
 grep -E "^fix|^repro" $O/repro_fix_variants.txt | cut -c1-130
 for rep in 1 2 3; do for a in _before_gvfix _xfix1 _xfix2 _xfix3; do for w in cfg1 lanc_dn3 lanc_readme_u8 lanc_dn3_rgba8 lanc_triple_u8 lanc_up2_u8 dn15 dn17; do
   E=""; if [ $w = dn15 -o $w = dn17 ]; then E="AVIRHIP_NO_SACC_ZS=1"; fi

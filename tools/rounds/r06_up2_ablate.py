@@ -1,23 +1,20 @@
 #!/usr/bin/env python3
-"""Same-box, same-process A/B of k_dnf's timing ablations (AVIRHIP_DNF_DBG is
-read per call): 0 the kernel as shipped; 32 no row-wave work in a chunk's last
-three marching steps -- the upper bound of what sharing the run-in's F rows
-between vertically adjacent chunks through L2 could buy (those rows are the
-first rows of the chunk below), with none of its costs and none of the load
-balancing it needs; 1 / 2 no column / no row arithmetic for reference. Timing
-only: modes != 0 compute wrong pixels.
+"""Same-box, same-process A/B of k_up2's ablation switches (debug library,
+`make -C avir_amd/csrc dbg`): AVIRHIP_UP2_DBG is read per call, so the modes
+alternate inside ONE process on ONE plan -- no box-to-box or run-to-run spread
+between the columns. Modes (up2.hip, U2_ABL_*): 0 the kernel as shipped;
+16 the H1 work of a 128-column strip (upper bound of that lever, none of its
+costs); 32 no horizontal phases in a chunk's last two steps (upper bound of
+sharing the run-in's T rows between vertically adjacent chunks through L2, none
+of its costs); 48 both. Timing only -- modes != 0 compute wrong pixels.
 
-(Bit 32 and the per-call reading of AVIRHIP_DNF_DBG live in the experiment kernel,
-tools/experiments/dnf_share.hip.txt -- copy it over avir_amd/csrc/dnf.hip together
-with the DnData fields it names to repeat the measurement; results:
-profiles/r06_dnf/.)
-
-usage: python tools/r06_dnf_ablate.py [modes...]"""
+usage: AVIRHIP_LIB=avir_amd/lib/libavirhip_dbg.so python tools/rounds/r06_up2_ablate.py
+"""
 import os
 import sys
 import time
 
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
 
 
 def main():
@@ -26,29 +23,28 @@ def main():
     from avir_amd import abi, synth
     lib = abi.load()
     dev = torch.device("cuda", 0)
-    modes = [int(m) for m in (sys.argv[1:] or ["0", "32", "1", "2"])]
-    for name, (sw, sh, nw, nh) in (("cfg4", (3840, 2160, 1280, 720)),
-                                   ("half", (3840, 2160, 1920, 1080))):
+    modes = [int(m) for m in (sys.argv[1:] or ["0", "16", "32", "48"])]
+    for name, (sw, sh) in (("cfg3", (3840, 2160)), ("cfg2", (1920, 1080))):
         src = torch.from_numpy(synth.lcg_f32((sh, sw, 4))).to(dev)
-        dst = torch.empty((nh, nw, 4), dtype=torch.float32, device=dev)
+        dst = torch.empty((2 * sh, 2 * sw, 4), dtype=torch.float32, device=dev)
         r = avir_amd.CImageResizer(16)
-        plan = r.plan(sw, sh, nw, nh, 4, 0.0, None, abi.F32, abi.F32)
+        plan = r.plan(sw, sh, 2 * sw, 2 * sh, 4, 0.0, None, abi.F32, abi.F32)
         st = torch.cuda.current_stream(dev).cuda_stream
 
         def step():
             abi.check(lib.avirhip_resize(plan, src.data_ptr(), abi.MEM_DEVICE,
                                          dst.data_ptr(), abi.MEM_DEVICE, st), "r")
-        os.environ["AVIRHIP_DNF_DBG"] = "0"
+        os.environ["AVIRHIP_UP2_DBG"] = "0"
         t0 = time.perf_counter()
-        while time.perf_counter() - t0 < 1.0:
+        while time.perf_counter() - t0 < 1.0:  # settle the clocks
             for _ in range(50):
                 step()
             torch.cuda.synchronize()
         res = {m: [] for m in modes}
-        n = 1000
+        n = 400 if name == "cfg3" else 1000
         for rep in range(5):
             for m in modes:
-                os.environ["AVIRHIP_DNF_DBG"] = str(m)
+                os.environ["AVIRHIP_UP2_DBG"] = str(m)
                 for _ in range(40):
                     step()
                 torch.cuda.synchronize()
@@ -67,7 +63,7 @@ def main():
             print("%s dbg=%-2d median %.4f ms (%+.1f %% vs dbg=%d)  runs %s" % (
                 name, m, med, (med / base - 1) * 100, modes[0],
                 " ".join("%.4f" % x for x in res[m])), flush=True)
-        os.environ["AVIRHIP_DNF_DBG"] = "0"
+        os.environ["AVIRHIP_UP2_DBG"] = "0"
 
 
 if __name__ == "__main__":

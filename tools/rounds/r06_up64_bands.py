@@ -3,7 +3,7 @@
 when a frame is resized in row bands (H pass of a band, then its V pass)? cfg3_dbl /
 cfg2_dbl whole against N sequential avirhip_resize_band calls, device-resident."""
 import os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import torch
 import bench
