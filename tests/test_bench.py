@@ -43,18 +43,22 @@ def test_bench_single_gpu_line():
 
 
 @gpu
-def test_bench_two_ranks_band_pipeline_gloo_dry_run():
-    port = 29700 + os.getpid() % 200
+@pytest.mark.parametrize("world", [2, 8])
+def test_bench_two_ranks_band_pipeline_gloo_dry_run(world):
+    """The driver's N > 1 command as far as one GPU can take it: `world` ranks
+    (2, and the 8 of BASELINE.json configs[2]) share the box's GPU over gloo --
+    band arithmetic, window-only source distribution, the stitch, the line."""
+    port = 29700 + os.getpid() % 200 + world
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
-           "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), "bench.py", "--gpus", "2", "--steps",
-           "3", "--warmup", "1", "--settle-ms", "0", "--backend", "gloo",
-           "--no-cpu"]
+           "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), "bench.py", "--gpus", str(world),
+           "--steps", "3", "--warmup", "1", "--settle-ms", "0", "--backend",
+           "gloo", "--no-cpu"]
     r = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True,
                        timeout=900)
     assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-3000:])
     d = _last_json(r.stdout)
-    assert d["n_gpus"] == 2 and d["scaling"] == "strong"
+    assert d["n_gpus"] == world and d["scaling"] == "strong"
     assert d["config"]["sharding"].startswith("row bands of ONE frame")
     assert d["parity"]["ok"], d["parity"]
     s = d["sharded"]
@@ -65,7 +69,8 @@ def test_bench_two_ranks_band_pipeline_gloo_dry_run():
     assert d["value_independent_frames"] == s["independent_frames"]["value"]
     # rank 0 was given its band's source rows only, the rest NaN
     w = d["config"]["source_rows_on_this_rank"]
-    assert w["first_row"] == 0 and w["rows"] < 1200 and w["of"] == 2160, w
+    assert w["first_row"] == 0 and w["of"] == 2160, w
+    assert w["rows"] < 2160 // world + 120, w
 
 
 @gpu

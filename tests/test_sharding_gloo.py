@@ -136,7 +136,7 @@ def test_sub_band_cuts():
 
 
 @pytest.mark.skipif(not rb.have_orc(), reason="oracle not built")
-@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("world", [2, 3, 8])
 def test_band_gather_gloo(world):
     _run_world(world, False)
 
