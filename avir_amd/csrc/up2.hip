@@ -193,6 +193,27 @@ __device__ __forceinline__ int clampi( int i, int hi )
 // (the S tile's LDS-DMA is a compiler builtin: the compiler's own wait-count
 // insertion drains it before the barrier; `make paranoid` drains by hand too)
 #define U2_SYNC() do { AVIRHIP_BARRIER_DRAIN(); __syncthreads(); } while( 0 )
+
+// Wave priority by interval (round 6, NOTEBOOK 10.11). The vertical interval
+// -- 430 packed multiply-adds per lane and step, the result stores -- runs one
+// step above the horizontal one (LDS window reads, the next tile's DMA): the
+// four waves of a SIMD belong to workgroups in different intervals, and the
+// arbiter's oldest-first choice otherwise lets a wave that is about to wait for
+// LDS anyway take issue slots from the one whose arithmetic paces the step.
+// Same-box, same-process: cfg3 -4.5 %, cfg2 -1.0 ... -1.5 %; any "vertical above
+// horizontal" pair measures the same, the reverse +0.4 ... -1.2 %. Results do
+// not depend on it.
+#define U2_PRIO_H 0
+#define U2_PRIO_V 1
+
+// s_setprio takes an immediate
+__device__ __forceinline__ void u2_setprio( const int p )
+{
+	if( p == 0 ) __builtin_amdgcn_s_setprio( 0 );
+	else if( p == 1 ) __builtin_amdgcn_s_setprio( 1 );
+	else if( p == 2 ) __builtin_amdgcn_s_setprio( 2 );
+	else __builtin_amdgcn_s_setprio( 3 );
+}
 #endif
 
 #ifdef U2_DBG
@@ -669,9 +690,11 @@ __attribute__(( amdgpu_waves_per_eu( 4, 4 ))) k_up2( const Up2Params P )
 			prefetch( ub + U2_RB );
 		}
 
+		u2_setprio( U2_PRIO_H );
 		h2_phase();
 
 		U2_SYNC();
+		u2_setprio( U2_PRIO_V );
 
 		// ======== interval A: V of this step, with H1 of the NEXT step woven
 		// into it (its LDS latency hides behind the vertical VALU work)
@@ -1082,10 +1105,22 @@ __attribute__(( amdgpu_waves_per_eu( 4, 4 ))) k_up2( const Up2Params P )
 			}
 
 #ifdef U2_DBG
+			// (bit 1024: wave priority by interval from the bits -- timing
+			// experiments, results unchanged: bits 6-7 the priority of the
+			// horizontal interval, bits 8-9 that of the vertical one)
+			u2_setprio( P.dbg & 1024 ? ( P.dbg >> 6 ) & 3 : U2_PRIO_H );
+
 			if( !tail_h2 )
+#else
+			u2_setprio( U2_PRIO_H );
 #endif
 			h2_phase();
 			U2_SYNC();
+#ifdef U2_DBG
+			u2_setprio( P.dbg & 1024 ? ( P.dbg >> 8 ) & 3 : U2_PRIO_V );
+#else
+			u2_setprio( U2_PRIO_V );
+#endif
 
 			if( decltype( RAMPC )::value )
 			{
