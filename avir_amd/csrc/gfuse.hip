@@ -232,6 +232,7 @@ __global__ void __launch_bounds__( 64 ) k_gf( const GFParams P )
 
 		const int buf = i & ( GF_NB - 1 );
 		const f4* const s = sbuf + buf * P.sbuf;
+		GP_PRIO_LOW();
 
 		if( u + GF_NB - 1 <= u_b )
 		{
@@ -297,6 +298,7 @@ __global__ void __launch_bounds__( 64 ) k_gf( const GFParams P )
 			}
 
 			__builtin_amdgcn_sched_barrier( 0 );
+			GP_PRIO_HIGH();
 
 			h = gp_dot< false, f4, NT >( NT,
 				[&]( const int t ) { return( w[ t % NT ]); },

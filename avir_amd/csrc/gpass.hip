@@ -228,6 +228,7 @@ __global__ void __launch_bounds__( 64 ) k_gh( const GHParams P )
 	{
 		const int buf = ( r - r0 ) & ( GH_NB - 1 );
 		const f4* const s = sbuf + buf * P.sbuf;
+		GP_PRIO_LOW();
 
 		if( SRC == 0 )
 		{
@@ -327,6 +328,7 @@ __global__ void __launch_bounds__( 64 ) k_gh( const GHParams P )
 				__builtin_amdgcn_sched_barrier( 0 );
 			}
 
+			GP_PRIO_HIGH();
 			o = gp_dot< LANC, f4, NTC >( nt,
 				[&]( const int t ) { return( NTC > 0 ?
 					w[ NTC > 0 ? t % ( NTC > 0 ? NTC : 1 ) : 0 ] : in[ t ]); },

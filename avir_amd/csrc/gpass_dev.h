@@ -12,6 +12,20 @@
 #include <stdio.h>
 #include <stdlib.h>
 
+// Wave priority inside a pass kernel's step (round 6, NOTEBOOK 10.11): low while
+// a wave issues its DMA and waits for a row, one level up from the arithmetic
+// on -- of the waves of a SIMD that are ready, the one that holds its row goes
+// first. Small here (these kernels wait more than they issue): 1080p x3 on the
+// fused kernel -2.0 %, 1080p -> 2500x1400 RGB uint8 -1.3 %, the others within
+// +-0.5 % (profiles/r06_up2_prio/pass_kernels_ab.txt). -DGP_NO_PRIO: without.
+#ifndef GP_NO_PRIO
+#define GP_PRIO_LOW() __builtin_amdgcn_s_setprio( 0 )
+#define GP_PRIO_HIGH() __builtin_amdgcn_s_setprio( 1 )
+#else
+#define GP_PRIO_LOW() do {} while( 0 )
+#define GP_PRIO_HIGH() do {} while( 0 )
+#endif
+
 namespace avirhip {
 
 typedef float f4 __attribute__(( ext_vector_type( 4 )));

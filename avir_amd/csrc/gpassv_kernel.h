@@ -528,6 +528,8 @@ __global__ void __launch_bounds__( 64 ) k_gv( const GVParams P )
 		// pinning the queue row in registers instead cost CLancIR 3840x2160 ->
 		// 1280x720 RGBA uint8 6 %). PRE runs the row through the FIR in the step
 		// that takes it over -- arithmetic, i.e. a wait -- and needs none.
+		GP_PRIO_LOW();
+
 		if( MODE != GP_PRE )
 		{
 			AVIRHIP_WAIT_LGKM( 0 );
@@ -577,6 +579,8 @@ __global__ void __launch_bounds__( 64 ) k_gv( const GVParams P )
 			qnext = *(const VT*) ( smem + ( P.rs + P.rc ) * ROWB + qr * 1024 +
 				( RPG == 2 ? (( i + 1 ) & 1 ) * 512 : 0 ) + lane * sizeof( VT ));
 		}
+
+		GP_PRIO_HIGH();
 
 		if( MODE == GP_PRE )
 		{

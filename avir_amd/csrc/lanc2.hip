@@ -28,6 +28,10 @@
 #include <stdlib.h>
 #include <type_traits>
 
+#ifndef L2_PRIO
+#define L2_PRIO 2 // (wave priority by phase: 1 vertical high, 2 horizontal high)
+#endif
+
 namespace avirhip {
 
 typedef float f2 __attribute__(( ext_vector_type( 2 )));
@@ -227,6 +231,7 @@ __global__ void __launch_bounds__( L2_NT ) k_lanc2( const Lanc2Params P )
 		const int ub = u0 + sb;
 
 		// ---- V: 8 source rows -> 16 intermediate rows (ring phase == row & 7)
+		__builtin_amdgcn_s_setprio( L2_PRIO == 1 ? 1 : 0 );
 		if( vact )
 		{
 			const Taps12 V = load_taps12( P.coef );
@@ -254,6 +259,13 @@ __global__ void __launch_bounds__( L2_NT ) k_lanc2( const Lanc2Params P )
 
 		AVIRHIP_BARRIER_DRAIN();
 		__syncthreads();
+		// (wave priority by phase, as in k_up2: the phase that carries the
+		// step's arithmetic and its stores -- here the horizontal one -- runs
+		// one level above the other; same-box A/B of both orders against none:
+		// 1080p -> 4K RGBA uint8 0.0402 / 0.0390 / 0.0368 ms (none / vertical
+		// high / horizontal high), RGB uint8 0.0540 / 0.0522 / 0.0506, cfg5
+		// 0.1088 / 0.1083 / 0.1072; profiles/r06_up2_prio)
+		__builtin_amdgcn_s_setprio( L2_PRIO == 1 ? 0 : 1 );
 
 		// next step's source rows start their trip from HBM now
 		if( sb + L2_RB < nsteps )
