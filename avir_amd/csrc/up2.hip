@@ -278,6 +278,19 @@ __attribute__(( amdgpu_waves_per_eu( 4, 4 ))) k_up2( const Up2Params P )
 #ifdef U2_DBG
 	const unsigned long long dbg_c0 = clock64();
 	const unsigned long long dbg_w0 = wall_clock64();
+
+	// (bits 2048 / 4096: the workgroups of a CU start apart -- by half a
+	// marching step in two groups, by eighths in eight -- instead of together)
+	if( P.dbg & ( 2048 | 4096 ))
+	{
+		const int slot = ( P.dbg & 2048 ? (( blockIdx.x >> 8 ) & 1 ) * 4 :
+			( blockIdx.x >> 8 ) & 7 );
+
+		for( int i = 0; i < slot; i++ )
+		{
+			__builtin_amdgcn_s_sleep( 25 ); // 1,600 cycles: an eighth of a step
+		}
+	}
 #endif
 	// XCD-aware dealing of (strip, chunk) work items (see fused.hip)
 	const int nwg = gridDim.x;
