@@ -997,7 +997,17 @@ static int exec_device( avirhip_plan* p, const void* src, void* dst,
 		( p -> in_type == AVIRHIP_U8 || p -> in_type == AVIRHIP_U16 ||
 		p -> in_type == AVIRHIP_F32 ) && p -> ch == 4 && gpass_takes_raw( p ));
 
-	if( need_pack && !raw && !graw )
+	// the exact-2x marching kernel reads RGB / RGBA uint8 / uint16 images as
+	// they lie when it also stores the caller's integer pixels (it may still
+	// refuse the call -- alignment, a source window: the pack pass runs then)
+	const bool uraw = ( need_pack && !p -> gamma && path == 4 && !p -> is_lancir &&
+		( p -> in_type == AVIRHIP_U8 || p -> in_type == AVIRHIP_U16 ) &&
+		p -> ch == 4 && ( p -> io_ch == 3 || p -> io_ch == 4 ) &&
+		( p -> out_type == AVIRHIP_U8 || p -> out_type == AVIRHIP_U16 ) &&
+		p -> dither == AVIRHIP_DITHER_DEF && up2_stores_io( p ) &&
+		getenv( "AVIRHIP_NO_FUSED_OUT" ) == nullptr );
+
+	if( need_pack && !raw && !graw && !uraw )
 	{
 		if(( rc = do_pack()) != 0 ) return( rc );
 	}
@@ -1070,6 +1080,23 @@ static int exec_device( avirhip_plan* p, const void* src, void* dst,
 				( p -> out_type == AVIRHIP_U8 || p -> out_type == AVIRHIP_U16 )) ||
 				p -> out_type == AVIRHIP_F32 ) &&
 				getenv( "AVIRHIP_NO_FUSED_OUT" ) == nullptr ? dst : nullptr );
+
+			rc = 1;
+
+			if( iout4 != nullptr && uraw )
+			{
+				rc = up2_run( p, nullptr, 0, nullptr, row0, row1, st, iout4, src,
+					p -> src_stride );
+
+				if( rc == 0 )
+				{
+					return( AVIRHIP_OK ); // (no pack pass, no epilogue)
+				}
+
+				if( rc != 1 ) return( rc );
+			}
+
+			if( uraw && ( rc = do_pack()) != 0 ) return( rc );
 
 			rc = 1;
 

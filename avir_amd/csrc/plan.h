@@ -401,7 +401,8 @@ bool fused_dn_both( const avirhip_plan* p );
 int up2_prepare( avirhip_plan* p );
 void up2_release( avirhip_plan* p );
 int up2_run( avirhip_plan* p, const float* src, long src_stride, float* dst,
-	int row0, int row1, hipStream_t st, void* iout = nullptr );
+	int row0, int row1, hipStream_t st, void* iout = nullptr,
+	const void* raw = nullptr, long raw_stride = 0 );
 bool up2_stores_io( const avirhip_plan* p );
 // whether up2_run / lanc2_run take this float RGBA call for certain (no refusal,
 // no fall-back to kernels that know nothing of a source window)

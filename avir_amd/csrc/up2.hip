@@ -255,11 +255,23 @@ __device__ __forceinline__ void u2_setprio( const int p )
 // P.ich channels stored by the vertical phase itself (a lane holds two
 // channels of a pixel: one store per channel, lanes without one carry an
 // out-of-range offset) -- no float result, no epilogue pass over it.
-template< bool VT, int IO = 0 >
+// SRC (VT only): 0 float RGBA pixels by 16-byte LDS-DMA; 10 * element size +
+// channels (13, 14, 23, 24: RGB / RGBA uint8 / uint16) the caller's integer
+// image as it lies -- packScanline's (float) cast and zero padding
+// (avir.h:2777-2840) without a float copy of the source: a lane DMAs the two
+// aligned dwords that hold its pixel into the first bytes of the pixel's own
+// region of the S tile, and -- the same lane, after its wave's DMA has landed,
+// before the interval's closing barrier -- reads them back, converts and writes
+// the float pixel in place. P.src then points at bytes, P.src_ss counts bytes.
+template< bool VT, int IO = 0, int SRC = 0 >
 __global__ void __launch_bounds__( U2_NT )
 __attribute__(( amdgpu_waves_per_eu( 4, 4 ))) k_up2( const Up2Params P )
 {
 	static_assert( IO == 0 || VT, "the fused output stage lives in the VT form" );
+	static_assert( SRC == 0 || VT, "raw sources live in the VT form" );
+	constexpr int SESZ = SRC / 10;       // bytes per source element (raw)
+	constexpr int SCH = SRC % 10;        // channels of a source pixel (raw)
+	constexpr int PXB = ( SRC != 0 ? SESZ * SCH : 16 ); // bytes per source pixel
 	// (IO 4 / 5: uint8 / uint16 results of an INTEGER source -- finite and far
 	// inside the int range, so the stage is add, convert, integer clamp)
 	constexpr int ESZ = ( IO == 1 || IO == 4 ? 1 : ( IO == 2 || IO == 5 ? 2 : 4 ));
@@ -323,7 +335,7 @@ __attribute__(( amdgpu_waves_per_eu( 4, 4 ))) k_up2( const Up2Params P )
 	const int dlane_b = ( xo * 4 + hf * 2 ) * 4; // byte offset within a row
 	const int drow_b = ( IO != 0 ? P.istride_b :
 		(int) P.dst_ss * 4 );                // bytes per destination row
-	const int srow_b = (int) P.src_ss * 4;   // bytes per source row
+	const int srow_b = (int) P.src_ss * ( SRC != 0 ? 1 : 4 ); // bytes per source row
 
 	// Buffer addressing (uniform 128-bit resource + 32-bit lane offset + scalar
 	// row offset): a load/store moves ONE address dword per lane instead of a
@@ -331,8 +343,15 @@ __attribute__(( amdgpu_waves_per_eu( 4, 4 ))) k_up2( const Up2Params P )
 	// wave sends to the memory pipeline. Both resources are based at this work
 	// item's first row so every offset fits 31 bits for any image size.
 	const int ubase = max( u0, P.rmin );
+	// (raw sources: a dword-aligned base -- its two low bits go into the lanes'
+	// offsets -- and the range the image's bytes end in, rounded up to a dword:
+	// a pixel's second dword beyond it reads 0 without touching memory)
+	const char* const sbase = (const char*) P.src + (long) ubase * srow_b;
+	const int rsh = ( SRC != 0 ? (int) ( (unsigned long long) sbase & 3 ) : 0 );
 	const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
-		(void*) ( P.src + (long) ubase * P.src_ss ), 0, 0x7fffffff, 0x00020000 );
+		(void*) ( sbase - rsh ), 0, ( SRC != 0 ?
+		( rsh + ( P.rmax - ubase ) * srow_b + P.sw * PXB + 3 ) & ~3 : 0x7fffffff ),
+		0x00020000 );
 	const __amdgpu_buffer_rsrc_t rdst = __builtin_amdgcn_make_buffer_rsrc(
 		(void*) ( P.dst + (long) ( qy0 * 2 - P.dst_row0 ) * P.dst_ss ), 0,
 		0x7fffffff, 0x00020000 );
@@ -375,7 +394,7 @@ __attribute__(( amdgpu_waves_per_eu( 4, 4 ))) k_up2( const Up2Params P )
 		{
 			const int r = tid / U2_SW;
 			const int sx = clampi( qx0 - 9 + ( tid - r * U2_SW ), P.sw - 1 );
-			pvoff = ( tid < RPI0 * U2_SW ? r * srow_b + sx * 16 : -1 );
+			pvoff = ( tid < RPI0 * U2_SW ? r * srow_b + sx * PXB + rsh : -1 );
 		}
 
 		if constexpr( IO != 0 )
@@ -447,8 +466,100 @@ __attribute__(( amdgpu_waves_per_eu( 4, 4 ))) k_up2( const Up2Params P )
 	const int wave = __builtin_amdgcn_readfirstlane( tid >> 6 );
 	const int wave_b = wave * 1024;
 
+	// raw sources: the byte offset (from rsrc's base) of this lane's pixel of
+	// DMA instruction k of the tile that starts at row ub; < 0: the lane has none
+	auto raw_off = [&]( const int k, const int ub ) -> int
+	{
+		if( ub >= P.rmin && ub + U2_RB <= P.rmax + 1 )
+		{
+			return( pvoff >= 0 ? pvoff + ( ub - ubase + k * RPI ) * srow_b : -1 );
+		}
+
+		// image top / bottom: rows clamp individually (rare path)
+		const int tid = fresh_tid( wave );
+		const int pr_r = tid / U2_SW;
+		const int pr_sx = clampi( qx0 - 9 + ( tid - pr_r * U2_SW ), P.sw - 1 );
+		const int sy = min( max( ub + k * RPI + pr_r, P.rmin ), P.rmax );
+
+		return( tid < RPI * U2_SW ? ( sy - ubase ) * srow_b + pr_sx * PXB + rsh :
+			-1 );
+	};
+
+	// raw sources: the tile's pixels, DMAed as pairs of dwords, become floats
+	// (called by every thread after vmcnt( 0 ), before the closing barrier)
+	auto land_raw = [&]( const int ub )
+	{
+		typedef const __attribute__(( address_space( 3 ))) unsigned* lds_cu;
+		unsigned d0[ NDMA ], d1[ NDMA ];
+		int off[ NDMA ];
+		const int lw = ( threadIdx.x & 63 ) * 4;
+#pragma unroll
+		for( int k = 0; k < NDMA; k++ )
+		{
+			off[ k ] = raw_off( k, ub );
+			const char* const st = (const char*) sS + k * RPI * U2_SW * 16 +
+				wave_b + lw;
+			d0[ k ] = *(lds_cu) (const void*) st;
+			d1[ k ] = *(lds_cu) (const void*) ( st + 256 );
+		}
+
+		// (every read above before any write below: the float pixels go where
+		// the wave's own dwords lay)
+		asm volatile( "s_waitcnt lgkmcnt(0)" ::: "memory" );
+#pragma unroll
+		for( int k = 0; k < NDMA; k++ )
+		{
+			if( off[ k ] >= 0 )
+			{
+				const unsigned sh = (unsigned) off[ k ] & 3u;
+				const unsigned lo = __builtin_amdgcn_alignbyte( d1[ k ], d0[ k ], sh );
+				f4 px;
+
+				if( SESZ == 1 )
+				{
+					px.x = (float) ( lo & 0xffu );
+					px.y = (float) (( lo >> 8 ) & 0xffu );
+					px.z = (float) (( lo >> 16 ) & 0xffu );
+					px.w = ( SCH == 4 ? (float) ( lo >> 24 ) : 0.0f );
+				}
+				else
+				{
+					const unsigned hi = d1[ k ] >> ( sh * 8 );
+					px.x = (float) ( lo & 0xffffu );
+					px.y = (float) ( lo >> 16 );
+					px.z = (float) ( hi & 0xffffu );
+					px.w = ( SCH == 4 ? (float) ( hi >> 16 ) : 0.0f );
+				}
+
+				*(f4*) ((char*) sS + k * RPI * U2_SW * 16 + wave_b + lw * 4 ) = px;
+			}
+		}
+	};
+
 	auto prefetch = [&]( const int ub )
 	{
+		if constexpr( SRC != 0 )
+		{
+#pragma unroll
+			for( int k = 0; k < NDMA; k++ )
+			{
+				const int o = raw_off( k, ub );
+
+				if( o >= 0 )
+				{
+					const ldsptr q = (ldsptr) ((char*) sS + k * RPI * U2_SW * 16 +
+						wave_b );
+					__builtin_amdgcn_raw_ptr_buffer_load_lds( rsrc, q, 4, o & ~3,
+						0, 0, U2_LDAUX );
+					__builtin_amdgcn_raw_ptr_buffer_load_lds( rsrc,
+						(ldsptr) ((char*) q + 256 ), 4, ( o & ~3 ) + 4, 0, 0,
+						U2_LDAUX );
+				}
+			}
+
+			return;
+		}
+
 		if( VT && ub >= P.rmin && ub + U2_RB <= P.rmax + 1 )
 		{
 			// (interior rows: the lane offset is the persistent one)
@@ -819,6 +930,13 @@ __attribute__(( amdgpu_waves_per_eu( 4, 4 ))) k_up2( const Up2Params P )
 	};
 
 	prefetch( u0 );
+
+	if constexpr( SRC != 0 )
+	{
+		AVIRHIP_WAIT_VM( 0 );
+		land_raw( u0 );
+	}
+
 	U2_SYNC();
 
 	{
@@ -1128,6 +1246,16 @@ __attribute__(( amdgpu_waves_per_eu( 4, 4 ))) k_up2( const Up2Params P )
 			u2_setprio( U2_PRIO_H );
 #endif
 			h2_phase();
+
+			if constexpr( SRC != 0 )
+			{
+				if( more )
+				{
+					AVIRHIP_WAIT_VM( 0 );
+					land_raw( ub + U2_RB );
+				}
+			}
+
 			U2_SYNC();
 #ifdef U2_DBG
 			u2_setprio( P.dbg & 1024 ? ( P.dbg >> 8 ) & 3 : U2_PRIO_V );
@@ -1371,8 +1499,12 @@ bool up2_takes_window( const avirhip_plan* p, const void* src, const void* dst )
 // vertical phase converts and stores there (no float result, no epilogue
 // pass); returns 1 if this plan's form of the kernel cannot (the caller then
 // runs with a float result).
+// `raw` != nullptr (with `iout`): the caller's integer image (uint8 / uint16,
+// 3 or 4 channels, `raw_stride` elements per row) instead of `src`; returns 1
+// if this call cannot take it (the caller then packs and calls again).
 int up2_run( avirhip_plan* p, const float* src, long src_stride, float* dst,
-	int row0, int row1, hipStream_t st, void* iout )
+	int row0, int row1, hipStream_t st, void* iout, const void* raw,
+	long raw_stride )
 {
 	const Up2Data* D = (const Up2Data*) p -> up2;
 	static const bool novt = ( getenv( "AVIRHIP_UP2_NOVT" ) != nullptr );
@@ -1405,10 +1537,33 @@ int up2_run( avirhip_plan* p, const float* src, long src_stride, float* dst,
 
 	}
 
+	// the integer image as it lies (k_up2< true, IO, SRC >): results of
+	// integer sources only (io 4 / 5), whole frames behind the pointer, every
+	// pixel inside two aligned dwords (uint16 RGBA: dword-aligned rows)
+	int srck = 0;
+
+	if( raw != nullptr )
+	{
+		const int esz = ( p -> in_type == AVIRHIP_U8 ? 1 : 2 );
+		const long sb = raw_stride * esz;
+
+		if(( io != 4 && io != 5 ) || ( p -> io_ch != 3 && p -> io_ch != 4 ) ||
+			p -> win_rows > 0 || ( (uintptr_t) raw & ( esz - 1 )) ||
+			( esz == 2 && p -> io_ch == 4 && (( (uintptr_t) raw | sb ) & 3 )) ||
+			sb >= ( 1L << 22 ) || getenv( "AVIRHIP_UP2_NO_RAW" ) != nullptr )
+		{
+			return( 1 );
+		}
+
+		srck = esz * 10 + p -> io_ch;
+		src = (const float*) raw;
+		src_stride = sb;
+	}
+
 	// source pixels travel as 16-byte LDS-DMA pieces, destination half-pixels
 	// as 8-byte stores
-	if( D == nullptr || ( (uintptr_t) src & 15 ) ||
-		( io == 0 && ( (uintptr_t) dst & 7 )) || ( src_stride & 3 ))
+	if( D == nullptr || ( srck == 0 && (( (uintptr_t) src & 15 ) ||
+		( src_stride & 3 ))) || ( io == 0 && ( (uintptr_t) dst & 7 )))
 	{
 		return( 1 );
 	}
@@ -1419,7 +1574,7 @@ int up2_run( avirhip_plan* p, const float* src, long src_stride, float* dst,
 	}
 
 	// the kernel addresses rows with 32-bit float offsets
-	if( (long) src_stride * 4 >= ( 1L << 22 ) ||
+	if(( srck == 0 && (long) src_stride * 4 >= ( 1L << 22 )) ||
 		(long) p -> new_w * 16 >= ( 1L << 22 ))
 	{
 		return( 1 );
@@ -1519,6 +1674,34 @@ int up2_run( avirhip_plan* p, const float* src, long src_stride, float* dst,
 
 	const char* pad = getenv( "AVIRHIP_UP2_LDSPAD" ); // residency experiments
 	const int ldspad = ( pad != nullptr ? atoi( pad ) : 0 );
+	if( srck != 0 )
+	{
+#define U2_RAW( IOK, SK ) hipLaunchKernelGGL(( k_up2< U2_RB == 8, \
+	U2_RB == 8 ? IOK : 0, U2_RB == 8 ? SK : 0 > ), dim3( items ), \
+	dim3( U2_NT ), ldspad, st, P )
+		if( io == 4 )
+		{
+			switch( srck )
+			{
+				case 13: U2_RAW( 4, 13 ); break;
+				case 14: U2_RAW( 4, 14 ); break;
+				case 23: U2_RAW( 4, 23 ); break;
+				default: U2_RAW( 4, 24 ); break;
+			}
+		}
+		else
+		{
+			switch( srck )
+			{
+				case 13: U2_RAW( 5, 13 ); break;
+				case 14: U2_RAW( 5, 14 ); break;
+				case 23: U2_RAW( 5, 23 ); break;
+				default: U2_RAW( 5, 24 ); break;
+			}
+		}
+#undef U2_RAW
+	}
+	else
 	if( io != 0 )
 	{
 		switch( io )
