@@ -2528,6 +2528,63 @@ def test_exact_2x_marching_kernel_stores_the_callers_pixels(ch, tin, tout, bits)
     assert ran >= 2, "path 4 took %d of the shapes" % ran
 
 
+@pytest.mark.parametrize("ch,tin,tout,bits", [
+    (3, np.uint8, np.uint8, 8), (4, np.uint8, np.uint8, 8),
+    (3, np.uint16, np.uint16, 16), (4, np.uint16, np.uint16, 16),
+    (3, np.uint8, np.uint16, 16), (4, np.uint16, np.uint8, 8)])
+def test_exact_2x_marching_kernel_reads_integer_images_as_they_lie(ch, tin, tout, bits, monkeypatch):
+    """k_up2< true, IO, SRC >: RGB / RGBA uint8 / uint16 sources of exact 2x plans
+    with integer results are read where they lie -- a lane DMAs the two aligned
+    dwords that hold its pixel and converts in place (packScanline,
+    avir.h:2777-2840, without a float copy of the source). Forced path 4 against
+    the reference: odd widths (rows starting at every byte alignment), frames of
+    a few rows, bands; device images at every byte offset of the base pointer;
+    the same call with the pack pass (AVIRHIP_UP2_NO_RAW) gives the same bytes."""
+    import torch
+    lib = abi.load()
+    dev = torch.device("cuda", 0)
+    ran = 0
+    for (sw, sh) in [(97, 61), (333, 40), (1001, 9), (50, 50), (642, 361)]:
+        raw8 = rb.lcg_u8((sh, sw, ch, np.dtype(tin).itemsize), seed=sw + ch)
+        src = np.ascontiguousarray(raw8).view(tin).reshape(sh, sw, ch)
+        nw, nh = sw * 2, sh * 2
+        want = _checker_avir(src, nw, nh, resbits=bits, out_dtype=tout)
+        r = avir_amd.CImageResizer(bits)
+        p = r.plan(sw, sh, nw, nh, ch, 0.0, None, avir_amd._NP2T[np.dtype(tin)],
+                   avir_amd._NP2T[np.dtype(tout)])
+        if lib.avirhip_plan_set_path(p, abi.PATH_UP2) != 0:
+            continue
+        ran += 1
+        got = r.resize(src, nw, nh, out_dtype=tout)
+        assert np.array_equal(got, want), (sw, sh, ch, tin, tout)
+        out = np.zeros((nh, nw, ch), tout)
+        for a_, b_ in [(0, nh // 3), (nh // 3, nh - 5), (nh - 5, nh)]:
+            abi.check(lib.avirhip_resize_band(
+                p, src.ctypes.data, abi.MEM_HOST, out[a_:b_].ctypes.data,
+                abi.MEM_HOST, a_, b_, None), "band")
+        assert np.array_equal(out, want), ("bands", sw, sh, ch)
+        # device images whose first byte sits at every alignment
+        esz = np.dtype(tin).itemsize
+        nbytes = src.size * esz
+        for off in range(0, 4, esz):
+            buf = torch.zeros(nbytes + 8, dtype=torch.uint8, device=dev)
+            buf[off:off + nbytes] = torch.from_numpy(
+                src.view(np.uint8).reshape(-1)).to(dev)
+            dst = torch.zeros(nh * nw * ch * np.dtype(tout).itemsize,
+                              dtype=torch.uint8, device=dev)
+            abi.check(lib.avirhip_resize_band(
+                p, buf.data_ptr() + off, abi.MEM_DEVICE, dst.data_ptr(),
+                abi.MEM_DEVICE, 0, nh, None), "device")
+            torch.cuda.synchronize()
+            g2 = dst.cpu().numpy().view(tout).reshape(nh, nw, ch)
+            assert np.array_equal(g2, want), ("base offset", off, sw, sh, ch)
+        monkeypatch.setenv("AVIRHIP_UP2_NO_RAW", "1")
+        g3 = r.resize(src, nw, nh, out_dtype=tout)
+        monkeypatch.delenv("AVIRHIP_UP2_NO_RAW")
+        assert np.array_equal(g3, want), ("pack pass", sw, sh, ch)
+    assert ran >= 3, "path 4 took %d of the shapes" % ran
+
+
 def test_exact_2x_integer_frames_take_the_marching_kernel_from_1080p_on():
     lib = abi.load()
     r8 = avir_amd.CImageResizer(8)
