@@ -20,10 +20,6 @@ for (sw, sh) in shapes:
             for tout in (np.uint8, np.uint16):
                 a = synth.lcg_u8((sh, sw, ch, np.dtype(tin).itemsize), seed=n + 3)
                 src = a.view(tin).reshape(sh, sw, ch)
-                outs = []
-                for path in (0, abi.PATH_GENERIC):
-                    r = avir_amd.CImageResizer(int(rng.choice([8, 10, 16])) if path == 0 else r.bits if hasattr(r, "bits") else 8)
-                    outs.append(None)
                 bits = int(rng.choice([8, 16])) if tout == np.uint16 else 8
                 res = {}
                 for name, path in (("auto", 0), ("generic", abi.PATH_GENERIC)):
@@ -31,6 +27,8 @@ for (sw, sh) in shapes:
                     p = r.plan(sw, sh, 2 * sw, 2 * sh, ch, 0.0, None, DT[np.dtype(tin)], DT[np.dtype(tout)])
                     if path:
                         assert lib.avirhip_plan_set_path(p, path) == 0
+                    else:
+                        lib.avirhip_plan_set_path(p, abi.PATH_UP2)  # (refused: the automatic path)
                     out = np.zeros((2 * sh, 2 * sw, ch), tout)
                     if name == "auto" and rng.rand() < 0.5 and sh > 4:
                         cuts = sorted(set([0, 2 * sh] + [int(rng.randint(0, 2 * sh + 1)) for _ in range(2)]))
